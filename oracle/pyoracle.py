@@ -1,0 +1,241 @@
+"""ctypes binding of the CPU oracle (oracle/libvct_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see oracle/vct_oracle.h).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+GB_PLANES = 23
+GB_P, GB_NW, GB_TW, GB_BW, GB_BUMPN, GB_ALBEDO, GB_SPEC, GB_SHADOW = 0, 3, 6, 9, 12, 15, 19, 22
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("V", C.c_int32),
+        ("G", C.c_float),
+        ("camera_pos", C.c_float * 3),
+        ("light_dir", C.c_float * 3),
+        ("ambient_factor", C.c_float),
+        ("shininess", C.c_float),
+        ("max_distance", C.c_float),
+        ("max_alpha", C.c_float),
+        ("tan_diffuse", C.c_float),
+        ("tan_specular", C.c_float),
+        ("wrap_repeat", C.c_int32),
+    ]
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("pos", C.c_void_p),
+        ("material", C.c_void_p),
+        ("albedo", C.c_void_p),
+        ("ntri", C.c_int32),
+        ("nmat", C.c_int32),
+        ("model_scale", C.c_float),
+        ("shadow_depth", C.c_void_p),
+        ("shadow_size", C.c_int32),
+        ("light_vp", C.c_float * 16),
+    ]
+
+
+def build():
+    """Compile the oracle with gcc if the .so is missing or stale."""
+    so = os.path.join(_HERE, "libvct_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("vct_oracle.cpp", "vct_oracle.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "libvct_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.vcto_level_offset_texels.restype = C.c_size_t
+        L.vcto_chain_texels.restype = C.c_size_t
+        L.vcto_trace.restype = C.c_uint64
+        L.vcto_f32_to_f16.restype = C.c_uint16
+        L.vcto_f32_to_f16.argtypes = [C.c_float]
+        L.vcto_f16_to_f32.restype = C.c_float
+        L.vcto_f16_to_f32.argtypes = [C.c_uint16]
+        L.vcto_shadow_tex.restype = C.c_float
+        L.vcto_shadow_tex.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.vcto_pcf25.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float]
+        L.vcto_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.vcto_cone.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_float, C.c_void_p]
+        L.vcto_max_steps.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.vcto_voxel_proj.argtypes = [C.c_float, C.c_int, C.c_void_p]
+        L.vcto_frag_to_voxel.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                         C.c_void_p]
+        L.vcto_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def default_params(V=128, **kw):
+    p = Params()
+    lib().vcto_default_params(C.byref(p))
+    p.V = V
+    for k, v in kw.items():
+        if k in ("camera_pos", "light_dir"):
+            getattr(p, k)[:] = list(v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def num_levels(V):
+    return lib().vcto_num_levels(V)
+
+
+def level_offset(V, level):
+    return lib().vcto_level_offset_texels(V, level)
+
+
+def chain_texels(V):
+    return lib().vcto_chain_texels(V)
+
+
+def build_mips(l0):
+    """l0: uint8 [V,V,V,4] (z,y,x order).  Returns the linear chain uint8 [chain_texels,4]."""
+    V = l0.shape[0]
+    chain = np.zeros((chain_texels(V), 4), np.uint8)
+    chain[: V ** 3] = l0.reshape(-1, 4)
+    lib().vcto_build_mips(_ptr(chain), V)
+    return chain
+
+
+def level_view(chain, V, level):
+    N = V >> level
+    o = level_offset(V, level)
+    return chain[o:o + N ** 3].reshape(N, N, N, 4)
+
+
+def sample(p, chain, pos, lod):
+    pos = np.asarray(pos, np.float32)
+    out = np.zeros(4, np.float32)
+    lib().vcto_sample(C.byref(p), _ptr(chain), _ptr(pos), float(lod), _ptr(out))
+    return out
+
+
+def cone(p, chain, P, Nw, d, tan_half):
+    P, Nw, d = (np.ascontiguousarray(a, np.float32) for a in (P, Nw, d))
+    out = np.zeros(4, np.float32)
+    steps = lib().vcto_cone(C.byref(p), _ptr(chain), _ptr(P), _ptr(Nw), _ptr(d),
+                            float(tan_half), _ptr(out))
+    return out, steps
+
+
+def cone_constants():
+    d = np.zeros(18, np.float32)
+    w = np.zeros(6, np.float32)
+    lib().vcto_cone_constants(_ptr(d), _ptr(w))
+    return d.reshape(6, 3), w
+
+
+def max_steps(p, tan_half):
+    lod = C.c_float()
+    n = lib().vcto_max_steps(C.byref(p), float(tan_half), C.byref(lod))
+    return n, lod.value
+
+
+def trace(p, chain, planes, nthreads=1, want_cones=False):
+    """planes: float32 [23, npix].  Returns dict(rgba32f, rgba16f, steps, cones, total_steps)."""
+    planes = np.ascontiguousarray(planes, np.float32)
+    assert planes.shape[0] == GB_PLANES
+    npix = planes.shape[1]
+    o32 = np.zeros((npix, 4), np.float32)
+    o16 = np.zeros((npix, 4), np.uint16)
+    steps = np.zeros((npix, 7), np.uint8)
+    cones = np.zeros((npix, 7, 4), np.float32) if want_cones else None
+    total = lib().vcto_trace(C.byref(p), _ptr(chain), _ptr(planes), npix, _ptr(o32), _ptr(o16),
+                             _ptr(steps), _ptr(cones), int(nthreads))
+    return dict(rgba32f=o32, rgba16f=o16, steps=steps, cones=cones, total_steps=int(total))
+
+
+def f32_to_f16(x):
+    return lib().vcto_f32_to_f16(float(x))
+
+
+def f16_to_f32(h):
+    return lib().vcto_f16_to_f32(int(h))
+
+
+def voxel_proj(G, axis):
+    m = np.zeros(16, np.float32)
+    lib().vcto_voxel_proj(float(G), int(axis), _ptr(m))
+    return m.reshape(4, 4).T.copy()   # row-major 4x4 (m was column-major)
+
+
+def dominant_axis(v0, v1, v2):
+    a, b, c = (np.ascontiguousarray(v, np.float32) for v in (v0, v1, v2))
+    return lib().vcto_dominant_axis(_ptr(a), _ptr(b), _ptr(c))
+
+
+def frag_to_voxel(V, axis, fx, fy, fz):
+    out = np.zeros(3, np.int32)
+    lib().vcto_frag_to_voxel(int(V), int(axis), float(fx), float(fy), float(fz), _ptr(out))
+    return out
+
+
+def shadow_tex(depth, u, v):
+    depth = np.ascontiguousarray(depth, np.float32)
+    return lib().vcto_shadow_tex(_ptr(depth), depth.shape[0], float(u), float(v))
+
+
+def pcf25(depth, coord, bias=0.002):
+    depth = np.ascontiguousarray(depth, np.float32)
+    c = np.ascontiguousarray(coord, np.float32)
+    return lib().vcto_pcf25(_ptr(depth), depth.shape[0], _ptr(c), float(bias))
+
+
+def make_scene(pos, material, albedo, model_scale=0.05, shadow_depth=None, light_vp=None):
+    """Keeps references to the numpy arrays alive on the returned struct."""
+    s = Scene()
+    s._keep = [np.ascontiguousarray(pos, np.float32).reshape(-1, 9),
+               np.ascontiguousarray(material, np.int32),
+               np.ascontiguousarray(albedo, np.float32).reshape(-1, 4)]
+    s.pos, s.material, s.albedo = (_ptr(a) for a in s._keep)
+    s.ntri = s._keep[0].shape[0]
+    s.nmat = s._keep[2].shape[0]
+    s.model_scale = model_scale
+    if shadow_depth is not None:
+        sd = np.ascontiguousarray(shadow_depth, np.float32)
+        s._keep.append(sd)
+        s.shadow_depth = _ptr(sd)
+        s.shadow_size = sd.shape[0]
+    else:
+        s.shadow_depth = None
+        s.shadow_size = 0
+    lv = np.eye(4, dtype=np.float32) if light_vp is None else np.asarray(light_vp, np.float32)
+    s.light_vp[:] = list(lv.T.reshape(-1))   # row-major in -> column-major struct
+    return s
+
+
+def voxelize_reference(p, scene):
+    V = p.V
+    l0 = np.zeros((V, V, V, 4), np.uint8)
+    lib().vcto_voxelize_reference(C.byref(p), C.byref(scene), _ptr(l0))
+    return l0
+
+
+def voxelize_conservative(p, scene, want_acc=False):
+    V = p.V
+    l0 = np.zeros((V, V, V, 4), np.uint8)
+    acc = np.zeros((V, V, V, 4), np.uint32) if want_acc else None
+    lib().vcto_voxelize_conservative(C.byref(p), C.byref(scene), _ptr(l0), _ptr(acc))
+    return (l0, acc) if want_acc else l0

@@ -1,0 +1,157 @@
+/*
+ * vct_oracle.h -- scalar CPU restatement of the voxel-cone-tracing GI path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is product code: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / the reported CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (AlerianEmperor/Voxel-Cone-Tracing) holds no tests,
+ * golden vectors or fixtures, and its implementation of this path is GLSL that
+ * only runs inside an OpenGL 4.3 driver (it cannot be compiled or run here).
+ * What pins this oracle instead: the known-answer tests derived from the shader
+ * text (tests/test_oracle_kat.py) and an independent numpy
+ * restatement (tests/np_restatement.py) of the same rules.
+ *
+ * Reference files restated (R = Voxel_Cone_Tracing_Final, S = R/Shader):
+ *   S/VoxelConeTracing.fs:43-66   constants, SampleVoxels
+ *   S/VoxelConeTracing.fs:82-107  Voxel_Cone_Tracing (cone march)
+ *   S/VoxelConeTracing.fs:165-228 gather + composite
+ *   S/VoxelConeTracing.vs:23-37   varyings (the "G-buffer" fields)
+ *   R/Voxel_Cone_Tracing.h:110-126,248  volume format, sampler state, mip build
+ *   R/Voxel_Cone_Tracing.h:128-134      voxelization projections
+ *   S/Voxelization.vs/.gs/.fs           voxelize + light inject
+ *   S/VoxelConeTracing.fs:132-163, S/Voxelization.fs:18-52  PCF
+ * Rules marked [GL] restate the OpenGL 4.3 core specification (the behaviour of
+ * the driver the reference calls into), see SURVEY.md Appendix A.
+ *
+ * All arithmetic is fp32, compiled with -ffp-contract=off; every fused
+ * multiply-add is an explicit fmaf() so that the HIP kernels can match it
+ * operation for operation.
+ */
+#ifndef VCT_ORACLE_H_
+#define VCT_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* G-buffer plane indices (fp32 SoA, 23 planes = 92 B / pixel). */
+enum {
+    VCTO_GB_P = 0,        /* Position_world            trace.vs:27 */
+    VCTO_GB_NW = 3,       /* Normal_world (raw)        trace.vs:31 */
+    VCTO_GB_TW = 6,       /* Tangent_world (raw)       trace.vs:32 */
+    VCTO_GB_BW = 9,       /* BiTangent_world (raw)     trace.vs:33 */
+    VCTO_GB_BUMPN = 12,   /* bump normal N (unit)      trace.fs:177 */
+    VCTO_GB_ALBEDO = 15,  /* matColor rgba             trace.fs:167 */
+    VCTO_GB_SPEC = 19,    /* specColor rgb (resolved)  trace.fs:209-210 */
+    VCTO_GB_SHADOW = 22,  /* shadow_value              trace.fs:186 */
+    VCTO_GB_PLANES = 23
+};
+
+typedef struct vcto_params {
+    int32_t V;              /* VoxelDimensions            VCT.h:16  */
+    float G;                /* VoxelGridWorldSize         VCT.h:17  */
+    float camera_pos[3];    /* CameraPosition             VCT.h:167 */
+    float light_dir[3];     /* LightDirection             VCT.h:14,168 */
+    float ambient_factor;   /* AmbientFactor              VCT.h:53  */
+    float shininess;        /* Shininess = 20             Mesh.h:86 */
+    float max_distance;     /* MAX_DISTANCE = 75          trace.fs:43 */
+    float max_alpha;        /* MAX_ALPHA = 0.95           trace.fs:44 */
+    float tan_diffuse;      /* 0.577                      trace.fs:198 */
+    float tan_specular;     /* 0.07                       trace.fs:218 */
+    int32_t wrap_repeat;    /* 1 = GL_REPEAT (reference default, VCT.h:110-113), 0 = clamp-to-edge */
+} vcto_params;
+
+void vcto_default_params(vcto_params* p);
+
+/* ---- volume: linear RGBA8 mip chain ------------------------------------------------
+ * level k has N=V>>k texels per side, texel (x,y,z) at ((z*N+y)*N+x)*4 bytes from the
+ * level's offset; levels are concatenated 0..log2(V).  [GL] A.1 */
+int vcto_num_levels(int V);
+size_t vcto_level_offset_texels(int V, int level);
+size_t vcto_chain_texels(int V);
+/* [GL] A.8 -- VCT.h:248 glGenerateMipmap: 2x2x2 box, per channel, requantised per level. */
+void vcto_build_mips(uint8_t* chain, int V);
+
+/* ---- sampler + cone ---------------------------------------------------------------- */
+/* trace.fs:59-66 + [GL] A.2 textureLod with LINEAR_MIPMAP_LINEAR / LINEAR. */
+void vcto_sample(const vcto_params* p, const uint8_t* chain, const float pos[3], float lod,
+                 float out[4]);
+/* trace.fs:82-107.  Returns the executed step count. */
+int vcto_cone(const vcto_params* p, const uint8_t* chain, const float P[3], const float Nw[3],
+              const float dir[3], float tan_half, float out[4]);
+/* trace.fs:46-57 */
+void vcto_cone_constants(float dirs[18], float weights[6]);
+/* trace.fs:90-104 on an empty volume: steps a cone of this aperture executes, and the
+ * lod of its last sample. */
+int vcto_max_steps(const vcto_params* p, float tan_half, float* last_lod);
+
+/* ---- per-pixel gather + composite  (trace.fs:165-228) -------------------------------
+ * gb: 23 floats of one pixel.  out: rgba.  steps[7] / cones[28] optional (6 diffuse + 1
+ * specular; cones = the vec4 each Voxel_Cone_Tracing call returned).  Returns 0 if the
+ * fragment was discarded (albedo.a < 0.5; out = clear colour VCT.h:156-159). */
+int vcto_shade_pixel(const vcto_params* p, const uint8_t* chain, const float gb[23],
+                     float out[4], uint8_t steps[7], float cones[28]);
+
+/* Whole-frame trace.  planes: [23][npix] fp32 SoA (linear pixel order).  out32f [npix][4],
+ * out16f [npix][4] (IEEE half, round-to-nearest-even), steps [npix][7], cones [npix][7][4];
+ * any output may be NULL.  nthreads<=1: scalar single thread; else static partition over
+ * std::thread.  Returns total executed cone steps. */
+uint64_t vcto_trace(const vcto_params* p, const uint8_t* chain, const float* planes,
+                    size_t npix, float* out32f, uint16_t* out16f, uint8_t* steps, float* cones,
+                    int nthreads);
+
+uint16_t vcto_f32_to_f16(float f);
+float vcto_f16_to_f32(uint16_t h);
+
+/* ---- shadow map PCF  (vox.fs:18-52, trace.fs:132-163; [GL] A.9) ---------------------
+ * depth: S*S fp32 in [0,1] (already quantised to 24-bit fixed by the producer), row-major,
+ * bilinear, clamp-to-edge.  coord = xyz*0.5+0.5 shadow coordinate.  Returns the number of
+ * the 25 taps that pass (caller scales by 1/25 (inject) or 0.111 (trace)). */
+int vcto_pcf25(const float* depth, int S, const float coord[3], float bias);
+float vcto_shadow_tex(const float* depth, int S, float u, float v);
+
+/* ---- voxelization ------------------------------------------------------------------- */
+/* VCT.h:128-134: ProjX/Y/Z = ortho(-G/2,G/2,-G/2,G/2,G/2,3G/2) * lookAt(...), column-major
+ * mat4 like glm.  axis 1,2,3 = X,Y,Z (vox.gs:34-39). */
+void vcto_voxel_proj(float G, int axis, float m[16]);
+/* vox.gs:24-39: dominant axis (1,2,3) of a world-space triangle. */
+int vcto_dominant_axis(const float v0[3], const float v1[3], const float v2[3]);
+/* vox.fs:58-86: fragment (window x, y, depth z in [0,1]) -> voxel index. */
+void vcto_frag_to_voxel(int V, int axis, float fx, float fy, float fz, int32_t out[3]);
+
+/* Triangle soup in MODEL space: pos [ntri][3][3] fp32, material id per triangle, material
+ * albedo table [nmat][4] (flat per-material albedo -- SURVEY.md A.7 allows this in place of
+ * the texture fetch at vox.fs:56).  model_scale = 0.05 (VCT.h:240).  light_vp: column-major
+ * DepthViewProjectionMatrix (VCT.h:84-86) applied to WORLD positions (the reference applies
+ * DepthVP*Model to model positions: the same point).  shadow may be NULL (PCF = 1). */
+typedef struct vcto_scene {
+    const float* pos;         /* [ntri*9] */
+    const int32_t* material;  /* [ntri] */
+    const float* albedo;      /* [nmat*4] */
+    int32_t ntri, nmat;
+    float model_scale;
+    const float* shadow_depth; /* [S*S] or NULL */
+    int32_t shadow_size;
+    float light_vp[16];
+} vcto_scene;
+
+/* Reference mode (A.7): dominant-axis VxV raster at pixel centres, top-left rule, value =
+ * unorm8(albedo.rgb * PCF25/25), a=255, last writer in triangle order wins (vox.fs:88).
+ * l0: V^3*4 bytes, linear, zero-initialised by the caller. */
+void vcto_voxelize_reference(const vcto_params* p, const vcto_scene* s, uint8_t* l0);
+/* North-star mode: conservative triangle/voxel-box overlap; every overlapped voxel receives
+ * one fragment whose value is evaluated at the voxel centre projected along the dominant
+ * axis onto the triangle (barycentrics clamped into the triangle); integer sum + count per
+ * voxel, resolved to the rounded mean.  acc (optional, may be NULL): [V^3][4] uint32
+ * (sum r, sum g, sum b, count). */
+void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
+                                uint32_t* acc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
