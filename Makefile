@@ -1,0 +1,26 @@
+# Build recipe: the product library (HIP, gfx950 only), the host-side facade demo, the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+PKG := voxel-cone-tracing_amd
+CSRC := $(PKG)/csrc
+HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+OBJS := $(CSRC)/vct_capi.o $(CSRC)/vct_trace.o $(CSRC)/vct_volume.o $(CSRC)/vct_voxelize.o
+LIB := $(PKG)/libvct_amd.so
+
+all: lib oracle
+
+lib: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vct_internal.h $(CSRC)/vct_layout.h include/vct.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle clean

@@ -1,0 +1,167 @@
+/*
+ * vct.h -- C ABI of the MI355X-native voxel-cone-tracing GI path (libvct_amd.so).
+ *
+ * This is the drop-in boundary.  The reference has no plugin / FFI interface: its boundary is
+ * the header-only `struct Voxel_Cone_Tracing` (R/Voxel_Cone_Tracing.h:11-252) that main.cpp
+ * calls directly (R/main.cpp:66,68,90).  The C++ facade of the same name in
+ * voxel-cone-tracing_amd/host/Voxel_Cone_Tracing.h keeps those member names and forwards to the
+ * entry points below; each entry point cites the reference code it replaces
+ * (R = Voxel_Cone_Tracing_Final, S = R/Shader).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative vct_status; vct_last_error() returns the message of the last failure (per context,
+ * or the creation failure when ctx == NULL).  Host pointers are caller-owned; all HBM is
+ * context-owned and released by vct_destroy().  One host thread per context, one context per
+ * GPU; every kernel runs on the context's HIP stream.  There is no CPU fallback: creation
+ * fails if no gfx950 device is usable.
+ */
+#ifndef VCT_H_
+#define VCT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCT_ABI_VERSION 1
+
+typedef enum vct_status {
+    VCT_OK = 0,
+    VCT_ERR_INVALID = -1,     /* bad argument / call order */
+    VCT_ERR_DEVICE = -2,      /* HIP runtime error (message in vct_last_error) */
+    VCT_ERR_NO_DEVICE = -3,   /* no usable GPU */
+    VCT_ERR_NOMEM = -4
+} vct_status;
+
+/* G-buffer: 23 fp32 planes per pixel (92 B) -- the per-fragment varyings and material fetches of
+ * S/VoxelConeTracing.vs:10-15 and S/VoxelConeTracing.fs:3-9,167,209 made explicit. */
+enum {
+    VCT_GB_POSITION = 0,   /* Position_world xyz            trace.vs:27 */
+    VCT_GB_NORMAL = 3,     /* Normal_world xyz (raw)        trace.vs:31 */
+    VCT_GB_TANGENT = 6,    /* Tangent_world xyz (raw)       trace.vs:32 */
+    VCT_GB_BITANGENT = 9,  /* BiTangent_world xyz (raw)     trace.vs:33 */
+    VCT_GB_BUMP_N = 12,    /* bump normal N (unit)          trace.fs:177 */
+    VCT_GB_ALBEDO = 15,    /* matColor rgba                 trace.fs:167 */
+    VCT_GB_SPECULAR = 19,  /* specColor rgb                 trace.fs:209-210 */
+    VCT_GB_SHADOW = 22,    /* shadow_value                  trace.fs:186 */
+    VCT_GB_PLANES = 23
+};
+
+typedef enum vct_gb_layout {
+    VCT_GB_LINEAR = 0,     /* planes[k][y*width + x] */
+    VCT_GB_TILED = 1       /* device layout: [tile][plane][64], tile = 8x8 px, lane = (y&7)*8+(x&7),
+                              tiles row-major over ceil(w/8) x ceil(h/8) */
+} vct_gb_layout;
+
+typedef enum vct_mem {
+    VCT_MEM_HOST = 0,
+    VCT_MEM_DEVICE = 1
+} vct_mem;
+
+typedef struct vct_gbuffer {
+    const float* planes;
+    int32_t width, height;
+    int32_t layout;        /* vct_gb_layout */
+    int32_t location;      /* vct_mem */
+} vct_gbuffer;
+
+/* Configuration = the reference's compile-time constants and public fields
+ * (R/Voxel_Cone_Tracing.h:14-53, S/VoxelConeTracing.fs:43-46), runtime-settable. */
+typedef struct vct_config {
+    int32_t abi_version;       /* VCT_ABI_VERSION */
+    int32_t device;            /* HIP device ordinal; -1 = current device */
+    int32_t voxel_dim;         /* VoxelDimensions: power of two in [8,1024]   VCT.h:16 */
+    float grid_world_size;     /* VoxelGridWorldSize = 150                     VCT.h:17 */
+    int32_t width, height;     /* screen_width/height                          VCT.h:24-25 */
+    int32_t shadow_map_size;   /* ShadowMapSize = 4096                         VCT.h:35 */
+    float model_scale;         /* ModelMatrix = scale(0.05)                    VCT.h:183,240 */
+    float ambient_factor;      /* AmbientFactor = 0.1                          VCT.h:53 */
+    float shininess;           /* Shininess = 20                               Mesh.h:86 */
+    float max_distance;        /* MAX_DISTANCE = 75                            trace.fs:43 */
+    float max_alpha;           /* MAX_ALPHA = 0.95                             trace.fs:44 */
+    float tan_diffuse;         /* 0.577                                        trace.fs:198 */
+    float tan_specular;        /* 0.07                                         trace.fs:218 */
+    int32_t wrap_repeat;       /* 1 = GL_REPEAT (VCT.h:110-113 leaves the GL default) */
+    int32_t debug_outputs;     /* 1 = also keep per-cone step counts and raw cone vec4s */
+    int32_t trace_variant;     /* 0 = default kernel; others select experimental variants */
+} vct_config;
+
+typedef struct vct_ctx vct_ctx;
+
+typedef enum vct_voxelize_mode {
+    VCT_VOX_CONSERVATIVE_AVG = 0,   /* north-star: conservative overlap + atomic integer average */
+    VCT_VOX_REFERENCE = 1           /* S/Voxelization.*: pixel-centre raster, last triangle wins */
+} vct_voxelize_mode;
+
+int vct_default_config(vct_config* cfg);
+
+/* Replaces the ctor + resource creation of init_voxel_cone_tracing (VCT.h:57-65,107-126):
+ * allocates the brick mip chain (zero-filled, like VCT.h:115-119) and frame buffers in HBM. */
+int vct_create(const vct_config* cfg, vct_ctx** out_ctx);
+void vct_destroy(vct_ctx* ctx);
+const char* vct_last_error(const vct_ctx* ctx);
+int vct_get_config(const vct_ctx* ctx, vct_config* cfg);
+
+/* Per-frame uniforms (VCT.h:167-168,171). */
+int vct_set_camera_position(vct_ctx* ctx, const float pos[3]);
+int vct_set_light_direction(vct_ctx* ctx, const float dir[3]);
+int vct_set_ambient_factor(vct_ctx* ctx, float ambient);
+int vct_set_cone_apertures(vct_ctx* ctx, float tan_diffuse, float tan_specular);
+
+/* Scene upload -- replaces Model/Mesh VBO setup (R/Mesh.h:49-82) for the two attributes the
+ * voxelizer reads (vox.vs:3-4).  pos: [ntri][3][3] model-space fp32; material: [ntri];
+ * albedo: [nmat][4] flat per-material albedo (stands in for DiffuseTexture, vox.fs:56). */
+int vct_upload_triangles(vct_ctx* ctx, const float* pos, const int32_t* material, int32_t ntri,
+                         const float* albedo, int32_t nmat);
+/* Shadow map produced by the depth pass (VCT.h:192-211): size*size fp32 depths in [0,1] plus the
+ * column-major DepthViewProjectionMatrix (VCT.h:84-86).  depth == NULL detaches it (PCF = 1). */
+int vct_upload_shadow_map(vct_ctx* ctx, const float* depth, int32_t size, const float light_vp[16]);
+
+/* DrawVoxelTexture (VCT.h:213-245) -> vox.vs / vox.gs / vox.fs: voxelize the uploaded triangles
+ * into per-voxel integer accumulators (mode selects coverage + resolve rule). */
+int vct_voxelize(vct_ctx* ctx, int32_t mode);
+/* vox.fs:88: resolve the accumulators into radiance level 0 (rgb = albedo * PCF shadow, a = 1). */
+int vct_inject_light(vct_ctx* ctx);
+/* glGenerateMipmap (VCT.h:126,248): 2x2x2 box, requantised per level, over the brick chain. */
+int vct_build_mips(vct_ctx* ctx);
+
+/* Volumes built elsewhere (fixtures, oracle-built volumes).  Linear layout: level k has
+ * N = V>>k texels per side, texel (x,y,z) at ((z*N+y)*N+x)*4, levels concatenated. */
+int vct_upload_volume_rgba8(vct_ctx* ctx, const uint8_t* level0_linear);
+int vct_upload_chain_rgba8(vct_ctx* ctx, const uint8_t* chain_linear);
+int vct_download_chain_rgba8(vct_ctx* ctx, uint8_t* chain_linear);
+size_t vct_chain_texels(int32_t voxel_dim);
+
+/* Render (VCT.h:146-190) -> trace.fs:165-228.  Traces the G-buffer through the brick chain and
+ * writes the frame as RGBA16F, row-major width*height*4 halves (8 B / px).  out location follows
+ * out_location (vct_mem).  A HOST G-buffer is uploaded (and tiled) first. */
+int vct_trace(vct_ctx* ctx, const vct_gbuffer* gb, void* out_rgba16f, int32_t out_location);
+/* Screen-tile slab [tile_row0, tile_row1) of the same frame (multi-GPU sharding): only those
+ * 8-pixel tile rows are traced; out addresses the full frame and only the slab's rows are
+ * written. */
+int vct_trace_slab(vct_ctx* ctx, const vct_gbuffer* gb, int32_t tile_row0, int32_t tile_row1,
+                   void* out_rgba16f, int32_t out_location);
+/* Re-run the trace kernel on the G-buffer already resident from the last vct_trace (no upload,
+ * no download); used for timing.  stream work only, asynchronous. */
+int vct_trace_resident(vct_ctx* ctx);
+int vct_synchronize(vct_ctx* ctx);
+
+/* Debug outputs of the last trace (config.debug_outputs = 1): steps [npix][7] uint8, cones
+ * [npix][7][4] fp32, linear pixel order. */
+int vct_download_steps(vct_ctx* ctx, uint8_t* steps);
+int vct_download_cones(vct_ctx* ctx, float* cones);
+/* Executed cone steps of the last trace (always counted). */
+int vct_last_step_count(vct_ctx* ctx, uint64_t* steps);
+/* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
+int vct_last_trace_ms(vct_ctx* ctx, float* ms);
+/* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the
+ * device pointers of the resident tiled G-buffer / RGBA16F frame. */
+int vct_get_stream(vct_ctx* ctx, void** hip_stream);
+int vct_get_frame_device(vct_ctx* ctx, void** rgba16f_dev, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bars: bit-exact for the integer/byte stages (layout, mips, voxelization) and for the
+march (per-cone step counts and raw cone vec4s); the RGBA16F frame within 1e-3 relative L2 of the
+oracle's fp32 frame (BASELINE.json north_star tolerance) -- in practice it matches the oracle's
+own fp16 rounding except where powf differs by an ulp."""
+import numpy as np
+import pytest
+
+import synth
+import vctpkg
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 1e-3   # north_star: "within 1e-3 relative L2 (fp32)"
+
+
+@pytest.fixture(scope="module")
+def vct():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return vctpkg.load()
+
+
+def make_ctx(vct, V, w, h, **kw):
+    return vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, debug_outputs=1, **kw))
+
+
+def check_frame(vct, oracle, ctx, chain, planes, w, h, p=None, rows=None):
+    p = p or oracle.default_params(ctx.cfg.voxel_dim)
+    ref = oracle.trace(p, chain, planes, nthreads=8, want_cones=True)
+    out = ctx.trace(planes, rows=rows)
+    steps, cones = ctx.steps(), ctx.cones()
+    sel = np.ones(h * w, bool)
+    if rows is not None:
+        sel[:] = False
+        sel[rows[0] * 8 * w: min(rows[1] * 8, h) * w] = True
+    assert np.array_equal(steps[sel], ref["steps"][sel]), "per-cone step counts differ"
+    assert np.array_equal(cones[sel].view(np.uint32), ref["cones"][sel].view(np.uint32)), \
+        "raw cone results are not bit-identical"
+    got = vct.half_to_float(out.reshape(-1, 4))[sel]
+    err = synth.rel_l2(got, ref["rgba32f"][sel])
+    assert err <= REL_L2_TOL, err
+    same16 = (out.reshape(-1, 4)[sel] == ref["rgba16f"][sel]).mean()
+    assert same16 > 0.999, same16
+    if rows is None:
+        assert ctx.last_step_count() == ref["total_steps"]
+    return ref, out
+
+
+@pytest.mark.parametrize("V", [16, 64])
+def test_layout_roundtrip_and_mips(vct, oracle, V):
+    l0 = synth.noise_volume(V, seed=V, occupancy=0.2)
+    chain = oracle.build_mips(l0)
+    with make_ctx(vct, V, 8, 8) as ctx:
+        ctx.upload_chain(chain)
+        assert np.array_equal(ctx.download_chain(), chain)          # linear <-> Morton
+        junk = np.random.default_rng(0).integers(0, 256, chain.shape, dtype=np.uint8)
+        junk[: V ** 3] = l0.reshape(-1, 4)
+        ctx.upload_chain(junk)
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), chain)          # HIP mips == oracle mips
+
+
+def test_mips_random_bytes_rounding(vct, oracle):
+    V = 32
+    l0 = np.random.default_rng(5).integers(0, 256, (V, V, V, 4), dtype=np.uint8)
+    chain = oracle.build_mips(l0)
+    with make_ctx(vct, V, 8, 8) as ctx:
+        ctx.upload_volume(l0)
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), chain)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_trace_random_gbuffer(vct, oracle, variant):
+    V, w, h = 64, 128, 128
+    chain = oracle.build_mips(synth.noise_volume(V))
+    planes = synth.random_gbuffer(w * h, seed=42, discard_frac=0.05)
+    with make_ctx(vct, V, w, h, trace_variant=variant) as ctx:
+        ctx.upload_chain(chain)
+        check_frame(vct, oracle, ctx, chain, planes, w, h)
+
+
+def test_trace_coherent_gbuffer_dense_volume(vct, oracle):
+    V, w, h = 64, 96, 64
+    chain = oracle.build_mips(synth.noise_volume(V, seed=3, occupancy=0.25))
+    planes = synth.coherent_gbuffer(w, h)
+    with make_ctx(vct, V, w, h) as ctx:
+        ctx.upload_chain(chain)
+        check_frame(vct, oracle, ctx, chain, planes, w, h)
+
+
+def test_trace_ragged_frame_and_uniforms(vct, oracle):
+    V, w, h = 32, 37, 21          # not multiples of the 8x8 tile
+    chain = oracle.build_mips(synth.noise_volume(V, seed=9, occupancy=0.1))
+    planes = synth.random_gbuffer(w * h, seed=1, discard_frac=0.2)
+    cam, light = (10.0, 20.0, -5.0), (0.3, 0.8, -0.4)
+    p = oracle.default_params(V, camera_pos=cam, light_dir=light, ambient_factor=0.6,
+                              tan_specular=0.105)
+    with make_ctx(vct, V, w, h, ambient_factor=0.6, tan_specular=0.105) as ctx:
+        ctx.upload_chain(chain)
+        ctx.set_camera_position(cam)
+        ctx.set_light_direction(light)
+        ref, out = check_frame(vct, oracle, ctx, chain, planes, w, h, p=p)
+        dead = planes[18] < 0.5
+        assert dead.any()
+        white = np.float16(1.0).view(np.uint16)
+        assert np.all(out.reshape(-1, 4)[dead] == white)       # VCT.h:156-159 (ambient >= 0.5)
+
+
+def test_trace_empty_and_opaque_volumes(vct, oracle):
+    V, w, h = 16, 16, 16
+    planes = synth.random_gbuffer(w * h, seed=2)
+    for rgba in ((0, 0, 0, 0), (51, 102, 204, 255), (128, 128, 128, 64)):
+        l0 = np.zeros((V, V, V, 4), np.uint8)
+        l0[...] = rgba
+        chain = oracle.build_mips(l0)
+        with make_ctx(vct, V, w, h) as ctx:
+            ctx.upload_chain(chain)
+            ref, _ = check_frame(vct, oracle, ctx, chain, planes, w, h)
+            if rgba[3] == 255:
+                assert np.all(ref["steps"] == 1)
+
+
+def test_trace_clamp_mode(vct, oracle):
+    V, w, h = 32, 32, 32
+    chain = oracle.build_mips(synth.noise_volume(V, seed=4, occupancy=0.3))
+    planes = synth.random_gbuffer(w * h, seed=6)
+    p = oracle.default_params(V, wrap_repeat=0)
+    with make_ctx(vct, V, w, h, wrap_repeat=0) as ctx:
+        ctx.upload_chain(chain)
+        check_frame(vct, oracle, ctx, chain, planes, w, h, p=p)
+
+
+def test_slab_equals_full_frame(vct, oracle):
+    V, w, h = 32, 64, 72          # 9 tile rows
+    chain = oracle.build_mips(synth.noise_volume(V, seed=8, occupancy=0.1))
+    planes = synth.random_gbuffer(w * h, seed=12)
+    with make_ctx(vct, V, w, h) as ctx:
+        ctx.upload_chain(chain)
+        full = ctx.trace(planes)
+        parts = np.zeros_like(full)
+        for r0, r1 in ((0, 3), (3, 4), (4, 9)):
+            slab = ctx.trace(planes, rows=(r0, r1))
+            parts[r0 * 8:r1 * 8] = slab[r0 * 8:r1 * 8]
+            assert not slab[:r0 * 8].any() and not slab[r1 * 8:].any()
+        assert np.array_equal(parts, full)      # bit-identical to the single-GPU frame
+        check_frame(vct, oracle, ctx, chain, planes, w, h, rows=(3, 7))
+
+
+def random_scene(ntri, seed, big=2):
+    r = np.random.default_rng(seed)
+    c = r.uniform(-1300, 1300, (ntri, 1, 3))
+    pos = c + r.normal(scale=25.0, size=(ntri, 3, 3))
+    pos[:big] = c[:big] + r.normal(scale=400.0, size=(big, 3, 3))     # a few large triangles
+    pos[big] = pos[big, 0][None, :]                                   # degenerate (point)
+    # axis-aligned wall: exercises exact-on-boundary overlap decisions
+    pos[big + 1] = [[-1000, -1000, 200], [1000, -1000, 200], [1000, 1000, 200]]
+    mat = r.integers(0, 5, ntri).astype(np.int32)
+    alb = r.uniform(0.1, 1.0, (5, 4)).astype(np.float32)
+    return pos.astype(np.float32), mat, alb
+
+
+def light_setup(S, seed):
+    r = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
+    depth = 0.5 + 0.2 * np.sin(xx * 0.11) * np.cos(yy * 0.07) + r.uniform(-0.01, 0.01, (S, S))
+    depth = np.round(depth * (2 ** 24 - 1)) / (2 ** 24 - 1)
+    vp = np.array([[1 / 120.0, 0, 0, 0], [0, 0, -1 / 120.0, 0], [0, -1 / 100.0, 0, 0],
+                   [0, 0, 0, 1]], np.float32)      # row-major light ortho looking down -Y
+    return depth.astype(np.float32), vp
+
+
+@pytest.mark.parametrize("with_shadow", [False, True])
+def test_voxelize_conservative_matches_oracle(vct, oracle, with_shadow):
+    V = 64
+    pos, mat, alb = random_scene(600, seed=21)
+    depth, vp = light_setup(256, 3) if with_shadow else (None, None)
+    p = oracle.default_params(V)
+    sc = oracle.make_scene(pos, mat, alb, shadow_depth=depth, light_vp=vp)
+    want_l0 = oracle.voxelize_conservative(p, sc)
+    assert 0.001 < (want_l0[..., 3] > 0).mean() < 0.5
+    want = oracle.build_mips(want_l0)
+    with make_ctx(vct, V, 8, 8) as ctx:
+        ctx.upload_triangles(pos, mat, alb)
+        if with_shadow:
+            ctx.upload_shadow_map(depth, vp)
+        ctx.voxelize()
+        ctx.inject_light()
+        ctx.build_mips()
+        got = ctx.download_chain()
+        assert np.array_equal(got, want)
+        # re-voxelizing is idempotent (accumulators are cleared, result is order-independent)
+        ctx.voxelize()
+        ctx.inject_light()
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), want)
+
+
+def test_call_order_errors(vct):
+    with make_ctx(vct, 16, 8, 8) as ctx:
+        with pytest.raises(vct.VctError):
+            ctx.voxelize()                      # no triangles yet
+        with pytest.raises(vct.VctError):
+            ctx.inject_light()                  # no accumulators yet
+        with pytest.raises(vct.VctError):
+            ctx.trace_resident()                # nothing resident
+        with pytest.raises(vct.VctError):
+            ctx.voxelize(vct.VOX_REFERENCE)
+        bad = np.zeros((23, 4 * 4), np.float32)
+        gb = vct.GBuffer()
+        gb.planes, gb.width, gb.height, gb.layout, gb.location = bad.ctypes.data, 4, 4, 0, 0
+        import ctypes as C
+        assert vct.lib().vct_trace(ctx._h, C.byref(gb), None, 0) != 0
+        assert b"size differs" in vct.lib().vct_last_error(ctx._h)

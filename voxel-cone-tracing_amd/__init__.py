@@ -1,0 +1,264 @@
+"""Thin ctypes binding of libvct_amd.so (the C ABI in include/vct.h).
+
+The directory name carries a hyphen, so import it through `vctpkg.load()` (repo root) or
+importlib; the module registers itself as `voxel_cone_tracing_amd`.  There is no Python or CPU
+implementation of any kernel here: if the HIP library is missing, import fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvct_amd.so")
+
+GB_PLANES = 23
+GB_LINEAR, GB_TILED = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+VOX_CONSERVATIVE_AVG, VOX_REFERENCE = 0, 1
+ABI_VERSION = 1
+
+# every symbol include/vct.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "vct_default_config", "vct_create", "vct_destroy", "vct_last_error", "vct_get_config",
+    "vct_set_camera_position", "vct_set_light_direction", "vct_set_ambient_factor",
+    "vct_set_cone_apertures", "vct_upload_triangles", "vct_upload_shadow_map", "vct_voxelize",
+    "vct_inject_light", "vct_build_mips", "vct_upload_volume_rgba8", "vct_upload_chain_rgba8",
+    "vct_download_chain_rgba8", "vct_chain_texels", "vct_trace", "vct_trace_slab",
+    "vct_trace_resident", "vct_synchronize", "vct_download_steps", "vct_download_cones",
+    "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream", "vct_get_frame_device",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("voxel_dim", C.c_int32),
+        ("grid_world_size", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
+        ("shadow_map_size", C.c_int32), ("model_scale", C.c_float),
+        ("ambient_factor", C.c_float), ("shininess", C.c_float), ("max_distance", C.c_float),
+        ("max_alpha", C.c_float), ("tan_diffuse", C.c_float), ("tan_specular", C.c_float),
+        ("wrap_repeat", C.c_int32), ("debug_outputs", C.c_int32), ("trace_variant", C.c_int32),
+    ]
+
+
+class GBuffer(C.Structure):
+    _fields_ = [("planes", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("layout", C.c_int32), ("location", C.c_int32)]
+
+
+class VctError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make lib` (hipcc --offload-arch=gfx950). "
+        "There is no CPU fallback for the voxel-cone-tracing path.")
+
+_lib = C.CDLL(LIB_PATH)
+_lib.vct_last_error.restype = C.c_char_p
+_lib.vct_last_error.argtypes = [C.c_void_p]
+_lib.vct_chain_texels.restype = C.c_size_t
+_lib.vct_chain_texels.argtypes = [C.c_int32]
+_lib.vct_destroy.restype = None
+_lib.vct_destroy.argtypes = [C.c_void_p]
+_lib.vct_create.argtypes = [C.c_void_p, C.c_void_p]
+for _n in ("vct_set_camera_position", "vct_set_light_direction", "vct_upload_volume_rgba8",
+           "vct_upload_chain_rgba8", "vct_download_chain_rgba8", "vct_download_steps",
+           "vct_download_cones", "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream",
+           "vct_get_config"):
+    getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p]
+_lib.vct_set_ambient_factor.argtypes = [C.c_void_p, C.c_float]
+_lib.vct_set_cone_apertures.argtypes = [C.c_void_p, C.c_float, C.c_float]
+_lib.vct_upload_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                      C.c_int32]
+_lib.vct_upload_shadow_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+_lib.vct_voxelize.argtypes = [C.c_void_p, C.c_int32]
+for _n in ("vct_inject_light", "vct_build_mips", "vct_trace_resident", "vct_synchronize"):
+    getattr(_lib, _n).argtypes = [C.c_void_p]
+_lib.vct_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+_lib.vct_trace_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+_lib.vct_get_frame_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def lib():
+    return _lib
+
+
+def default_config(**kw):
+    cfg = Config()
+    _lib.vct_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def chain_texels(V):
+    return _lib.vct_chain_texels(V)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One context per GPU; mirrors the call order of the reference's orchestrator
+    (ctor -> init: voxelize, inject, mips -> Render per frame; VCT.h:57-190)."""
+
+    def __init__(self, cfg=None, **kw):
+        cfg = cfg or default_config(**kw)
+        self._h = C.c_void_p()
+        rc = _lib.vct_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise VctError(f"vct_create failed ({rc}): {_lib.vct_last_error(None).decode()}")
+        self.cfg = Config()
+        _lib.vct_get_config(self._h, C.byref(self.cfg))
+
+    def close(self):
+        if self._h:
+            _lib.vct_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise VctError(f"{what} failed ({rc}): {_lib.vct_last_error(self._h).decode()}")
+
+    # --- uniforms
+    def set_camera_position(self, pos):
+        a = np.ascontiguousarray(pos, np.float32)
+        self._ck(_lib.vct_set_camera_position(self._h, _ptr(a)), "vct_set_camera_position")
+
+    def set_light_direction(self, d):
+        a = np.ascontiguousarray(d, np.float32)
+        self._ck(_lib.vct_set_light_direction(self._h, _ptr(a)), "vct_set_light_direction")
+
+    def set_ambient_factor(self, a):
+        self._ck(_lib.vct_set_ambient_factor(self._h, float(a)), "vct_set_ambient_factor")
+
+    def set_cone_apertures(self, td, ts):
+        self._ck(_lib.vct_set_cone_apertures(self._h, float(td), float(ts)), "vct_set_cone_apertures")
+
+    # --- scene / volume
+    def upload_triangles(self, pos, material, albedo):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 9)
+        material = np.ascontiguousarray(material, np.int32)
+        albedo = np.ascontiguousarray(albedo, np.float32).reshape(-1, 4)
+        self._ck(_lib.vct_upload_triangles(self._h, _ptr(pos), _ptr(material), pos.shape[0],
+                                           _ptr(albedo), albedo.shape[0]), "vct_upload_triangles")
+
+    def upload_shadow_map(self, depth, light_vp_rowmajor):
+        if depth is None:
+            self._ck(_lib.vct_upload_shadow_map(self._h, None, 0, None), "vct_upload_shadow_map")
+            return
+        depth = np.ascontiguousarray(depth, np.float32)
+        m = np.ascontiguousarray(np.asarray(light_vp_rowmajor, np.float32).T)   # -> column-major
+        self._ck(_lib.vct_upload_shadow_map(self._h, _ptr(depth), depth.shape[0], _ptr(m)),
+                 "vct_upload_shadow_map")
+
+    def voxelize(self, mode=VOX_CONSERVATIVE_AVG):
+        self._ck(_lib.vct_voxelize(self._h, mode), "vct_voxelize")
+
+    def inject_light(self):
+        self._ck(_lib.vct_inject_light(self._h), "vct_inject_light")
+
+    def build_mips(self):
+        self._ck(_lib.vct_build_mips(self._h), "vct_build_mips")
+
+    def upload_volume(self, l0):
+        l0 = np.ascontiguousarray(l0, np.uint8)
+        assert l0.size == self.cfg.voxel_dim ** 3 * 4
+        self._ck(_lib.vct_upload_volume_rgba8(self._h, _ptr(l0)), "vct_upload_volume_rgba8")
+
+    def upload_chain(self, chain):
+        chain = np.ascontiguousarray(chain, np.uint8)
+        assert chain.size == chain_texels(self.cfg.voxel_dim) * 4
+        self._ck(_lib.vct_upload_chain_rgba8(self._h, _ptr(chain)), "vct_upload_chain_rgba8")
+
+    def download_chain(self):
+        out = np.zeros((chain_texels(self.cfg.voxel_dim), 4), np.uint8)
+        self._ck(_lib.vct_download_chain_rgba8(self._h, _ptr(out)), "vct_download_chain_rgba8")
+        return out
+
+    # --- trace
+    def _gb(self, planes, layout, location):
+        gb = GBuffer()
+        gb.planes = planes if isinstance(planes, int) else planes.ctypes.data
+        gb.width, gb.height = self.cfg.width, self.cfg.height
+        gb.layout, gb.location = layout, location
+        return gb
+
+    def trace(self, planes, rows=None, layout=GB_LINEAR, out_device_ptr=None):
+        """planes: float32 [23, h*w] numpy (host) or an int device pointer (location=device).
+        Returns the RGBA16F frame as uint16 [h, w, 4] (host) unless out_device_ptr is given."""
+        location = MEM_DEVICE if isinstance(planes, int) else MEM_HOST
+        if location == MEM_HOST:
+            planes = np.ascontiguousarray(planes, np.float32)
+        gb = self._gb(planes, layout, location)
+        h, w = self.cfg.height, self.cfg.width
+        if out_device_ptr is not None:
+            out, optr, oloc = None, C.c_void_p(out_device_ptr), MEM_DEVICE
+        else:
+            out = np.zeros((h, w, 4), np.uint16)
+            optr, oloc = _ptr(out), MEM_HOST
+        if rows is None:
+            self._ck(_lib.vct_trace(self._h, C.byref(gb), optr, oloc), "vct_trace")
+        else:
+            self._ck(_lib.vct_trace_slab(self._h, C.byref(gb), rows[0], rows[1], optr, oloc),
+                     "vct_trace_slab")
+        return out
+
+    def trace_resident(self):
+        self._ck(_lib.vct_trace_resident(self._h), "vct_trace_resident")
+
+    def synchronize(self):
+        self._ck(_lib.vct_synchronize(self._h), "vct_synchronize")
+
+    def steps(self):
+        out = np.zeros((self.cfg.height * self.cfg.width, 7), np.uint8)
+        self._ck(_lib.vct_download_steps(self._h, _ptr(out)), "vct_download_steps")
+        return out
+
+    def cones(self):
+        out = np.zeros((self.cfg.height * self.cfg.width, 7, 4), np.float32)
+        self._ck(_lib.vct_download_cones(self._h, _ptr(out)), "vct_download_cones")
+        return out
+
+    def last_step_count(self):
+        v = C.c_uint64()
+        self._ck(_lib.vct_last_step_count(self._h, C.byref(v)), "vct_last_step_count")
+        return v.value
+
+    def last_trace_ms(self):
+        v = C.c_float()
+        self._ck(_lib.vct_last_trace_ms(self._h, C.byref(v)), "vct_last_trace_ms")
+        return v.value
+
+    def stream(self):
+        v = C.c_void_p()
+        self._ck(_lib.vct_get_stream(self._h, C.byref(v)), "vct_get_stream")
+        return v.value
+
+    def frame_device(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(_lib.vct_get_frame_device(self._h, C.byref(p), C.byref(n)), "vct_get_frame_device")
+        return p.value, n.value
+
+
+def half_to_float(u16):
+    return np.asarray(u16, np.uint16).view(np.float16).astype(np.float32)

@@ -1,0 +1,611 @@
+// vct_capi.hip -- the C ABI declared in include/vct.h: context, HBM ownership, launch sequencing.
+//
+// Counterpart of the reference's orchestrator struct (R/Voxel_Cone_Tracing.h:11-252): where that
+// owns GL object names and issues draws, this owns HBM buffers and issues HIP kernels on one
+// stream.  No CPU fallback exists: every entry point that computes launches a kernel or fails.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vct.h"
+#include "vct_internal.h"
+
+struct vct_ctx {
+    vct_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    uint32_t* chain = nullptr;        // Morton chain
+    size_t chain_texels = 0;
+    uint32_t* staging = nullptr;      // linear staging for up/downloads (size of level 0)
+    int nlev = 0;
+
+    float* gb_linear = nullptr;       // [23][w*h] staging
+    float* gb_tiled = nullptr;        // [tiles][23][64]
+    const float* gb_current = nullptr;   // tiled buffer the next resident trace reads
+    uint16_t* frame = nullptr;        // RGBA16F [h][w][4]
+    uint8_t* dbg_steps = nullptr;
+    float* dbg_cones = nullptr;
+    unsigned long long* step_counter = nullptr;
+    int32_t* tile_counter = nullptr;
+    VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
+    int n_diffuse = 0, n_specular = 0;
+    bool steps_dirty = true;
+    int last_row0 = 0, last_row1 = 0;
+    bool have_trace = false;
+
+    float cam[3] = {0.0f, 4.0f, 0.0f};        // VCT.h:8
+    float light[3] = {0.0f, 1.0f, 0.25f};     // VCT.h:14
+
+    // scene
+    float* tri_pos = nullptr;
+    int32_t* tri_mat = nullptr;
+    float* mat_albedo = nullptr;
+    int32_t ntri = 0, nmat = 0;
+    float* shadow = nullptr;
+    int32_t shadow_size = 0;
+    float light_vp[16];
+    unsigned long long* acc = nullptr;
+    int32_t* big_list = nullptr;
+    int32_t* big_count = nullptr;
+    bool acc_valid = false;
+    int acc_mode = 0;
+};
+
+namespace {
+
+std::string g_create_error;
+
+int fail(vct_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail((c), e_ == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE,     \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// The step sequence of trace.fs:90-104, evaluated with the reference's operation order:
+//   dist = vs; while (dist < MAX) { diameter = max(vs, 2*t*dist); lod = log2(diameter/vs); ...
+//   dist += diameter; }   and the [GL] textureLod level selection for that lod.
+int build_steps(const vct_config& cfg, float tan_half, std::vector<VctStep>& out) {
+    out.clear();
+    const int maxl = vct_ilog2(cfg.voxel_dim);
+    const float vs = cfg.grid_world_size / (float)cfg.voxel_dim;
+    float dist = vs;
+    while (dist < cfg.max_distance) {
+        if ((int)out.size() >= VCT_MAX_STEPS) return -1;
+        VctStep s;
+        const float diameter = fmaxf(vs, 2.0f * tan_half * dist);
+        const float lod = log2f(diameter / vs);
+        s.dist = dist;
+        s.diameter = diameter;
+        s.occ_den = 1.0f + 0.03f * diameter;
+        float lam = lod;
+        if (!(lam > 0.0f)) {
+            s.two_levels = 0; s.level = 0; s.level2 = 0; s.frac = 0.0f;
+        } else {
+            if (lam > (float)maxl) lam = (float)maxl;
+            const float fl = floorf(lam);
+            s.two_levels = 1;
+            s.level = (int)fl;
+            s.level2 = s.level + 1 > maxl ? maxl : s.level + 1;
+            s.frac = lam - fl;
+        }
+        s.pad = 0;
+        out.push_back(s);
+        const float nd = dist + diameter;
+        if (!(nd > dist)) return -1;   // would never terminate
+        dist = nd;
+    }
+    return 0;
+}
+
+int refresh_steps(vct_ctx* c) {
+    if (!c->steps_dirty) return VCT_OK;
+    std::vector<VctStep> d, s;
+    if (build_steps(c->cfg, c->cfg.tan_diffuse, d) || build_steps(c->cfg, c->cfg.tan_specular, s))
+        return fail(c, VCT_ERR_INVALID, "cone aperture needs more than VCT_MAX_STEPS march steps");
+    HIP_TRY(c, hipMemcpyAsync(c->steps_dev, d.data(), d.size() * sizeof(VctStep),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->steps_dev + VCT_MAX_STEPS, s.data(), s.size() * sizeof(VctStep),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // d, s go out of scope
+    c->n_diffuse = (int)d.size();
+    c->n_specular = (int)s.size();
+    c->steps_dirty = false;
+    return VCT_OK;
+}
+
+// Levels staged in LDS: the longest tail of the chain that fits the budget.
+int pick_lds_first_level(int V, int nlev, size_t budget_bytes) {
+    int first = nlev;
+    size_t bytes = 0;
+    for (int l = nlev - 1; l >= 0; --l) {
+        const size_t n = (size_t)(V >> l);
+        const size_t add = n * n * n * 4;
+        if (bytes + add > budget_bytes) break;
+        bytes += add;
+        first = l;
+    }
+    return first;
+}
+
+int tiles_x(const vct_ctx* c) { return (c->cfg.width + VCT_TILE - 1) / VCT_TILE; }
+int tiles_y(const vct_ctx* c) { return (c->cfg.height + VCT_TILE - 1) / VCT_TILE; }
+size_t gb_tiled_floats(const vct_ctx* c) {
+    return (size_t)tiles_x(c) * tiles_y(c) * VCT_GB_NPLANES * VCT_TILE_PIX;
+}
+
+int launch_trace(vct_ctx* c, int row0, int row1) {
+    int rc = refresh_steps(c);
+    if (rc) return rc;
+    VctTraceParams p;
+    memset(&p, 0, sizeof(p));
+    p.chain = c->chain;
+    for (int l = 0; l < c->nlev; ++l) p.level_off[l] = (uint32_t)vct_level_offset(c->cfg.voxel_dim, l);
+    p.V = c->cfg.voxel_dim;
+    p.nlev = c->nlev;
+    p.G = c->cfg.grid_world_size;
+    p.half_G = c->cfg.grid_world_size * 0.5f;                       // trace.fs:61
+    p.vs = c->cfg.grid_world_size / (float)c->cfg.voxel_dim;        // trace.fs:90
+    for (int i = 0; i < 3; ++i) { p.cam[i] = c->cam[i]; p.light[i] = c->light[i]; }
+    p.ambient = c->cfg.ambient_factor;
+    p.shininess = c->cfg.shininess;
+    p.max_alpha = c->cfg.max_alpha;
+    p.wrap_repeat = c->cfg.wrap_repeat;
+    p.steps_diffuse = c->steps_dev;
+    p.steps_specular = c->steps_dev + VCT_MAX_STEPS;
+    p.n_diffuse = c->n_diffuse;
+    p.n_specular = c->n_specular;
+    p.width = c->cfg.width;
+    p.height = c->cfg.height;
+    p.tiles_x = tiles_x(c);
+    p.tiles_y = tiles_y(c);
+    p.tile_row0 = row0;
+    p.tile_row1 = row1;
+    const int variant = c->cfg.trace_variant;
+    size_t budget = 20 * 1024;
+    if (variant == 1) budget = 0;
+    if (variant == 2) budget = 150 * 1024;
+    p.lds_first_level = pick_lds_first_level(p.V, p.nlev, budget);
+    p.gbuf = c->gb_current;
+    p.out = c->frame;
+    p.dbg_steps = c->cfg.debug_outputs ? c->dbg_steps : nullptr;
+    p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
+    p.step_counter = c->step_counter;
+    p.tile_counter = c->tile_counter;
+    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->last_row0 = row0;
+    c->last_row1 = row1;
+    c->have_trace = true;
+    return VCT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vct_default_config(vct_config* cfg) {
+    if (!cfg) return VCT_ERR_INVALID;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = VCT_ABI_VERSION;
+    cfg->device = -1;
+    cfg->voxel_dim = 128;            // VCT.h:16
+    cfg->grid_world_size = 150.0f;   // VCT.h:17
+    cfg->width = 1280;               // VCT.h:24
+    cfg->height = 720;               // VCT.h:25
+    cfg->shadow_map_size = 4096;     // VCT.h:35
+    cfg->model_scale = 0.05f;        // VCT.h:183
+    cfg->ambient_factor = 0.1f;      // VCT.h:53
+    cfg->shininess = 20.0f;          // Mesh.h:86
+    cfg->max_distance = 75.0f;       // trace.fs:43
+    cfg->max_alpha = 0.95f;          // trace.fs:44
+    cfg->tan_diffuse = 0.577f;       // trace.fs:198
+    cfg->tan_specular = 0.07f;       // trace.fs:218
+    cfg->wrap_repeat = 1;
+    cfg->debug_outputs = 0;
+    cfg->trace_variant = 0;
+    return VCT_OK;
+}
+
+size_t vct_chain_texels(int32_t V) {
+    if (!is_pow2(V)) return 0;
+    return (size_t)vct_level_offset(V, vct_ilog2(V) + 1);
+}
+
+int vct_create(const vct_config* cfg, vct_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, VCT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != VCT_ABI_VERSION)
+        return fail(nullptr, VCT_ERR_INVALID, "vct_config.abi_version mismatch");
+    if (!is_pow2(cfg->voxel_dim) || cfg->voxel_dim < 8 || cfg->voxel_dim > 1024)
+        return fail(nullptr, VCT_ERR_INVALID, "voxel_dim must be a power of two in [8,1024]");
+    if (cfg->width <= 0 || cfg->height <= 0 || !(cfg->grid_world_size > 0.0f))
+        return fail(nullptr, VCT_ERR_INVALID, "bad frame size or grid size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, VCT_ERR_NO_DEVICE,
+                    "no HIP device: this library has no CPU path (MI355X / gfx950 required)");
+    vct_ctx* c = new vct_ctx();
+    c->cfg = *cfg;
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) { delete c; return fail(nullptr, VCT_ERR_INVALID, "device ordinal out of range"); }
+    c->device = dev;
+    c->cfg.device = dev;
+#define CREATE_TRY(expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            std::string m = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+            vct_destroy(c);                                                                  \
+            return fail(nullptr, e_ == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE, m); \
+        }                                                                                    \
+    } while (0)
+    CREATE_TRY(hipSetDevice(dev));
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&c->ev0));
+    CREATE_TRY(hipEventCreate(&c->ev1));
+    const int V = cfg->voxel_dim;
+    c->nlev = vct_ilog2(V) + 1;
+    c->chain_texels = vct_chain_texels(V);
+    CREATE_TRY(hipMalloc(&c->chain, c->chain_texels * 4));
+    CREATE_TRY(hipMemsetAsync(c->chain, 0, c->chain_texels * 4, c->stream));   // VCT.h:115-119
+    const size_t npix = (size_t)cfg->width * cfg->height;
+    CREATE_TRY(hipMalloc(&c->gb_tiled, gb_tiled_floats(c) * sizeof(float)));
+    CREATE_TRY(hipMemsetAsync(c->gb_tiled, 0, gb_tiled_floats(c) * sizeof(float), c->stream));
+    CREATE_TRY(hipMalloc(&c->frame, npix * 8));
+    CREATE_TRY(hipMemsetAsync(c->frame, 0, npix * 8, c->stream));
+    CREATE_TRY(hipMalloc(&c->step_counter, sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&c->tile_counter, sizeof(int32_t)));
+    CREATE_TRY(hipMalloc(&c->steps_dev, 2 * VCT_MAX_STEPS * sizeof(VctStep)));
+    if (cfg->debug_outputs) {
+        CREATE_TRY(hipMalloc(&c->dbg_steps, npix * 7));
+        CREATE_TRY(hipMalloc(&c->dbg_cones, npix * 28 * sizeof(float)));
+        CREATE_TRY(hipMemsetAsync(c->dbg_steps, 0, npix * 7, c->stream));
+        CREATE_TRY(hipMemsetAsync(c->dbg_cones, 0, npix * 28 * sizeof(float), c->stream));
+    }
+    CREATE_TRY(hipStreamSynchronize(c->stream));
+#undef CREATE_TRY
+    memset(c->light_vp, 0, sizeof(c->light_vp));
+    c->light_vp[0] = c->light_vp[5] = c->light_vp[10] = c->light_vp[15] = 1.0f;
+    c->gb_current = c->gb_tiled;
+    *out = c;
+    return VCT_OK;
+}
+
+void vct_destroy(vct_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
+                    c->dbg_cones, c->step_counter, c->tile_counter, c->steps_dev, c->tri_pos,
+                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->big_count};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* vct_last_error(const vct_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int vct_get_config(const vct_ctx* c, vct_config* cfg) {
+    if (!c || !cfg) return VCT_ERR_INVALID;
+    *cfg = c->cfg;
+    return VCT_OK;
+}
+
+int vct_set_camera_position(vct_ctx* c, const float pos[3]) {
+    if (!c || !pos) return VCT_ERR_INVALID;
+    memcpy(c->cam, pos, 12);
+    return VCT_OK;
+}
+
+int vct_set_light_direction(vct_ctx* c, const float dir[3]) {
+    if (!c || !dir) return VCT_ERR_INVALID;
+    memcpy(c->light, dir, 12);
+    return VCT_OK;
+}
+
+int vct_set_ambient_factor(vct_ctx* c, float a) {
+    if (!c) return VCT_ERR_INVALID;
+    c->cfg.ambient_factor = a;
+    return VCT_OK;
+}
+
+int vct_set_cone_apertures(vct_ctx* c, float td, float ts) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!(td > 0.0f) || !(ts > 0.0f)) return fail(c, VCT_ERR_INVALID, "aperture must be > 0");
+    c->cfg.tan_diffuse = td;
+    c->cfg.tan_specular = ts;
+    c->steps_dirty = true;
+    return VCT_OK;
+}
+
+// ---- scene -----------------------------------------------------------------------------
+
+int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, int32_t ntri,
+                         const float* albedo, int32_t nmat) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!pos || !material || !albedo || ntri <= 0 || nmat <= 0)
+        return fail(c, VCT_ERR_INVALID, "vct_upload_triangles: null or empty input");
+    for (int32_t i = 0; i < ntri; ++i)
+        if (material[i] < 0 || material[i] >= nmat)
+            return fail(c, VCT_ERR_INVALID, "vct_upload_triangles: material index out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->tri_pos) { (void)hipFree(c->tri_pos); c->tri_pos = nullptr; }
+    if (c->tri_mat) { (void)hipFree(c->tri_mat); c->tri_mat = nullptr; }
+    if (c->mat_albedo) { (void)hipFree(c->mat_albedo); c->mat_albedo = nullptr; }
+    if (c->big_list) { (void)hipFree(c->big_list); c->big_list = nullptr; }
+    HIP_TRY(c, hipMalloc(&c->tri_pos, (size_t)ntri * 9 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->tri_mat, (size_t)ntri * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc(&c->mat_albedo, (size_t)nmat * 4 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->big_list, (size_t)ntri * sizeof(int32_t)));
+    if (!c->big_count) HIP_TRY(c, hipMalloc(&c->big_count, sizeof(int32_t)));
+    HIP_TRY(c, hipMemcpyAsync(c->tri_pos, pos, (size_t)ntri * 9 * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->tri_mat, material, (size_t)ntri * sizeof(int32_t),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->mat_albedo, albedo, (size_t)nmat * 4 * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ntri = ntri;
+    c->nmat = nmat;
+    return VCT_OK;
+}
+
+int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const float light_vp[16]) {
+    if (!c) return VCT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->shadow) { (void)hipFree(c->shadow); c->shadow = nullptr; c->shadow_size = 0; }
+    if (!depth) return VCT_OK;
+    if (size <= 0 || !light_vp) return fail(c, VCT_ERR_INVALID, "vct_upload_shadow_map: bad size");
+    HIP_TRY(c, hipMalloc(&c->shadow, (size_t)size * size * sizeof(float)));
+    HIP_TRY(c, hipMemcpyAsync(c->shadow, depth, (size_t)size * size * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->shadow_size = size;
+    memcpy(c->light_vp, light_vp, 64);
+    return VCT_OK;
+}
+
+int vct_voxelize(vct_ctx* c, int32_t mode) {
+    if (!c) return VCT_ERR_INVALID;
+    if (mode != VCT_VOX_CONSERVATIVE_AVG)
+        return fail(c, VCT_ERR_INVALID, "vct_voxelize: only VCT_VOX_CONSERVATIVE_AVG is implemented");
+    if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_voxelize: no triangles uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
+    if (!c->acc) HIP_TRY(c, hipMalloc(&c->acc, nvox * 16));
+    HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->big_count, 0, sizeof(int32_t), c->stream));
+    VctVoxParams p;
+    memset(&p, 0, sizeof(p));
+    p.V = c->cfg.voxel_dim;
+    p.G = c->cfg.grid_world_size;
+    p.model_scale = c->cfg.model_scale;
+    p.pos = c->tri_pos;
+    p.material = c->tri_mat;
+    p.albedo = c->mat_albedo;
+    p.ntri = c->ntri;
+    p.shadow = c->shadow;
+    p.shadow_size = c->shadow_size;
+    memcpy(p.light_vp, c->light_vp, 64);
+    p.acc = c->acc;
+    p.big_list = c->big_list;
+    p.big_count = c->big_count;
+    p.mode = mode;
+    HIP_TRY(c, vct_launch_voxelize(p, c->stream));
+    c->acc_valid = true;
+    c->acc_mode = mode;
+    return VCT_OK;
+}
+
+int vct_inject_light(vct_ctx* c) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!c->acc_valid) return fail(c, VCT_ERR_INVALID, "vct_inject_light: call vct_voxelize first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, vct_launch_resolve(c->acc, c->chain, c->cfg.voxel_dim, c->acc_mode, c->stream));
+    return VCT_OK;
+}
+
+int vct_build_mips(vct_ctx* c) {
+    if (!c) return VCT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, vct_launch_build_mips(c->chain, c->cfg.voxel_dim, c->stream));
+    return VCT_OK;
+}
+
+// ---- volume up/download -----------------------------------------------------------------
+
+static int ensure_staging(vct_ctx* c) {
+    if (c->staging) return VCT_OK;
+    const size_t n = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
+    HIP_TRY(c, hipMalloc(&c->staging, n * 4));
+    return VCT_OK;
+}
+
+static int upload_levels(vct_ctx* c, const uint8_t* lin, int nlevels) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc) return rc;
+    const int V = c->cfg.voxel_dim;
+    for (int l = 0; l < nlevels; ++l) {
+        const int N = V >> l;
+        const size_t off = (size_t)vct_level_offset(V, l), n = (size_t)N * N * N;
+        HIP_TRY(c, hipMemcpyAsync(c->staging, lin + off * 4, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, vct_launch_linear_to_morton(c->staging, c->chain + off, N, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return VCT_OK;
+}
+
+int vct_upload_volume_rgba8(vct_ctx* c, const uint8_t* l0) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!l0) return fail(c, VCT_ERR_INVALID, "vct_upload_volume_rgba8: null volume");
+    return upload_levels(c, l0, 1);
+}
+
+int vct_upload_chain_rgba8(vct_ctx* c, const uint8_t* chain) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!chain) return fail(c, VCT_ERR_INVALID, "vct_upload_chain_rgba8: null chain");
+    return upload_levels(c, chain, c->nlev);
+}
+
+int vct_download_chain_rgba8(vct_ctx* c, uint8_t* chain) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!chain) return fail(c, VCT_ERR_INVALID, "vct_download_chain_rgba8: null destination");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc) return rc;
+    const int V = c->cfg.voxel_dim;
+    for (int l = 0; l < c->nlev; ++l) {
+        const int N = V >> l;
+        const size_t off = (size_t)vct_level_offset(V, l), n = (size_t)N * N * N;
+        HIP_TRY(c, vct_launch_morton_to_linear(c->chain + off, c->staging, N, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(chain + off * 4, c->staging, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return VCT_OK;
+}
+
+// ---- trace -------------------------------------------------------------------------------
+
+static int bind_gbuffer(vct_ctx* c, const vct_gbuffer* gb) {
+    if (!gb || !gb->planes) return fail(c, VCT_ERR_INVALID, "vct_trace: null G-buffer");
+    if (gb->width != c->cfg.width || gb->height != c->cfg.height)
+        return fail(c, VCT_ERR_INVALID, "vct_trace: G-buffer size differs from the context's frame");
+    const size_t npix = (size_t)c->cfg.width * c->cfg.height;
+    if (gb->layout == VCT_GB_TILED) {
+        if (gb->location == VCT_MEM_DEVICE) {
+            c->gb_current = gb->planes;     // zero-copy: trace reads the caller's HBM buffer
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(c->gb_tiled, gb->planes, gb_tiled_floats(c) * sizeof(float),
+                                      hipMemcpyHostToDevice, c->stream));
+            c->gb_current = c->gb_tiled;
+        }
+        return VCT_OK;
+    }
+    if (gb->layout != VCT_GB_LINEAR) return fail(c, VCT_ERR_INVALID, "vct_trace: unknown G-buffer layout");
+    const float* src = gb->planes;
+    if (gb->location == VCT_MEM_HOST) {
+        if (!c->gb_linear) HIP_TRY(c, hipMalloc(&c->gb_linear, npix * VCT_GB_NPLANES * sizeof(float)));
+        HIP_TRY(c, hipMemcpyAsync(c->gb_linear, gb->planes, npix * VCT_GB_NPLANES * sizeof(float),
+                                  hipMemcpyHostToDevice, c->stream));
+        src = c->gb_linear;
+    }
+    HIP_TRY(c, vct_launch_tile_gbuffer(src, c->gb_tiled, c->cfg.width, c->cfg.height, c->stream));
+    c->gb_current = c->gb_tiled;
+    return VCT_OK;
+}
+
+int vct_trace_slab(vct_ctx* c, const vct_gbuffer* gb, int32_t row0, int32_t row1, void* out,
+                   int32_t out_location) {
+    if (!c) return VCT_ERR_INVALID;
+    if (row0 < 0 || row1 > tiles_y(c) || row0 > row1)
+        return fail(c, VCT_ERR_INVALID, "vct_trace_slab: tile-row range outside the frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = bind_gbuffer(c, gb);
+    if (rc) return rc;
+    rc = launch_trace(c, row0, row1);
+    if (rc) return rc;
+    if (out) {
+        const int y0 = row0 * VCT_TILE;
+        const int y1 = row1 * VCT_TILE < c->cfg.height ? row1 * VCT_TILE : c->cfg.height;
+        if (y1 > y0) {
+            const size_t off = (size_t)y0 * c->cfg.width * 8, bytes = (size_t)(y1 - y0) * c->cfg.width * 8;
+            HIP_TRY(c, hipMemcpyAsync((char*)out + off, (const char*)c->frame + off, bytes,
+                                      out_location == VCT_MEM_DEVICE ? hipMemcpyDeviceToDevice
+                                                                     : hipMemcpyDeviceToHost,
+                                      c->stream));
+        }
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCT_OK;
+}
+
+int vct_trace(vct_ctx* c, const vct_gbuffer* gb, void* out, int32_t out_location) {
+    if (!c) return VCT_ERR_INVALID;
+    return vct_trace_slab(c, gb, 0, tiles_y(c), out, out_location);
+}
+
+int vct_trace_resident(vct_ctx* c) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "vct_trace_resident: no G-buffer resident yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return launch_trace(c, c->last_row0, c->last_row1);
+}
+
+int vct_synchronize(vct_ctx* c) {
+    if (!c) return VCT_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCT_OK;
+}
+
+int vct_download_steps(vct_ctx* c, uint8_t* steps) {
+    if (!c || !steps) return VCT_ERR_INVALID;
+    if (!c->dbg_steps) return fail(c, VCT_ERR_INVALID, "context created without debug_outputs");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(steps, c->dbg_steps, (size_t)c->cfg.width * c->cfg.height * 7,
+                         hipMemcpyDeviceToHost));
+    return VCT_OK;
+}
+
+int vct_download_cones(vct_ctx* c, float* cones) {
+    if (!c || !cones) return VCT_ERR_INVALID;
+    if (!c->dbg_cones) return fail(c, VCT_ERR_INVALID, "context created without debug_outputs");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(cones, c->dbg_cones, (size_t)c->cfg.width * c->cfg.height * 28 * sizeof(float),
+                         hipMemcpyDeviceToHost));
+    return VCT_OK;
+}
+
+int vct_last_step_count(vct_ctx* c, uint64_t* steps) {
+    if (!c || !steps) return VCT_ERR_INVALID;
+    if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    HIP_TRY(c, hipMemcpy(&v, c->step_counter, sizeof(v), hipMemcpyDeviceToHost));
+    *steps = v;
+    return VCT_OK;
+}
+
+int vct_last_trace_ms(vct_ctx* c, float* ms) {
+    if (!c || !ms) return VCT_ERR_INVALID;
+    if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return VCT_OK;
+}
+
+int vct_get_stream(vct_ctx* c, void** s) {
+    if (!c || !s) return VCT_ERR_INVALID;
+    *s = (void*)c->stream;
+    return VCT_OK;
+}
+
+int vct_get_frame_device(vct_ctx* c, void** p, size_t* bytes) {
+    if (!c || !p) return VCT_ERR_INVALID;
+    *p = c->frame;
+    if (bytes) *bytes = (size_t)c->cfg.width * c->cfg.height * 8;
+    return VCT_OK;
+}
+
+}  // extern "C"

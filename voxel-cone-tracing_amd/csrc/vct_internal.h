@@ -1,0 +1,79 @@
+// vct_internal.h -- shared between the C-ABI translation unit and the kernel files.
+#ifndef VCT_INTERNAL_H_
+#define VCT_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vct_layout.h"
+
+#define VCT_TILE 8
+#define VCT_TILE_PIX 64
+#define VCT_GB_NPLANES 23
+#define VCT_MAX_STEPS 1024
+
+// One entry per march step of a cone aperture.  The step sequence of trace.fs:90-104 (dist,
+// diameter, lod) does not depend on the pixel, only on (V, G, tanHalfAngle, MAX_DISTANCE): the
+// host evaluates it once with the reference's operation order and the kernel reads it through
+// the scalar cache.
+struct VctStep {
+    float dist;        // trace.fs:91,103
+    float diameter;    // trace.fs:96
+    float occ_den;     // 1 + 0.03*diameter            trace.fs:101
+    float frac;        // fract(lod) after [GL] clamp  trace.fs:97
+    int32_t level;     // floor(lod)
+    int32_t level2;    // min(level+1, maxLevel)
+    int32_t two_levels;  // lod > 0 (minification): blend level/level2; else level 0 only
+    int32_t pad;
+};
+
+struct VctTraceParams {
+    const uint32_t* chain;              // Morton chain, RGBA8 packed
+    uint32_t level_off[VCT_MAX_LEVELS]; // texel offsets
+    int32_t V, nlev;
+    float G, half_G, vs;
+    float cam[3];
+    float light[3];
+    float ambient, shininess, max_alpha;
+    int32_t wrap_repeat;
+    const VctStep* steps_diffuse;
+    const VctStep* steps_specular;
+    int32_t n_diffuse, n_specular;
+    int32_t width, height, tiles_x, tiles_y;
+    int32_t tile_row0, tile_row1;       // slab [row0,row1)
+    int32_t lds_first_level;            // first level staged in LDS (>= nlev: none)
+    const float* gbuf;                  // tiled [tile][23][64]
+    uint16_t* out;                      // RGBA16F [h][w][4]
+    uint8_t* dbg_steps;                 // [npix][7] or null
+    float* dbg_cones;                   // [npix][7][4] or null
+    unsigned long long* step_counter;   // total executed steps
+    int32_t* tile_counter;              // dynamic tile queue head (persistent variants)
+};
+
+struct VctVoxParams {
+    int32_t V;
+    float G, model_scale;
+    const float* pos;          // [ntri][9]
+    const int32_t* material;   // [ntri]
+    const float* albedo;       // [nmat][4]
+    int32_t ntri;
+    const float* shadow;       // [S*S] or null
+    int32_t shadow_size;
+    float light_vp[16];
+    unsigned long long* acc;   // [V^3][2]: (sumR | sumG<<32), (sumB | count<<32), Morton order
+    int32_t* big_list;         // triangles deferred to the block-per-triangle pass
+    int32_t* big_count;
+    int32_t mode;
+};
+
+hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);
+hipError_t vct_launch_linear_to_morton(const uint32_t* lin, uint32_t* mor, int N, hipStream_t s);
+hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N, hipStream_t s);
+hipError_t vct_launch_build_mips(uint32_t* chain, int V, hipStream_t s);
+hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
+                                   hipStream_t s);
+hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s);
+hipError_t vct_launch_resolve(const unsigned long long* acc, uint32_t* level0, int V, int mode,
+                              hipStream_t s);
+
+#endif

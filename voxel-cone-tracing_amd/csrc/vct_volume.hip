@@ -1,0 +1,151 @@
+// vct_volume.hip -- layout conversion and mip build over the Morton brick chain.
+//
+// vct_launch_build_mips replaces glGenerateMipmap(GL_TEXTURE_3D) (VCT.h:126,248): 2x2x2 box
+// mean per channel, rounded to the nearest unorm8 and requantised level by level
+// (OpenGL 4.3 core mipmap generation).  In Morton order the 8 children of a
+// texel are 32 contiguous bytes, so one wave turns a 2 KiB brick (512 texels) into 64 + 8 + 1
+// texels of the next three levels: three levels per launch, pure streaming, HBM-bound.
+#include "vct_internal.h"
+
+namespace {
+
+__global__ void k_linear_to_morton(const uint32_t* __restrict__ lin, uint32_t* __restrict__ mor,
+                                   int N, int shift) {
+    const size_t total = (size_t)N * N * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t x = (uint32_t)(i & (size_t)(N - 1));
+        const uint32_t y = (uint32_t)((i >> shift) & (size_t)(N - 1));
+        const uint32_t z = (uint32_t)(i >> (2 * shift));
+        mor[vct_morton3(x, y, z)] = lin[i];
+    }
+}
+
+__global__ void k_morton_to_linear(const uint32_t* __restrict__ mor, uint32_t* __restrict__ lin,
+                                   int N, int shift) {
+    const size_t total = (size_t)N * N * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t x = (uint32_t)(i & (size_t)(N - 1));
+        const uint32_t y = (uint32_t)((i >> shift) & (size_t)(N - 1));
+        const uint32_t z = (uint32_t)(i >> (2 * shift));
+        lin[i] = mor[vct_morton3(x, y, z)];
+    }
+}
+
+// mean of 8 RGBA8 texels per channel, (sum + 4) >> 3, on two 16-bit-lane SWAR accumulators
+__device__ __forceinline__ uint32_t box8(uint32_t rb, uint32_t ga) {
+    rb = ((rb + 0x00040004u) >> 3) & 0x00ff00ffu;
+    ga = ((ga + 0x00040004u) >> 3) & 0x00ff00ffu;
+    return rb | (ga << 8);
+}
+
+// src: level L (count texels), dst1..3: levels L+1..L+3 (nout of them exist).
+__global__ void __launch_bounds__(256)
+k_mip3(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst1, uint32_t* __restrict__ dst2,
+       uint32_t* __restrict__ dst3, uint32_t count, int nout) {
+    const uint32_t n1 = count >> 3;
+    const uint32_t nthreads_needed = (n1 + 63u) & ~63u;   // whole waves so shuffles are defined
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nthreads_needed;
+         t += gridDim.x * blockDim.x) {
+        uint32_t q = 0;
+        if (t < n1) {
+            const uint4* s4 = reinterpret_cast<const uint4*>(src) + 2 * (size_t)t;
+            const uint4 a = s4[0], b = s4[1];
+            const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t rb = 0, ga = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                rb += v[i] & 0x00ff00ffu;
+                ga += (v[i] >> 8) & 0x00ff00ffu;
+            }
+            q = box8(rb, ga);
+            dst1[t] = q;
+        }
+        if (nout < 2) continue;
+        uint32_t rb = q & 0x00ff00ffu, ga = (q >> 8) & 0x00ff00ffu;
+        rb += __shfl_xor(rb, 1); ga += __shfl_xor(ga, 1);
+        rb += __shfl_xor(rb, 2); ga += __shfl_xor(ga, 2);
+        rb += __shfl_xor(rb, 4); ga += __shfl_xor(ga, 4);
+        const uint32_t q2 = box8(rb, ga);
+        const uint32_t n2 = n1 >> 3;
+        if ((t & 7u) == 0u && (t >> 3) < n2) dst2[t >> 3] = q2;
+        if (nout < 3) continue;
+        rb = q2 & 0x00ff00ffu; ga = (q2 >> 8) & 0x00ff00ffu;
+        rb += __shfl_xor(rb, 8); ga += __shfl_xor(ga, 8);
+        rb += __shfl_xor(rb, 16); ga += __shfl_xor(ga, 16);
+        rb += __shfl_xor(rb, 32); ga += __shfl_xor(ga, 32);
+        const uint32_t n3 = n2 >> 3;
+        if ((t & 63u) == 0u && (t >> 6) < n3) dst3[t >> 6] = box8(rb, ga);
+    }
+}
+
+// planes [23][h*w] -> tiled [tile][23][64]; pixels outside the frame are zero (albedo.a = 0).
+__global__ void k_tile_gbuffer(const float* __restrict__ planes, float* __restrict__ tiled, int w,
+                               int h, int tiles_x, int tiles_y) {
+    const size_t total = (size_t)tiles_x * tiles_y * VCT_GB_NPLANES * VCT_TILE_PIX;
+    const size_t npix = (size_t)w * h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const size_t r = i >> 6;
+        const int plane = (int)(r % VCT_GB_NPLANES);
+        const size_t tile = r / VCT_GB_NPLANES;
+        const int ty = (int)(tile / tiles_x), tx = (int)(tile - (size_t)ty * tiles_x);
+        const int x = tx * VCT_TILE + (lane & 7), y = ty * VCT_TILE + (lane >> 3);
+        float v = 0.0f;
+        if (x < w && y < h) v = planes[(size_t)plane * npix + (size_t)y * w + x];
+        tiled[i] = v;
+    }
+}
+
+inline int grid_for(size_t n, int threads) {
+    size_t b = (n + threads - 1) / threads;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+hipError_t vct_launch_linear_to_morton(const uint32_t* lin, uint32_t* mor, int N, hipStream_t s) {
+    const size_t n = (size_t)N * N * N;
+    hipLaunchKernelGGL(k_linear_to_morton, dim3(grid_for(n, 256)), dim3(256), 0, s, lin, mor, N,
+                       vct_ilog2(N));
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N, hipStream_t s) {
+    const size_t n = (size_t)N * N * N;
+    hipLaunchKernelGGL(k_morton_to_linear, dim3(grid_for(n, 256)), dim3(256), 0, s, mor, lin, N,
+                       vct_ilog2(N));
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_build_mips(uint32_t* chain, int V, hipStream_t s) {
+    const int nlev = vct_ilog2(V) + 1;
+    for (int L = 0; L + 1 < nlev; L += 3) {
+        const int nout = (nlev - 1 - L) < 3 ? (nlev - 1 - L) : 3;
+        const uint32_t n = (uint32_t)(V >> L);
+        const uint32_t count = n * n * n;
+        uint32_t* src = chain + vct_level_offset(V, L);
+        uint32_t* d1 = chain + vct_level_offset(V, L + 1);
+        uint32_t* d2 = nout >= 2 ? chain + vct_level_offset(V, L + 2) : nullptr;
+        uint32_t* d3 = nout >= 3 ? chain + vct_level_offset(V, L + 3) : nullptr;
+        const size_t threads_needed = ((size_t)(count >> 3) + 63) & ~(size_t)63;
+        hipLaunchKernelGGL(k_mip3, dim3(grid_for(threads_needed, 256)), dim3(256), 0, s, src, d1,
+                           d2, d3, count, nout);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
+                                   hipStream_t s) {
+    const int tx = (w + VCT_TILE - 1) / VCT_TILE, ty = (h + VCT_TILE - 1) / VCT_TILE;
+    const size_t n = (size_t)tx * ty * VCT_GB_NPLANES * VCT_TILE_PIX;
+    hipLaunchKernelGGL(k_tile_gbuffer, dim3(grid_for(n, 256)), dim3(256), 0, s, planes_linear, tiled,
+                       w, h, tx, ty);
+    return hipGetLastError();
+}
