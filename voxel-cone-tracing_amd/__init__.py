@@ -9,6 +9,14 @@ import os
 
 import numpy as np
 
+try:
+    # torch bundles its own libamdhip64.so.7 (same soname as /opt/rocm's): whichever is loaded
+    # first serves the whole process, and torch breaks on the other one.  Load torch's first so
+    # that torch tensors, streams and this library share one HIP runtime.
+    import torch  # noqa: F401
+except ImportError:  # pure ctypes use without torch is fine
+    pass
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvct_amd.so")
 

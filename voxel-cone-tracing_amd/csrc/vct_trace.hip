@@ -27,9 +27,12 @@ __device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ F3 cross3(F3 a, F3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+// IEEE-correct fp32 divide / sqrt (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt; the
+// __fsqrt_rn intrinsic maps to the 1-ulp native sqrt and must not be used here).
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
+__device__ __forceinline__ float sqrt_rn(float a) { return __builtin_sqrtf(a); }
 __device__ __forceinline__ F3 normalize3(F3 a) {
-    const float l = __fsqrt_rn(dot3(a, a));
+    const float l = sqrt_rn(dot3(a, a));
     return {div_rn(a.x, l), div_rn(a.y, l), div_rn(a.z, l)};
 }
 __device__ __forceinline__ F3 reflect3(F3 I, F3 N) {

@@ -100,7 +100,7 @@ __device__ __forceinline__ void setup_tri(const VctVoxParams& p, int t, TriSetup
     // vox.gs:24-39 dominant axis
     const F3 e1 = sub3(w[0], w[1]), e2 = sub3(w[2], w[0]);
     F3 nn = cross3(e1, e2);
-    const float len = __fsqrt_rn(dot3(nn, nn));
+    const float len = __builtin_sqrtf(dot3(nn, nn));
     const float nx = fabsf(__fdiv_rn(nn.x, len)), ny = fabsf(__fdiv_rn(nn.y, len)),
                 nz = fabsf(__fdiv_rn(nn.z, len));
     int axis;
