@@ -6,7 +6,14 @@ HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -
 OBJS := $(CSRC)/vct_capi.o $(CSRC)/vct_trace.o $(CSRC)/vct_volume.o $(CSRC)/vct_voxelize.o
 LIB := $(PKG)/libvct_amd.so
 
-all: lib oracle
+HOSTLIB := $(PKG)/libvct_host.so
+
+all: lib host oracle
+
+host: $(HOSTLIB)
+
+$(HOSTLIB): $(PKG)/host/vct_host.cpp $(PKG)/host/vct_host.h
+	g++ -O2 -std=c++17 -fPIC -Wall -Wextra -shared -o $@ $(PKG)/host/vct_host.cpp
 
 lib: $(LIB)
 
@@ -20,7 +27,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) $(HOSTLIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib host oracle clean
