@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_gpu.sh output directory (gpurun_out/prof_<tag>) into the small text
+summary committed under profiles/: per-kernel stats of the kernel-trace pass and per-kernel means
+of every PMC counter collected."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    lines = []
+    for f in sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)):
+        lines.append(f"== kernel stats ({os.path.relpath(f, src)}) ==")
+        with open(f) as fh:
+            lines += [ln.rstrip() for ln in fh]
+    # per-dispatch durations of the trace kernel from the raw kernel trace
+    for f in sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)):
+        d = defaultdict(list)
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        lines.append("== per-kernel durations from kernel_trace.csv (us): n / mean / min / max ==")
+        for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+            lines.append(f"{k[:90]:90s} {len(v):5d} {sum(v)/len(v):10.2f} {min(v):10.2f} {max(v):10.2f}")
+    for p in sorted(glob.glob(os.path.join(src, "pmc*"))):
+        if not os.path.isdir(p):
+            continue
+        for f in sorted(glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True)):
+            acc = defaultdict(lambda: defaultdict(list))
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            lines.append(f"== PMC {os.path.basename(p)}: per-kernel mean counter value per dispatch ==")
+            for k, cs in acc.items():
+                for c, v in cs.items():
+                    lines.append(f"{k[:70]:70s} {c:34s} n={len(v):4d} mean={sum(v)/len(v):.6g}")
+    if os.path.exists(os.path.join(src, "passes.txt")):
+        lines.append("== passes ==")
+        lines += [ln.rstrip() for ln in open(os.path.join(src, "passes.txt"))]
+    with open(dst, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
