@@ -32,10 +32,10 @@ struct vct_ctx {
     uint8_t* dbg_steps = nullptr;
     float* dbg_cones = nullptr;
     unsigned long long* step_counter = nullptr;
-    int32_t* tile_counter = nullptr;
     VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
     int n_diffuse = 0, n_specular = 0;
     bool steps_dirty = true;
+    bool fast_div = false;            // set by refresh_steps: constant divisors admit the FMA division
     int last_row0 = 0, last_row1 = 0;
     bool have_trace = false;
 
@@ -90,8 +90,8 @@ int build_steps(const vct_config& cfg, float tan_half, std::vector<VctStep>& out
         const float diameter = fmaxf(vs, 2.0f * tan_half * dist);
         const float lod = log2f(diameter / vs);
         s.dist = dist;
-        s.diameter = diameter;
         s.occ_den = 1.0f + 0.03f * diameter;
+        s.occ_rcp = 1.0f / s.occ_den;
         float lam = lod;
         if (!(lam > 0.0f)) {
             s.two_levels = 0; s.level = 0; s.level2 = 0; s.frac = 0.0f;
@@ -112,6 +112,19 @@ int build_steps(const vct_config& cfg, float tan_half, std::vector<VctStep>& out
     return 0;
 }
 
+// The kernel divides by wave-uniform constants (half_G, the per-step occlusion denominators) with
+// q = x*r; two rounds of { e = fma(-d,q,x); q = fma(e,r,q) }, r = RN(1/d).  After the first round q
+// is a faithful rounding of x/d, so the second returns the correctly rounded quotient (Markstein's
+// theorem) -- for every divisor whose significand is not all ones and whose reciprocal is a normal
+// number.  Divisors outside that set switch the kernel to the IEEE divide.
+bool divisor_ok(float d) {
+    uint32_t b;
+    memcpy(&b, &d, 4);
+    const uint32_t e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
+    if (!(d > 0.0f) || e == 0xffu) return false;
+    return m != 0x7fffffu && e >= 4 && e <= 250;   // d and 1/d both far from the subnormal range
+}
+
 int refresh_steps(vct_ctx* c) {
     if (!c->steps_dirty) return VCT_OK;
     std::vector<VctStep> d, s;
@@ -124,22 +137,12 @@ int refresh_steps(vct_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // d, s go out of scope
     c->n_diffuse = (int)d.size();
     c->n_specular = (int)s.size();
+    bool ok = divisor_ok(c->cfg.grid_world_size * 0.5f);
+    for (const VctStep& st : d) ok = ok && divisor_ok(st.occ_den);
+    for (const VctStep& st : s) ok = ok && divisor_ok(st.occ_den);
+    c->fast_div = ok;
     c->steps_dirty = false;
     return VCT_OK;
-}
-
-// Levels staged in LDS: the longest tail of the chain that fits the budget.
-int pick_lds_first_level(int V, int nlev, size_t budget_bytes) {
-    int first = nlev;
-    size_t bytes = 0;
-    for (int l = nlev - 1; l >= 0; --l) {
-        const size_t n = (size_t)(V >> l);
-        const size_t add = n * n * n * 4;
-        if (bytes + add > budget_bytes) break;
-        bytes += add;
-        first = l;
-    }
-    return first;
 }
 
 int tiles_x(const vct_ctx* c) { return (c->cfg.width + VCT_TILE - 1) / VCT_TILE; }
@@ -165,6 +168,8 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.shininess = c->cfg.shininess;
     p.max_alpha = c->cfg.max_alpha;
     p.wrap_repeat = c->cfg.wrap_repeat;
+    p.half_G_rcp = 1.0f / p.half_G;
+    p.fast_div = c->fast_div ? 1 : 0;
     p.steps_diffuse = c->steps_dev;
     p.steps_specular = c->steps_dev + VCT_MAX_STEPS;
     p.n_diffuse = c->n_diffuse;
@@ -176,18 +181,13 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.tile_row0 = row0;
     p.tile_row1 = row1;
     const int variant = c->cfg.trace_variant;
-    size_t budget = 20 * 1024;
-    if (variant == 1) budget = 0;
-    if (variant == 2) budget = 150 * 1024;
-    p.lds_first_level = pick_lds_first_level(p.V, p.nlev, budget);
     p.gbuf = c->gb_current;
     p.out = c->frame;
     p.dbg_steps = c->cfg.debug_outputs ? c->dbg_steps : nullptr;
     p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
     p.step_counter = c->step_counter;
-    p.tile_counter = c->tile_counter;
-    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long),
+                              c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -272,8 +272,7 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     CREATE_TRY(hipMemsetAsync(c->gb_tiled, 0, gb_tiled_floats(c) * sizeof(float), c->stream));
     CREATE_TRY(hipMalloc(&c->frame, npix * 8));
     CREATE_TRY(hipMemsetAsync(c->frame, 0, npix * 8, c->stream));
-    CREATE_TRY(hipMalloc(&c->step_counter, sizeof(unsigned long long)));
-    CREATE_TRY(hipMalloc(&c->tile_counter, sizeof(int32_t)));
+    CREATE_TRY(hipMalloc(&c->step_counter, VCT_STEP_COUNTERS * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&c->steps_dev, 2 * VCT_MAX_STEPS * sizeof(VctStep)));
     if (cfg->debug_outputs) {
         CREATE_TRY(hipMalloc(&c->dbg_steps, npix * 7));
@@ -295,7 +294,7 @@ void vct_destroy(vct_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
-                    c->dbg_cones, c->step_counter, c->tile_counter, c->steps_dev, c->tri_pos,
+                    c->dbg_cones, c->step_counter, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->big_count};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -581,9 +580,11 @@ int vct_last_step_count(vct_ctx* c, uint64_t* steps) {
     if (!c || !steps) return VCT_ERR_INVALID;
     if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long v = 0;
-    HIP_TRY(c, hipMemcpy(&v, c->step_counter, sizeof(v), hipMemcpyDeviceToHost));
-    *steps = v;
+    unsigned long long v[VCT_STEP_COUNTERS];
+    HIP_TRY(c, hipMemcpy(v, c->step_counter, sizeof(v), hipMemcpyDeviceToHost));
+    unsigned long long sum = 0;
+    for (int i = 0; i < VCT_STEP_COUNTERS; ++i) sum += v[i];
+    *steps = sum;
     return VCT_OK;
 }
 

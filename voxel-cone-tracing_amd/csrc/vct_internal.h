@@ -11,6 +11,7 @@
 #define VCT_TILE_PIX 64
 #define VCT_GB_NPLANES 23
 #define VCT_MAX_STEPS 1024
+#define VCT_STEP_COUNTERS 256   // bank of executed-step counters (power of two)
 
 // One entry per march step of a cone aperture.  The step sequence of trace.fs:90-104 (dist,
 // diameter, lod) does not depend on the pixel, only on (V, G, tanHalfAngle, MAX_DISTANCE): the
@@ -18,7 +19,7 @@
 // the scalar cache.
 struct VctStep {
     float dist;        // trace.fs:91,103
-    float diameter;    // trace.fs:96
+    float occ_rcp;     // RN(1 / occ_den): reciprocal for the exact constant division (vct_trace.hip)
     float occ_den;     // 1 + 0.03*diameter            trace.fs:101
     float frac;        // fract(lod) after [GL] clamp  trace.fs:97
     int32_t level;     // floor(lod)
@@ -32,6 +33,8 @@ struct VctTraceParams {
     uint32_t level_off[VCT_MAX_LEVELS]; // texel offsets
     int32_t V, nlev;
     float G, half_G, vs;
+    float half_G_rcp;                   // RN(1 / half_G)
+    int32_t fast_div;                   // 1: every constant divisor admits the FMA-corrected division
     float cam[3];
     float light[3];
     float ambient, shininess, max_alpha;
@@ -41,13 +44,11 @@ struct VctTraceParams {
     int32_t n_diffuse, n_specular;
     int32_t width, height, tiles_x, tiles_y;
     int32_t tile_row0, tile_row1;       // slab [row0,row1)
-    int32_t lds_first_level;            // first level staged in LDS (>= nlev: none)
     const float* gbuf;                  // tiled [tile][23][64]
     uint16_t* out;                      // RGBA16F [h][w][4]
     uint8_t* dbg_steps;                 // [npix][7] or null
     float* dbg_cones;                   // [npix][7][4] or null
-    unsigned long long* step_counter;   // total executed steps
-    int32_t* tile_counter;              // dynamic tile queue head (persistent variants)
+    unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] partial sums of executed steps
 };
 
 struct VctVoxParams {
