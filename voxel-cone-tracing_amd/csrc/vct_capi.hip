@@ -104,6 +104,20 @@ int build_steps(const vct_config& cfg, float tan_half, std::vector<VctStep>& out
             s.frac = lam - fl;
         }
         s.pad = 0;
+        // frac == 0: the blend is fma(0, tri(level2), 1*tri(level)) = tri(level) exactly (texels are
+        // finite and >= +0), so the second level need not be sampled.
+        if (s.two_levels && s.frac == 0.0f) s.two_levels = 0;
+        auto ref = [&](int level) {
+            VctLevelRef r;
+            const int lg = maxl - level;
+            r.off = (uint32_t)vct_level_offset(cfg.voxel_dim, level);
+            r.mask_x = 0x09249249u & (uint32_t)((1ull << (3 * lg)) - 1ull);
+            r.fN = (float)(1 << lg);
+            r.m = (1 << lg) - 1;
+            return r;
+        };
+        s.l1 = ref(s.level);
+        s.l2 = ref(s.level2);
         out.push_back(s);
         const float nd = dist + diameter;
         if (!(nd > dist)) return -1;   // would never terminate

@@ -17,15 +17,23 @@
 // diameter, lod) does not depend on the pixel, only on (V, G, tanHalfAngle, MAX_DISTANCE): the
 // host evaluates it once with the reference's operation order and the kernel reads it through
 // the scalar cache.
-struct VctStep {
+struct VctLevelRef {    // one mip level as the sampler needs it (all wave-uniform)
+    uint32_t off;      // texel offset of the level in the chain
+    uint32_t mask_x;   // x bits of the level's Morton index: 0x09249249 & (N^3 - 1)
+    float fN;          // N = V >> level, as float
+    int32_t m;         // N - 1
+};
+
+struct VctStep {       // 64 B: one s_load_dwordx16 per march step
     float dist;        // trace.fs:91,103
     float occ_rcp;     // RN(1 / occ_den): reciprocal for the exact constant division (vct_trace.hip)
     float occ_den;     // 1 + 0.03*diameter            trace.fs:101
     float frac;        // fract(lod) after [GL] clamp  trace.fs:97
     int32_t level;     // floor(lod)
     int32_t level2;    // min(level+1, maxLevel)
-    int32_t two_levels;  // lod > 0 (minification): blend level/level2; else level 0 only
+    int32_t two_levels;  // lod > 0 (minification) and frac != 0: blend level/level2; else `level` only
     int32_t pad;
+    VctLevelRef l1, l2;
 };
 
 struct VctTraceParams {

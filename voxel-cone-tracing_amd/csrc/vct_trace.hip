@@ -96,20 +96,18 @@ struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
 // called in wave-uniform control flow with at least one lane `act`.  Lanes without `act` help
 // fetch the block and return garbage-free zeros / unused values.
 template <bool WRAP, bool COOP>
-__device__ __forceinline__ F4 sample_level(const VctTraceParams& p, int level, float ux, float uy,
-                                           float uz, bool act, float4* __restrict__ blk,
-                                           const LaneBlock& lb) {
-    const int lg = p.nlev - 1 - level;          // log2(N)
-    const int N = 1 << lg, m = N - 1;
-    const float fN = (float)N;
+__device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, const VctLevelRef lv,
+                                           float ux, float uy, float uz, bool act,
+                                           float4* __restrict__ blk, const LaneBlock& lb) {
+    const int m = lv.m;
+    const float fN = lv.fN;
     // ux * fN is exact (power of two), so the fused form is the oracle's (ux*fN) - 0.5f bit for bit
     const float u = fmaf(ux, fN, -0.5f), v = fmaf(uy, fN, -0.5f), w = fmaf(uz, fN, -0.5f);
     const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
     const float a = u - fu, b = v - fv, c = w - fw;
     const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
-    const uint32_t* __restrict__ base = p.chain + p.level_off[level];
-    const uint32_t MX = 0x09249249u & (uint32_t)((1ull << (3 * lg)) - 1ull);
-    const uint32_t MY = MX << 1, MZ = MX << 2;
+    const uint32_t* __restrict__ base = chain + lv.off;
+    const uint32_t MX = lv.mask_x, MY = MX << 1, MZ = MX << 2;
 
     F4 r = {0.0f, 0.0f, 0.0f, 0.0f};
     bool coop = false;
@@ -207,17 +205,34 @@ __device__ __forceinline__ F4 sample_level(const VctTraceParams& p, int level, f
 }
 
 // trace.fs:82-107 with the pixel-independent step sequence read from `tab`.
+// The step table is read through the constant address space: a wave-uniform index then becomes one
+// scalar s_load_dwordx16 instead of vector loads + v_readfirstlane, and the entry of step k+1 is
+// requested while step k is being marched.
+typedef const __attribute__((address_space(4))) VctStep* StepTable;
+
+__device__ __forceinline__ VctStep load_step(StepTable t, int k) {
+    VctStep s;
+    s.dist = t[k].dist; s.occ_rcp = t[k].occ_rcp; s.occ_den = t[k].occ_den; s.frac = t[k].frac;
+    s.level = t[k].level; s.level2 = t[k].level2; s.two_levels = t[k].two_levels; s.pad = 0;
+    s.l1.off = t[k].l1.off; s.l1.mask_x = t[k].l1.mask_x; s.l1.fN = t[k].l1.fN; s.l1.m = t[k].l1.m;
+    s.l2.off = t[k].l2.off; s.l2.mask_x = t[k].l2.mask_x; s.l2.fN = t[k].l2.fN; s.l2.m = t[k].l2.m;
+    return s;
+}
+
 template <bool WRAP, bool FASTDIV, bool COOP>
 __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3 start, F3 dir,
-                                         const VctStep* __restrict__ tab, int n,
+                                         const VctStep* tab_global, int n,
                                          float4* __restrict__ blk, const LaneBlock& lb,
                                          int& steps_out) {
+    const StepTable tab = (StepTable)tab_global;
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, alpha = 0.0f, occ = 0.0f;
     int steps = 0;
+    VctStep nxt = load_step(tab, 0);
     for (int k = 0; k < n; ++k) {
         const bool act = alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
         if (!__any(act)) break;
-        const VctStep st = tab[k];
+        const VctStep st = nxt;
+        nxt = load_step(tab, k + 1 < n ? k + 1 : k);
         // trace.fs:98 + :61-63.  (q * 0.5f is exact, so fmaf(q, .5, .5) is the oracle's q*.5f + .5f.)
         const float px = start.x + dir.x * st.dist;
         const float py = start.y + dir.y * st.dist;
@@ -225,9 +240,9 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
         const float ux = fmaf(div_const<FASTDIV>(px, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
         const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
         const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        F4 vc = sample_level<WRAP, COOP>(p, st.level, ux, uy, uz, act, blk, lb);
-        if (st.two_levels && st.frac != 0.0f) {
-            const F4 t2 = sample_level<WRAP, COOP>(p, st.level2, ux, uy, uz, act, blk + 64, lb);
+        F4 vc = sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, blk, lb);
+        if (st.two_levels) {
+            const F4 t2 = sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, blk + 64, lb);
             const float g = 1.0f - st.frac;
             vc.x = fmaf(st.frac, t2.x, g * vc.x);
             vc.y = fmaf(st.frac, t2.y, g * vc.y);
