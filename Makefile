@@ -2,7 +2,10 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 PKG := voxel-cone-tracing_amd
 CSRC := $(PKG)/csrc
-HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+# -ffp-contract=off: the kernels mirror the oracle's fp32 operation order (explicit fmaf only).
+# -fno-slp-vectorize: packed fp32 (v_pk_fma_f32 ...) issues at half rate on gfx950, so SLP packing buys
+#   nothing and costs v_mov shuffles (trace kernel 1.01 -> 0.87 ms, profiles/r01c).
+HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function
 OBJS := $(CSRC)/vct_capi.o $(CSRC)/vct_trace.o $(CSRC)/vct_volume.o $(CSRC)/vct_voxelize.o
 LIB := $(PKG)/libvct_amd.so
 

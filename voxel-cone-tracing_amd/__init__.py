@@ -18,7 +18,8 @@ except ImportError:  # pure ctypes use without torch is fine
     pass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvct_amd.so")
+# VCT_AMD_LIB: path of an alternative build of the same library (A/B experiments only)
+LIB_PATH = os.environ.get("VCT_AMD_LIB") or os.path.join(_HERE, "libvct_amd.so")
 
 GB_PLANES = 23
 GB_LINEAR, GB_TILED = 0, 1

@@ -277,13 +277,16 @@ __constant__ float kConeDirs[18] = {0.0f, 0.0f, 1.0f,
 __constant__ float kConeWeights[6] = {0.25f, 0.15f, 0.15f, 0.15f, 0.15f, 0.15f};   // trace.fs:48
 
 #define VCT_WAVES_PER_BLOCK 4
+#ifndef VCT_TRACE_MIN_WAVES
+#define VCT_TRACE_MIN_WAVES 6     // waves per SIMD the register allocator must leave room for (<= 80 VGPRs)
+#endif
 
 // One wave per tile, lane = pixel, the 7 cones in sequence; 4 horizontally adjacent tiles per
 // workgroup.  Workgroups are dealt to XCDs round-robin by the dispatcher (block b -> XCD b % 8), so
 // the tile order is remapped to give every XCD one contiguous run of tiles: neighbouring tiles
 // march through neighbouring voxels and share that XCD's L2.
 template <bool WRAP, bool FASTDIV, bool COOP>
-__global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK)
+__global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_TRACE_MIN_WAVES)
 k_trace_tile(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_WAVES_PER_BLOCK][2][64];
     const int lane = threadIdx.x & 63;
@@ -305,34 +308,30 @@ k_trace_tile(const VctTraceParams p) {
     const int tile = p.tile_row0 * p.tiles_x + ti;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
     const int x = tx * VCT_TILE + (lane & 7), y = ty * VCT_TILE + (lane >> 3);
+    // The G-buffer is read in three stages (cone frame, specular direction, composite) instead of
+    // once up front: the 23 planes are only L1/L2 re-reads, while every VGPR kept live across the
+    // march loops costs occupancy, and resident waves are what hides the sampler's latency chain.
     const float* gb = p.gbuf + (size_t)tile * (VCT_GB_NPLANES * VCT_TILE_PIX) + lane;
-    float g[VCT_GB_NPLANES];
-#pragma unroll
-    for (int k = 0; k < VCT_GB_NPLANES; ++k) g[k] = gb[k * VCT_TILE_PIX];
-
+#define VCT_GB(k) gb[(k) * VCT_TILE_PIX]
     const bool in_frame = (x < p.width) && (y < p.height);
-    const bool alive = in_frame && !(g[18] < 0.5f);                 // trace.fs:171 discard
-    const F3 P = f3(g[0], g[1], g[2]), Nw = f3(g[3], g[4], g[5]);
-    const F3 T = f3(g[6], g[7], g[8]), B = f3(g[9], g[10], g[11]);
-    const F3 N = f3(g[12], g[13], g[14]);
-    const float shadow = g[22];
+    const bool alive = in_frame && !(VCT_GB(18) < 0.5f);            // trace.fs:171 discard
+    const size_t pix = (size_t)y * p.width + x;
 
-    // trace.fs:175: inverse(transpose(mat3(T,B,N))) = columns (BxN, NxT, TxB) / det
-    const F3 c0 = cross3(B, Nw), c1 = cross3(Nw, T), c2 = cross3(T, B);
-    const float inv_det = div_rn(1.0f, dot3(T, c0));
-    const F3 k0 = f3(c0.x * inv_det, c0.y * inv_det, c0.z * inv_det);
-    const F3 k1 = f3(c1.x * inv_det, c1.y * inv_det, c1.z * inv_det);
-    const F3 k2 = f3(c2.x * inv_det, c2.y * inv_det, c2.z * inv_det);
-
-    const F3 L = normalize3(f3(p.light[0], p.light[1], p.light[2]));        // :179
-    const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
-    const float cos_theta = fmaxf(dot3(N, L), 0.0f);                        // :188
-    const float direct_diffuse = shadow * cos_theta;                        // :192
-    const F3 start = f3(P.x + Nw.x * p.vs, P.y + Nw.y * p.vs, P.z + Nw.z * p.vs);   // :92
+    F3 start, k0, k1, k2;
+    {
+        const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2)), Nw = f3(VCT_GB(3), VCT_GB(4), VCT_GB(5));
+        const F3 T = f3(VCT_GB(6), VCT_GB(7), VCT_GB(8)), B = f3(VCT_GB(9), VCT_GB(10), VCT_GB(11));
+        // trace.fs:175: inverse(transpose(mat3(T,B,N))) = columns (BxN, NxT, TxB) / det
+        const F3 c0 = cross3(B, Nw), c1 = cross3(Nw, T), c2 = cross3(T, B);
+        const float inv_det = div_rn(1.0f, dot3(T, c0));
+        k0 = f3(c0.x * inv_det, c0.y * inv_det, c0.z * inv_det);
+        k1 = f3(c1.x * inv_det, c1.y * inv_det, c1.z * inv_det);
+        k2 = f3(c2.x * inv_det, c2.y * inv_det, c2.z * inv_det);
+        start = f3(P.x + Nw.x * p.vs, P.y + Nw.y * p.vs, P.z + Nw.z * p.vs);       // :92
+    }
 
     float ind[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int nsteps[7];
-    const size_t pix = (size_t)y * p.width + x;
+    int total = 0;
 #pragma unroll 1
     for (int i = 0; i < 6; ++i) {                                           // :196-199
         const float ddx = kConeDirs[3 * i], ddy = kConeDirs[3 * i + 1], ddz = kConeDirs[3 * i + 2];
@@ -342,7 +341,7 @@ k_trace_tile(const VctTraceParams p) {
         int st;
         const F4 c = cone_march<WRAP, FASTDIV, COOP>(p, alive, start, dir, p.steps_diffuse,
                                                      p.n_diffuse, blk, lb, st);
-        nsteps[i] = st;
+        total += st;
         const float wgt = kConeWeights[i];
         ind[0] = fmaf(wgt, c.x, ind[0]);
         ind[1] = fmaf(wgt, c.y, ind[1]);
@@ -352,51 +351,70 @@ k_trace_tile(const VctTraceParams p) {
             float* d = p.dbg_cones + pix * 28 + 4 * i;
             d[0] = c.x; d[1] = c.y; d[2] = c.z; d[3] = c.w;
         }
+        if (p.dbg_steps && in_frame) p.dbg_steps[pix * 7 + i] = (uint8_t)st;
     }
-    const float occlusion = 1.0f - ind[3];                                  // :201
-    const float dr = (direct_diffuse + occlusion * ind[0]) * g[15];         // :205
-    const float dg = (direct_diffuse + occlusion * ind[1]) * g[16];
-    const float db = (direct_diffuse + occlusion * ind[2]) * g[17];
 
-    const F3 R = normalize3(reflect3(f3(L.x * -1.0f, L.y * -1.0f, L.z * -1.0f), N));   // :212
-    const float spec = powf(fmaxf(dot3(E, R), 0.0f), p.shininess);          // :213
-    const float direct_spec = spec * shadow;                                // :214
-    const F3 Rd = normalize3(reflect3(f3(E.x * -1.0f, E.y * -1.0f, E.z * -1.0f), N));  // :217
-    int st6;
-    const F4 sc = cone_march<WRAP, FASTDIV, COOP>(p, alive, start, Rd, p.steps_specular,
-                                                  p.n_specular, blk, lb, st6);
-    nsteps[6] = st6;
-    if (p.dbg_cones && alive) {
-        float* d = p.dbg_cones + pix * 28 + 24;
-        d[0] = sc.x; d[1] = sc.y; d[2] = sc.z; d[3] = sc.w;
+    // stage 2: specular cone along reflect(-E, N) with the bump normal           trace.fs:217-218
+    const float* gb2 = gb;
+    asm volatile("" : "+v"(gb2));       // a fresh pointer: re-read instead of keeping planes live
+#undef VCT_GB
+#define VCT_GB(k) gb2[(k) * VCT_TILE_PIX]
+    F4 sc;
+    {
+        const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2));
+        const F3 N = f3(VCT_GB(12), VCT_GB(13), VCT_GB(14));
+        const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
+        const F3 Rd = normalize3(reflect3(f3(E.x * -1.0f, E.y * -1.0f, E.z * -1.0f), N));  // :217
+        int st6;
+        sc = cone_march<WRAP, FASTDIV, COOP>(p, alive, start, Rd, p.steps_specular, p.n_specular,
+                                             blk, lb, st6);
+        total += st6;
+        if (p.dbg_cones && alive) {
+            float* d = p.dbg_cones + pix * 28 + 24;
+            d[0] = sc.x; d[1] = sc.y; d[2] = sc.z; d[3] = sc.w;
+        }
+        if (p.dbg_steps && in_frame) p.dbg_steps[pix * 7 + 6] = (uint8_t)st6;
     }
-    const float spec_occ = 1.0f - sc.w;                                     // :221
-    const float sr = (sc.x + spec_occ * direct_spec) * g[19];               // :223
-    const float sg = (sc.y + spec_occ * direct_spec) * g[20];
-    const float sb = (sc.z + spec_occ * direct_spec) * g[21];
-    const float ar = p.ambient * g[15] * occlusion;                         // :225
-    const float ag = p.ambient * g[16] * occlusion;
-    const float ab = p.ambient * g[17] * occlusion;
 
-    float o0 = ar + dr + sr, o1 = ag + dg + sg, o2 = ab + db + sb, o3 = g[18];   // :227
-    if (!alive) {                                                           // VCT.h:156-159
-        const float cc = p.ambient < 0.5f ? 0.5f : 1.0f;
-        o0 = cc; o1 = cc; o2 = cc; o3 = 1.0f;
-    }
-    int total = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) total += alive ? nsteps[i] : 0;
+    // stage 3: composite                                                          trace.fs:179-227
+    const float* gb3 = gb;
+    asm volatile("" : "+v"(gb3));
+#undef VCT_GB
+#define VCT_GB(k) gb3[(k) * VCT_TILE_PIX]
     if (in_frame) {
+        const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2));
+        const F3 N = f3(VCT_GB(12), VCT_GB(13), VCT_GB(14));
+        const float alb_r = VCT_GB(15), alb_g = VCT_GB(16), alb_b = VCT_GB(17), alb_a = VCT_GB(18);
+        const float shadow = VCT_GB(22);
+        const F3 L = normalize3(f3(p.light[0], p.light[1], p.light[2]));        // :179
+        const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
+        const float cos_theta = fmaxf(dot3(N, L), 0.0f);                        // :188
+        const float direct_diffuse = shadow * cos_theta;                        // :192
+        const float occlusion = 1.0f - ind[3];                                  // :201
+        const float dr = (direct_diffuse + occlusion * ind[0]) * alb_r;         // :205
+        const float dg = (direct_diffuse + occlusion * ind[1]) * alb_g;
+        const float db = (direct_diffuse + occlusion * ind[2]) * alb_b;
+        const F3 R = normalize3(reflect3(f3(L.x * -1.0f, L.y * -1.0f, L.z * -1.0f), N));   // :212
+        const float spec = powf(fmaxf(dot3(E, R), 0.0f), p.shininess);          // :213
+        const float direct_spec = spec * shadow;                                // :214
+        const float spec_occ = 1.0f - sc.w;                                     // :221
+        const float sr = (sc.x + spec_occ * direct_spec) * VCT_GB(19);          // :223
+        const float sg = (sc.y + spec_occ * direct_spec) * VCT_GB(20);
+        const float sb = (sc.z + spec_occ * direct_spec) * VCT_GB(21);
+        const float ar = p.ambient * alb_r * occlusion;                         // :225
+        const float ag = p.ambient * alb_g * occlusion;
+        const float ab = p.ambient * alb_b * occlusion;
+        float o0 = ar + dr + sr, o1 = ag + dg + sg, o2 = ab + db + sb, o3 = alb_a;   // :227
+        if (!alive) {                                                           // VCT.h:156-159
+            const float cc = p.ambient < 0.5f ? 0.5f : 1.0f;
+            o0 = cc; o1 = cc; o2 = cc; o3 = 1.0f;
+        }
         uint2 pk;
         pk.x = pack_half2(o0, o1);
         pk.y = pack_half2(o2, o3);
         *reinterpret_cast<uint2*>(p.out + pix * 4) = pk;
-        if (p.dbg_steps) {
-            uint8_t* d = p.dbg_steps + pix * 7;
-#pragma unroll
-            for (int i = 0; i < 7; ++i) d[i] = alive ? (uint8_t)nsteps[i] : (uint8_t)0;
-        }
     }
+#undef VCT_GB
     // executed-step count: wave reduction, then one atomic into a counter bank (a single word
     // would serialise ~32k same-address atomics per 1080p frame)
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
