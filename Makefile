@@ -11,7 +11,7 @@ LIB := $(PKG)/libvct_amd.so
 
 HOSTLIB := $(PKG)/libvct_host.so
 
-all: lib host oracle
+all: lib host oracle demo
 
 host: $(HOSTLIB)
 
@@ -19,6 +19,13 @@ $(HOSTLIB): $(PKG)/host/vct_host.cpp $(PKG)/host/vct_host.h
 	g++ -O2 -std=c++17 -fPIC -Wall -Wextra -shared -o $@ $(PKG)/host/vct_host.cpp
 
 lib: $(LIB)
+
+# headless caller written against the facade header (the reference application's call sequence)
+DEMO := $(PKG)/vct_demo
+demo: $(DEMO)
+$(DEMO): $(PKG)/host/demo_main.cpp $(PKG)/host/Voxel_Cone_Tracing.h include/vct.h $(LIB) $(HOSTLIB)
+	g++ -O2 -std=c++17 -Wall -Wextra -o $@ $(PKG)/host/demo_main.cpp -L$(PKG) -lvct_amd -lvct_host \
+	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vct_internal.h $(CSRC)/vct_layout.h include/vct.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -30,7 +37,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(OBJS) $(LIB) $(HOSTLIB)
+	rm -f $(OBJS) $(LIB) $(HOSTLIB) $(DEMO)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib host oracle clean
+.PHONY: all lib host oracle demo clean

@@ -80,6 +80,7 @@ def main():
     import vctpkg
     vct = vctpkg.load()
     from voxel_cone_tracing_amd import scene as sc
+    from voxel_cone_tracing_amd import slabs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,25 +132,17 @@ def main():
             ctx.synchronize()
             gi = {"voxelize": None, "inject_resolve": None, "build_mips": e[0].elapsed_time(e[1])}
 
-    # ---- slab of this rank ----
-    tiles_y = (h + 7) // 8
-    rows_per_rank = (tiles_y + world - 1) // world
-    r0 = min(rank * rows_per_rank, tiles_y)
-    r1 = min(r0 + rows_per_rank, tiles_y)
-    slab_px = max(0, min(r1 * 8, h) - r0 * 8) * w
-    padded_rows = world * rows_per_rank * 8
-    frame_t = torch.zeros((padded_rows, w, 4), dtype=torch.float16, device=f"cuda:{local_rank}")
-    out_ptr = frame_t.data_ptr()
+    # ---- slab of this rank (voxel-cone-tracing_amd/slabs.py) ----
+    fg = slabs.FrameGather(h, w, world, rank, f"cuda:{local_rank}")
+    r0, r1 = slabs.partition(h, world)[rank]
+    y0, y1 = fg.my_rows()
+    slab_px = max(0, y1 - y0) * w
 
     # first trace uploads + tiles the G-buffer; afterwards everything is resident in HBM
-    ctx.trace(inp["planes"], rows=(r0, r1), out_device_ptr=out_ptr)
+    ctx.trace(inp["planes"], rows=(r0, r1), out_device_ptr=fg.slab.data_ptr() - y0 * w * 8
+              if y1 > y0 else fg.slab.data_ptr())
     steps_slab = ctx.last_step_count()
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [frame_t[r * rows_per_rank * 8:(r + 1) * rows_per_rank * 8] for r in range(world)]
-    my_slab = frame_t[rank * rows_per_rank * 8:(rank + 1) * rows_per_rank * 8]
     frame_dev, _ = ctx.frame_device()
-    y0, y1 = r0 * 8, min(r1 * 8, h)
     slab_src = None
     if world > 1 and y1 > y0:     # zero-copy torch view of the context-owned RGBA16F slab
         slab_src = torch.as_tensor(_DevView(frame_dev + y0 * w * 8, ((y1 - y0), w, 4)),
@@ -158,10 +151,10 @@ def main():
     def one_step():
         ctx.trace_resident()                      # the trace kernel, on the context stream
         if world > 1:
-            with torch.cuda.stream(ext_stream):   # slab -> gather buffer, then ONE gather
+            with torch.cuda.stream(ext_stream):   # slab -> gather buffer, then ONE gather (RCCL)
                 if slab_src is not None:
-                    frame_t[y0:y1].copy_(slab_src, non_blocking=True)
-                dist.gather(my_slab, gather_list, dst=0)
+                    fg.slab[: y1 - y0].copy_(slab_src, non_blocking=True)
+                fg.gather()
 
     def fence():
         if world > 1:

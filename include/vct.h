@@ -158,6 +158,12 @@ int vct_last_step_count(vct_ctx* ctx, uint64_t* steps);
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);
 /* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the
  * device pointers of the resident tiled G-buffer / RGBA16F frame. */
+/* Self-test of the kernel's constant division (x / d as x*r corrected by two FMA rounds, r = RN(1/d)):
+ * runs it on the GPU over every fp32 x of its domain (x == +0 or 2^-100 <= |x| < inf, normal quotient)
+ * next to the IEEE divide and returns the number of x whose quotient differs.  0 is the guarantee the
+ * trace kernel relies on (vct_trace.hip shows why the march never leaves that domain in a way that
+ * could change a result). */
+int vct_selftest_const_divide(vct_ctx* ctx, float d, uint64_t* mismatches);
 int vct_get_stream(vct_ctx* ctx, void** hip_stream);
 int vct_get_frame_device(vct_ctx* ctx, void** rgba16f_dev, size_t* bytes);
 

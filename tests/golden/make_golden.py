@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors under tests/golden/.
+
+The reference (AlerianEmperor/Voxel-Cone-Tracing) holds no tests, fixtures or golden images, and
+its implementation of this path is GLSL that cannot run here: these vectors are
+therefore produced by the build's own scalar oracle (oracle/vct_oracle.cpp) on seeded inputs.  They
+pin (1) the oracle against regressions / compiler drift and (2) the HIP path against fixed expected
+outputs without the oracle library being present at run time.
+
+    python tests/golden/make_golden.py        # rewrites the .npz files
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import synth                      # noqa: E402
+from oracle import pyoracle       # noqa: E402
+
+
+def small_scene(seed=5, ntri=60):
+    r = np.random.default_rng(seed)
+    c = r.uniform(-1200, 1200, (ntri, 1, 3))
+    pos = (c + r.normal(scale=120.0, size=(ntri, 3, 3))).astype(np.float32)
+    pos[0] = [[-1400, -1000, -1400], [1400, -1000, -1400], [1400, -1000, 1400]]    # a floor triangle
+    mat = r.integers(0, 3, ntri).astype(np.int32)
+    alb = np.array([[0.8, 0.2, 0.2, 1], [0.2, 0.8, 0.2, 1], [0.6, 0.6, 0.9, 1]], np.float32)
+    return pos, mat, alb
+
+
+def trace_case(V, w, h, vol_seed, gb_seed, occupancy, coherent, **params):
+    l0 = synth.noise_volume(V, seed=vol_seed, occupancy=occupancy)
+    chain = pyoracle.build_mips(l0)
+    planes = synth.coherent_gbuffer(w, h, seed=gb_seed) if coherent else \
+        synth.random_gbuffer(w * h, seed=gb_seed, discard_frac=0.1)
+    p = pyoracle.default_params(V, **params)
+    ref = pyoracle.trace(p, chain, planes, nthreads=1, want_cones=True)
+    return dict(V=V, w=w, h=h, level0=l0, planes=planes, chain=chain, rgba32f=ref["rgba32f"],
+                rgba16f=ref["rgba16f"], steps=ref["steps"], cones=ref["cones"],
+                total_steps=np.int64(ref["total_steps"]),
+                params=np.array([params.get("tan_diffuse", 0.577), params.get("tan_specular", 0.07),
+                                 params.get("ambient_factor", 0.1), params.get("wrap_repeat", 1)],
+                                np.float32))
+
+
+def main():
+    # 1. SURVEY.md 8c suggestion: 16^3 volume + 8x8 G-buffer -> 64 RGBA fp32 + 64x7 step counts
+    np.savez_compressed(os.path.join(HERE, "trace_v16_8x8_random.npz"),
+                        **trace_case(16, 8, 8, 11, 42, 0.15, False))
+    # 2. a screen-coherent tile set (cooperative sampler path), ragged frame
+    np.savez_compressed(os.path.join(HERE, "trace_v32_20x12_coherent.npz"),
+                        **trace_case(32, 20, 12, 3, 3, 0.25, True))
+    # 3. clamp-to-edge wrap mode + a wider specular aperture (config 5 roughness sweep)
+    np.savez_compressed(os.path.join(HERE, "trace_v16_8x8_clamp_glossy.npz"),
+                        **trace_case(16, 8, 8, 12, 7, 0.2, False, wrap_repeat=0, tan_specular=0.2))
+    # 4. voxelization (conservative + integer average) + mip chain of a small triangle soup
+    V = 32
+    pos, mat, alb = small_scene()
+    p = pyoracle.default_params(V)
+    sc = pyoracle.make_scene(pos, mat, alb)
+    l0, acc = pyoracle.voxelize_conservative(p, sc, want_acc=True)
+    np.savez_compressed(os.path.join(HERE, "voxelize_v32.npz"), V=V, pos=pos, material=mat, albedo=alb,
+                        level0=l0, count=acc[..., 3].astype(np.uint16), chain=pyoracle.build_mips(l0))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""Committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py).
+
+CPU: the oracle must reproduce them bit for bit (regression / compiler-drift guard).
+GPU: the HIP path must reproduce them through the C ABI WITHOUT the oracle being involved."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRACE_CASES = sorted(glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+REL_L2_TOL = 1e-3      # BASELINE.json north_star: within 1e-3 relative L2 (fp32)
+
+
+def _params_kw(g):
+    td, ts, amb, wrap = g["params"]
+    return dict(tan_diffuse=float(td), tan_specular=float(ts), ambient_factor=float(amb),
+                wrap_repeat=int(wrap))
+
+
+def test_fixture_set_is_complete():
+    assert len(TRACE_CASES) == 3
+    assert os.path.exists(os.path.join(GOLDEN, "voxelize_v32.npz"))
+
+
+@pytest.mark.parametrize("path", TRACE_CASES, ids=os.path.basename)
+def test_oracle_reproduces_golden_trace(oracle, path):
+    g = np.load(path)
+    V = int(g["V"])
+    chain = oracle.build_mips(g["level0"])
+    assert np.array_equal(chain, g["chain"])
+    ref = oracle.trace(oracle.default_params(V, **_params_kw(g)), chain, g["planes"], nthreads=2,
+                       want_cones=True)
+    assert np.array_equal(ref["steps"], g["steps"])
+    assert np.array_equal(ref["cones"].view(np.uint32), g["cones"].view(np.uint32))
+    assert np.array_equal(ref["rgba32f"].view(np.uint32), g["rgba32f"].view(np.uint32))
+    assert np.array_equal(ref["rgba16f"], g["rgba16f"])
+    assert ref["total_steps"] == int(g["total_steps"])
+
+
+def test_oracle_reproduces_golden_voxelization(oracle):
+    g = np.load(os.path.join(GOLDEN, "voxelize_v32.npz"))
+    V = int(g["V"])
+    sc = oracle.make_scene(g["pos"], g["material"], g["albedo"])
+    l0, acc = oracle.voxelize_conservative(oracle.default_params(V), sc, want_acc=True)
+    assert np.array_equal(l0, g["level0"])
+    assert np.array_equal(acc[..., 3], g["count"])
+    assert np.array_equal(oracle.build_mips(l0), g["chain"])
+    assert 0.01 < (l0[..., 3] > 0).mean() < 0.6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("path", TRACE_CASES, ids=os.path.basename)
+def test_hip_reproduces_golden_trace(path, variant):
+    import vctpkg
+    vct = vctpkg.load()
+    g = np.load(path)
+    V, w, h = int(g["V"]), int(g["w"]), int(g["h"])
+    kw = _params_kw(g)
+    with vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, debug_outputs=1,
+                                        trace_variant=variant, **kw)) as ctx:
+        ctx.upload_volume(g["level0"])
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), g["chain"])
+        out = ctx.trace(g["planes"])
+        assert np.array_equal(ctx.steps(), g["steps"])
+        assert np.array_equal(ctx.cones().view(np.uint32), g["cones"].view(np.uint32))
+        assert ctx.last_step_count() == int(g["total_steps"])
+        err = synth.rel_l2(vct.half_to_float(out.reshape(-1, 4)), g["rgba32f"])
+        assert err <= REL_L2_TOL, err
+        assert (out.reshape(-1, 4) == g["rgba16f"]).mean() > 0.995
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_voxelization():
+    import vctpkg
+    vct = vctpkg.load()
+    g = np.load(os.path.join(GOLDEN, "voxelize_v32.npz"))
+    with vct.Context(vct.default_config(voxel_dim=int(g["V"]), width=8, height=8)) as ctx:
+        ctx.upload_triangles(g["pos"], g["material"], g["albedo"])
+        ctx.voxelize()
+        ctx.inject_light()
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), g["chain"])

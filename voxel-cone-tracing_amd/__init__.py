@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "vct_download_chain_rgba8", "vct_chain_texels", "vct_trace", "vct_trace_slab",
     "vct_trace_resident", "vct_synchronize", "vct_download_steps", "vct_download_cones",
     "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream", "vct_get_frame_device",
+    "vct_selftest_const_divide",
 ]
 
 
@@ -88,6 +89,7 @@ for _n in ("vct_inject_light", "vct_build_mips", "vct_trace_resident", "vct_sync
 _lib.vct_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
 _lib.vct_trace_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
 _lib.vct_get_frame_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.vct_selftest_const_divide.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
 
 
 def lib():
@@ -256,6 +258,11 @@ class Context:
     def last_trace_ms(self):
         v = C.c_float()
         self._ck(_lib.vct_last_trace_ms(self._h, C.byref(v)), "vct_last_trace_ms")
+        return v.value
+
+    def selftest_const_divide(self, d):
+        v = C.c_uint64()
+        self._ck(_lib.vct_selftest_const_divide(self._h, float(d), C.byref(v)), "vct_selftest_const_divide")
         return v.value
 
     def stream(self):

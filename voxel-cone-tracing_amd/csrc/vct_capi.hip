@@ -151,9 +151,16 @@ int refresh_steps(vct_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // d, s go out of scope
     c->n_diffuse = (int)d.size();
     c->n_specular = (int)s.size();
-    bool ok = divisor_ok(c->cfg.grid_world_size * 0.5f);
-    for (const VctStep& st : d) ok = ok && divisor_ok(st.occ_den);
-    for (const VctStep& st : s) ok = ok && divisor_ok(st.occ_den);
+    // preconditions of the kernel's FMA division (vct_trace.hip div_const): admissible divisors, and
+    // occlusion numerators bounded away from the underflow range (blend factors 0 or >= 2^-10,
+    // 1 - alpha >= 2^-5 while a cone is live)
+    bool ok = divisor_ok(c->cfg.grid_world_size * 0.5f) && (1.0f - c->cfg.max_alpha) >= 0x1p-5f;
+    auto blend_ok = [](const VctStep& st) {
+        if (!st.two_levels) return true;
+        return st.frac >= 0x1p-10f && (1.0f - st.frac) >= 0x1p-10f;
+    };
+    for (const VctStep& st : d) ok = ok && divisor_ok(st.occ_den) && blend_ok(st);
+    for (const VctStep& st : s) ok = ok && divisor_ok(st.occ_den) && blend_ok(st);
     c->fast_div = ok;
     c->steps_dirty = false;
     return VCT_OK;
@@ -607,6 +614,24 @@ int vct_last_trace_ms(vct_ctx* c, float* ms) {
     if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return VCT_OK;
+}
+
+int vct_selftest_const_divide(vct_ctx* c, float d, uint64_t* mismatches) {
+    if (!c || !mismatches) return VCT_ERR_INVALID;
+    if (!divisor_ok(d)) return fail(c, VCT_ERR_INVALID, "divisor outside the set the FMA division is proven for");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, vct_launch_divide_selftest(d, c->step_counter, c->stream));
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(v, c->step_counter, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *mismatches = v[0];
+    if (v[0]) {      // not a failure of the call: leave one offending x readable for diagnosis
+        char msg[96];
+        snprintf(msg, sizeof(msg), "const divide by %.9g: %llu mismatches, e.g. x bits 0x%08llx", d, v[0], v[1]);
+        c->err = msg;
+    }
     return VCT_OK;
 }
 

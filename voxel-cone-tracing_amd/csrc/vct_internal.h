@@ -76,6 +76,7 @@ struct VctVoxParams {
 };
 
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);
+hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s);
 hipError_t vct_launch_linear_to_morton(const uint32_t* lin, uint32_t* mor, int N, hipStream_t s);
 hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N, hipStream_t s);
 hipError_t vct_launch_build_mips(uint32_t* chain, int V, hipStream_t s);

@@ -58,9 +58,19 @@ __device__ __forceinline__ F3 reflect3(F3 I, F3 N) {
     return {I.x - d * N.x, I.y - d * N.y, I.z - d * N.z};
 }
 
-// x / d for a wave-uniform divisor d with r = RN(1/d): correctly rounded for every finite x whose
-// quotient is a normal number (host-side precondition on d: vct_capi.hip divisor_ok).  Five
-// 2-cycle instructions instead of v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup.
+// x / d for a wave-uniform divisor d with r = RN(1/d): correctly rounded for x == +0 and every
+// finite |x| >= 2^-100 whose quotient is a normal number (host-side precondition on d:
+// vct_capi.hip divisor_ok; below ~2^-102 the exact remainder e can underflow; -0 returns +0).
+// Five 2-cycle instructions instead of v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup.
+// Checked against the IEEE divide over every fp32 x of that domain by vct_selftest_const_divide.
+// The march stays inside the domain by construction:
+//   * coordinates: |x| < 2^-100 or x == -0 gives |q| < 2^-26, and u = fma(q, .5, .5) = 0.5 for any
+//     such q, exactly as with the IEEE quotient;
+//   * occlusion numerator oma * vc.w: never -0, and either +0 or >= 2^-98 -- a non-zero filter
+//     fraction is >= 2^-25 (u = fma(ux, N, -0.5) is exact and a multiple of 2^-25 near 0), so a
+//     non-zero trilinear weight is >= 2^-75, a non-zero texel >= 1/255, the level blend factors are
+//     0 or >= 2^-10 and oma >= 2^-5 (both checked on the host: vct_capi.hip refresh_steps).
+#define VCT_DIV_TINY 0x1p-100f
 template <bool FAST>
 __device__ __forceinline__ float div_const(float x, float d, float r) {
     if (!FAST) return x / d;
@@ -233,7 +243,8 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
         if (!__any(act)) break;
         const VctStep st = nxt;
         nxt = load_step(tab, k + 1 < n ? k + 1 : k);
-        // trace.fs:98 + :61-63.  (q * 0.5f is exact, so fmaf(q, .5, .5) is the oracle's q*.5f + .5f.)
+        // trace.fs:98 + :61-63.  (q * 0.5f is exact, so fmaf(q, .5, .5) is the oracle's q*.5f + .5f;
+        // a coordinate below div_const's 2^-100 domain gives |q| < 2^-26 and u = 0.5 either way.)
         const float px = start.x + dir.x * st.dist;
         const float py = start.y + dir.y * st.dist;
         const float pz = start.z + dir.z * st.dist;
@@ -435,7 +446,32 @@ hipError_t launch_v(const VctTraceParams& p, int variant, int blocks, hipStream_
                         : launch<WRAP, FASTDIV, true>(p, blocks, s);
 }
 
+// every fp32 bit pattern: div_const<true> against the IEEE divide
+__global__ void __launch_bounds__(256)
+k_divide_selftest(float d, float r, unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    const unsigned long long total = 1ull << 32;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)i);
+        if (!(fabsf(x) <= 3.0e38f)) continue;                 // inf / nan
+        if (fabsf(x) < VCT_DIV_TINY && (uint32_t)i != 0u) continue;   // outside the documented domain
+        const float want = x / d;
+        if (want != 0.0f && fabsf(want) < 1.17549435e-38f) continue;   // subnormal quotient
+        if (fabsf(want) > 3.0e38f) continue;
+        const float got = div_const<true>(x, d, r);
+        if (__float_as_uint(got) != __float_as_uint(want)) { ++bad; mismatches[1] = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace
+
+hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s) {
+    hipLaunchKernelGGL(k_divide_selftest, dim3(256 * 16), dim3(256), 0, s, d, 1.0f / d, mismatches);
+    return hipGetLastError();
+}
 
 // variant 0: cooperative sampler with per-lane fallback (default); 1: per-lane sampler only.
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s) {

@@ -1,0 +1,273 @@
+// Voxel_Cone_Tracing.h -- call-compatible facade over the MI355X C ABI (include/vct.h).
+//
+// Stands where the reference's header-only orchestrator stands (R/Voxel_Cone_Tracing.h:11-252): a
+// caller written against the reference -- `camera` global, `Voxel_Cone_Tracing(w, h, window)`,
+// `init_voxel_cone_tracing()`, `Render()` per frame (R/main.cpp:64-68,90) -- compiles against this
+// header unchanged in those lines.  The type, member and method names are the reference's public
+// surface; nothing else is shared: there is no GL, no GLSL and no glm here.  Where the reference
+// binds GL objects and issues draws, each method forwards to the C ABI:
+//
+//   init_voxel_cone_tracing()  VCT.h:67-140   -> vct_create, scene upload, DrawDepthTexture, DrawVoxelTexture
+//   DrawDepthTexture()         VCT.h:192-211  -> shadow-map input stage (host raster, vct_host.h) + vct_upload_shadow_map
+//   DrawVoxelTexture()         VCT.h:213-250  -> vct_voxelize + vct_inject_light + vct_build_mips
+//   Render()                   VCT.h:146-190  -> G-buffer input stage (host raster) + vct_trace -> RGBA16F frame
+//
+// Differences a caller can observe, all forced by running headless on a compute GPU:
+//   * `GLFWwindow` is an opaque forward declaration; Render() does not query the window size.
+//   * The frame lands in an RGBA16F host buffer (`Frame()`), not in GL framebuffer 0.
+//   * `VoxelDimensions` / `VoxelGridWorldSize` are plain members (the reference declares them const,
+//     which pins it to 128^3): set them before init_voxel_cone_tracing().
+//   * `model` is loaded from a procedural scene name instead of the reference's absolute Windows
+//     path (VCT.h:77; the reference ships no assets): "procedural:atrium" or "procedural:cornell".
+//   * Errors keep the reference's print-and-continue behaviour (VCT.h:101-105) and are also
+//     readable through `last_status` / vct_last_error(ctx).
+#ifndef VOXEL_CONE_TRACING_FACADE_H_
+#define VOXEL_CONE_TRACING_FACADE_H_
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vct.h"
+#include "vct_host.h"
+
+struct GLFWwindow;   // opaque: the headless build never dereferences it (the reference does once, VCT.h:149)
+
+// ---- the few glm spellings the reference's public fields use -----------------------------------
+struct vec3 {
+    float x, y, z;
+    vec3() : x(0), y(0), z(0) {}
+    vec3(float a, float b, float c) : x(a), y(b), z(c) {}
+    vec3 operator+(const vec3& o) const { return vec3(x + o.x, y + o.y, z + o.z); }
+    vec3 operator-(const vec3& o) const { return vec3(x - o.x, y - o.y, z - o.z); }
+    vec3 operator*(float s) const { return vec3(x * s, y * s, z * s); }
+    vec3& operator+=(const vec3& o) { x += o.x; y += o.y; z += o.z; return *this; }
+    vec3& operator-=(const vec3& o) { x -= o.x; y -= o.y; z -= o.z; return *this; }
+};
+struct mat4 {          // column-major like glm: m[col*4 + row]
+    float m[16];
+    mat4() { memset(m, 0, sizeof(m)); m[0] = m[5] = m[10] = m[15] = 1.0f; }
+};
+namespace vct_facade {
+inline float dot(const vec3& a, const vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline vec3 cross(const vec3& a, const vec3& b) {
+    return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline vec3 normalize(const vec3& a) { const float l = sqrtf(dot(a, a)); return a * (1.0f / l); }
+inline float radians(float deg) { return deg * 0.017453292519943295f; }
+inline mat4 mul(const mat4& a, const mat4& b) {
+    mat4 r;
+    for (int c = 0; c < 4; ++c)
+        for (int row = 0; row < 4; ++row) {
+            float s = 0.0f;
+            for (int k = 0; k < 4; ++k) s += a.m[k * 4 + row] * b.m[c * 4 + k];
+            r.m[c * 4 + row] = s;
+        }
+    return r;
+}
+inline mat4 ortho(float l, float r, float b, float t, float n, float f) {
+    mat4 o;
+    o.m[0] = 2.0f / (r - l); o.m[5] = 2.0f / (t - b); o.m[10] = -2.0f / (f - n);
+    o.m[12] = -(r + l) / (r - l); o.m[13] = -(t + b) / (t - b); o.m[14] = -(f + n) / (f - n);
+    return o;
+}
+inline mat4 lookAt(const vec3& eye, const vec3& center, const vec3& up) {
+    const vec3 f = normalize(center - eye), s = normalize(cross(f, up)), u = cross(s, f);
+    mat4 o;
+    o.m[0] = s.x; o.m[4] = s.y; o.m[8] = s.z;
+    o.m[1] = u.x; o.m[5] = u.y; o.m[9] = u.z;
+    o.m[2] = -f.x; o.m[6] = -f.y; o.m[10] = -f.z;
+    o.m[12] = -dot(s, eye); o.m[13] = -dot(u, eye); o.m[14] = dot(f, eye);
+    return o;
+}
+}  // namespace vct_facade
+
+// ---- Camera: the fly camera main.cpp drives (R/Camera.h:28-145), same members and defaults -----
+enum Camera_Direction { FORWARD, BACKWARD, LEFT, RIGHT, UP, DOWN };
+
+class Camera {
+public:
+    vec3 position, Front, Up, Right, WorldUp;
+    float Yaw, Pitch;
+    float MovementSpeed, MouseSensitivity, Zoom;
+
+    explicit Camera(vec3 position_ = vec3(0.0f, 0.0f, 0.0f), vec3 Up_ = vec3(0.0f, 1.0f, 0.0f),
+                    float Yaw_ = -90.0f, float Pitch_ = 0.0f)
+        : position(position_), Front(0.0f, 0.0f, -1.0f), Up(0.0f, 1.0f, 0.0f), WorldUp(Up_),
+          Yaw(Yaw_), Pitch(Pitch_), MovementSpeed(2.6f), MouseSensitivity(0.1f), Zoom(45.0f) {
+        UpdateCamera();
+    }
+    mat4 GetViewMatrix() const { return vct_facade::lookAt(position, position + Front, Up); }
+    void ProcessKeyBoard(Camera_Direction direction, float& deltaTime) {
+        const float v = MovementSpeed * deltaTime;
+        switch (direction) {
+            case FORWARD: position += Front * v; break;
+            case BACKWARD: position -= Front * v; break;
+            case LEFT: position -= Right * v; break;
+            case RIGHT: position += Right * v; break;
+            case UP: position += WorldUp * v; break;
+            case DOWN: position -= WorldUp * v; break;
+        }
+    }
+    void ProcessMouseMovement(float& xOffset, float& yOffset, bool constrainPitch = true) {
+        xOffset *= MouseSensitivity;
+        yOffset *= MouseSensitivity;
+        Yaw += xOffset;
+        Pitch += yOffset;
+        if (constrainPitch) Pitch = fminf(fmaxf(Pitch, -89.0f), 89.0f);
+        UpdateCamera();
+    }
+    void ProcessMouseScroll(float yOffset) { Zoom = fminf(fmaxf(Zoom - yOffset, 1.0f), 45.0f); }
+    void UpdateCamera() {
+        using namespace vct_facade;
+        const float cy = cosf(radians(Yaw)), sy = sinf(radians(Yaw));
+        const float cp = cosf(radians(Pitch)), sp = sinf(radians(Pitch));
+        Front = normalize(vec3(cy * cp, sp, sy * cp));
+        Right = normalize(cross(Front, WorldUp));
+        Up = normalize(cross(Right, Front));
+    }
+};
+
+// the header-defined global main.cpp mutates (VCT.h:8)
+inline Camera camera(vec3(0.0f, 4.0f, 0.0f));
+
+// ---- Model: scene container (R/Model.h).  Procedural stand-ins, see the header comment. --------
+struct Model {
+    vcth_scene* scene = nullptr;
+    std::string path;
+    Model() {}
+    explicit Model(const std::string& p) { Load(p); }
+    Model(const Model&) = delete;
+    Model& operator=(const Model&) = delete;
+    ~Model() { if (scene) vcth_scene_destroy(scene); }
+    bool Load(const std::string& p) {
+        if (scene) { vcth_scene_destroy(scene); scene = nullptr; }
+        path = p;
+        if (p == "procedural:cornell") scene = vcth_scene_create(0, 1.0f, 1234u);
+        else if (p == "procedural:atrium") scene = vcth_scene_create(1, 1.0f, 1234u);
+        if (!scene) printf("ERROR::MODEL: cannot load '%s' (use procedural:atrium | procedural:cornell)\n", p.c_str());
+        return scene != nullptr;
+    }
+};
+
+struct Voxel_Cone_Tracing {
+    // Global properties                                                        VCT.h:14-17
+    vec3 lightDirection = vec3(0.0f, 1.0f, 0.25f);
+    int VoxelDimensions = 128;
+    float VoxelGridWorldSize = 150.0f;
+
+    GLFWwindow* window = nullptr;
+    int screen_width = 1280;                                                 // VCT.h:24-25
+    int screen_height = 720;
+
+    unsigned ShadowMapSize = 4096;                                           // VCT.h:35
+
+    mat4 DepthViewProjectionMatrix, ProjX, ProjY, ProjZ;                     // VCT.h:42-45
+    Model model;                                                             // VCT.h:48
+    std::string model_path = "procedural:atrium";
+
+    bool ShowDiffuse = true, ShowIndirectDiffuse = true, ShowSpecular = true,
+         ShowIndirectSpecular = true, ShowAmbientOcclusion = true;           // VCT.h:51 (never uploaded there either)
+    float AmbientFactor = 0.1f;                                              // VCT.h:53
+
+    // what replaces the GL object names (Depth_FBO, Depth_Texture, VoxelTexture)
+    vct_ctx* ctx = nullptr;
+    int last_status = VCT_OK;
+    std::vector<float> Depth_Texture;        // ShadowMapSize^2 depths in [0,1]
+    std::vector<float> GBuffer;              // 23 planes, linear
+    std::vector<uint16_t> FrameRGBA16F;      // screen_width * screen_height * 4 halves
+
+    Voxel_Cone_Tracing() {}
+    Voxel_Cone_Tracing(int screen_width_, int screen_height_, GLFWwindow*& window_)
+        : window(window_), screen_width(screen_width_), screen_height(screen_height_) {}
+    Voxel_Cone_Tracing(const Voxel_Cone_Tracing&) = delete;
+    Voxel_Cone_Tracing& operator=(const Voxel_Cone_Tracing&) = delete;
+    ~Voxel_Cone_Tracing() { if (ctx) vct_destroy(ctx); }
+
+    void init_voxel_cone_tracing() {
+        using namespace vct_facade;
+        vct_config cfg;
+        vct_default_config(&cfg);
+        cfg.voxel_dim = VoxelDimensions;
+        cfg.grid_world_size = VoxelGridWorldSize;
+        cfg.width = screen_width;
+        cfg.height = screen_height;
+        cfg.shadow_map_size = (int32_t)ShadowMapSize;
+        cfg.ambient_factor = AmbientFactor;
+        if (!check(vct_create(&cfg, &ctx), "vct_create")) return;
+        if (!model.Load(model_path)) { last_status = VCT_ERR_INVALID; return; }
+
+        // VCT.h:84-86 and :128-134 (the projections are kept as public data; the HIP voxelizer maps
+        // world -> voxel directly, which is what the three of them amount to: SURVEY.md a8)
+        const float L[3] = {lightDirection.x, lightDirection.y, lightDirection.z};
+        vcth_light_view_proj(L, DepthViewProjectionMatrix.m);
+        const float G = VoxelGridWorldSize, h = G * 0.5f;
+        const mat4 o = ortho(-h, h, -h, h, h, G * 1.5f);
+        ProjX = mul(o, lookAt(vec3(G, 0, 0), vec3(0, 0, 0), vec3(0, 1, 0)));
+        ProjY = mul(o, lookAt(vec3(0, G, 0), vec3(0, 0, 0), vec3(0, 0, -1)));
+        ProjZ = mul(o, lookAt(vec3(0, 0, G), vec3(0, 0, 0), vec3(0, 1, 0)));
+
+        const int32_t ntri = vcth_scene_num_triangles(model.scene), nmat = vcth_scene_num_materials(model.scene);
+        std::vector<float> pos((size_t)ntri * 9), albedo((size_t)nmat * 4);
+        std::vector<int32_t> material((size_t)ntri);
+        vcth_scene_get(model.scene, pos.data(), material.data(), albedo.data(), nullptr);
+        if (!check(vct_upload_triangles(ctx, pos.data(), material.data(), ntri, albedo.data(), nmat),
+                   "vct_upload_triangles")) return;
+        DrawDepthTexture();     // VCT.h:138
+        DrawVoxelTexture();     // VCT.h:139
+    }
+
+    void Render() {
+        if (!ctx || !model.scene) return;
+        vct_set_ambient_factor(ctx, AmbientFactor);
+        const float cam[3] = {camera.position.x, camera.position.y, camera.position.z};   // VCT.h:167
+        const float L[3] = {lightDirection.x, lightDirection.y, lightDirection.z};         // VCT.h:168
+        vct_set_camera_position(ctx, cam);
+        vct_set_light_direction(ctx, L);
+        vcth_camera hc;
+        memcpy(hc.position, cam, sizeof(cam));
+        hc.yaw = camera.Yaw; hc.pitch = camera.Pitch; hc.zoom = camera.Zoom;
+        hc.z_near = 0.1f; hc.z_far = 1000.0f;                                              // VCT.h:162
+        GBuffer.resize((size_t)VCT_GB_PLANES * screen_width * screen_height);
+        vcth_render_gbuffer(model.scene, 0.05f, &hc, screen_width, screen_height,
+                            Depth_Texture.empty() ? nullptr : Depth_Texture.data(), (int32_t)ShadowMapSize,
+                            DepthViewProjectionMatrix.m, GBuffer.data());
+        vct_gbuffer gb;
+        gb.planes = GBuffer.data();
+        gb.width = screen_width; gb.height = screen_height;
+        gb.layout = VCT_GB_LINEAR; gb.location = VCT_MEM_HOST;
+        FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
+        check(vct_trace(ctx, &gb, FrameRGBA16F.data(), VCT_MEM_HOST), "vct_trace");
+    }
+
+    void DrawDepthTexture() {
+        if (!ctx || !model.scene) return;
+        Depth_Texture.resize((size_t)ShadowMapSize * ShadowMapSize);
+        vcth_render_shadow_map(model.scene, 0.05f, DepthViewProjectionMatrix.m, (int32_t)ShadowMapSize,
+                               Depth_Texture.data());
+        check(vct_upload_shadow_map(ctx, Depth_Texture.data(), (int32_t)ShadowMapSize,
+                                    DepthViewProjectionMatrix.m), "vct_upload_shadow_map");
+    }
+
+    void DrawVoxelTexture() {
+        if (!ctx) return;
+        if (!check(vct_voxelize(ctx, VCT_VOX_CONSERVATIVE_AVG), "vct_voxelize")) return;
+        if (!check(vct_inject_light(ctx), "vct_inject_light")) return;
+        check(vct_build_mips(ctx), "vct_build_mips");                       // VCT.h:248
+    }
+
+    const uint16_t* Frame() const { return FrameRGBA16F.data(); }
+
+private:
+    bool check(int rc, const char* what) {
+        last_status = rc;
+        if (rc != VCT_OK) printf("ERROR::VCT::%s: %s\n", what, vct_last_error(ctx));
+        return rc == VCT_OK;
+    }
+};
+
+#endif

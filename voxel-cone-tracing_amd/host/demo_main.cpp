@@ -1,0 +1,90 @@
+// demo_main.cpp -- headless caller with the reference application's call sequence
+// (R/main.cpp:64-68 set-up, :77-94 frame loop) against the facade header: proves that a caller
+// written for the reference's orchestrator drives the MI355X path unchanged.  Instead of a GLFW
+// window and swap-buffers it renders N frames, prints a checksum of the last RGBA16F frame and
+// optionally writes it as a tonemapped PPM.
+//
+//   vct_demo [--scene procedural:atrium|procedural:cornell] [--voxels 128] [--size 1280x720]
+//            [--shadow 4096] [--frames 3] [--ppm out.ppm]
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "Voxel_Cone_Tracing.h"
+
+static const int SCREEN_WIDTH = 1280;
+static const int SCREEN_HEIGHT = 720;
+
+static float half_to_float(uint16_t h) {
+    const uint32_t s = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    float f;
+    if (e == 0) f = ldexpf((float)m, -24);
+    else if (e == 31) f = m ? NAN : INFINITY;
+    else f = ldexpf((float)(m | 0x400u), (int)e - 25);
+    return s ? -f : f;
+}
+
+int main(int argc, char** argv) {
+    int w = SCREEN_WIDTH, h = SCREEN_HEIGHT, frames = 3, voxels = 128, shadow = 4096;
+    const char* scene = "procedural:atrium";
+    const char* ppm = nullptr;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--scene")) scene = argv[i + 1];
+        else if (!strcmp(argv[i], "--voxels")) voxels = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--size")) sscanf(argv[i + 1], "%dx%d", &w, &h);
+        else if (!strcmp(argv[i], "--shadow")) shadow = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--frames")) frames = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--ppm")) ppm = argv[i + 1];
+    }
+    GLFWwindow* window = nullptr;          // no window system on a compute node
+
+    camera.MovementSpeed = 5.0f;           // R/main.cpp:64-65
+    camera.MouseSensitivity = 0.5f;
+    if (!strcmp(scene, "procedural:cornell")) {
+        camera.position = vec3(0.0f, 0.0f, 58.0f);
+    } else {
+        camera.position = vec3(-56.0f, -9.0f, 2.0f);
+        camera.Yaw = 0.0f; camera.Pitch = 8.0f;
+        camera.UpdateCamera();
+    }
+    Voxel_Cone_Tracing voxel_cone_tracing(w, h, window);    // R/main.cpp:66
+    voxel_cone_tracing.VoxelDimensions = voxels;
+    voxel_cone_tracing.ShadowMapSize = (unsigned)shadow;
+    voxel_cone_tracing.model_path = scene;
+    voxel_cone_tracing.init_voxel_cone_tracing();           // R/main.cpp:68
+    if (voxel_cone_tracing.last_status != VCT_OK) return 2;
+
+    float delta_time = 0.05f;
+    for (int f = 0; f < frames; ++f) {                      // R/main.cpp:77-94
+        if (f > 0) camera.ProcessKeyBoard(FORWARD, delta_time);
+        voxel_cone_tracing.Render();
+        if (voxel_cone_tracing.last_status != VCT_OK) return 3;
+    }
+    const uint16_t* fr = voxel_cone_tracing.Frame();
+    const size_t n = (size_t)w * h * 4;
+    uint64_t sum = 1469598103934665603ull;                  // FNV-1a over the RGBA16F halves
+    for (size_t i = 0; i < n; ++i) { sum ^= fr[i]; sum *= 1099511628211ull; }
+    uint64_t steps = 0;
+    vct_last_step_count(voxel_cone_tracing.ctx, &steps);
+    float ms = 0.0f;
+    vct_last_trace_ms(voxel_cone_tracing.ctx, &ms);
+    printf("frames=%d size=%dx%d voxels=%d cone_steps=%llu trace_ms=%.3f fnv1a=%016llx\n", frames, w, h,
+           voxels, (unsigned long long)steps, ms, (unsigned long long)sum);
+    if (ppm) {
+        FILE* fp = fopen(ppm, "wb");
+        if (!fp) return 4;
+        fprintf(fp, "P6\n%d %d\n255\n", w, h);
+        for (int y = h - 1; y >= 0; --y)            // row 0 is the bottom row of the GL window
+            for (int x = 0; x < w; ++x) {
+                unsigned char px[3];
+                for (int c = 0; c < 3; ++c) {
+                    float v = half_to_float(fr[((size_t)y * w + x) * 4 + c]);
+                    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                    px[c] = (unsigned char)(powf(v, 1.0f / 2.2f) * 255.0f + 0.5f);
+                }
+                fwrite(px, 1, 3, fp);
+            }
+        fclose(fp);
+    }
+    return 0;
+}
