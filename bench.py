@@ -196,6 +196,7 @@ def main():
         # roofline of the dominant kernel (trace) on this rank's launch
         alg_bytes = steps_slab * BYTES_PER_STEP + slab_px * BYTES_PER_PIXEL
         achieved = alg_bytes / (float(np.mean(kernel_ms)) * 1e-3) / 1e9
+        traffic, traffic_note = pmc_traffic(args, world, float(np.mean(kernel_ms)))
         result = {
             "metric": "Mcones/s (+ ms per GI pass), Sponza-class 256^3 @1080p",
             "value": round(value, 1),
@@ -220,9 +221,12 @@ def main():
             | {"trace": round(kernel_ms_avg, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None,
-                         "note": "algorithmic bytes = steps*64 + px*100 per launch / HIP-event "
-                                 "kernel time; the 73 MiB chain is Infinity-Cache resident at 256^3"},
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "achieved = (cone steps*64 B + px*100 B) per launch / HIP-event kernel "
+                                 "time on the context stream. At 256^3 the 73 MiB chain is L2/Infinity-"
+                                 "Cache resident and the kernel is VALU-issue bound (DESIGN.md 3.1), so "
+                                 "frac against the HBM peak may exceed 1. " + traffic_note},
         }
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(args, inp, ctx, vct)
@@ -231,6 +235,23 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, world, kernel_ms):
+    """HBM GB/s actually moved by the trace kernel: PMC bytes per launch from the committed rocprofv3
+    counter passes of this same command (profiles/trace_traffic.json, written by
+    tools/summarize_prof.py with the FETCH_SIZE x2 correction calibrated on this box) / this run's
+    kernel time.  Only valid for the default single-GPU workload."""
+    path = os.path.join(ROOT, "profiles", "trace_traffic.json")
+    default = (world == 1 and args.voxel_dim == 256 and args.width == 1920 and args.height == 1080
+               and args.scene == "atrium" and args.variant == 0)
+    if not default or not os.path.exists(path):
+        return None, "traffic: no PMC pass for this configuration."
+    with open(path) as fh:
+        t = json.load(fh)
+    gbs = t["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+    return round(gbs, 1), (f"traffic = PMC HBM bytes per launch ({t['hbm_bytes_per_launch'] / 1e6:.0f} MB, "
+                           f"{t['source']}: (2*FETCH_SIZE+WRITE_SIZE)*1024) / kernel time, GB/s.")
 
 
 class _DevView:

@@ -37,6 +37,25 @@ def main():
             for k, cs in acc.items():
                 for c, v in cs.items():
                     lines.append(f"{k[:70]:70s} {c:34s} n={len(v):4d} mean={sum(v)/len(v):.6g}")
+    # HBM traffic of the trace kernel per launch, corrected as calibrated on this box
+    # (profiles/r01_fetch_write_calibration.txt): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024
+    traffic = {}
+    for p in sorted(glob.glob(os.path.join(src, "pmc*"))):
+        for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if "k_trace_tile" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                        traffic.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if len(traffic) == 2 and len(sys.argv) > 3:
+        import json
+        fetch = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
+        write = sum(traffic["WRITE_SIZE"]) / len(traffic["WRITE_SIZE"])
+        with open(sys.argv[3], "w") as fh:
+            json.dump({"kernel": "k_trace_tile", "source": os.path.basename(dst),
+                       "fetch_size_kib": fetch, "write_size_kib": write,
+                       "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+                       "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, calibrated with tools/fetch_calib.hip"}, fh, indent=1)
+        lines.append(f"== trace kernel HBM bytes per launch (corrected): {(2.0 * fetch + write) * 1024.0:.4g} ==")
     if os.path.exists(os.path.join(src, "passes.txt")):
         lines.append("== passes ==")
         lines += [ln.rstrip() for ln in open(os.path.join(src, "passes.txt"))]

@@ -301,7 +301,9 @@ __global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_TRACE_MIN_WAVES)
 k_trace_tile(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_WAVES_PER_BLOCK][2][64];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // wave-uniform by construction; readfirstlane tells the compiler, so tile indices, the tile's
+    // G-buffer base and the LDS slab base live in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float4* blk = &lds_blk[wave][0][0];
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
@@ -318,15 +320,24 @@ k_trace_tile(const VctTraceParams p) {
 
     const int tile = p.tile_row0 * p.tiles_x + ti;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    // Pixel / G-buffer addresses are re-derived from the lane id wherever they are needed (a few
+    // integer ops) rather than carried in 64-bit VGPR pairs across the march loops, where they
+    // would be spilled to scratch under the 80-VGPR budget.
+    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto pixel_index = [&](int l) {
+        return (size_t)(ty * VCT_TILE + (l >> 3)) * p.width + (tx * VCT_TILE + (l & 7));
+    };
+    auto gbuf_ptr = [&](int l) {
+        return p.gbuf + (size_t)tile * (VCT_GB_NPLANES * VCT_TILE_PIX) + l;
+    };
     const int x = tx * VCT_TILE + (lane & 7), y = ty * VCT_TILE + (lane >> 3);
     // The G-buffer is read in three stages (cone frame, specular direction, composite) instead of
     // once up front: the 23 planes are only L1/L2 re-reads, while every VGPR kept live across the
     // march loops costs occupancy, and resident waves are what hides the sampler's latency chain.
-    const float* gb = p.gbuf + (size_t)tile * (VCT_GB_NPLANES * VCT_TILE_PIX) + lane;
+    const float* gb = gbuf_ptr(lane);
 #define VCT_GB(k) gb[(k) * VCT_TILE_PIX]
     const bool in_frame = (x < p.width) && (y < p.height);
     const bool alive = in_frame && !(VCT_GB(18) < 0.5f);            // trace.fs:171 discard
-    const size_t pix = (size_t)y * p.width + x;
 
     F3 start, k0, k1, k2;
     {
@@ -359,15 +370,14 @@ k_trace_tile(const VctTraceParams p) {
         ind[2] = fmaf(wgt, c.z, ind[2]);
         ind[3] = fmaf(wgt, c.w, ind[3]);
         if (p.dbg_cones && alive) {
-            float* d = p.dbg_cones + pix * 28 + 4 * i;
+            float* d = p.dbg_cones + pixel_index(fresh_lane()) * 28 + 4 * i;
             d[0] = c.x; d[1] = c.y; d[2] = c.z; d[3] = c.w;
         }
-        if (p.dbg_steps && in_frame) p.dbg_steps[pix * 7 + i] = (uint8_t)st;
+        if (p.dbg_steps && in_frame) p.dbg_steps[pixel_index(fresh_lane()) * 7 + i] = (uint8_t)st;
     }
 
     // stage 2: specular cone along reflect(-E, N) with the bump normal           trace.fs:217-218
-    const float* gb2 = gb;
-    asm volatile("" : "+v"(gb2));       // a fresh pointer: re-read instead of keeping planes live
+    const float* gb2 = gbuf_ptr(fresh_lane());   // a fresh pointer: re-read instead of keeping planes live
 #undef VCT_GB
 #define VCT_GB(k) gb2[(k) * VCT_TILE_PIX]
     F4 sc;
@@ -381,15 +391,14 @@ k_trace_tile(const VctTraceParams p) {
                                              blk, lb, st6);
         total += st6;
         if (p.dbg_cones && alive) {
-            float* d = p.dbg_cones + pix * 28 + 24;
+            float* d = p.dbg_cones + pixel_index(fresh_lane()) * 28 + 24;
             d[0] = sc.x; d[1] = sc.y; d[2] = sc.z; d[3] = sc.w;
         }
-        if (p.dbg_steps && in_frame) p.dbg_steps[pix * 7 + 6] = (uint8_t)st6;
+        if (p.dbg_steps && in_frame) p.dbg_steps[pixel_index(fresh_lane()) * 7 + 6] = (uint8_t)st6;
     }
 
     // stage 3: composite                                                          trace.fs:179-227
-    const float* gb3 = gb;
-    asm volatile("" : "+v"(gb3));
+    const float* gb3 = gbuf_ptr(fresh_lane());
 #undef VCT_GB
 #define VCT_GB(k) gb3[(k) * VCT_TILE_PIX]
     if (in_frame) {
@@ -423,7 +432,7 @@ k_trace_tile(const VctTraceParams p) {
         uint2 pk;
         pk.x = pack_half2(o0, o1);
         pk.y = pack_half2(o2, o3);
-        *reinterpret_cast<uint2*>(p.out + pix * 4) = pk;
+        *reinterpret_cast<uint2*>(p.out + pixel_index(fresh_lane()) * 4) = pk;
     }
 #undef VCT_GB
     // executed-step count: wave reduction, then one atomic into a counter bank (a single word
