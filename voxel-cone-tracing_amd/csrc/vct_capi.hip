@@ -51,10 +51,16 @@ struct vct_ctx {
     int32_t shadow_size = 0;
     float light_vp[16];
     unsigned long long* acc = nullptr;
+    // voxelization plan (geometry only; built by vct_upload_triangles) and sparse-resolve state
+    uint2* worklist = nullptr;
+    uint32_t n_entries = 0;
     int32_t* big_list = nullptr;
-    int32_t* big_count = nullptr;
-    bool acc_valid = false;
-    int acc_mode = 0;
+    int32_t n_big = 0;
+    uint32_t* plan = nullptr;          // [2] device counters used while planning
+    uint32_t* brick_flags = nullptr;   // [V^3/512] touched in the pending pass
+    uint32_t* brick_prev = nullptr;    // [V^3/512] touched in the pass level 0 currently shows
+    bool acc_pending = false;          // accumulators hold an unresolved voxelize pass
+    bool level0_dirty = false;         // level 0 was written by an upload: next resolve is dense
 };
 
 namespace {
@@ -218,6 +224,28 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     return VCT_OK;
 }
 
+VctVoxParams vox_params(const vct_ctx* c) {
+    VctVoxParams p;
+    memset(&p, 0, sizeof(p));
+    p.V = c->cfg.voxel_dim;
+    p.G = c->cfg.grid_world_size;
+    p.model_scale = c->cfg.model_scale;
+    p.pos = c->tri_pos;
+    p.material = c->tri_mat;
+    p.albedo = c->mat_albedo;
+    p.ntri = c->ntri;
+    p.shadow = c->shadow;
+    p.shadow_size = c->shadow_size;
+    memcpy(p.light_vp, c->light_vp, 64);
+    p.acc = c->acc;
+    p.worklist = c->worklist;
+    p.n_entries = c->n_entries;
+    p.big_list = c->big_list;
+    p.n_big = c->n_big;
+    p.brick_flags = c->brick_flags;
+    return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -316,7 +344,8 @@ void vct_destroy(vct_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->steps_dev, c->tri_pos,
-                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->big_count};
+                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
+                    c->brick_flags, c->brick_prev};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -374,20 +403,35 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     if (c->tri_mat) { (void)hipFree(c->tri_mat); c->tri_mat = nullptr; }
     if (c->mat_albedo) { (void)hipFree(c->mat_albedo); c->mat_albedo = nullptr; }
     if (c->big_list) { (void)hipFree(c->big_list); c->big_list = nullptr; }
+    if (c->worklist) { (void)hipFree(c->worklist); c->worklist = nullptr; }
+    c->n_entries = 0;
+    c->n_big = 0;
     HIP_TRY(c, hipMalloc(&c->tri_pos, (size_t)ntri * 9 * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->tri_mat, (size_t)ntri * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc(&c->mat_albedo, (size_t)nmat * 4 * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&c->big_list, (size_t)ntri * sizeof(int32_t)));
-    if (!c->big_count) HIP_TRY(c, hipMalloc(&c->big_count, sizeof(int32_t)));
+    if (!c->plan) HIP_TRY(c, hipMalloc(&c->plan, 2 * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpyAsync(c->tri_pos, pos, (size_t)ntri * 9 * sizeof(float),
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->tri_mat, material, (size_t)ntri * sizeof(int32_t),
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->mat_albedo, albedo, (size_t)nmat * 4 * sizeof(float),
                               hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ntri = ntri;
     c->nmat = nmat;
+    // voxelization plan: count, allocate, fill (the candidate voxels depend only on the geometry)
+    VctVoxParams p = vox_params(c);
+    uint32_t counts[2] = {0, 0};
+    HIP_TRY(c, hipMemsetAsync(c->plan, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, vct_launch_vox_plan(p, c->plan, nullptr, nullptr, false, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(counts, c->plan, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (counts[0]) HIP_TRY(c, hipMalloc(&c->worklist, (size_t)counts[0] * sizeof(uint2)));
+    if (counts[1]) HIP_TRY(c, hipMalloc(&c->big_list, (size_t)counts[1] * sizeof(int32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->plan, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, vct_launch_vox_plan(p, c->plan, c->worklist, c->big_list, true, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_entries = counts[0];
+    c->n_big = (int32_t)counts[1];
     return VCT_OK;
 }
 
@@ -413,36 +457,33 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_voxelize: no triangles uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
-    if (!c->acc) HIP_TRY(c, hipMalloc(&c->acc, nvox * 16));
-    HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->big_count, 0, sizeof(int32_t), c->stream));
-    VctVoxParams p;
-    memset(&p, 0, sizeof(p));
-    p.V = c->cfg.voxel_dim;
-    p.G = c->cfg.grid_world_size;
-    p.model_scale = c->cfg.model_scale;
-    p.pos = c->tri_pos;
-    p.material = c->tri_mat;
-    p.albedo = c->mat_albedo;
-    p.ntri = c->ntri;
-    p.shadow = c->shadow;
-    p.shadow_size = c->shadow_size;
-    memcpy(p.light_vp, c->light_vp, 64);
-    p.acc = c->acc;
-    p.big_list = c->big_list;
-    p.big_count = c->big_count;
+    const size_t nbricks = nvox / 512;
+    if (!c->acc) {      // zeroed once: every resolve re-zeroes what it consumed
+        HIP_TRY(c, hipMalloc(&c->acc, nvox * 16));
+        HIP_TRY(c, hipMalloc(&c->brick_flags, nbricks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->brick_prev, nbricks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->brick_flags, 0, nbricks * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->brick_prev, 0, nbricks * sizeof(uint32_t), c->stream));
+    } else if (c->acc_pending) {   // a pass that was never resolved: discard it
+        HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->brick_flags, 0, nbricks * sizeof(uint32_t), c->stream));
+    }
+    VctVoxParams p = vox_params(c);
     p.mode = mode;
     HIP_TRY(c, vct_launch_voxelize(p, c->stream));
-    c->acc_valid = true;
-    c->acc_mode = mode;
+    c->acc_pending = true;
     return VCT_OK;
 }
 
 int vct_inject_light(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
-    if (!c->acc_valid) return fail(c, VCT_ERR_INVALID, "vct_inject_light: call vct_voxelize first");
+    if (!c->acc_pending) return fail(c, VCT_ERR_INVALID, "vct_inject_light: call vct_voxelize first");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, vct_launch_resolve(c->acc, c->chain, c->cfg.voxel_dim, c->acc_mode, c->stream));
+    HIP_TRY(c, vct_launch_resolve(c->acc, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
+                                  c->level0_dirty, c->stream));
+    c->acc_pending = false;
+    c->level0_dirty = false;
     return VCT_OK;
 }
 
@@ -464,6 +505,7 @@ static int ensure_staging(vct_ctx* c) {
 
 static int upload_levels(vct_ctx* c, const uint8_t* lin, int nlevels) {
     HIP_TRY(c, hipSetDevice(c->device));
+    c->level0_dirty = true;     // level 0 no longer mirrors brick_prev: next resolve is dense
     int rc = ensure_staging(c);
     if (rc) return rc;
     const int V = c->cfg.voxel_dim;

@@ -70,8 +70,11 @@ struct VctVoxParams {
     int32_t shadow_size;
     float light_vp[16];
     unsigned long long* acc;   // [V^3][2]: (sumR | sumG<<32), (sumB | count<<32), Morton order
-    int32_t* big_list;         // triangles deferred to the block-per-triangle pass
-    int32_t* big_count;
+    const uint2* worklist;     // (triangle, candidate voxel of its bbox), built at upload (k_vox_plan)
+    uint32_t n_entries;
+    const int32_t* big_list;   // triangles with more than VCT_VOX_BIG candidates
+    int32_t n_big;
+    uint32_t* brick_flags;     // [V^3 / 512] raised by fragments, consumed by the sparse resolve
     int32_t mode;
 };
 
@@ -82,8 +85,10 @@ hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N
 hipError_t vct_launch_build_mips(uint32_t* chain, int V, hipStream_t s);
 hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
                                    hipStream_t s);
+hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* worklist,
+                               int32_t* big_list, bool write, hipStream_t s);
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s);
-hipError_t vct_launch_resolve(const unsigned long long* acc, uint32_t* level0, int V, int mode,
-                              hipStream_t s);
+hipError_t vct_launch_resolve(unsigned long long* acc, uint32_t* level0, uint32_t* flags,
+                              uint32_t* prev, int V, bool dense, hipStream_t s);
 
 #endif

@@ -9,8 +9,17 @@
 // turns them into the rounded mean.  fp32 operation order mirrors the scalar oracle
 // (compile with -ffp-contract=off).
 //
-// Work distribution: one thread per triangle for triangles whose voxel bounding box is small;
-// larger ones are deferred to a second pass with one workgroup per triangle.
+// Work distribution: fragment-parallel.  The candidate voxels of a triangle (its clipped voxel
+// bounding box) depend only on the geometry, so a work list of (triangle, candidate voxel)
+// entries is built ONCE when the triangles are uploaded (k_vox_plan); every voxelize pass -- e.g.
+// after the light moved -- is then one thread per candidate voxel over that list: neighbouring
+// lanes test neighbouring voxels of the same triangle (coherent PCF taps, balanced waves, 8
+// waves/SIMD of independent fragments to hide the 25-tap shadow fetch latency).  Triangles with
+// more than VCT_VOX_BIG candidates go to a workgroup-per-triangle pass instead of flooding the list.
+//
+// Sparse resolve: a fragment also raises its 8^3 brick's flag; k_resolve_sparse visits only bricks
+// flagged in this pass or the previous one (to clear what is no longer covered), writes the rounded
+// mean into level 0 and zeroes the accumulators it read, so they never need a memset again.
 #include "vct_internal.h"
 
 namespace {
@@ -52,16 +61,69 @@ __device__ __forceinline__ float shadow_tex(const float* __restrict__ depth, int
     return acc;
 }
 
-// vox.fs:18-52 (count of passing taps; caller divides by 25)
+// One axis of the 5 PCF taps: texel indices and filter fraction of tap offsets -2..2, each computed
+// exactly as shadow_tex() does for that tap.
+struct TapAxis { int i0[5], i1[5]; float a[5]; };
+__device__ __forceinline__ void tap_axis(float coord, float inv, float fS, float top, int S, TapAxis& t) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float u = coord + inv * (float)(k - 2);
+        const float x = u * fS - 0.5f;
+        const float fx = floorf(x);
+        t.a[k] = x - fx;
+        const float f1 = fx + 1.0f;
+        t.i0[k] = !(fx > 0.0f) ? 0 : (fx >= top ? S - 1 : (int)fx);
+        t.i1[k] = !(f1 > 0.0f) ? 0 : (f1 >= top ? S - 1 : (int)f1);
+    }
+}
+
+// vox.fs:18-52 (count of passing taps; caller divides by 25).  The 25 bilinear taps sit one texel
+// apart, so they normally share a 6x6 texel window: when every tap's upper index equals the next
+// tap's lower index on both axes (checked per lane) the window is loaded once (36 loads instead of
+// 100) and each tap is evaluated from registers with its own exact weights; lanes whose indices
+// are irregular (fp rounding at a texel boundary, clamped borders) take the tap-by-tap path.  Same
+// bits either way.
 __device__ __forceinline__ int pcf25(const float* __restrict__ depth, int S, F3 c, float bias) {
     const float inv = __fdiv_rn(1.0f, (float)S);
+    const float fS = (float)S, top = (float)(S - 1);
+    TapAxis X, Y;
+    tap_axis(c.x, inv, fS, top, S, X);
+    tap_axis(c.y, inv, fS, top, S, Y);
+    bool regular = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) regular = regular && X.i1[k] == X.i0[k + 1] && Y.i1[k] == Y.i0[k + 1];
+    const float cur = c.z - bias;
     int count = 0;
-    for (int x = -2; x <= 2; ++x)
-        for (int y = -2; y <= 2; ++y) {
-            const float ox = inv * (float)x, oy = inv * (float)y;
-            const float closest = shadow_tex(depth, S, c.x + ox, c.y + oy);
-            if (c.z - bias <= closest) ++count;
-        }
+    if (regular) {
+        int col[6], row[6];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { col[k] = X.i0[k]; row[k] = Y.i0[k]; }
+        col[5] = X.i1[4]; row[5] = Y.i1[4];
+        float d[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[j][i] = depth[(size_t)row[j] * S + col[i]];
+#pragma unroll
+        for (int x = 0; x < 5; ++x)
+#pragma unroll
+            for (int y = 0; y < 5; ++y) {
+                const float a = X.a[x], b = Y.a[y];
+                const float a0 = 1.0f - a, b0 = 1.0f - b;
+                float acc = (a0 * b0) * d[y][x];
+                acc = fmaf(a * b0, d[y][x + 1], acc);
+                acc = fmaf(a0 * b, d[y + 1][x], acc);
+                acc = fmaf(a * b, d[y + 1][x + 1], acc);
+                if (cur <= acc) ++count;
+            }
+    } else {
+        for (int x = -2; x <= 2; ++x)
+            for (int y = -2; y <= 2; ++y) {
+                const float ox = inv * (float)x, oy = inv * (float)y;
+                const float closest = shadow_tex(depth, S, c.x + ox, c.y + oy);
+                if (cur <= closest) ++count;
+            }
+    }
     return count;
 }
 
@@ -185,37 +247,87 @@ __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& 
     }
     const unsigned long long cr = to_unorm8(r.alb[0] * sh), cg = to_unorm8(r.alb[1] * sh),
                              cb = to_unorm8(r.alb[2] * sh);                          // vox.fs:88
-    unsigned long long* a = p.acc + 2 * (size_t)vct_morton3((uint32_t)i, (uint32_t)j, (uint32_t)k);
+    const uint32_t vox = vct_morton3((uint32_t)i, (uint32_t)j, (uint32_t)k);
+    unsigned long long* a = p.acc + 2 * (size_t)vox;
     atomicAdd(a, cr | (cg << 32));
     atomicAdd(a + 1, cb | (1ull << 32));
+    p.brick_flags[vox >> 9] = 1u;      // benign race: every writer stores the same value
 }
 
-#define VCT_SMALL_BBOX 27
+#define VCT_VOX_BIG 4096
 
-__global__ void __launch_bounds__(256)
-k_voxelize_small(const VctVoxParams p) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= p.ntri) return;
-    TriSetup r;
-    setup_tri(p, t, r);
-    if (!r.valid) return;
+__device__ __forceinline__ long long tri_candidates(const TriSetup& r) {
+    if (!r.valid) return 0;
     const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
-    if (nx <= 0 || ny <= 0 || nz <= 0) return;
-    const long long cnt = (long long)nx * ny * nz;
-    if (cnt > VCT_SMALL_BBOX) {
-        const int slot = atomicAdd(p.big_count, 1);
-        p.big_list[slot] = t;
-        return;
+    if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+    return (long long)nx * ny * nz;
+}
+
+// Builds the work list.  WRITE = false: only totals (plan[0] = list entries, plan[1] = big
+// triangles); WRITE = true: entries (triangle, chunk) and the big-triangle list.  Entry order is
+// irrelevant (integer accumulation), so workgroups claim ranges with one atomic each.
+template <bool WRITE>
+__global__ void __launch_bounds__(256)
+k_vox_plan(const VctVoxParams p, uint32_t* plan, uint2* worklist, int32_t* big_list) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t block_base;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t chunks = 0;
+    bool big = false;
+    if (t < p.ntri) {
+        TriSetup r;
+        setup_tri(p, t, r);
+        const long long cnt = tri_candidates(r);
+        if (cnt > VCT_VOX_BIG) big = true;
+        else chunks = (uint32_t)cnt;
     }
-    for (int k = r.lo[2]; k <= r.hi[2]; ++k)
-        for (int j = r.lo[1]; j <= r.hi[1]; ++j)
-            for (int i = r.lo[0]; i <= r.hi[0]; ++i) fragment(p, r, i, j, k);
+    // workgroup exclusive scan of `chunks`
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = chunks;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) wave_base += wave_tot[w];
+        total += wave_tot[w];
+    }
+    if (threadIdx.x == 0) block_base = total ? atomicAdd(&plan[0], total) : 0u;
+    __syncthreads();
+    if (big) {
+        const uint32_t slot = atomicAdd(&plan[1], 1u);
+        if (WRITE) big_list[slot] = t;
+    }
+    if (WRITE) {
+        const uint32_t first = block_base + wave_base + incl - chunks;
+        for (uint32_t c = 0; c < chunks; ++c) worklist[first + c] = make_uint2((uint32_t)t, c);
+    }
+}
+
+// one thread per candidate voxel
+__global__ void __launch_bounds__(256)
+k_voxelize_list(const VctVoxParams p) {
+    const size_t total = (size_t)p.n_entries;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+         c += (size_t)gridDim.x * blockDim.x) {
+        const uint2 e = p.worklist[c];
+        TriSetup r;
+        setup_tri(p, (int)e.x, r);
+        const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1;
+        const int v = (int)e.y;
+        const int i = r.lo[0] + v % nx;
+        const int j = r.lo[1] + (v / nx) % ny;
+        const int k = r.lo[2] + v / (nx * ny);
+        fragment(p, r, i, j, k);
+    }
 }
 
 __global__ void __launch_bounds__(256)
 k_voxelize_big(const VctVoxParams p) {
-    const int nbig = *p.big_count;
-    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
+    for (int b = blockIdx.x; b < p.n_big; b += gridDim.x) {
         const int t = p.big_list[b];
         TriSetup r;
         setup_tri(p, t, r);
@@ -230,41 +342,73 @@ k_voxelize_big(const VctVoxParams p) {
     }
 }
 
-// accumulators -> RGBA8 level 0 (Morton), rounded mean, a = 255 where any fragment landed
+__device__ __forceinline__ uint32_t resolve_voxel(ulonglong2 a) {
+    const uint32_t c = (uint32_t)(a.y >> 32);
+    if (!c) return 0u;
+    const uint32_t h = c >> 1;
+    const uint32_t r = ((uint32_t)a.x + h) / c, g = ((uint32_t)(a.x >> 32) + h) / c,
+                   b = ((uint32_t)a.y + h) / c;
+    return r | (g << 8) | (b << 16) | 0xff000000u;      // vox.fs:88: a = 1
+}
+
+// accumulators -> RGBA8 level 0 (Morton), rounded mean, a = 255 where any fragment landed.
+// One wave per 8^3 brick (512 voxels, one contiguous 8 KiB run of accumulators); bricks that were
+// touched neither in this pass nor in the previous one are skipped unless `dense`.
 __global__ void __launch_bounds__(256)
-k_resolve(const unsigned long long* __restrict__ acc, uint32_t* __restrict__ level0, size_t nvox) {
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox;
-         v += (size_t)gridDim.x * blockDim.x) {
-        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(acc)[v];
-        const uint32_t c = (uint32_t)(a.y >> 32);
-        uint32_t out = 0;
-        if (c) {
-            const uint32_t h = c >> 1;
-            const uint32_t r = ((uint32_t)a.x + h) / c, g = ((uint32_t)(a.x >> 32) + h) / c,
-                           b = ((uint32_t)a.y + h) / c;
-            out = r | (g << 8) | (b << 16) | 0xff000000u;
+k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ level0,
+                 uint32_t* __restrict__ flags, uint32_t* __restrict__ prev, uint32_t nbricks,
+                 uint32_t brick_voxels, int dense) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nbricks; b += waves) {
+        const uint32_t now = flags[b], before = prev[b];
+        if (!dense && !(now | before)) continue;
+        ulonglong2* a2 = reinterpret_cast<ulonglong2*>(acc) + (size_t)b * brick_voxels;
+        uint32_t* l0 = level0 + (size_t)b * brick_voxels;
+        for (uint32_t v = lane; v < brick_voxels; v += 64) {
+            const ulonglong2 a = a2[v];
+            l0[v] = resolve_voxel(a);
+            if (a.y) a2[v] = make_ulonglong2(0ull, 0ull);
         }
-        level0[v] = out;
+        if (lane == 0) { prev[b] = now; flags[b] = 0u; }
     }
 }
 
 }  // namespace
 
-hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
+hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* worklist,
+                               int32_t* big_list, bool write, hipStream_t s) {
     if (p.ntri <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_voxelize_small, dim3((p.ntri + 255) / 256), dim3(256), 0, s, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_voxelize_big, dim3(256 * 8), dim3(256), 0, s, p);
+    const dim3 grid((p.ntri + 255) / 256), block(256);
+    if (write) hipLaunchKernelGGL(k_vox_plan<true>, grid, block, 0, s, p, plan, worklist, big_list);
+    else hipLaunchKernelGGL(k_vox_plan<false>, grid, block, 0, s, p, plan, worklist, big_list);
     return hipGetLastError();
 }
 
-hipError_t vct_launch_resolve(const unsigned long long* acc, uint32_t* level0, int V, int mode,
-                              hipStream_t s) {
-    (void)mode;
-    const size_t nvox = (size_t)V * V * V;
-    size_t blocks = (nvox + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, acc, level0, nvox);
+hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
+    if (p.n_entries > 0) {
+        const size_t threads = (size_t)p.n_entries;
+        size_t blocks = (threads + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL(k_voxelize_list, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (p.n_big > 0) {
+        const int blocks = p.n_big < 256 * 8 ? p.n_big : 256 * 8;
+        hipLaunchKernelGGL(k_voxelize_big, dim3(blocks), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    return hipSuccess;
+}
+
+hipError_t vct_launch_resolve(unsigned long long* acc, uint32_t* level0, uint32_t* flags,
+                              uint32_t* prev, int V, bool dense, hipStream_t s) {
+    const uint32_t brick_voxels = V >= 8 ? 512u : (uint32_t)(V * V * V);
+    const uint32_t nbricks = (uint32_t)(((size_t)V * V * V) / brick_voxels);
+    size_t blocks = ((size_t)nbricks + 3) / 4;      // 4 waves per workgroup, one brick per wave
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)blocks), dim3(256), 0, s, acc, level0, flags,
+                       prev, nbricks, brick_voxels, dense ? 1 : 0);
     return hipGetLastError();
 }
