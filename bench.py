@@ -92,10 +92,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the voxel-cone-tracing path has no CPU fallback")
+    # VCT_BENCH_BACKEND=gloo: functional test of the N-rank control flow on a box with fewer GPUs
+    # than ranks (ranks share devices, the gather is staged on the host) -- never a measurement.
+    backend = os.environ.get("VCT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w, h, V = args.width, args.height, args.voxel_dim
     inp = build_inputs(args, vct, sc)
@@ -138,22 +146,18 @@ def main():
     y0, y1 = fg.my_rows()
     slab_px = max(0, y1 - y0) * w
 
-    # first trace uploads + tiles the G-buffer; afterwards everything is resident in HBM
-    ctx.trace(inp["planes"], rows=(r0, r1), out_device_ptr=fg.slab.data_ptr() - y0 * w * 8
-              if y1 > y0 else fg.slab.data_ptr())
+    # first trace uploads + tiles the G-buffer; afterwards everything is resident in HBM.  The kernel
+    # writes this rank's slab straight into the gather buffer (full-frame addressing: the buffer's
+    # base minus the slab's first row), so a step is kernel + one gather, no copies.
+    base = fg.slab.data_ptr() - y0 * w * 8
+    ctx.set_frame_target(base)
+    ctx.trace(inp["planes"], rows=(r0, r1), out_device_ptr=base)
     steps_slab = ctx.last_step_count()
-    frame_dev, _ = ctx.frame_device()
-    slab_src = None
-    if world > 1 and y1 > y0:     # zero-copy torch view of the context-owned RGBA16F slab
-        slab_src = torch.as_tensor(_DevView(frame_dev + y0 * w * 8, ((y1 - y0), w, 4)),
-                                   device=f"cuda:{local_rank}")
 
     def one_step():
         ctx.trace_resident()                      # the trace kernel, on the context stream
         if world > 1:
-            with torch.cuda.stream(ext_stream):   # slab -> gather buffer, then ONE gather (RCCL)
-                if slab_src is not None:
-                    fg.slab[: y1 - y0].copy_(slab_src, non_blocking=True)
+            with torch.cuda.stream(ext_stream):   # ONE gather (RCCL), ordered after the kernel
                 fg.gather()
 
     def fence():
@@ -177,9 +181,10 @@ def main():
         kernel_ms.append(ctx.last_trace_ms())
     fence()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-    steps_all = torch.tensor([steps_slab], dtype=torch.float64, device=f"cuda:{local_rank}")
-    kmax = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=f"cuda:{local_rank}")
+    red_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    steps_all = torch.tensor([steps_slab], dtype=torch.float64, device=red_dev)
+    kmax = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(steps_all, op=dist.ReduceOp.SUM)
@@ -187,6 +192,17 @@ def main():
     dt = float(tmax.item())
     total_steps = int(steps_all.item())
     kernel_ms_avg = float(kmax.item())
+
+    gather_ok = None
+    if world > 1:
+        # acceptance check of SURVEY.md 8e, untimed: the gathered frame is bit-identical to the frame
+        # one GPU traces alone
+        full = fg.gather()
+        torch.cuda.synchronize()
+        if rank == 0:
+            ctx.set_frame_target(None)
+            alone = ctx.trace(inp["planes"])
+            gather_ok = bool(np.array_equal(full.cpu().numpy().view(np.uint16), alone))
 
     if rank == 0:
         npix = w * h
@@ -214,8 +230,11 @@ def main():
                                    f"specular cone/px, trace of a resident G-buffer",
                        "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7,
                        "parallelism": "single GPU" if world == 1 else
-                       f"{world} screen-tile slabs + 1 RCCL gather", "trace_variant": args.variant},
+                       f"{world} screen-tile slabs + 1 RCCL gather" +
+                       ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]"),
+                       "trace_variant": args.variant},
             "cone_steps_per_frame": total_steps,
+            "gathered_frame_equals_single_gpu_frame": gather_ok,
             "trace_kernel_ms": round(kernel_ms_avg, 4),
             "gi_pass_ms": {k: (None if v is None else round(v, 4)) for k, v in gi.items()}
             | {"trace": round(kernel_ms_avg, 4)},
@@ -252,14 +271,6 @@ def pmc_traffic(args, world, kernel_ms):
     gbs = t["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
     return round(gbs, 1), (f"traffic = PMC HBM bytes per launch ({t['hbm_bytes_per_launch'] / 1e6:.0f} MB, "
                            f"{t['source']}: (2*FETCH_SIZE+WRITE_SIZE)*1024) / kernel time, GB/s.")
-
-
-class _DevView:
-    """Zero-copy view of context-owned HBM as a torch tensor (__cuda_array_interface__)."""
-
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f2",
-                                         "data": (int(ptr), False), "version": 2}
 
 
 def cpu_baseline(args, inp, ctx, vct):

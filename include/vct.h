@@ -146,6 +146,11 @@ int vct_trace_slab(vct_ctx* ctx, const vct_gbuffer* gb, int32_t tile_row0, int32
 /* Re-run the trace kernel on the G-buffer already resident from the last vct_trace (no upload,
  * no download); used for timing.  stream work only, asynchronous. */
 int vct_trace_resident(vct_ctx* ctx);
+/* Redirect the trace kernel's RGBA16F output to caller-owned HBM (full-frame addressing: pixel (x,y)
+ * at ((y*width + x) * 4) halves from `rgba16f_dev`); NULL restores the context-owned frame.  A slab
+ * rank passes its gather buffer minus the slab's first row so the kernel writes the gather buffer
+ * directly (no device-to-device copy per frame).  The caller keeps the memory alive. */
+int vct_set_frame_target(vct_ctx* ctx, void* rgba16f_dev);
 int vct_synchronize(vct_ctx* ctx);
 
 /* Debug outputs of the last trace (config.debug_outputs = 1): steps [npix][7] uint8, cones

@@ -279,10 +279,17 @@ def test_frame_gather_single_rank_device_path(vct, oracle):
     planes = synth.random_gbuffer(w * h, seed=12)
     with make_ctx(vct, V, w, h) as ctx:
         ctx.upload_chain(chain)
-        fg = slabs.FrameGather(h, w, 1, 0, "cuda:0")
-        r0, r1 = slabs.partition(h, 1)[0]
-        ctx.trace(planes, rows=(r0, r1), out_device_ptr=fg.slab.data_ptr())
-        frame = fg.gather()
-        torch.cuda.synchronize()
         want = ctx.trace(planes)
-        assert np.array_equal(frame.cpu().numpy().view(np.uint16), want)
+        # a middle slab of a 3-way split, written by the kernel straight into its gather buffer
+        world, rank = 3, 1
+        fg = slabs.FrameGather(h, w, world, rank, "cuda:0", root=rank)
+        r0, r1 = slabs.partition(h, world)[rank]
+        y0, y1 = fg.my_rows()
+        ctx.set_frame_target(fg.slab.data_ptr() - y0 * w * 8)
+        ctx.trace(planes, rows=(r0, r1), out_device_ptr=fg.slab.data_ptr() - y0 * w * 8)
+        ctx.trace_resident()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(fg.slab[: y1 - y0].cpu().numpy().view(np.uint16), want[y0:y1])
+        ctx.set_frame_target(None)
+        assert np.array_equal(ctx.trace(planes), want)

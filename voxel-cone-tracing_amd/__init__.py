@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vct_download_chain_rgba8", "vct_chain_texels", "vct_trace", "vct_trace_slab",
     "vct_trace_resident", "vct_synchronize", "vct_download_steps", "vct_download_cones",
     "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream", "vct_get_frame_device",
-    "vct_selftest_const_divide",
+    "vct_selftest_const_divide", "vct_set_frame_target",
 ]
 
 
@@ -89,6 +89,7 @@ for _n in ("vct_inject_light", "vct_build_mips", "vct_trace_resident", "vct_sync
 _lib.vct_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
 _lib.vct_trace_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
 _lib.vct_get_frame_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.vct_set_frame_target.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_selftest_const_divide.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
 
 
@@ -233,6 +234,11 @@ class Context:
             self._ck(_lib.vct_trace_slab(self._h, C.byref(gb), rows[0], rows[1], optr, oloc),
                      "vct_trace_slab")
         return out
+
+    def set_frame_target(self, dev_ptr):
+        """Kernel output goes to caller-owned HBM (full-frame addressing); None restores the default."""
+        self._ck(_lib.vct_set_frame_target(self._h, C.c_void_p(dev_ptr) if dev_ptr else None),
+                 "vct_set_frame_target")
 
     def trace_resident(self):
         self._ck(_lib.vct_trace_resident(self._h), "vct_trace_resident")

@@ -29,6 +29,7 @@ struct vct_ctx {
     float* gb_tiled = nullptr;        // [tiles][23][64]
     const float* gb_current = nullptr;   // tiled buffer the next resident trace reads
     uint16_t* frame = nullptr;        // RGBA16F [h][w][4]
+    uint16_t* frame_target = nullptr; // caller-owned output (vct_set_frame_target) or null
     uint8_t* dbg_steps = nullptr;
     float* dbg_cones = nullptr;
     unsigned long long* step_counter = nullptr;
@@ -209,7 +210,7 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.tile_row1 = row1;
     const int variant = c->cfg.trace_variant;
     p.gbuf = c->gb_current;
-    p.out = c->frame;
+    p.out = c->frame_target ? c->frame_target : c->frame;
     p.dbg_steps = c->cfg.debug_outputs ? c->dbg_steps : nullptr;
     p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
     p.step_counter = c->step_counter;
@@ -593,7 +594,8 @@ int vct_trace_slab(vct_ctx* c, const vct_gbuffer* gb, int32_t row0, int32_t row1
         const int y1 = row1 * VCT_TILE < c->cfg.height ? row1 * VCT_TILE : c->cfg.height;
         if (y1 > y0) {
             const size_t off = (size_t)y0 * c->cfg.width * 8, bytes = (size_t)(y1 - y0) * c->cfg.width * 8;
-            HIP_TRY(c, hipMemcpyAsync((char*)out + off, (const char*)c->frame + off, bytes,
+            const char* src = (const char*)(c->frame_target ? c->frame_target : c->frame);
+            HIP_TRY(c, hipMemcpyAsync((char*)out + off, src + off, bytes,
                                       out_location == VCT_MEM_DEVICE ? hipMemcpyDeviceToDevice
                                                                      : hipMemcpyDeviceToHost,
                                       c->stream));
@@ -613,6 +615,12 @@ int vct_trace_resident(vct_ctx* c) {
     if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "vct_trace_resident: no G-buffer resident yet");
     HIP_TRY(c, hipSetDevice(c->device));
     return launch_trace(c, c->last_row0, c->last_row1);
+}
+
+int vct_set_frame_target(vct_ctx* c, void* dev) {
+    if (!c) return VCT_ERR_INVALID;
+    c->frame_target = (uint16_t*)dev;
+    return VCT_OK;
 }
 
 int vct_synchronize(vct_ctx* c) {
@@ -685,7 +693,7 @@ int vct_get_stream(vct_ctx* c, void** s) {
 
 int vct_get_frame_device(vct_ctx* c, void** p, size_t* bytes) {
     if (!c || !p) return VCT_ERR_INVALID;
-    *p = c->frame;
+    *p = c->frame_target ? c->frame_target : c->frame;
     if (bytes) *bytes = (size_t)c->cfg.width * c->cfg.height * 8;
     return VCT_OK;
 }

@@ -97,6 +97,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// HIP's __ballot()/__any() lower to v_cndmask + v_cmp_ne; the builtin is the compare mask itself.
+__device__ __forceinline__ unsigned long long ballot64(bool pred) {
+    return __builtin_amdgcn_ballot_w64(pred);
+}
+
 struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
     int lane;
     uint32_t sbx, sby, sbz;     // dilated (l&3), ((l>>2)&3)<<1, (l>>4)<<2
@@ -124,14 +129,14 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
     int ax = 0, ay = 0, az = 0, dx = 0, dy = 0, dz = 0;
     if (COOP) {
         // anchor = footprint of the tile's centre pixel (lane 27) if it is live, else the first live lane
-        const unsigned long long am = __ballot(act);
+        const unsigned long long am = ballot64(act);
         const int src = ((am >> 27) & 1ull) ? 27 : (int)__ffsll((long long)am) - 1;
         ax = __builtin_amdgcn_readlane(i0, src) - 1;
         ay = __builtin_amdgcn_readlane(j0, src) - 1;
         az = __builtin_amdgcn_readlane(k0, src) - 1;
         dx = i0 - ax; dy = j0 - ay; dz = k0 - az;
         const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
-        coop = __ballot(act && far > 2u) == 0ull;
+        coop = ballot64(act && far > 2u) == 0ull;
     }
     if (COOP && coop) {
         uint32_t idx;
@@ -149,7 +154,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             idx = vct_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
         }
         const uint32_t t = base[idx];
-        if (__ballot(t != 0u) != 0ull) {     // all 64 texels zero: every footprint sums to exactly +0
+        if (ballot64(t != 0u) != 0ull) {     // all 64 texels zero: every footprint sums to exactly +0
             float4 d;
             d.x = unorm8(t & 0xffu);
             d.y = unorm8((t >> 8) & 0xffu);
@@ -240,7 +245,7 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
     VctStep nxt = load_step(tab, 0);
     for (int k = 0; k < n; ++k) {
         const bool act = alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
-        if (!__any(act)) break;
+        if (ballot64(act) == 0ull) break;
         const VctStep st = nxt;
         nxt = load_step(tab, k + 1 < n ? k + 1 : k);
         // trace.fs:98 + :61-63.  (q * 0.5f is exact, so fmaf(q, .5, .5) is the oracle's q*.5f + .5f;

@@ -55,6 +55,15 @@ class FrameGather:
         if self.world == 1:
             self.frame[: self.rows].copy_(self.slab)
             return self.frame[: self.height]
+        if self.slab.is_cuda and dist.get_backend(self.group) == "gloo":
+            # functional testing only (several ranks sharing one GPU cannot use RCCL): stage on the host
+            send = self.slab.cpu()
+            recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == self.root else None
+            dist.gather(send, recv, dst=self.root, group=self.group)
+            if self.rank == self.root:
+                for r in range(self.world):
+                    self.frame[r * self.rows:(r + 1) * self.rows].copy_(recv[r])
+            return self.frame[: self.height] if self.rank == self.root else None
         recv = None
         if self.rank == self.root:
             recv = [self.frame[r * self.rows:(r + 1) * self.rows] for r in range(self.world)]
