@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell", "noise"])
     ap.add_argument("--shadow-size", type=int, default=4096)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--bounces", type=int, default=1, choices=[1, 2],
+                    help="2 = re-inject lit voxels once before the screen trace (BASELINE config 3)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the oracle baseline sample (0 disables)")
     return ap.parse_args()
@@ -108,7 +110,8 @@ def main():
     w, h, V = args.width, args.height, args.voxel_dim
     inp = build_inputs(args, vct, sc)
     cfg = vct.default_config(voxel_dim=V, width=w, height=h, device=local_rank,
-                             trace_variant=args.variant, shadow_map_size=args.shadow_size)
+                             trace_variant=args.variant, shadow_map_size=args.shadow_size,
+                             voxel_attributes=1 if args.bounces == 2 else 0)
     ctx = vct.Context(cfg)
     ctx.set_camera_position(inp["cam"])
     ctx.set_light_direction(inp["light"])
@@ -130,9 +133,16 @@ def main():
                 e[1].record(); ctx.inject_light()
                 e[2].record(); ctx.build_mips()
                 e[3].record()
+                if args.bounces == 2:
+                    e.append(ev())
+                    ctx.bounce()                 # bounce kernel + mips of the bounce-1 chain
+                    e[4].record()
                 ctx.synchronize()
             gi = {"voxelize": e[0].elapsed_time(e[1]), "inject_resolve": e[1].elapsed_time(e[2]),
                   "build_mips": e[2].elapsed_time(e[3])}
+            if args.bounces == 2:
+                gi["bounce_and_mips"] = e[3].elapsed_time(e[4])
+                gi["bounce_cone_steps"] = float(ctx.last_step_count())
         else:
             ctx.upload_volume(inp["volume"])
             e = [ev(), ev()]
@@ -228,7 +238,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{inp['label']}, {V}^3 RGBA8 brick chain, {w}x{h}, 6 diffuse + 1 "
                                    f"specular cone/px, trace of a resident G-buffer",
-                       "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7,
+                       "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7, "bounces": args.bounces,
                        "parallelism": "single GPU" if world == 1 else
                        f"{world} screen-tile slabs + 1 RCCL gather" +
                        ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]"),

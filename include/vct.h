@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 1
+#define VCT_ABI_VERSION 2
 
 typedef enum vct_status {
     VCT_OK = 0,
@@ -86,6 +86,8 @@ typedef struct vct_config {
     int32_t wrap_repeat;       /* 1 = GL_REPEAT (VCT.h:110-113 leaves the GL default) */
     int32_t debug_outputs;     /* 1 = also keep per-cone step counts and raw cone vec4s */
     int32_t trace_variant;     /* 0 = default kernel; others select experimental variants */
+    int32_t voxel_attributes;  /* 1 = the voxelizer also keeps per-voxel mean albedo + face normal
+                                  (needed by vct_bounce; 24 B/voxel of extra accumulators) */
 } vct_config;
 
 typedef struct vct_ctx vct_ctx;
@@ -126,6 +128,17 @@ int vct_voxelize(vct_ctx* ctx, int32_t mode);
 int vct_inject_light(vct_ctx* ctx);
 /* glGenerateMipmap (VCT.h:126,248): 2x2x2 box, requantised per level, over the brick chain. */
 int vct_build_mips(vct_ctx* ctx);
+
+/* Second bounce (north-star, BASELINE.json config 3; the reference's README claims 2 bounces but its
+ * code injects once -- VCT.h:138-139 -- so the definition is this build's, oracle/vct_oracle.h):
+ * every occupied voxel gathers 6 diffuse cones from the current (bounce-0) chain along its stored
+ * normal and adds albedo * occlusion-weighted irradiance; the result becomes level 0 of a second
+ * chain, its mips are built, and vct_trace reads that chain until the next vct_inject_light.
+ * Needs config.voxel_attributes = 1 and vct_voxelize + vct_inject_light + vct_build_mips first. */
+int vct_bounce(vct_ctx* ctx);
+/* Per-voxel attributes of the last resolve (config.voxel_attributes = 1): V^3 * 4 bytes each, linear
+ * voxel order; albedo rgb (a = 255 where occupied), normal xyz biased by +128 (w = 255 where occupied). */
+int vct_download_voxel_attributes(vct_ctx* ctx, uint8_t* albedo, uint8_t* normal);
 
 /* Volumes built elsewhere (fixtures, oracle-built volumes).  Linear layout: level k has
  * N = V>>k texels per side, texel (x,y,z) at ((z*N+y)*N+x)*4, levels concatenated. */

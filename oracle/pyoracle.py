@@ -78,6 +78,9 @@ def lib():
                                          C.c_void_p]
         L.vcto_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vcto_bounce.restype = C.c_uint64
+        L.vcto_bounce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vcto_voxelize_conservative_attr.argtypes = [C.c_void_p] * 6
         _LIB = L
     return _LIB
 
@@ -239,3 +242,23 @@ def voxelize_conservative(p, scene, want_acc=False):
     acc = np.zeros((V, V, V, 4), np.uint32) if want_acc else None
     lib().vcto_voxelize_conservative(C.byref(p), C.byref(scene), _ptr(l0), _ptr(acc))
     return (l0, acc) if want_acc else l0
+
+
+def voxelize_conservative_attr(p, scene):
+    """Returns (l0, attr_albedo, attr_normal), each uint8 [V,V,V,4]."""
+    V = p.V
+    l0 = np.zeros((V, V, V, 4), np.uint8)
+    alb = np.zeros((V, V, V, 4), np.uint8)
+    nrm = np.zeros((V, V, V, 4), np.uint8)
+    lib().vcto_voxelize_conservative_attr(C.byref(p), C.byref(scene), _ptr(l0), None, _ptr(alb), _ptr(nrm))
+    return l0, alb, nrm
+
+
+def bounce(p, chain0, attr_albedo, attr_normal, nthreads=1):
+    """One re-injection bounce.  Returns (level0' uint8 [V,V,V,4], cone steps executed)."""
+    V = p.V
+    out = np.zeros((V, V, V, 4), np.uint8)
+    a = np.ascontiguousarray(attr_albedo, np.uint8)
+    n = np.ascontiguousarray(attr_normal, np.uint8)
+    steps = lib().vcto_bounce(C.byref(p), _ptr(chain0), _ptr(a), _ptr(n), _ptr(out), int(nthreads))
+    return out, int(steps)

@@ -637,6 +637,11 @@ inline bool cons_overlap(const ConsSetup& c, int i, int j, int k) {
 
 void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
                                 uint32_t* acc_out) {
+    vcto_voxelize_conservative_attr(p, s, l0, acc_out, nullptr, nullptr);
+}
+
+void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
+                                     uint32_t* acc_out, uint8_t* attr_albedo, uint8_t* attr_normal) {
     const int V = p->V;
     const float fV = (float)V;
     const size_t nvox = (size_t)V * V * V;
@@ -644,8 +649,21 @@ void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8
     uint32_t* acc = acc_out;
     if (!acc) { local.assign(nvox * 4, 0u); acc = local.data(); }
     else memset(acc, 0, nvox * 16);
+    const bool want_attr = attr_albedo || attr_normal;
+    std::vector<uint32_t> asum;      // [nvox][6]: albedo rgb sums, biased normal xyz sums
+    if (want_attr) asum.assign(nvox * 6, 0u);
     for (int t = 0; t < s->ntri; ++t) {
         const TriSetup ts = setup_tri(s, t);
+        uint32_t fa[6] = {0, 0, 0, 0, 0, 0};
+        if (want_attr) {
+            const float* alb = s->albedo + 4 * (size_t)s->material[t];
+            const V3 fn = normalize(cross(sub(ts.w[1], ts.w[0]), sub(ts.w[2], ts.w[0])));
+            const float fc[3] = {fn.x, fn.y, fn.z};
+            for (int c = 0; c < 3; ++c) {
+                fa[c] = to_unorm8(alb[c]);
+                fa[3 + c] = (uint32_t)((int)floorf(fc[c] * 127.0f + 0.5f) + 128);
+            }
+        }
         V3 g[3];
         for (int k = 0; k < 3; ++k)
             g[k] = {(ts.w[k].x / p->G + 0.5f) * fV, (ts.w[k].y / p->G + 0.5f) * fV,
@@ -686,8 +704,23 @@ void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8
                     frag_value(s, t, dc, rgb);
                     uint32_t* a = acc + 4 * (((size_t)k * V + j) * V + i);
                     a[0] += rgb[0]; a[1] += rgb[1]; a[2] += rgb[2]; a[3] += 1u;
+                    if (want_attr) {
+                        uint32_t* q = asum.data() + 6 * (((size_t)k * V + j) * V + i);
+                        for (int c = 0; c < 6; ++c) q[c] += fa[c];
+                    }
                 }
     }
+    if (want_attr)
+        for (size_t v = 0; v < nvox; ++v) {
+            const uint32_t c = acc[4 * v + 3], h = c >> 1;
+            const uint32_t* q = asum.data() + 6 * v;
+            for (int k = 0; k < 3; ++k) {
+                if (attr_albedo) attr_albedo[4 * v + k] = c ? (uint8_t)((q[k] + h) / c) : 0;
+                if (attr_normal) attr_normal[4 * v + k] = c ? (uint8_t)((q[3 + k] + h) / c) : 0;
+            }
+            if (attr_albedo) attr_albedo[4 * v + 3] = c ? 255 : 0;
+            if (attr_normal) attr_normal[4 * v + 3] = c ? 255 : 0;
+        }
     for (size_t v = 0; v < nvox; ++v) {
         const uint32_t* a = acc + 4 * v;
         uint8_t* d = l0 + 4 * v;
@@ -698,6 +731,61 @@ void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8
         d[2] = (uint8_t)((a[2] + h) / c);
         d[3] = 255;
     }
+}
+
+uint64_t vcto_bounce(const vcto_params* p, const uint8_t* chain0, const uint8_t* attr_albedo,
+                     const uint8_t* attr_normal, uint8_t* out_l0, int nthreads) {
+    const int V = p->V;
+    const size_t nvox = (size_t)V * V * V;
+    const float fV = (float)V;
+    memcpy(out_l0, chain0, nvox * 4);
+    auto work = [&](size_t lo, size_t hi, uint64_t* total) {
+        uint64_t steps = 0;
+        for (size_t v = lo; v < hi; ++v) {
+            const uint8_t* src = chain0 + 4 * v;
+            if (src[3] == 0) continue;
+            const uint8_t* nq = attr_normal + 4 * v;
+            const V3 nraw = {(float)((int)nq[0] - 128), (float)((int)nq[1] - 128), (float)((int)nq[2] - 128)};
+            if (nraw.x == 0.0f && nraw.y == 0.0f && nraw.z == 0.0f) continue;
+            const int i = (int)(v % (size_t)V), j = (int)((v / (size_t)V) % (size_t)V), k = (int)(v / ((size_t)V * V));
+            const V3 P = {(((float)i + 0.5f) / fV - 0.5f) * p->G, (((float)j + 0.5f) / fV - 0.5f) * p->G,
+                          (((float)k + 0.5f) / fV - 0.5f) * p->G};
+            const V3 n = normalize(nraw);
+            const V3 helper = fabsf(n.y) < 0.9f ? V3{0.0f, 1.0f, 0.0f} : V3{1.0f, 0.0f, 0.0f};
+            const V3 t = normalize(cross(helper, n));
+            const V3 b = cross(n, t);
+            float ind[4] = {0, 0, 0, 0};
+            for (int c = 0; c < 6; ++c) {
+                const float* d = kConeDirs + 3 * c;
+                V3 dir = {t.x * d[0] + b.x * d[1] + n.x * d[2], t.y * d[0] + b.y * d[1] + n.y * d[2],
+                          t.z * d[0] + b.z * d[1] + n.z * d[2]};
+                dir = normalize(dir);
+                float cone[4];
+                steps += (uint64_t)cone_trace(p, chain0, P, n, dir, p->tan_diffuse, cone);
+                for (int ch = 0; ch < 4; ++ch) ind[ch] = fmaf(kConeWeights[c], cone[ch], ind[ch]);
+            }
+            const float occlusion = 1.0f - ind[3];
+            const uint8_t* alb = attr_albedo + 4 * v;
+            uint8_t* dst = out_l0 + 4 * v;
+            for (int ch = 0; ch < 3; ++ch)
+                dst[ch] = to_unorm8(unorm8(src[ch]) + unorm8(alb[ch]) * (occlusion * ind[ch]));
+        }
+        *total = steps;
+    };
+    if (nthreads <= 1) {
+        uint64_t t = 0;
+        work(0, nvox, &t);
+        return t;
+    }
+    std::vector<uint64_t> totals((size_t)nthreads, 0);
+    std::vector<std::thread> th;
+    const size_t per = (nvox + (size_t)nthreads - 1) / (size_t)nthreads;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t]() { work(std::min(nvox, per * t), std::min(nvox, per * (t + 1)), &totals[(size_t)t]); });
+    for (auto& x : th) x.join();
+    uint64_t sum = 0;
+    for (auto v : totals) sum += v;
+    return sum;
 }
 
 }  // extern "C"

@@ -151,6 +151,32 @@ void vcto_voxelize_reference(const vcto_params* p, const vcto_scene* s, uint8_t*
 void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
                                 uint32_t* acc);
 
+/* ---- second bounce (north-star; BASELINE.json config 3) ---------------------------------------
+ * The reference has NO code for this: its README claims "2 bounces" (README.md:16) but the
+ * orchestrator injects direct light once and gathers once (VCT.h:138-139, vox.fs:88).  The
+ * definition below is the build's own ("every occupied voxel gathers 6
+ * diffuse cones from the bounce-0 volume along a stored voxel normal and adds albedo*irradiance,
+ * re-mip, then screen trace"), restated here so the HIP kernel has something to be checked against.
+ *
+ * Per-voxel attributes come from the conservative voxelizer: every fragment also contributes its
+ * material albedo (unorm8, before the shadow factor) and its triangle's front-face unit normal
+ * n = normalize(cross(v1-v0, v2-v0)) (CCW = front, R/main.cpp:57-58), quantised to
+ * floor(n*127 + 0.5) + 128 in [1,255]; the voxel keeps the rounded integer means.
+ *   attr_albedo [V^3][4] uint8 (rgb, a = 255 where occupied), attr_normal [V^3][4] uint8 (biased
+ *   xyz, w = 255 where occupied), linear voxel order like l0.  Either may be NULL. */
+void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
+                                     uint32_t* acc, uint8_t* attr_albedo, uint8_t* attr_normal);
+/* One bounce: for every voxel of level 0 with a != 0 and a non-zero stored normal,
+ *   P = ((idx + 0.5)/V - 0.5) * G,  n = normalize(stored normal),
+ *   frame t = normalize(cross(|n.y| < 0.9 ? (0,1,0) : (1,0,0), n)), b = cross(n, t),
+ *   cone_i = Voxel_Cone_Tracing(from P with Normal_world = n, normalize(t*d.x + b*d.y + n*d.z), tan_diffuse)
+ *   gathered like trace.fs:194-201: ind = sum w_i * cone_i, occlusion = 1 - ind.a,
+ *   out.rgb = unorm8(l0.rgb/255 + albedo.rgb/255 * (occlusion * ind.rgb)),  out.a = l0.a.
+ * Other voxels are copied.  chain0: full bounce-0 mip chain (linear); out_l0: V^3*4 bytes.
+ * Returns the number of cone steps executed. */
+uint64_t vcto_bounce(const vcto_params* p, const uint8_t* chain0, const uint8_t* attr_albedo,
+                     const uint8_t* attr_normal, uint8_t* out_l0, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,8 +65,15 @@ def main():
     p = pyoracle.default_params(V)
     sc = pyoracle.make_scene(pos, mat, alb)
     l0, acc = pyoracle.voxelize_conservative(p, sc, want_acc=True)
+    chain0 = pyoracle.build_mips(l0)
+    # ... and the second bounce on top of it (BASELINE.json config 3; oracle/vct_oracle.h vcto_bounce)
+    l0b, attr_alb, attr_nrm = pyoracle.voxelize_conservative_attr(p, sc)
+    assert np.array_equal(l0b, l0)
+    l1, bounce_steps = pyoracle.bounce(p, chain0, attr_alb, attr_nrm)
     np.savez_compressed(os.path.join(HERE, "voxelize_v32.npz"), V=V, pos=pos, material=mat, albedo=alb,
-                        level0=l0, count=acc[..., 3].astype(np.uint16), chain=pyoracle.build_mips(l0))
+                        level0=l0, count=acc[..., 3].astype(np.uint16), chain=chain0,
+                        attr_albedo=attr_alb, attr_normal=attr_nrm, bounce_level0=l1,
+                        bounce_steps=np.int64(bounce_steps), bounce_chain=pyoracle.build_mips(l1))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -50,6 +50,11 @@ def test_oracle_reproduces_golden_voxelization(oracle):
     assert np.array_equal(acc[..., 3], g["count"])
     assert np.array_equal(oracle.build_mips(l0), g["chain"])
     assert 0.01 < (l0[..., 3] > 0).mean() < 0.6
+    l0b, alb, nrm = oracle.voxelize_conservative_attr(oracle.default_params(V), sc)
+    assert np.array_equal(l0b, l0) and np.array_equal(alb, g["attr_albedo"]) and np.array_equal(nrm, g["attr_normal"])
+    l1, steps = oracle.bounce(oracle.default_params(V), g["chain"], alb, nrm, nthreads=2)
+    assert np.array_equal(l1, g["bounce_level0"]) and steps == int(g["bounce_steps"])
+    assert (l1 != l0).any()
 
 
 @pytest.mark.gpu
@@ -80,9 +85,15 @@ def test_hip_reproduces_golden_voxelization():
     import vctpkg
     vct = vctpkg.load()
     g = np.load(os.path.join(GOLDEN, "voxelize_v32.npz"))
-    with vct.Context(vct.default_config(voxel_dim=int(g["V"]), width=8, height=8)) as ctx:
+    with vct.Context(vct.default_config(voxel_dim=int(g["V"]), width=8, height=8,
+                                        voxel_attributes=1)) as ctx:
         ctx.upload_triangles(g["pos"], g["material"], g["albedo"])
         ctx.voxelize()
         ctx.inject_light()
         ctx.build_mips()
         assert np.array_equal(ctx.download_chain(), g["chain"])
+        alb, nrm = ctx.voxel_attributes()
+        assert np.array_equal(alb, g["attr_albedo"]) and np.array_equal(nrm, g["attr_normal"])
+        ctx.bounce()
+        assert ctx.last_step_count() == int(g["bounce_steps"])
+        assert np.array_equal(ctx.download_chain(), g["bounce_chain"])

@@ -293,3 +293,53 @@ def test_frame_gather_single_rank_device_path(vct, oracle):
         assert np.array_equal(fg.slab[: y1 - y0].cpu().numpy().view(np.uint16), want[y0:y1])
         ctx.set_frame_target(None)
         assert np.array_equal(ctx.trace(planes), want)
+
+
+@pytest.mark.parametrize("with_shadow", [False, True])
+def test_second_bounce_matches_oracle(vct, oracle, with_shadow):
+    """BASELINE.json config 3 (2-bounce), at test size: voxel attributes, the bounce-1 level 0 and
+    its mip chain are bit-identical to the oracle's, and so is the screen trace through it."""
+    V, w, h = 32, 24, 16
+    pos, mat, alb = random_scene(300, seed=33)
+    depth, vp = light_setup(128, 5) if with_shadow else (None, None)
+    p = oracle.default_params(V)
+    sc = oracle.make_scene(pos, mat, alb, shadow_depth=depth, light_vp=vp)
+    l0, want_alb, want_nrm = oracle.voxelize_conservative_attr(p, sc)
+    chain0 = oracle.build_mips(l0)
+    want_l1, want_steps = oracle.bounce(p, chain0, want_alb, want_nrm, nthreads=8)
+    want_chain1 = oracle.build_mips(want_l1)
+    assert (want_l1 != l0).any() and want_steps > 0
+    planes = synth.random_gbuffer(w * h, seed=4)
+    with make_ctx(vct, V, w, h, voxel_attributes=1) as ctx:
+        with pytest.raises(vct.VctError):
+            ctx.bounce()                          # nothing voxelized yet
+        ctx.upload_triangles(pos, mat, alb)
+        if with_shadow:
+            ctx.upload_shadow_map(depth, vp)
+        ctx.voxelize()
+        ctx.inject_light()
+        with pytest.raises(vct.VctError):
+            ctx.bounce()                          # mips of bounce 0 not built yet
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), chain0)
+        got_alb, got_nrm = ctx.voxel_attributes()
+        assert np.array_equal(got_alb, want_alb)
+        assert np.array_equal(got_nrm, want_nrm)
+        ctx.bounce()
+        assert ctx.last_step_count() == want_steps
+        assert np.array_equal(ctx.download_chain(), want_chain1)
+        check_frame(vct, oracle, ctx, want_chain1, planes, w, h)      # the trace reads the bounce-1 chain
+        ctx.voxelize()                                                # a new inject returns to bounce 0
+        ctx.inject_light()
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), chain0)
+        check_frame(vct, oracle, ctx, chain0, planes, w, h)
+
+
+def test_bounce_needs_attributes(vct):
+    pos, mat, alb = random_scene(50, seed=1)
+    with make_ctx(vct, 16, 8, 8) as ctx:
+        ctx.upload_triangles(pos, mat, alb)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        with pytest.raises(vct.VctError):
+            ctx.bounce()

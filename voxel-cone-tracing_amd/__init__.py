@@ -25,7 +25,7 @@ GB_PLANES = 23
 GB_LINEAR, GB_TILED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 VOX_CONSERVATIVE_AVG, VOX_REFERENCE = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/vct.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -36,7 +36,8 @@ ABI_SYMBOLS = [
     "vct_download_chain_rgba8", "vct_chain_texels", "vct_trace", "vct_trace_slab",
     "vct_trace_resident", "vct_synchronize", "vct_download_steps", "vct_download_cones",
     "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream", "vct_get_frame_device",
-    "vct_selftest_const_divide", "vct_set_frame_target",
+    "vct_selftest_const_divide", "vct_set_frame_target", "vct_bounce",
+    "vct_download_voxel_attributes",
 ]
 
 
@@ -48,6 +49,7 @@ class Config(C.Structure):
         ("ambient_factor", C.c_float), ("shininess", C.c_float), ("max_distance", C.c_float),
         ("max_alpha", C.c_float), ("tan_diffuse", C.c_float), ("tan_specular", C.c_float),
         ("wrap_repeat", C.c_int32), ("debug_outputs", C.c_int32), ("trace_variant", C.c_int32),
+        ("voxel_attributes", C.c_int32),
     ]
 
 
@@ -84,7 +86,8 @@ _lib.vct_upload_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_in
                                       C.c_int32]
 _lib.vct_upload_shadow_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
 _lib.vct_voxelize.argtypes = [C.c_void_p, C.c_int32]
-for _n in ("vct_inject_light", "vct_build_mips", "vct_trace_resident", "vct_synchronize"):
+_lib.vct_download_voxel_attributes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+for _n in ("vct_inject_light", "vct_build_mips", "vct_trace_resident", "vct_synchronize", "vct_bounce"):
     getattr(_lib, _n).argtypes = [C.c_void_p]
 _lib.vct_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
 _lib.vct_trace_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
@@ -191,6 +194,17 @@ class Context:
 
     def build_mips(self):
         self._ck(_lib.vct_build_mips(self._h), "vct_build_mips")
+
+    def bounce(self):
+        self._ck(_lib.vct_bounce(self._h), "vct_bounce")
+
+    def voxel_attributes(self):
+        V = self.cfg.voxel_dim
+        alb = np.zeros((V, V, V, 4), np.uint8)
+        nrm = np.zeros((V, V, V, 4), np.uint8)
+        self._ck(_lib.vct_download_voxel_attributes(self._h, _ptr(alb), _ptr(nrm)),
+                 "vct_download_voxel_attributes")
+        return alb, nrm
 
     def upload_volume(self, l0):
         l0 = np.ascontiguousarray(l0, np.uint8)

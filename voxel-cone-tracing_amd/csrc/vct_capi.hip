@@ -20,7 +20,13 @@ struct vct_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
 
-    uint32_t* chain = nullptr;        // Morton chain
+    uint32_t* chain = nullptr;        // Morton chain (bounce 0: direct light)
+    uint32_t* chain_b = nullptr;      // second chain (bounce 1), allocated by vct_bounce
+    bool use_chain_b = false;         // the trace reads chain_b until the next vct_inject_light
+    unsigned long long* acc_attr = nullptr;   // [V^3][3] attribute accumulators (cfg.voxel_attributes)
+    uint32_t* attr_albedo = nullptr;  // [V^3] resolved mean albedo, Morton order
+    uint32_t* attr_normal = nullptr;  // [V^3] resolved mean normal (biased), Morton order
+    bool mips_valid = false;
     size_t chain_texels = 0;
     uint32_t* staging = nullptr;      // linear staging for up/downloads (size of level 0)
     int nlev = 0;
@@ -179,29 +185,35 @@ size_t gb_tiled_floats(const vct_ctx* c) {
     return (size_t)tiles_x(c) * tiles_y(c) * VCT_GB_NPLANES * VCT_TILE_PIX;
 }
 
-int launch_trace(vct_ctx* c, int row0, int row1) {
-    int rc = refresh_steps(c);
-    if (rc) return rc;
-    VctTraceParams p;
+// everything the march needs (shared by the screen trace and the bounce)
+void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chain) {
     memset(&p, 0, sizeof(p));
-    p.chain = c->chain;
+    p.chain = chain;
     for (int l = 0; l < c->nlev; ++l) p.level_off[l] = (uint32_t)vct_level_offset(c->cfg.voxel_dim, l);
     p.V = c->cfg.voxel_dim;
     p.nlev = c->nlev;
     p.G = c->cfg.grid_world_size;
     p.half_G = c->cfg.grid_world_size * 0.5f;                       // trace.fs:61
     p.vs = c->cfg.grid_world_size / (float)c->cfg.voxel_dim;        // trace.fs:90
-    for (int i = 0; i < 3; ++i) { p.cam[i] = c->cam[i]; p.light[i] = c->light[i]; }
-    p.ambient = c->cfg.ambient_factor;
-    p.shininess = c->cfg.shininess;
-    p.max_alpha = c->cfg.max_alpha;
-    p.wrap_repeat = c->cfg.wrap_repeat;
     p.half_G_rcp = 1.0f / p.half_G;
     p.fast_div = c->fast_div ? 1 : 0;
+    p.max_alpha = c->cfg.max_alpha;
+    p.wrap_repeat = c->cfg.wrap_repeat;
     p.steps_diffuse = c->steps_dev;
     p.steps_specular = c->steps_dev + VCT_MAX_STEPS;
     p.n_diffuse = c->n_diffuse;
     p.n_specular = c->n_specular;
+    p.step_counter = c->step_counter;
+}
+
+int launch_trace(vct_ctx* c, int row0, int row1) {
+    int rc = refresh_steps(c);
+    if (rc) return rc;
+    VctTraceParams p;
+    fill_march_params(c, p, c->use_chain_b ? c->chain_b : c->chain);
+    for (int i = 0; i < 3; ++i) { p.cam[i] = c->cam[i]; p.light[i] = c->light[i]; }
+    p.ambient = c->cfg.ambient_factor;
+    p.shininess = c->cfg.shininess;
     p.width = c->cfg.width;
     p.height = c->cfg.height;
     p.tiles_x = tiles_x(c);
@@ -213,7 +225,6 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.out = c->frame_target ? c->frame_target : c->frame;
     p.dbg_steps = c->cfg.debug_outputs ? c->dbg_steps : nullptr;
     p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
-    p.step_counter = c->step_counter;
     HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long),
                               c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -244,6 +255,7 @@ VctVoxParams vox_params(const vct_ctx* c) {
     p.big_list = c->big_list;
     p.n_big = c->n_big;
     p.brick_flags = c->brick_flags;
+    p.acc_attr = c->acc_attr;
     return p;
 }
 
@@ -271,6 +283,7 @@ int vct_default_config(vct_config* cfg) {
     cfg->wrap_repeat = 1;
     cfg->debug_outputs = 0;
     cfg->trace_variant = 0;
+    cfg->voxel_attributes = 0;
     return VCT_OK;
 }
 
@@ -346,7 +359,7 @@ void vct_destroy(vct_ctx* c) {
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
-                    c->brick_flags, c->brick_prev};
+                    c->brick_flags, c->brick_prev, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -466,9 +479,18 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->brick_flags, 0, nbricks * sizeof(uint32_t), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->brick_prev, 0, nbricks * sizeof(uint32_t), c->stream));
+        if (c->cfg.voxel_attributes) {
+            HIP_TRY(c, hipMalloc(&c->acc_attr, nvox * 24));
+            HIP_TRY(c, hipMalloc(&c->attr_albedo, nvox * 4));
+            HIP_TRY(c, hipMalloc(&c->attr_normal, nvox * 4));
+            HIP_TRY(c, hipMemsetAsync(c->acc_attr, 0, nvox * 24, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->attr_albedo, 0, nvox * 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->attr_normal, 0, nvox * 4, c->stream));
+        }
     } else if (c->acc_pending) {   // a pass that was never resolved: discard it
         HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->brick_flags, 0, nbricks * sizeof(uint32_t), c->stream));
+        if (c->acc_attr) HIP_TRY(c, hipMemsetAsync(c->acc_attr, 0, nvox * 24, c->stream));
     }
     VctVoxParams p = vox_params(c);
     p.mode = mode;
@@ -482,9 +504,11 @@ int vct_inject_light(vct_ctx* c) {
     if (!c->acc_pending) return fail(c, VCT_ERR_INVALID, "vct_inject_light: call vct_voxelize first");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, vct_launch_resolve(c->acc, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
-                                  c->level0_dirty, c->stream));
+                                  c->level0_dirty, c->acc_attr, c->attr_albedo, c->attr_normal, c->stream));
     c->acc_pending = false;
     c->level0_dirty = false;
+    c->use_chain_b = false;
+    c->mips_valid = false;
     return VCT_OK;
 }
 
@@ -492,6 +516,58 @@ int vct_build_mips(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, vct_launch_build_mips(c->chain, c->cfg.voxel_dim, c->stream));
+    c->mips_valid = true;
+    c->use_chain_b = false;
+    return VCT_OK;
+}
+
+int vct_bounce(vct_ctx* c) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!c->cfg.voxel_attributes || !c->attr_normal)
+        return fail(c, VCT_ERR_INVALID, "vct_bounce: needs config.voxel_attributes = 1 and a voxelize + inject pass");
+    if (c->acc_pending || !c->mips_valid)
+        return fail(c, VCT_ERR_INVALID, "vct_bounce: call vct_inject_light and vct_build_mips first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = refresh_steps(c);
+    if (rc) return rc;
+    const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
+    if (!c->chain_b) HIP_TRY(c, hipMalloc(&c->chain_b, c->chain_texels * 4));
+    // untouched voxels keep their bounce-0 value (zero where empty)
+    HIP_TRY(c, hipMemcpyAsync(c->chain_b, c->chain, nvox * 4, hipMemcpyDeviceToDevice, c->stream));
+    VctTraceParams p;
+    fill_march_params(c, p, c->chain);
+    p.attr_albedo = c->attr_albedo;
+    p.attr_normal = c->attr_normal;
+    p.brick_prev = c->brick_prev;
+    p.bounce_out = c->chain_b;
+    p.nbricks = (uint32_t)(nvox / 512);
+    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, vct_launch_bounce(p, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, c->stream));
+    c->use_chain_b = true;
+    c->have_trace = true;      // step counter / event pair now describe the bounce launch
+    return VCT_OK;
+}
+
+int vct_download_voxel_attributes(vct_ctx* c, uint8_t* albedo, uint8_t* normal) {
+    if (!c || !albedo || !normal) return VCT_ERR_INVALID;
+    if (!c->attr_albedo) return fail(c, VCT_ERR_INVALID, "no voxel attributes (config.voxel_attributes, vct_voxelize + vct_inject_light)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->staging) {
+        const size_t n = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
+        HIP_TRY(c, hipMalloc(&c->staging, n * 4));
+    }
+    const int V = c->cfg.voxel_dim;
+    const size_t n = (size_t)V * V * V;
+    const uint32_t* src[2] = {c->attr_albedo, c->attr_normal};
+    uint8_t* dst[2] = {albedo, normal};
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(c, vct_launch_morton_to_linear(src[k], c->staging, V, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dst[k], c->staging, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return VCT_OK;
 }
 
@@ -506,6 +582,8 @@ static int ensure_staging(vct_ctx* c) {
 
 static int upload_levels(vct_ctx* c, const uint8_t* lin, int nlevels) {
     HIP_TRY(c, hipSetDevice(c->device));
+    c->use_chain_b = false;
+    c->mips_valid = nlevels > 1;
     c->level0_dirty = true;     // level 0 no longer mirrors brick_prev: next resolve is dense
     int rc = ensure_staging(c);
     if (rc) return rc;
@@ -542,7 +620,8 @@ int vct_download_chain_rgba8(vct_ctx* c, uint8_t* chain) {
     for (int l = 0; l < c->nlev; ++l) {
         const int N = V >> l;
         const size_t off = (size_t)vct_level_offset(V, l), n = (size_t)N * N * N;
-        HIP_TRY(c, vct_launch_morton_to_linear(c->chain + off, c->staging, N, c->stream));
+        const uint32_t* active = c->use_chain_b ? c->chain_b : c->chain;
+        HIP_TRY(c, vct_launch_morton_to_linear(active + off, c->staging, N, c->stream));
         HIP_TRY(c, hipMemcpyAsync(chain + off * 4, c->staging, n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }

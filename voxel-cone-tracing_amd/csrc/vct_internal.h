@@ -57,6 +57,12 @@ struct VctTraceParams {
     uint8_t* dbg_steps;                 // [npix][7] or null
     float* dbg_cones;                   // [npix][7][4] or null
     unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] partial sums of executed steps
+    // second bounce (k_bounce): per-voxel attributes (Morton order), touched-brick flags, output level 0
+    const uint32_t* attr_albedo;
+    const uint32_t* attr_normal;
+    const uint32_t* brick_prev;
+    uint32_t* bounce_out;
+    uint32_t nbricks;
 };
 
 struct VctVoxParams {
@@ -75,6 +81,7 @@ struct VctVoxParams {
     const int32_t* big_list;   // triangles with more than VCT_VOX_BIG candidates
     int32_t n_big;
     uint32_t* brick_flags;     // [V^3 / 512] raised by fragments, consumed by the sparse resolve
+    unsigned long long* acc_attr;   // [V^3][3]: (albR | albG<<32), (albB | nX<<32), (nY | nZ<<32) or null
     int32_t mode;
 };
 
@@ -89,6 +96,8 @@ hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* wor
                                int32_t* big_list, bool write, hipStream_t s);
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s);
 hipError_t vct_launch_resolve(unsigned long long* acc, uint32_t* level0, uint32_t* flags,
-                              uint32_t* prev, int V, bool dense, hipStream_t s);
+                              uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
+                              uint32_t* attr_albedo, uint32_t* attr_normal, hipStream_t s);
+hipError_t vct_launch_bounce(const VctTraceParams& p, hipStream_t s);
 
 #endif

@@ -145,6 +145,7 @@ struct TriSetup {
     int ua, ub;
     float area;
     float alb[3];
+    uint32_t attr[6];   // per-fragment voxel attributes: unorm8 albedo rgb, biased quantised face normal xyz
     bool valid;
 };
 
@@ -207,6 +208,17 @@ __device__ __forceinline__ void setup_tri(const VctVoxParams& p, int t, TriSetup
     r.area = (ax1 - ax0) * (ay2 - ay0) - (ax2 - ax0) * (ay1 - ay0);
     const float* alb = p.albedo + 4 * (size_t)p.material[t];
     r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
+    if (p.acc_attr) {
+        // front-face unit normal n = normalize(cross(v1-v0, v2-v0)), quantised floor(n*127+.5)+128
+        const F3 fn = cross3(sub3(w[1], w[0]), sub3(w[2], w[0]));
+        const float fl = __builtin_sqrtf(dot3(fn, fn));
+        const float fc[3] = {__fdiv_rn(fn.x, fl), __fdiv_rn(fn.y, fl), __fdiv_rn(fn.z, fl)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r.attr[k] = to_unorm8(alb[k]);
+            r.attr[3 + k] = (uint32_t)((int)floorf(fc[k] * 127.0f + 0.5f) + 128);
+        }
+    }
 }
 
 __device__ __forceinline__ bool overlap(const TriSetup& c, int i, int j, int k) {
@@ -252,6 +264,12 @@ __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& 
     atomicAdd(a, cr | (cg << 32));
     atomicAdd(a + 1, cb | (1ull << 32));
     p.brick_flags[vox >> 9] = 1u;      // benign race: every writer stores the same value
+    if (p.acc_attr) {
+        unsigned long long* q = p.acc_attr + 3 * (size_t)vox;
+        atomicAdd(q, (unsigned long long)r.attr[0] | ((unsigned long long)r.attr[1] << 32));
+        atomicAdd(q + 1, (unsigned long long)r.attr[2] | ((unsigned long long)r.attr[3] << 32));
+        atomicAdd(q + 2, (unsigned long long)r.attr[4] | ((unsigned long long)r.attr[5] << 32));
+    }
 }
 
 #define VCT_VOX_BIG 4096
@@ -357,7 +375,8 @@ __device__ __forceinline__ uint32_t resolve_voxel(ulonglong2 a) {
 __global__ void __launch_bounds__(256)
 k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ level0,
                  uint32_t* __restrict__ flags, uint32_t* __restrict__ prev, uint32_t nbricks,
-                 uint32_t brick_voxels, int dense) {
+                 uint32_t brick_voxels, int dense, unsigned long long* __restrict__ acc_attr,
+                 uint32_t* __restrict__ attr_albedo, uint32_t* __restrict__ attr_normal) {
     const int lane = threadIdx.x & 63;
     const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nbricks; b += waves) {
@@ -369,6 +388,23 @@ k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ le
             const ulonglong2 a = a2[v];
             l0[v] = resolve_voxel(a);
             if (a.y) a2[v] = make_ulonglong2(0ull, 0ull);
+            if (acc_attr) {
+                const size_t vox = (size_t)b * brick_voxels + v;
+                unsigned long long* q = acc_attr + 3 * vox;
+                const uint32_t c = (uint32_t)(a.y >> 32);
+                uint32_t alb = 0u, nrm = 0u;
+                if (c) {
+                    const unsigned long long q0 = q[0], q1 = q[1], q2 = q[2];
+                    const uint32_t h = c >> 1;
+                    alb = (((uint32_t)q0 + h) / c) | ((((uint32_t)(q0 >> 32) + h) / c) << 8) |
+                          ((((uint32_t)q1 + h) / c) << 16) | 0xff000000u;
+                    nrm = (((uint32_t)(q1 >> 32) + h) / c) | ((((uint32_t)q2 + h) / c) << 8) |
+                          ((((uint32_t)(q2 >> 32) + h) / c) << 16) | 0xff000000u;
+                    q[0] = 0ull; q[1] = 0ull; q[2] = 0ull;
+                }
+                attr_albedo[vox] = alb;
+                attr_normal[vox] = nrm;
+            }
         }
         if (lane == 0) { prev[b] = now; flags[b] = 0u; }
     }
@@ -403,12 +439,13 @@ hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
 }
 
 hipError_t vct_launch_resolve(unsigned long long* acc, uint32_t* level0, uint32_t* flags,
-                              uint32_t* prev, int V, bool dense, hipStream_t s) {
+                              uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
+                              uint32_t* attr_albedo, uint32_t* attr_normal, hipStream_t s) {
     const uint32_t brick_voxels = V >= 8 ? 512u : (uint32_t)(V * V * V);
     const uint32_t nbricks = (uint32_t)(((size_t)V * V * V) / brick_voxels);
     size_t blocks = ((size_t)nbricks + 3) / 4;      // 4 waves per workgroup, one brick per wave
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)blocks), dim3(256), 0, s, acc, level0, flags,
-                       prev, nbricks, brick_voxels, dense ? 1 : 0);
+                       prev, nbricks, brick_voxels, dense ? 1 : 0, acc_attr, attr_albedo, attr_normal);
     return hipGetLastError();
 }
