@@ -6,7 +6,7 @@ CSRC := $(PKG)/csrc
 # -fno-slp-vectorize: packed fp32 (v_pk_fma_f32 ...) issues at half rate on gfx950, so SLP packing buys
 #   nothing and costs v_mov shuffles (trace kernel 1.01 -> 0.87 ms, profiles/r01c).
 HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function
-OBJS := $(CSRC)/vct_capi.o $(CSRC)/vct_trace.o $(CSRC)/vct_volume.o $(CSRC)/vct_voxelize.o
+OBJS := $(CSRC)/vct_capi.o $(CSRC)/vct_trace.o $(CSRC)/vct_volume.o $(CSRC)/vct_voxelize.o $(CSRC)/vct_raster.o
 LIB := $(PKG)/libvct_amd.so
 
 HOSTLIB := $(PKG)/libvct_host.so
@@ -16,7 +16,7 @@ all: lib host oracle demo
 host: $(HOSTLIB)
 
 $(HOSTLIB): $(PKG)/host/vct_host.cpp $(PKG)/host/vct_host.h
-	g++ -O2 -std=c++17 -fPIC -Wall -Wextra -shared -o $@ $(PKG)/host/vct_host.cpp
+	g++ -O2 -std=c++17 -ffp-contract=off -fPIC -Wall -Wextra -shared -o $@ $(PKG)/host/vct_host.cpp
 
 lib: $(LIB)
 

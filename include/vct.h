@@ -121,6 +121,29 @@ int vct_upload_triangles(vct_ctx* ctx, const float* pos, const int32_t* material
  * column-major DepthViewProjectionMatrix (VCT.h:84-86).  depth == NULL detaches it (PCF = 1). */
 int vct_upload_shadow_map(vct_ctx* ctx, const float* depth, int32_t size, const float light_vp[16]);
 
+/* ---- raster input stages on the GPU ------------------------------------------
+ * Per-vertex frame of the uploaded triangles (R/Mesh.h:12-19 normal / tangent / bitangent, attribs
+ * 1,3,4 of S/VoxelConeTracing.vs) and the per-material specular colour (trace.fs:209): normal,
+ * tangent, bitangent [ntri][3][3] model space, specular [nmat][3].  Call after vct_upload_triangles. */
+int vct_upload_mesh_attributes(vct_ctx* ctx, const float* normal, const float* tangent,
+                               const float* bitangent, const float* specular);
+/* DrawDepthTexture (VCT.h:192-211, S/Shadow.vs/.fs): rasterises the uploaded triangles from the light
+ * (column-major DepthViewProjectionMatrix, VCT.h:84-86) into the context's shadow map of
+ * config.shadow_map_size^2 24-bit depths -- the map vct_voxelize and vct_render_gbuffer then read. */
+int vct_render_shadow_map(vct_ctx* ctx, const float light_vp[16]);
+int vct_download_shadow_map(vct_ctx* ctx, float* depth);
+/* The vertex + fixed-function part of Render (VCT.h:161-189, S/VoxelConeTracing.vs, depth test LESS,
+ * back faces culled) and the non-cone per-fragment inputs of S/VoxelConeTracing.fs (bump normal,
+ * material colours, PCF shadow term): fills the resident tiled G-buffer from the uploaded mesh for
+ * the column-major view-projection matrix (VCT.h:161-163).  Follow with vct_trace_resident or
+ * vct_trace_current. */
+int vct_render_gbuffer(vct_ctx* ctx, const float view_proj[16]);
+/* Linear planes [23][h*w] of the resident G-buffer. */
+int vct_download_gbuffer(vct_ctx* ctx, float* planes);
+/* Trace the resident G-buffer (vct_render_gbuffer, or the last vct_trace upload) and return the frame
+ * like vct_trace. */
+int vct_trace_current(vct_ctx* ctx, void* out_rgba16f, int32_t out_location);
+
 /* DrawVoxelTexture (VCT.h:213-245) -> vox.vs / vox.gs / vox.fs: voxelize the uploaded triangles
  * into per-voxel integer accumulators (mode selects coverage + resolve rule). */
 int vct_voxelize(vct_ctx* ctx, int32_t mode);

@@ -37,7 +37,8 @@ ABI_SYMBOLS = [
     "vct_trace_resident", "vct_synchronize", "vct_download_steps", "vct_download_cones",
     "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream", "vct_get_frame_device",
     "vct_selftest_const_divide", "vct_set_frame_target", "vct_bounce",
-    "vct_download_voxel_attributes",
+    "vct_download_voxel_attributes", "vct_upload_mesh_attributes", "vct_render_shadow_map",
+    "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer", "vct_trace_current",
 ]
 
 
@@ -87,6 +88,10 @@ _lib.vct_upload_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_in
 _lib.vct_upload_shadow_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
 _lib.vct_voxelize.argtypes = [C.c_void_p, C.c_int32]
 _lib.vct_download_voxel_attributes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.vct_upload_mesh_attributes.argtypes = [C.c_void_p] * 5
+for _n in ("vct_render_shadow_map", "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer"):
+    getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p]
+_lib.vct_trace_current.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 for _n in ("vct_inject_light", "vct_build_mips", "vct_trace_resident", "vct_synchronize", "vct_bounce"):
     getattr(_lib, _n).argtypes = [C.c_void_p]
 _lib.vct_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
@@ -194,6 +199,36 @@ class Context:
 
     def build_mips(self):
         self._ck(_lib.vct_build_mips(self._h), "vct_build_mips")
+
+    # --- raster input stages on the GPU
+    def upload_mesh_attributes(self, normal, tangent, bitangent, specular):
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (normal, tangent, bitangent, specular)]
+        self._ck(_lib.vct_upload_mesh_attributes(self._h, *(_ptr(a) for a in arrs)),
+                 "vct_upload_mesh_attributes")
+
+    def render_shadow_map(self, light_vp_colmajor):
+        m = np.ascontiguousarray(light_vp_colmajor, np.float32).reshape(16)
+        self._ck(_lib.vct_render_shadow_map(self._h, _ptr(m)), "vct_render_shadow_map")
+
+    def download_shadow_map(self):
+        S = self.cfg.shadow_map_size
+        out = np.zeros((S, S), np.float32)
+        self._ck(_lib.vct_download_shadow_map(self._h, _ptr(out)), "vct_download_shadow_map")
+        return out
+
+    def render_gbuffer(self, view_proj_colmajor):
+        m = np.ascontiguousarray(view_proj_colmajor, np.float32).reshape(16)
+        self._ck(_lib.vct_render_gbuffer(self._h, _ptr(m)), "vct_render_gbuffer")
+
+    def download_gbuffer(self):
+        out = np.zeros((GB_PLANES, self.cfg.width * self.cfg.height), np.float32)
+        self._ck(_lib.vct_download_gbuffer(self._h, _ptr(out)), "vct_download_gbuffer")
+        return out
+
+    def trace_current(self):
+        out = np.zeros((self.cfg.height, self.cfg.width, 4), np.uint16)
+        self._ck(_lib.vct_trace_current(self._h, _ptr(out), MEM_HOST), "vct_trace_current")
+        return out
 
     def bounce(self):
         self._ck(_lib.vct_bounce(self._h), "vct_bounce")

@@ -45,6 +45,7 @@ struct vct_ctx {
     bool fast_div = false;            // set by refresh_steps: constant divisors admit the FMA division
     int last_row0 = 0, last_row1 = 0;
     bool have_trace = false;
+    bool have_gbuffer = false;        // a G-buffer is resident (uploaded by vct_trace or rendered)
 
     float cam[3] = {0.0f, 4.0f, 0.0f};        // VCT.h:8
     float light[3] = {0.0f, 1.0f, 0.25f};     // VCT.h:14
@@ -56,6 +57,15 @@ struct vct_ctx {
     int32_t ntri = 0, nmat = 0;
     float* shadow = nullptr;
     int32_t shadow_size = 0;
+    // raster input stages
+    float* tri_nrm = nullptr;
+    float* tri_tan = nullptr;
+    float* tri_bit = nullptr;
+    float* mat_specular = nullptr;
+    unsigned long long* vis = nullptr;
+    size_t vis_words = 0;
+    int32_t* raster_big = nullptr;
+    int32_t* raster_big_count = nullptr;
     float light_vp[16];
     unsigned long long* acc = nullptr;
     // voxelization plan (geometry only; built by vct_upload_triangles) and sparse-resolve state
@@ -359,7 +369,9 @@ void vct_destroy(vct_ctx* c) {
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
-                    c->brick_flags, c->brick_prev, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal};
+                    c->brick_flags, c->brick_prev, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
+                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->vis, c->raster_big,
+                    c->raster_big_count};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -461,6 +473,108 @@ int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const fl
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->shadow_size = size;
     memcpy(c->light_vp, light_vp, 64);
+    return VCT_OK;
+}
+
+// ---- raster input stages ------------------------------------------------------------------
+
+static int raster_args(vct_ctx* c, size_t pixels, VctRasterArgs& a) {
+    if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "no triangles uploaded");
+    if (c->vis_words < pixels) {
+        if (c->vis) { (void)hipFree(c->vis); c->vis = nullptr; c->vis_words = 0; }
+        HIP_TRY(c, hipMalloc(&c->vis, pixels * sizeof(unsigned long long)));
+        c->vis_words = pixels;
+    }
+    if (!c->raster_big) HIP_TRY(c, hipMalloc(&c->raster_big, (size_t)c->ntri * 2 * sizeof(int32_t)));
+    if (!c->raster_big_count) HIP_TRY(c, hipMalloc(&c->raster_big_count, sizeof(int32_t)));
+    memset(&a, 0, sizeof(a));
+    a.pos = c->tri_pos;
+    a.nrm = c->tri_nrm; a.tan = c->tri_tan; a.bit = c->tri_bit;
+    a.material = c->tri_mat;
+    a.albedo = c->mat_albedo;
+    a.specular = c->mat_specular;
+    a.ntri = c->ntri;
+    a.model_scale = c->cfg.model_scale;
+    a.vis = c->vis;
+    a.big_list = c->raster_big;
+    a.big_count = c->raster_big_count;
+    return VCT_OK;
+}
+
+int vct_upload_mesh_attributes(vct_ctx* c, const float* normal, const float* tangent,
+                               const float* bitangent, const float* specular) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!normal || !tangent || !bitangent || !specular)
+        return fail(c, VCT_ERR_INVALID, "vct_upload_mesh_attributes: null input");
+    if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_upload_mesh_attributes: call vct_upload_triangles first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    float** dst[3] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit};
+    const float* src[3] = {normal, tangent, bitangent};
+    const size_t bytes = (size_t)c->ntri * 9 * sizeof(float);
+    for (int k = 0; k < 3; ++k) {
+        if (*dst[k]) { (void)hipFree(*dst[k]); *dst[k] = nullptr; }
+        HIP_TRY(c, hipMalloc(dst[k], bytes));
+        HIP_TRY(c, hipMemcpyAsync(*dst[k], src[k], bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    if (c->mat_specular) { (void)hipFree(c->mat_specular); c->mat_specular = nullptr; }
+    HIP_TRY(c, hipMalloc(&c->mat_specular, (size_t)c->nmat * 3 * sizeof(float)));
+    HIP_TRY(c, hipMemcpyAsync(c->mat_specular, specular, (size_t)c->nmat * 3 * sizeof(float),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCT_OK;
+}
+
+int vct_render_shadow_map(vct_ctx* c, const float light_vp[16]) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!light_vp) return fail(c, VCT_ERR_INVALID, "vct_render_shadow_map: null matrix");
+    const int S = c->cfg.shadow_map_size;
+    if (S <= 0) return fail(c, VCT_ERR_INVALID, "vct_render_shadow_map: config.shadow_map_size <= 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    VctRasterArgs a;
+    int rc = raster_args(c, (size_t)S * S, a);
+    if (rc) return rc;
+    if (c->shadow && c->shadow_size != S) { (void)hipFree(c->shadow); c->shadow = nullptr; }
+    if (!c->shadow) HIP_TRY(c, hipMalloc(&c->shadow, (size_t)S * S * sizeof(float)));
+    c->shadow_size = S;
+    memcpy(c->light_vp, light_vp, 64);
+    HIP_TRY(c, vct_launch_shadow_raster(a, light_vp, S, c->shadow, c->stream));
+    return VCT_OK;
+}
+
+int vct_download_shadow_map(vct_ctx* c, float* depth) {
+    if (!c || !depth) return VCT_ERR_INVALID;
+    if (!c->shadow) return fail(c, VCT_ERR_INVALID, "no shadow map");
+    HIP_TRY(c, hipMemcpyAsync(depth, c->shadow, (size_t)c->shadow_size * c->shadow_size * sizeof(float),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCT_OK;
+}
+
+int vct_render_gbuffer(vct_ctx* c, const float view_proj[16]) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!view_proj) return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer: null matrix");
+    if (!c->tri_nrm) return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer: call vct_upload_mesh_attributes first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    VctRasterArgs a;
+    int rc = raster_args(c, (size_t)c->cfg.width * c->cfg.height, a);
+    if (rc) return rc;
+    HIP_TRY(c, vct_launch_gbuffer_raster(a, view_proj, c->cfg.width, c->cfg.height, c->shadow,
+                                         c->shadow_size, c->light_vp, c->gb_tiled, c->stream));
+    c->gb_current = c->gb_tiled;
+    c->last_row0 = 0;
+    c->last_row1 = tiles_y(c);
+    c->have_gbuffer = true;
+    return VCT_OK;
+}
+
+int vct_download_gbuffer(vct_ctx* c, float* planes) {
+    if (!c || !planes) return VCT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->cfg.width * c->cfg.height * VCT_GB_NPLANES;
+    if (!c->gb_linear) HIP_TRY(c, hipMalloc(&c->gb_linear, n * sizeof(float)));
+    HIP_TRY(c, vct_launch_untile_gbuffer(c->gb_current, c->gb_linear, c->cfg.width, c->cfg.height, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(planes, c->gb_linear, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VCT_OK;
 }
 
@@ -666,6 +780,7 @@ int vct_trace_slab(vct_ctx* c, const vct_gbuffer* gb, int32_t row0, int32_t row1
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = bind_gbuffer(c, gb);
     if (rc) return rc;
+    c->have_gbuffer = true;
     rc = launch_trace(c, row0, row1);
     if (rc) return rc;
     if (out) {
@@ -689,9 +804,25 @@ int vct_trace(vct_ctx* c, const vct_gbuffer* gb, void* out, int32_t out_location
     return vct_trace_slab(c, gb, 0, tiles_y(c), out, out_location);
 }
 
+int vct_trace_current(vct_ctx* c, void* out, int32_t out_location) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!c->have_gbuffer) return fail(c, VCT_ERR_INVALID, "vct_trace_current: no G-buffer resident yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = launch_trace(c, 0, tiles_y(c));
+    if (rc) return rc;
+    if (out) {
+        const char* src = (const char*)(c->frame_target ? c->frame_target : c->frame);
+        HIP_TRY(c, hipMemcpyAsync(out, src, (size_t)c->cfg.width * c->cfg.height * 8,
+                                  out_location == VCT_MEM_DEVICE ? hipMemcpyDeviceToDevice
+                                                                 : hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCT_OK;
+}
+
 int vct_trace_resident(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
-    if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "vct_trace_resident: no G-buffer resident yet");
+    if (!c->have_gbuffer) return fail(c, VCT_ERR_INVALID, "vct_trace_resident: no G-buffer resident yet");
     HIP_TRY(c, hipSetDevice(c->device));
     return launch_trace(c, c->last_row0, c->last_row1);
 }

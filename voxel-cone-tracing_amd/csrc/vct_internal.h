@@ -85,6 +85,28 @@ struct VctVoxParams {
     int32_t mode;
 };
 
+// inputs of the raster stages (vct_raster.hip); all device pointers
+struct VctRasterArgs {
+    const float* pos;            // [ntri][9] model space
+    const float* nrm;            // [ntri][9] per-vertex normal / tangent / bitangent (G-buffer only)
+    const float* tan;
+    const float* bit;
+    const int32_t* material;     // [ntri]
+    const float* albedo;         // [nmat][4]
+    const float* specular;       // [nmat][3]
+    int32_t ntri;
+    float model_scale;
+    unsigned long long* vis;     // visibility words, max(W*H, S*S)
+    int32_t* big_list;           // [2*ntri]
+    int32_t* big_count;
+};
+
+hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
+                                    hipStream_t s);
+hipError_t vct_launch_gbuffer_raster(const VctRasterArgs& a, const float view_proj[16], int W, int H,
+                                     const float* shadow, int shadow_size, const float light_vp[16],
+                                     float* tiled, hipStream_t s);
+hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s);
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s);
 hipError_t vct_launch_linear_to_morton(const uint32_t* lin, uint32_t* mor, int N, hipStream_t s);

@@ -1,0 +1,391 @@
+// vct_raster.hip -- the two raster input stages of the GI path on the GPU.
+//
+//   shadow map  DrawDepthTexture (VCT.h:192-211, S/Shadow.vs): depth-only orthographic raster from
+//               the light, back faces culled, 24-bit depth.
+//   G-buffer    the vertex + fixed-function part of the main draw (S/VoxelConeTracing.vs:23-37,
+//               perspective raster, depth test LESS, back-face cull: R/main.cpp:55-58) and the
+//               per-fragment inputs of S/VoxelConeTracing.fs that are not cone tracing: bump normal
+//               (:110-128 with a flat height map), material colours (:167,:209-210), the 25-tap PCF
+//               shadow term with its 0.111 scale (:132-163).  Output: the tiled 23-plane G-buffer
+//               k_trace_tile reads, written in place -- a frame never leaves HBM.
+//
+// Rasterisation rules are those of the CPU rasteriser in host/vct_host.cpp (the checker of these
+// stages): near-plane clip, window coordinates snapped to 1/256 pixel, edge functions in double
+// (exact with snapped inputs, so shared edges are watertight), pixel-centre sampling, top-left
+// rule, CCW front faces.  Visibility is order-independent here: one 64-bit atomicMin per covered
+// pixel on (depth bits << 32 | triangle id * 2 + sub-triangle) -- the nearest fragment wins and ties
+// go to the earliest triangle, which is what "depth test LESS in submission order" produces.  The
+// shading pass then re-derives the winning fragment from its triangle; nothing per-fragment is
+// stored besides the 8-byte visibility word.
+#include "vct_internal.h"
+
+namespace {
+
+struct RVert { float c[4]; };
+
+__device__ __forceinline__ void xform4(const float* m, float x, float y, float z, float out[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = m[r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r];
+}
+
+// Near-plane clip (z >= -w) of a clip-space triangle; `t01[i]` is the interpolation parameter of
+// the vertex inserted after input vertex i (or < 0 when poly vertex i is an input vertex).
+struct ClipPoly {
+    RVert v[4];
+    int src_a[4], src_b[4];     // poly vertex = lerp(in[src_a], in[src_b], t); src_b < 0: copy of src_a
+    float t[4];
+    int n;
+};
+
+__device__ __forceinline__ void clip_near(const RVert in[3], ClipPoly& p) {
+    p.n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const RVert& a = in[i];
+        const RVert& b = in[(i + 1) % 3];
+        const float da = a.c[2] + a.c[3], db = b.c[2] + b.c[3];
+        if (da >= 0.0f) {
+            p.v[p.n] = a; p.src_a[p.n] = i; p.src_b[p.n] = -1; p.t[p.n] = 0.0f; ++p.n;
+        }
+        if ((da >= 0.0f) != (db >= 0.0f)) {
+            const float t = __fdiv_rn(da, da - db);
+            RVert r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.c[k] = a.c[k] + (b.c[k] - a.c[k]) * t;
+            p.v[p.n] = r; p.src_a[p.n] = i; p.src_b[p.n] = (i + 1) % 3; p.t[p.n] = t; ++p.n;
+        }
+    }
+}
+
+struct SubTri {
+    double sx[3], sy[3], area, sgn;
+    float sz[3], iw[3];
+    int x0, x1, y0, y1;
+    bool ok;
+};
+
+__device__ __forceinline__ void setup_subtri(const RVert* v0, const RVert* v1, const RVert* v2, int W,
+                                             int H, SubTri& s) {
+    const RVert* v[3] = {v0, v1, v2};
+    s.ok = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!(v[k]->c[3] > 1e-20f)) return;
+        s.iw[k] = __fdiv_rn(1.0f, v[k]->c[3]);
+        s.sx[k] = floor((double)((v[k]->c[0] * s.iw[k] * 0.5f + 0.5f) * (float)W) * 256.0 + 0.5) / 256.0;
+        s.sy[k] = floor((double)((v[k]->c[1] * s.iw[k] * 0.5f + 0.5f) * (float)H) * 256.0 + 0.5) / 256.0;
+        s.sz[k] = v[k]->c[2] * s.iw[k] * 0.5f + 0.5f;
+    }
+    double area = (s.sx[1] - s.sx[0]) * (s.sy[2] - s.sy[0]) - (s.sx[2] - s.sx[0]) * (s.sy[1] - s.sy[0]);
+    if (area == 0.0 || area != area) return;
+    if (area < 0.0) return;                             // back face (CCW = front), always culled
+    s.sgn = 1.0;
+    s.area = area;
+    s.x0 = max(0, (int)floor(fmin(fmin(s.sx[0], s.sx[1]), s.sx[2])));
+    s.x1 = min(W - 1, (int)floor(fmax(fmax(s.sx[0], s.sx[1]), s.sx[2])));
+    s.y0 = max(0, (int)floor(fmin(fmin(s.sy[0], s.sy[1]), s.sy[2])));
+    s.y1 = min(H - 1, (int)floor(fmax(fmax(s.sy[0], s.sy[1]), s.sy[2])));
+    s.ok = s.x1 >= s.x0 && s.y1 >= s.y0;
+}
+
+// pixel-centre coverage + barycentrics; returns false when the pixel is not covered
+__device__ __forceinline__ bool cover(const SubTri& s, int px, int py, float& b0, float& b1, float& b2,
+                                      float& z) {
+    const double cx = (double)px + 0.5, cy = (double)py + 0.5;
+    double e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;
+        const double dx = (s.sx[b] - s.sx[a]) * s.sgn, dy = (s.sy[b] - s.sy[a]) * s.sgn;
+        e[k] = dx * (cy - s.sy[a]) - dy * (cx - s.sx[a]);
+        const bool top_left = (dy > 0.0) || (dy == 0.0 && dx < 0.0);
+        if (e[k] < 0.0 || (e[k] == 0.0 && !top_left)) return false;
+    }
+    b0 = (float)(e[0] / s.area);
+    b1 = (float)(e[1] / s.area);
+    b2 = 1.0f - b0 - b1;
+    z = b0 * s.sz[0] + b1 * s.sz[1] + b2 * s.sz[2];
+    z = z + 0.0f;      // -0 -> +0: depth is ordered through its bit pattern below
+    // far-plane clip (and NaN); z == 1 can never pass "LESS" against a depth buffer cleared to 1
+    return z >= 0.0f && z < 1.0f;
+}
+
+struct RasterParams {
+    const float* pos;            // [ntri][9] model space
+    int32_t ntri;
+    float model_scale;
+    float vp[16];                // column-major view-projection applied to world positions
+    int32_t W, H;
+    unsigned long long* vis;     // [H][W] (depth bits << 32) | (tri * 2 + sub); ~0 = empty
+    int32_t* big_list;           // (tri * 2 + sub) of sub-triangles left to the workgroup pass
+    int32_t* big_count;
+};
+
+__device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVert in[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float* q = p.pos + (size_t)t * 9 + 3 * k;
+        xform4(p.vp, q[0] * p.model_scale, q[1] * p.model_scale, q[2] * p.model_scale, in[k].c);
+    }
+}
+
+#define VCT_RASTER_SMALL 64      // bounding-box pixels a single thread rasterises itself
+
+// one thread per triangle: small sub-triangles are rasterised inline, the rest deferred
+__global__ void __launch_bounds__(256)
+k_raster_vis(const RasterParams p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.ntri) return;
+    RVert in[3];
+    load_clip_tri(p, t, in);
+    ClipPoly poly;
+    clip_near(in, poly);
+    if (poly.n < 3) return;
+    for (int f = 1; f + 1 < poly.n; ++f) {
+        SubTri s;
+        setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
+        if (!s.ok) continue;
+        const unsigned long long id = (unsigned long long)(uint32_t)(t * 2 + (f - 1));
+        const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
+        if (box > VCT_RASTER_SMALL) {
+            p.big_list[atomicAdd(p.big_count, 1)] = (int32_t)id;
+            continue;
+        }
+        for (int py = s.y0; py <= s.y1; ++py)
+            for (int px = s.x0; px <= s.x1; ++px) {
+                float b0, b1, b2, z;
+                if (!cover(s, px, py, b0, b1, b2, z)) continue;
+                atomicMin(&p.vis[(size_t)py * p.W + px], ((unsigned long long)__float_as_uint(z) << 32) | id);
+            }
+    }
+}
+
+// one workgroup per deferred sub-triangle, threads stride over its bounding box
+__global__ void __launch_bounds__(256)
+k_raster_vis_big(const RasterParams p) {
+    const int nbig = *p.big_count;
+    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const int id = p.big_list[b];
+        const int t = id >> 1, f = (id & 1) + 1;
+        RVert in[3];
+        load_clip_tri(p, t, in);
+        ClipPoly poly;
+        clip_near(in, poly);
+        SubTri s;
+        setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
+        const int bw = s.x1 - s.x0 + 1;
+        const long long box = (long long)bw * (s.y1 - s.y0 + 1);
+        for (long long i = threadIdx.x; i < box; i += blockDim.x) {
+            const int px = s.x0 + (int)(i % bw), py = s.y0 + (int)(i / bw);
+            float b0, b1, b2, z;
+            if (!cover(s, px, py, b0, b1, b2, z)) continue;
+            atomicMin(&p.vis[(size_t)py * p.W + px],
+                      ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(uint32_t)id);
+        }
+    }
+}
+
+// visibility words -> DEPTH_COMPONENT24 depths in [0,1] (cleared to 1)
+__global__ void __launch_bounds__(256)
+k_vis_to_depth24(const unsigned long long* __restrict__ vis, float* __restrict__ depth, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long v = vis[i];
+        const float z = v == ~0ull ? 1.0f : __uint_as_float((uint32_t)(v >> 32));
+        depth[i] = (float)(floor((double)z * 16777215.0 + 0.5) / 16777215.0);
+    }
+}
+
+struct ShadeParams {
+    RasterParams r;
+    const float* nrm;            // [ntri][9]
+    const float* tan;
+    const float* bit;
+    const int32_t* material;     // [ntri]
+    const float* albedo;         // [nmat][4]
+    const float* specular;       // [nmat][3]
+    const float* shadow;         // [S*S] or null
+    int32_t shadow_size;
+    float light_vp[16];
+    float* tiled;                // [tile][23][64]
+    int32_t tiles_x;
+};
+
+// [GL] bilinear clamp-to-edge fetch with the operation order of host/vct_host.cpp shadow_fetch
+__device__ __forceinline__ float shadow_fetch(const float* __restrict__ depth, int S, float u, float v) {
+    const float x = u * (float)S - 0.5f, y = v * (float)S - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    const float top = (float)(S - 1);
+    auto cl = [&](float f) -> int { return f < 0.0f ? 0 : (f > top ? S - 1 : (int)f); };
+    const int i0 = cl(fx), i1 = cl(fx + 1.0f), j0 = cl(fy), j1 = cl(fy + 1.0f);
+    const float d00 = depth[(size_t)j0 * S + i0], d10 = depth[(size_t)j0 * S + i1];
+    const float d01 = depth[(size_t)j1 * S + i0], d11 = depth[(size_t)j1 * S + i1];
+    return (1.0f - a) * (1.0f - b) * d00 + a * (1.0f - b) * d10 + (1.0f - a) * b * d01 + a * b * d11;
+}
+
+// one thread per pixel, 64 threads = one 8x8 tile of the tiled G-buffer
+__global__ void __launch_bounds__(256)
+k_gbuffer_shade(const ShadeParams p) {
+    const int W = p.r.W, H = p.r.H;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    if (ty * VCT_TILE >= H) return;
+    const int px = tx * VCT_TILE + (lane & 7), py = ty * VCT_TILE + (lane >> 3);
+    float* out = p.tiled + (size_t)tile * (VCT_GB_NPLANES * VCT_TILE_PIX) + lane;
+    float g[VCT_GB_NPLANES];
+#pragma unroll
+    for (int k = 0; k < VCT_GB_NPLANES; ++k) g[k] = 0.0f;
+    unsigned long long v = ~0ull;
+    if (px < W && py < H) v = p.r.vis[(size_t)py * W + px];
+    if (v != ~0ull) {
+        const int id = (int)(uint32_t)v;
+        const int t = id >> 1, f = (id & 1) + 1;
+        RVert in[3];
+        load_clip_tri(p.r, t, in);
+        ClipPoly poly;
+        clip_near(in, poly);
+        SubTri s;
+        setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], W, H, s);
+        float b0, b1, b2, z;
+        cover(s, px, py, b0, b1, b2, z);
+        // perspective-correct interpolation of the 12 varyings (trace.vs:27,31-33)
+        const float q0 = b0 * s.iw[0], q1 = b1 * s.iw[1], q2 = b2 * s.iw[2];
+        const float qs = __fdiv_rn(1.0f, q0 + q1 + q2);
+        const int pv[3] = {0, f, f + 1};
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            float var[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int pi = pv[k];
+                auto attr = [&](int vert) -> float {
+                    const size_t o = (size_t)t * 9 + 3 * vert + (i % 3);
+                    const float* src = i < 3 ? p.r.pos : (i < 6 ? p.nrm : (i < 9 ? p.tan : p.bit));
+                    return src[o] * p.r.model_scale;
+                };
+                const float va = attr(poly.src_a[pi]);
+                var[k] = poly.src_b[pi] < 0 ? va : va + (attr(poly.src_b[pi]) - va) * poly.t[pi];
+            }
+            g[i] = (q0 * var[0] + q1 * var[1] + q2 * var[2]) * qs;
+        }
+        // CalcBumpNormal with a flat height map: normalize(TBN * (0,0,1)), TBN = inverse(transpose(M))
+        const float Tx = g[6], Ty = g[7], Tz = g[8], Bx = g[9], By = g[10], Bz = g[11];
+        const float Nx = g[3], Ny = g[4], Nz = g[5];
+        const float c2x = Ty * Bz - Tz * By, c2y = Tz * Bx - Tx * Bz, c2z = Tx * By - Ty * Bx;   // T x B
+        const float bnx = By * Nz - Bz * Ny, bny = Bz * Nx - Bx * Nz, bnz = Bx * Ny - By * Nx;   // B x N
+        const float det = Tx * bnx + Ty * bny + Tz * bnz;
+        const float inv = __fdiv_rn(1.0f, det);
+        const float ux = c2x * inv, uy = c2y * inv, uz = c2z * inv;
+        const float len = __builtin_sqrtf(ux * ux + uy * uy + uz * uz);
+        const float il = len > 0.0f ? __fdiv_rn(1.0f, len) : 0.0f;      // host normalize(): a * (1/l)
+        g[12] = len > 0.0f ? ux * il : 0.0f;
+        g[13] = len > 0.0f ? uy * il : 0.0f;
+        g[14] = len > 0.0f ? uz * il : 0.0f;
+        const int m = p.material[t];
+        const float* alb = p.albedo + 4 * (size_t)m;
+        const float* sp = p.specular + 3 * (size_t)m;
+        g[15] = alb[0]; g[16] = alb[1]; g[17] = alb[2]; g[18] = alb[3];           // trace.fs:167
+        const bool has_gb = __builtin_sqrtf(sp[1] * sp[1] + sp[2] * sp[2]) > 0.0f;
+        g[19] = sp[0];
+        g[20] = has_gb ? sp[1] : sp[0];                                           // trace.fs:210
+        g[21] = has_gb ? sp[2] : sp[0];
+        float shadow = 25.0f * 0.111f;
+        if (p.shadow) {
+            float d[4];
+            xform4(p.light_vp, g[0], g[1], g[2], d);                              // trace.vs:28
+            const float cx = d[0] * 0.5f + 0.5f, cy = d[1] * 0.5f + 0.5f, cz = d[2] * 0.5f + 0.5f;
+            const float cur = __fdiv_rn(cz, d[3]) - 0.002f;
+            const float step = __fdiv_rn(1.0f, (float)p.shadow_size);
+            float cnt = 0.0f;
+            for (int x = -2; x <= 2; ++x)
+                for (int y = -2; y <= 2; ++y) {
+                    const float ox = step * (float)x, oy = step * (float)y;       // trace.fs:147
+                    if (cur <= shadow_fetch(p.shadow, p.shadow_size, cx + ox, cy + oy)) cnt += 1.0f;
+                }
+            shadow = cnt * 0.111f;                                                // trace.fs:158
+        }
+        g[22] = shadow;
+    }
+#pragma unroll
+    for (int k = 0; k < VCT_GB_NPLANES; ++k) out[k * VCT_TILE_PIX] = g[k];
+}
+
+// tiled [tile][23][64] -> linear planes [23][h*w] (downloads / tests)
+__global__ void k_untile_gbuffer(const float* __restrict__ tiled, float* __restrict__ planes, int w, int h,
+                                 int tiles_x) {
+    const size_t npix = (size_t)w * h;
+    const size_t total = npix * VCT_GB_NPLANES;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int plane = (int)(i / npix);
+        const size_t pix = i - (size_t)plane * npix;
+        const int y = (int)(pix / w), x = (int)(pix - (size_t)y * w);
+        const size_t tile = (size_t)(y / VCT_TILE) * tiles_x + x / VCT_TILE;
+        const int lane = (y % VCT_TILE) * VCT_TILE + (x % VCT_TILE);
+        planes[i] = tiled[(tile * VCT_GB_NPLANES + plane) * VCT_TILE_PIX + lane];
+    }
+}
+
+RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int H) {
+    RasterParams r;
+    r.pos = a.pos;
+    r.ntri = a.ntri;
+    r.model_scale = a.model_scale;
+    for (int i = 0; i < 16; ++i) r.vp[i] = vp[i];
+    r.W = W;
+    r.H = H;
+    r.vis = a.vis;
+    r.big_list = a.big_list;
+    r.big_count = a.big_count;
+    return r;
+}
+
+hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(r.vis, 0xff, (size_t)r.W * r.H * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(r.big_count, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    if (r.ntri <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_raster_vis, dim3((r.ntri + 255) / 256), dim3(256), 0, s, r);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_raster_vis_big, dim3(256 * 8), dim3(256), 0, s, r);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
+                                    hipStream_t s) {
+    const RasterParams r = make_raster(a, light_vp, S, S);
+    hipError_t e = run_visibility(r, s);
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)S * S;
+    hipLaunchKernelGGL(k_vis_to_depth24, dim3(256 * 8), dim3(256), 0, s, a.vis, depth, n);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_gbuffer_raster(const VctRasterArgs& a, const float view_proj[16], int W, int H,
+                                     const float* shadow, int shadow_size, const float light_vp[16],
+                                     float* tiled, hipStream_t s) {
+    ShadeParams p;
+    p.r = make_raster(a, view_proj, W, H);
+    hipError_t e = run_visibility(p.r, s);
+    if (e != hipSuccess) return e;
+    p.nrm = a.nrm; p.tan = a.tan; p.bit = a.bit;
+    p.material = a.material; p.albedo = a.albedo; p.specular = a.specular;
+    p.shadow = shadow; p.shadow_size = shadow_size;
+    for (int i = 0; i < 16; ++i) p.light_vp[i] = light_vp[i];
+    p.tiled = tiled;
+    p.tiles_x = (W + VCT_TILE - 1) / VCT_TILE;
+    const int tiles = p.tiles_x * ((H + VCT_TILE - 1) / VCT_TILE);
+    hipLaunchKernelGGL(k_gbuffer_shade, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s) {
+    const int tx = (w + VCT_TILE - 1) / VCT_TILE;
+    hipLaunchKernelGGL(k_untile_gbuffer, dim3(256 * 8), dim3(256), 0, s, tiled, planes_linear, w, h, tx);
+    return hipGetLastError();
+}

@@ -7,10 +7,12 @@
 // surface; nothing else is shared: there is no GL, no GLSL and no glm here.  Where the reference
 // binds GL objects and issues draws, each method forwards to the C ABI:
 //
-//   init_voxel_cone_tracing()  VCT.h:67-140   -> vct_create, scene upload, DrawDepthTexture, DrawVoxelTexture
-//   DrawDepthTexture()         VCT.h:192-211  -> shadow-map input stage (host raster, vct_host.h) + vct_upload_shadow_map
+//   init_voxel_cone_tracing()  VCT.h:67-140   -> vct_create, mesh upload, DrawDepthTexture, DrawVoxelTexture
+//   DrawDepthTexture()         VCT.h:192-211  -> vct_render_shadow_map (GPU depth raster from the light)
 //   DrawVoxelTexture()         VCT.h:213-250  -> vct_voxelize + vct_inject_light + vct_build_mips
-//   Render()                   VCT.h:146-190  -> G-buffer input stage (host raster) + vct_trace -> RGBA16F frame
+//   Render()                   VCT.h:146-190  -> vct_render_gbuffer (GPU raster of the main draw's vertex and
+//                                                non-cone fragment work) + vct_trace_current -> RGBA16F frame
+// Every stage runs on the GPU and a frame never leaves HBM until Frame() is read.
 //
 // Differences a caller can observe, all forced by running headless on a compute GPU:
 //   * `GLFWwindow` is an opaque forward declaration; Render() does not query the window size.
@@ -177,8 +179,6 @@ struct Voxel_Cone_Tracing {
     // what replaces the GL object names (Depth_FBO, Depth_Texture, VoxelTexture)
     vct_ctx* ctx = nullptr;
     int last_status = VCT_OK;
-    std::vector<float> Depth_Texture;        // ShadowMapSize^2 depths in [0,1]
-    std::vector<float> GBuffer;              // 23 planes, linear
     std::vector<uint16_t> FrameRGBA16F;      // screen_width * screen_height * 4 halves
 
     Voxel_Cone_Tracing() {}
@@ -212,11 +212,15 @@ struct Voxel_Cone_Tracing {
         ProjZ = mul(o, lookAt(vec3(0, 0, G), vec3(0, 0, 0), vec3(0, 1, 0)));
 
         const int32_t ntri = vcth_scene_num_triangles(model.scene), nmat = vcth_scene_num_materials(model.scene);
-        std::vector<float> pos((size_t)ntri * 9), albedo((size_t)nmat * 4);
+        std::vector<float> pos((size_t)ntri * 9), albedo((size_t)nmat * 4), specular((size_t)nmat * 3);
         std::vector<int32_t> material((size_t)ntri);
-        vcth_scene_get(model.scene, pos.data(), material.data(), albedo.data(), nullptr);
+        vcth_scene_get(model.scene, pos.data(), material.data(), albedo.data(), specular.data());
         if (!check(vct_upload_triangles(ctx, pos.data(), material.data(), ntri, albedo.data(), nmat),
                    "vct_upload_triangles")) return;
+        std::vector<float> nrm((size_t)ntri * 9), tan((size_t)ntri * 9), bit((size_t)ntri * 9);
+        vcth_scene_get_frames(model.scene, nrm.data(), tan.data(), bit.data());
+        if (!check(vct_upload_mesh_attributes(ctx, nrm.data(), tan.data(), bit.data(), specular.data()),
+                   "vct_upload_mesh_attributes")) return;
         DrawDepthTexture();     // VCT.h:138
         DrawVoxelTexture();     // VCT.h:139
     }
@@ -232,25 +236,16 @@ struct Voxel_Cone_Tracing {
         memcpy(hc.position, cam, sizeof(cam));
         hc.yaw = camera.Yaw; hc.pitch = camera.Pitch; hc.zoom = camera.Zoom;
         hc.z_near = 0.1f; hc.z_far = 1000.0f;                                              // VCT.h:162
-        GBuffer.resize((size_t)VCT_GB_PLANES * screen_width * screen_height);
-        vcth_render_gbuffer(model.scene, 0.05f, &hc, screen_width, screen_height,
-                            Depth_Texture.empty() ? nullptr : Depth_Texture.data(), (int32_t)ShadowMapSize,
-                            DepthViewProjectionMatrix.m, GBuffer.data());
-        vct_gbuffer gb;
-        gb.planes = GBuffer.data();
-        gb.width = screen_width; gb.height = screen_height;
-        gb.layout = VCT_GB_LINEAR; gb.location = VCT_MEM_HOST;
+        float vp[16];
+        vcth_camera_view_proj(&hc, screen_width, screen_height, vp);                       // VCT.h:161-163
+        if (!check(vct_render_gbuffer(ctx, vp), "vct_render_gbuffer")) return;
         FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
-        check(vct_trace(ctx, &gb, FrameRGBA16F.data(), VCT_MEM_HOST), "vct_trace");
+        check(vct_trace_current(ctx, FrameRGBA16F.data(), VCT_MEM_HOST), "vct_trace_current");
     }
 
     void DrawDepthTexture() {
         if (!ctx || !model.scene) return;
-        Depth_Texture.resize((size_t)ShadowMapSize * ShadowMapSize);
-        vcth_render_shadow_map(model.scene, 0.05f, DepthViewProjectionMatrix.m, (int32_t)ShadowMapSize,
-                               Depth_Texture.data());
-        check(vct_upload_shadow_map(ctx, Depth_Texture.data(), (int32_t)ShadowMapSize,
-                                    DepthViewProjectionMatrix.m), "vct_upload_shadow_map");
+        check(vct_render_shadow_map(ctx, DepthViewProjectionMatrix.m), "vct_render_shadow_map");
     }
 
     void DrawVoxelTexture() {

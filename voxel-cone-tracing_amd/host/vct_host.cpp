@@ -398,6 +398,29 @@ void vcth_scene_get(const vcth_scene* s, float* pos, int32_t* material, float* a
     }
 }
 
+void vcth_scene_get_frames(const vcth_scene* s, float* normal, float* tangent, float* bitangent) {
+    if (normal) memcpy(normal, s->nrm.data(), s->nrm.size() * sizeof(float));
+    if (tangent) memcpy(tangent, s->tan.data(), s->tan.size() * sizeof(float));
+    if (bitangent) memcpy(bitangent, s->bit.data(), s->bit.size() * sizeof(float));
+}
+
+static M4 camera_vp(const vcth_camera* cam, int32_t W, int32_t H) {
+    const float deg = 3.14159265358979f / 180.0f;
+    const V3 pos = {cam->position[0], cam->position[1], cam->position[2]};
+    const V3 front = normalize(V3{cosf(cam->yaw * deg) * cosf(cam->pitch * deg), sinf(cam->pitch * deg),
+                                  sinf(cam->yaw * deg) * cosf(cam->pitch * deg)});   // Camera.h:136-143
+    const V3 right = normalize(cross(front, V3{0, 1, 0}));
+    const V3 up = normalize(cross(right, front));
+    const M4 view = look_at(pos, pos + front, up);                                   // Camera.h:77
+    const M4 proj = perspective(cam->zoom * deg, (float)W / (float)H, cam->z_near, cam->z_far);   // VCT.h:162
+    return mul(proj, view);
+}
+
+void vcth_camera_view_proj(const vcth_camera* cam, int32_t width, int32_t height, float out_vp[16]) {
+    const M4 vp = camera_vp(cam, width, height);
+    memcpy(out_vp, vp.m, 64);
+}
+
 void vcth_light_view_proj(const float L[3], float out_vp[16]) {
     const M4 v = look_at({L[0], L[1], L[2]}, {0, 0, 0}, {0, 1, 0});     // VCT.h:84
     const M4 p = ortho(-120, 120, -120, 120, -100, 100);                // VCT.h:85
@@ -429,15 +452,7 @@ void vcth_render_gbuffer(const vcth_scene* s, float model_scale, const vcth_came
     memset(planes, 0, npix * 23 * sizeof(float));
     std::vector<float> zbuf(npix, 1.0f);
     std::vector<int32_t> mat(npix, -1);
-    const float deg = 3.14159265358979f / 180.0f;
-    const V3 pos = {cam->position[0], cam->position[1], cam->position[2]};
-    const V3 front = normalize(V3{cosf(cam->yaw * deg) * cosf(cam->pitch * deg), sinf(cam->pitch * deg),
-                                  sinf(cam->yaw * deg) * cosf(cam->pitch * deg)});   // Camera.h:136-143
-    const V3 right = normalize(cross(front, V3{0, 1, 0}));
-    const V3 up = normalize(cross(right, front));
-    const M4 view = look_at(pos, pos + front, up);                                   // Camera.h:77
-    const M4 proj = perspective(cam->zoom * deg, (float)W / (float)H, cam->z_near, cam->z_far);   // VCT.h:162
-    const M4 vp = mul(proj, view);
+    const M4 vp = camera_vp(cam, W, H);
     const size_t ntri = s->mat.size();
     for (size_t t = 0; t < ntri; ++t) {
         RVert v[3];

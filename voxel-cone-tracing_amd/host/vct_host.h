@@ -46,6 +46,11 @@ int32_t vcth_scene_num_materials(const vcth_scene* s);
 void vcth_scene_get(const vcth_scene* s, float* pos, int32_t* material, float* albedo,
                     float* specular);
 
+/* Per-vertex frame (R/Mesh.h:12-19): normal, tangent, bitangent [ntri*9] each; any may be NULL. */
+void vcth_scene_get_frames(const vcth_scene* s, float* normal, float* tangent, float* bitangent);
+/* VCT.h:161-163: perspective(radians(Zoom), w/h, near, far) * camera.GetViewMatrix(), column-major. */
+void vcth_camera_view_proj(const vcth_camera* cam, int32_t width, int32_t height, float out_vp[16]);
+
 /* VCT.h:84-86: DepthViewProjectionMatrix = ortho(-120,120,-120,120,-100,100) * lookAt(L,0,+Y),
  * column-major. */
 void vcth_light_view_proj(const float light_dir[3], float out_vp[16]);

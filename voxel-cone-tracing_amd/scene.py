@@ -27,6 +27,8 @@ _lib.vcth_scene_num_triangles.argtypes = [C.c_void_p]
 _lib.vcth_scene_num_materials.argtypes = [C.c_void_p]
 _lib.vcth_scene_get.argtypes = [C.c_void_p] * 5
 _lib.vcth_light_view_proj.argtypes = [C.c_void_p, C.c_void_p]
+_lib.vcth_scene_get_frames.argtypes = [C.c_void_p] * 4
+_lib.vcth_camera_view_proj.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
 _lib.vcth_render_shadow_map.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
 _lib.vcth_render_gbuffer.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -46,6 +48,21 @@ def default_camera(position=None, yaw=None, pitch=None, zoom=None):
     return cam
 
 
+def camera_view_proj(cam, w, h):
+    """Column-major view-projection (float32[16]) of VCT.h:161-163 for this camera and frame size."""
+    vp = np.zeros(16, np.float32)
+    _lib.vcth_camera_view_proj(C.byref(cam), w, h, vp.ctypes.data)
+    return vp
+
+
+def light_view_proj(light_dir):
+    """Column-major DepthViewProjectionMatrix (float32[16]) of VCT.h:84-86."""
+    L = np.ascontiguousarray(light_dir, np.float32)
+    vp = np.zeros(16, np.float32)
+    _lib.vcth_light_view_proj(L.ctypes.data, vp.ctypes.data)
+    return vp
+
+
 class Scene:
     def __init__(self, kind, detail=1.0, seed=1234):
         self._h = _lib.vcth_scene_create(kind, float(detail), int(seed))
@@ -59,6 +76,12 @@ class Scene:
         self.specular = np.zeros((self.nmat, 3), np.float32)
         _lib.vcth_scene_get(self._h, self.pos.ctypes.data, self.material.ctypes.data,
                             self.albedo.ctypes.data, self.specular.ctypes.data)
+
+    def frames(self):
+        """Per-vertex (normal, tangent, bitangent), each float32 [ntri, 9]."""
+        out = [np.zeros((self.ntri, 9), np.float32) for _ in range(3)]
+        _lib.vcth_scene_get_frames(self._h, *(a.ctypes.data for a in out))
+        return out
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
