@@ -182,6 +182,9 @@ int vct_trace_slab(vct_ctx* ctx, const vct_gbuffer* gb, int32_t tile_row0, int32
 /* Re-run the trace kernel on the G-buffer already resident from the last vct_trace (no upload,
  * no download); used for timing.  stream work only, asynchronous. */
 int vct_trace_resident(vct_ctx* ctx);
+/* Same for the tile-row slab [tile_row0, tile_row1) of the resident G-buffer; later
+ * vct_trace_resident calls repeat this slab. */
+int vct_trace_resident_rows(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
 /* Redirect the trace kernel's RGBA16F output to caller-owned HBM (full-frame addressing: pixel (x,y)
  * at ((y*width + x) * 4) halves from `rgba16f_dev`); NULL restores the context-owned frame.  A slab
  * rank passes its gather buffer minus the slab's first row so the kernel writes the gather buffer

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream", "vct_get_frame_device",
     "vct_selftest_const_divide", "vct_set_frame_target", "vct_bounce",
     "vct_download_voxel_attributes", "vct_upload_mesh_attributes", "vct_render_shadow_map",
-    "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer", "vct_trace_current",
+    "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer", "vct_trace_current", "vct_trace_resident_rows",
 ]
 
 
@@ -92,6 +92,7 @@ _lib.vct_upload_mesh_attributes.argtypes = [C.c_void_p] * 5
 for _n in ("vct_render_shadow_map", "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer"):
     getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_trace_current.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+_lib.vct_trace_resident_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
 for _n in ("vct_inject_light", "vct_build_mips", "vct_trace_resident", "vct_synchronize", "vct_bounce"):
     getattr(_lib, _n).argtypes = [C.c_void_p]
 _lib.vct_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
@@ -224,6 +225,10 @@ class Context:
         out = np.zeros((GB_PLANES, self.cfg.width * self.cfg.height), np.float32)
         self._ck(_lib.vct_download_gbuffer(self._h, _ptr(out)), "vct_download_gbuffer")
         return out
+
+    def trace_gbuffer_rows(self, row0, row1):
+        """Asynchronous trace of tile rows [row0, row1) of the resident G-buffer."""
+        self._ck(_lib.vct_trace_resident_rows(self._h, row0, row1), "vct_trace_resident_rows")
 
     def trace_current(self):
         out = np.zeros((self.cfg.height, self.cfg.width, 4), np.uint16)

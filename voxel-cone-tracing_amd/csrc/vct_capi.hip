@@ -820,6 +820,15 @@ int vct_trace_current(vct_ctx* c, void* out, int32_t out_location) {
     return VCT_OK;
 }
 
+int vct_trace_resident_rows(vct_ctx* c, int32_t row0, int32_t row1) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!c->have_gbuffer) return fail(c, VCT_ERR_INVALID, "vct_trace_resident_rows: no G-buffer resident yet");
+    if (row0 < 0 || row1 > tiles_y(c) || row0 > row1)
+        return fail(c, VCT_ERR_INVALID, "vct_trace_resident_rows: tile-row range outside the frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return launch_trace(c, row0, row1);
+}
+
 int vct_trace_resident(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     if (!c->have_gbuffer) return fail(c, VCT_ERR_INVALID, "vct_trace_resident: no G-buffer resident yet");
