@@ -65,7 +65,9 @@ struct vct_ctx {
     unsigned long long* vis = nullptr;
     size_t vis_words = 0;
     int32_t* raster_big = nullptr;
-    int32_t* raster_big_count = nullptr;
+    int32_t* raster_big_count = nullptr;      // [0] huge sub-triangles, [1] tile work items, [2] wave list
+    uint2* raster_items = nullptr;
+    uint32_t raster_item_capacity = 0;
     float light_vp[16];
     unsigned long long* acc = nullptr;
     // voxelization plan (geometry only; built by vct_upload_triangles) and sparse-resolve state
@@ -371,7 +373,7 @@ void vct_destroy(vct_ctx* c) {
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
                     c->brick_flags, c->brick_prev, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->vis, c->raster_big,
-                    c->raster_big_count};
+                    c->raster_big_count, c->raster_items};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -430,6 +432,9 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     if (c->mat_albedo) { (void)hipFree(c->mat_albedo); c->mat_albedo = nullptr; }
     if (c->big_list) { (void)hipFree(c->big_list); c->big_list = nullptr; }
     if (c->worklist) { (void)hipFree(c->worklist); c->worklist = nullptr; }
+    if (c->raster_big) { (void)hipFree(c->raster_big); c->raster_big = nullptr; }   // sized by ntri
+    float** frames[3] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit};                   // belong to the old mesh
+    for (float** f : frames) if (*f) { (void)hipFree(*f); *f = nullptr; }
     c->n_entries = 0;
     c->n_big = 0;
     HIP_TRY(c, hipMalloc(&c->tri_pos, (size_t)ntri * 9 * sizeof(float)));
@@ -485,8 +490,16 @@ static int raster_args(vct_ctx* c, size_t pixels, VctRasterArgs& a) {
         HIP_TRY(c, hipMalloc(&c->vis, pixels * sizeof(unsigned long long)));
         c->vis_words = pixels;
     }
-    if (!c->raster_big) HIP_TRY(c, hipMalloc(&c->raster_big, (size_t)c->ntri * 2 * sizeof(int32_t)));
-    if (!c->raster_big_count) HIP_TRY(c, hipMalloc(&c->raster_big_count, sizeof(int32_t)));
+    if (!c->raster_big) HIP_TRY(c, hipMalloc(&c->raster_big, (size_t)c->ntri * 4 * sizeof(int32_t)));
+    if (!c->raster_big_count) HIP_TRY(c, hipMalloc(&c->raster_big_count, 3 * sizeof(int32_t)));
+    // tile work items: 16x16-pixel pieces of large triangles; pixels/16 entries is ~16x the typical
+    // demand (sum of visible bounding boxes ~ a few frames' worth of pixels); overflow is handled
+    const size_t want_items = pixels / 16 + 4096;
+    if (c->raster_item_capacity < want_items) {
+        if (c->raster_items) { (void)hipFree(c->raster_items); c->raster_items = nullptr; }
+        HIP_TRY(c, hipMalloc(&c->raster_items, want_items * sizeof(uint2)));
+        c->raster_item_capacity = (uint32_t)want_items;
+    }
     memset(&a, 0, sizeof(a));
     a.pos = c->tri_pos;
     a.nrm = c->tri_nrm; a.tan = c->tri_tan; a.bit = c->tri_bit;
@@ -498,6 +511,11 @@ static int raster_args(vct_ctx* c, size_t pixels, VctRasterArgs& a) {
     a.vis = c->vis;
     a.big_list = c->raster_big;
     a.big_count = c->raster_big_count;
+    a.items = c->raster_items;
+    a.item_count = reinterpret_cast<uint32_t*>(c->raster_big_count + 1);
+    a.wave_list = c->raster_big + (size_t)c->ntri * 2;
+    a.wave_count = reinterpret_cast<uint32_t*>(c->raster_big_count + 2);
+    a.item_capacity = c->raster_item_capacity;
     return VCT_OK;
 }
 

@@ -97,8 +97,13 @@ struct VctRasterArgs {
     int32_t ntri;
     float model_scale;
     unsigned long long* vis;     // visibility words, max(W*H, S*S)
-    int32_t* big_list;           // [2*ntri]
-    int32_t* big_count;
+    int32_t* wave_list;          // [2*ntri] medium sub-triangles
+    uint32_t* wave_count;
+    int32_t* big_list;           // [2*ntri] huge sub-triangles
+    int32_t* big_count;          // followed in memory by item_count and wave_count (one memset)
+    uint2* items;                // tile work items of the raster pass
+    uint32_t* item_count;
+    uint32_t item_capacity;
 };
 
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,

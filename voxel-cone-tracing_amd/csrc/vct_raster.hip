@@ -117,8 +117,13 @@ struct RasterParams {
     float vp[16];                // column-major view-projection applied to world positions
     int32_t W, H;
     unsigned long long* vis;     // [H][W] (depth bits << 32) | (tri * 2 + sub); ~0 = empty
-    int32_t* big_list;           // (tri * 2 + sub) of sub-triangles left to the workgroup pass
+    int32_t* wave_list;          // (tri * 2 + sub) of medium sub-triangles (one wave each)
+    uint32_t* wave_count;
+    int32_t* big_list;           // (tri * 2 + sub) of huge sub-triangles (tiles emitted by a workgroup)
     int32_t* big_count;
+    uint2* items;                // tile work items: (tri * 2 + sub, tile_y << 16 | tile_x)
+    uint32_t* item_count;
+    uint32_t item_capacity;
 };
 
 __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVert in[3]) {
@@ -129,9 +134,44 @@ __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVer
     }
 }
 
-#define VCT_RASTER_SMALL 64      // bounding-box pixels a single thread rasterises itself
+// Work granularity by bounding-box size (the bench scene: half of the visible triangles cover <= 64
+// pixels, 91-100 % <= 256, the largest ~2k; a Cornell wall covers the whole frame):
+#define VCT_RASTER_SMALL 16      // <= this many pixels: rasterised inline by the triangle's own thread
+#define VCT_RASTER_WAVE 4096     // <= this many: one wave, lanes stride the bounding box
+#define VCT_RTILE 16             // larger: cut into 16x16-pixel work items by a workgroup
 
-// one thread per triangle: small sub-triangles are rasterised inline, the rest deferred
+__device__ __forceinline__ void plot(const RasterParams& p, const SubTri& s, int px, int py,
+                                     unsigned long long id) {
+    float b0, b1, b2, z;
+    if (!cover(s, px, py, b0, b1, b2, z)) return;
+    atomicMin(&p.vis[(size_t)py * p.W + px], ((unsigned long long)__float_as_uint(z) << 32) | id);
+}
+
+// tile range of a sub-triangle's bounding box
+struct TileBox { int tx0, ty0, tw, th; };
+__device__ __forceinline__ TileBox tile_box(const SubTri& s) {
+    TileBox t;
+    t.tx0 = s.x0 / VCT_RTILE; t.ty0 = s.y0 / VCT_RTILE;
+    t.tw = s.x1 / VCT_RTILE - t.tx0 + 1; t.th = s.y1 / VCT_RTILE - t.ty0 + 1;
+    return t;
+}
+
+// Emit tile i of the box as a work item; if the item buffer is full, rasterise the tile right here.
+template <class Loop>
+__device__ __forceinline__ void emit_tile(const RasterParams& p, const SubTri& s, const TileBox& tb, int i,
+                                          unsigned long long id, Loop serial_pixels) {
+    const int tx = tb.tx0 + i % tb.tw, ty = tb.ty0 + i / tb.tw;
+    const uint32_t slot = atomicAdd(p.item_count, 1u);
+    if (slot < p.item_capacity) {
+        p.items[slot] = make_uint2((uint32_t)id, ((uint32_t)ty << 16) | (uint32_t)tx);
+        return;
+    }
+    const int x0 = max(s.x0, tx * VCT_RTILE), x1 = min(s.x1, tx * VCT_RTILE + VCT_RTILE - 1);
+    const int y0 = max(s.y0, ty * VCT_RTILE), y1 = min(s.y1, ty * VCT_RTILE + VCT_RTILE - 1);
+    serial_pixels(x0, x1, y0, y1);
+}
+
+// one thread per triangle: clip, cull, classify; tiny sub-triangles are rasterised inline
 __global__ void __launch_bounds__(256)
 k_raster_vis(const RasterParams p) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,41 +187,72 @@ k_raster_vis(const RasterParams p) {
         if (!s.ok) continue;
         const unsigned long long id = (unsigned long long)(uint32_t)(t * 2 + (f - 1));
         const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
-        if (box > VCT_RASTER_SMALL) {
-            p.big_list[atomicAdd(p.big_count, 1)] = (int32_t)id;
+        if (box <= VCT_RASTER_SMALL) {
+            for (int py = s.y0; py <= s.y1; ++py)
+                for (int px = s.x0; px <= s.x1; ++px) plot(p, s, px, py, id);
             continue;
         }
-        for (int py = s.y0; py <= s.y1; ++py)
-            for (int px = s.x0; px <= s.x1; ++px) {
-                float b0, b1, b2, z;
-                if (!cover(s, px, py, b0, b1, b2, z)) continue;
-                atomicMin(&p.vis[(size_t)py * p.W + px], ((unsigned long long)__float_as_uint(z) << 32) | id);
-            }
+        if (box <= VCT_RASTER_WAVE) p.wave_list[atomicAdd(p.wave_count, 1u)] = (int32_t)id;
+        else p.big_list[atomicAdd(p.big_count, 1)] = (int32_t)id;
     }
 }
 
-// one workgroup per deferred sub-triangle, threads stride over its bounding box
+__device__ __forceinline__ bool rebuild_subtri(const RasterParams& p, int id, SubTri& s) {
+    const int t = id >> 1, f = (id & 1) + 1;
+    RVert in[3];
+    load_clip_tri(p, t, in);
+    ClipPoly poly;
+    clip_near(in, poly);
+    setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
+    return s.ok;
+}
+
+// one wave per medium sub-triangle: 64 bounding-box pixels per iteration
 __global__ void __launch_bounds__(256)
-k_raster_vis_big(const RasterParams p) {
+k_raster_waves(const RasterParams p) {
+    const uint32_t n = *p.wave_count;
+    const int lane = threadIdx.x & 63;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        const int id = p.wave_list[w];
+        SubTri s;
+        if (!rebuild_subtri(p, id, s)) continue;
+        const int bw = s.x1 - s.x0 + 1;
+        const int box = bw * (s.y1 - s.y0 + 1);
+        for (int i = lane; i < box; i += 64)
+            plot(p, s, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+    }
+}
+
+// one workgroup per huge sub-triangle: its threads emit the tile work items in parallel
+__global__ void __launch_bounds__(256)
+k_raster_emit_big(const RasterParams p) {
     const int nbig = *p.big_count;
     for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
         const int id = p.big_list[b];
-        const int t = id >> 1, f = (id & 1) + 1;
-        RVert in[3];
-        load_clip_tri(p, t, in);
-        ClipPoly poly;
-        clip_near(in, poly);
         SubTri s;
-        setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
-        const int bw = s.x1 - s.x0 + 1;
-        const long long box = (long long)bw * (s.y1 - s.y0 + 1);
-        for (long long i = threadIdx.x; i < box; i += blockDim.x) {
-            const int px = s.x0 + (int)(i % bw), py = s.y0 + (int)(i / bw);
-            float b0, b1, b2, z;
-            if (!cover(s, px, py, b0, b1, b2, z)) continue;
-            atomicMin(&p.vis[(size_t)py * p.W + px],
-                      ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(uint32_t)id);
-        }
+        if (!rebuild_subtri(p, id, s)) continue;
+        const TileBox tb = tile_box(s);
+        for (int i = threadIdx.x; i < tb.tw * tb.th; i += blockDim.x)
+            emit_tile(p, s, tb, i, (unsigned long long)(uint32_t)id, [&](int x0, int x1, int y0, int y1) {
+                for (int py = y0; py <= y1; ++py)
+                    for (int px = x0; px <= x1; ++px) plot(p, s, px, py, (unsigned long long)(uint32_t)id);
+            });
+    }
+}
+
+// one workgroup per tile work item, one pixel per thread
+__global__ void __launch_bounds__(VCT_RTILE * VCT_RTILE)
+k_raster_tiles(const RasterParams p) {
+    const uint32_t n = min(*p.item_count, p.item_capacity);
+    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+        const uint2 e = p.items[it];
+        SubTri s;
+        if (!rebuild_subtri(p, (int)e.x, s)) continue;
+        const int px = (int)(e.y & 0xffffu) * VCT_RTILE + (int)(threadIdx.x % VCT_RTILE);
+        const int py = (int)(e.y >> 16) * VCT_RTILE + (int)(threadIdx.x / VCT_RTILE);
+        if (px < s.x0 || px > s.x1 || py < s.y0 || py > s.y1) continue;
+        plot(p, s, px, py, (unsigned long long)e.x);
     }
 }
 
@@ -297,12 +368,54 @@ k_gbuffer_shade(const ShadeParams p) {
             const float cx = d[0] * 0.5f + 0.5f, cy = d[1] * 0.5f + 0.5f, cz = d[2] * 0.5f + 0.5f;
             const float cur = __fdiv_rn(cz, d[3]) - 0.002f;
             const float step = __fdiv_rn(1.0f, (float)p.shadow_size);
+            // The 25 taps sit one texel apart: when every tap's upper texel index equals the next
+            // tap's lower one on both axes (checked per lane) the shared 6x6 window is loaded once
+            // and each tap is evaluated with its own exact fractions; otherwise tap by tap.
+            const int S = p.shadow_size;
+            const float fS = (float)S, top = (float)(S - 1);
+            int xi0[5], xi1[5], yj0[5], yj1[5];
+            float xa[5], yb[5];
+            bool regular = true;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float ux = (cx + step * (float)(k - 2)) * fS - 0.5f, uy = (cy + step * (float)(k - 2)) * fS - 0.5f;
+                const float fx = floorf(ux), fy = floorf(uy);
+                xa[k] = ux - fx; yb[k] = uy - fy;
+                const float fx1 = fx + 1.0f, fy1 = fy + 1.0f;
+                xi0[k] = fx < 0.0f ? 0 : (fx > top ? S - 1 : (int)fx);
+                xi1[k] = fx1 < 0.0f ? 0 : (fx1 > top ? S - 1 : (int)fx1);
+                yj0[k] = fy < 0.0f ? 0 : (fy > top ? S - 1 : (int)fy);
+                yj1[k] = fy1 < 0.0f ? 0 : (fy1 > top ? S - 1 : (int)fy1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) regular = regular && xi1[k] == xi0[k + 1] && yj1[k] == yj0[k + 1];
             float cnt = 0.0f;
-            for (int x = -2; x <= 2; ++x)
-                for (int y = -2; y <= 2; ++y) {
-                    const float ox = step * (float)x, oy = step * (float)y;       // trace.fs:147
-                    if (cur <= shadow_fetch(p.shadow, p.shadow_size, cx + ox, cy + oy)) cnt += 1.0f;
-                }
+            if (regular) {
+                int col[6], row[6];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { col[k] = xi0[k]; row[k] = yj0[k]; }
+                col[5] = xi1[4]; row[5] = yj1[4];
+                float dd[6][6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) dd[j][i] = p.shadow[(size_t)row[j] * S + col[i]];
+#pragma unroll
+                for (int x = 0; x < 5; ++x)
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) {
+                        const float a = xa[x], b = yb[y];
+                        const float tap = (1.0f - a) * (1.0f - b) * dd[y][x] + a * (1.0f - b) * dd[y][x + 1] +
+                                          (1.0f - a) * b * dd[y + 1][x] + a * b * dd[y + 1][x + 1];
+                        if (cur <= tap) cnt += 1.0f;
+                    }
+            } else {
+                for (int x = -2; x <= 2; ++x)
+                    for (int y = -2; y <= 2; ++y) {
+                        const float ox = step * (float)x, oy = step * (float)y;       // trace.fs:147
+                        if (cur <= shadow_fetch(p.shadow, p.shadow_size, cx + ox, cy + oy)) cnt += 1.0f;
+                    }
+            }
             shadow = cnt * 0.111f;                                                // trace.fs:158
         }
         g[22] = shadow;
@@ -336,21 +449,32 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
     r.W = W;
     r.H = H;
     r.vis = a.vis;
+    r.wave_list = a.wave_list;
+    r.wave_count = a.wave_count;
     r.big_list = a.big_list;
     r.big_count = a.big_count;
+    r.items = a.items;
+    r.item_count = a.item_count;
+    r.item_capacity = a.item_capacity;
     return r;
 }
 
 hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
     hipError_t e = hipMemsetAsync(r.vis, 0xff, (size_t)r.W * r.H * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(r.big_count, 0, sizeof(int32_t), s);
+    e = hipMemsetAsync(r.big_count, 0, 3 * sizeof(int32_t), s);     // big, item and wave counters
     if (e != hipSuccess) return e;
     if (r.ntri <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_raster_vis, dim3((r.ntri + 255) / 256), dim3(256), 0, s, r);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_raster_vis_big, dim3(256 * 8), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(k_raster_waves, dim3(256 * 16), dim3(256), 0, s, r);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_raster_emit_big, dim3(256 * 4), dim3(256), 0, s, r);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_raster_tiles, dim3(256 * 32), dim3(VCT_RTILE * VCT_RTILE), 0, s, r);
     return hipGetLastError();
 }
 
