@@ -19,8 +19,8 @@
 //   * The frame lands in an RGBA16F host buffer (`Frame()`), not in GL framebuffer 0.
 //   * `VoxelDimensions` / `VoxelGridWorldSize` are plain members (the reference declares them const,
 //     which pins it to 128^3): set them before init_voxel_cone_tracing().
-//   * `model` is loaded from a procedural scene name instead of the reference's absolute Windows
-//     path (VCT.h:77; the reference ships no assets): "procedural:atrium" or "procedural:cornell".
+//   * `model_path` replaces the reference's hard-coded absolute Windows path (VCT.h:77; the reference
+//     ships no assets): "procedural:atrium", "procedural:cornell", or the path of a Wavefront .obj.
 //   * Errors keep the reference's print-and-continue behaviour (VCT.h:101-105) and are also
 //     readable through `last_status` / vct_last_error(ctx).
 #ifndef VOXEL_CONE_TRACING_FACADE_H_
@@ -149,9 +149,12 @@ struct Model {
     bool Load(const std::string& p) {
         if (scene) { vcth_scene_destroy(scene); scene = nullptr; }
         path = p;
+        char err[256] = "";
         if (p == "procedural:cornell") scene = vcth_scene_create(0, 1.0f, 1234u);
         else if (p == "procedural:atrium") scene = vcth_scene_create(1, 1.0f, 1234u);
-        if (!scene) printf("ERROR::MODEL: cannot load '%s' (use procedural:atrium | procedural:cornell)\n", p.c_str());
+        else scene = vcth_scene_load_obj(p.c_str(), err);             // R/Model.h:39-61
+        if (!scene) printf("ERROR::MODEL: cannot load '%s' (%s; or use procedural:atrium | procedural:cornell)\n",
+                           p.c_str(), err);
         return scene != nullptr;
     }
 };

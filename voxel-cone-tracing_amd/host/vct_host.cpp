@@ -4,7 +4,12 @@
 #include <math.h>
 #include <string.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
+#include <map>
+#include <string>
 #include <vector>
 
 namespace {
@@ -382,6 +387,131 @@ vcth_scene* vcth_scene_create(int kind, float detail, uint32_t seed) {
     if (kind == 0) build_cornell(s);
     else if (kind == 1) build_atrium(s, detail, seed);
     else { delete s; return nullptr; }
+    return s;
+}
+
+vcth_scene* vcth_scene_load_obj(const char* path, char* error) {
+    auto failmsg = [&](const std::string& m) -> vcth_scene* {
+        if (error) snprintf(error, 256, "%s", m.c_str());
+        return nullptr;
+    };
+    if (!path) return failmsg("null path");
+    FILE* fp = fopen(path, "r");
+    if (!fp) return failmsg(std::string("cannot open ") + path);
+    const std::string dir = std::string(path).find_last_of('/') == std::string::npos
+                                ? std::string() : std::string(path).substr(0, std::string(path).find_last_of('/') + 1);
+    std::vector<V3> vp, vn;
+    std::vector<float> vt;                       // u, v pairs
+    struct Corner { int p, t, n; };
+    std::vector<Corner> corners;                 // 3 per triangle
+    std::vector<int32_t> tri_mat;
+    std::vector<Material> mats;
+    std::map<std::string, int> mat_index;
+    auto material = [&](const std::string& name) {
+        auto it = mat_index.find(name);
+        if (it != mat_index.end()) return it->second;
+        Material m = {{0.7f, 0.7f, 0.7f, 1.0f}, {0.2f, 0.2f, 0.2f}};
+        mats.push_back(m);
+        return mat_index[name] = (int)mats.size() - 1;
+    };
+    auto load_mtl = [&](const std::string& file) {
+        FILE* mf = fopen((dir + file).c_str(), "r");
+        if (!mf) return;                          // like assimp: a missing .mtl leaves default materials
+        char line[1024];
+        int cur = -1;
+        while (fgets(line, sizeof(line), mf)) {
+            char name[512];
+            float a, b, c;
+            if (sscanf(line, " newmtl %511s", name) == 1) cur = material(name);
+            else if (cur >= 0 && sscanf(line, " Kd %f %f %f", &a, &b, &c) == 3) {
+                mats[(size_t)cur].albedo[0] = a; mats[(size_t)cur].albedo[1] = b; mats[(size_t)cur].albedo[2] = c;
+            } else if (cur >= 0 && sscanf(line, " Ks %f %f %f", &a, &b, &c) == 3) {
+                mats[(size_t)cur].spec[0] = a; mats[(size_t)cur].spec[1] = b; mats[(size_t)cur].spec[2] = c;
+            } else if (cur >= 0 && sscanf(line, " d %f", &a) == 1) mats[(size_t)cur].albedo[3] = a;
+        }
+        fclose(mf);
+    };
+    int cur_mat = -1;
+    char line[4096];
+    while (fgets(line, sizeof(line), fp)) {
+        float a, b, c;
+        char name[512];
+        if (line[0] == 'v' && line[1] == ' ' && sscanf(line + 2, "%f %f %f", &a, &b, &c) == 3) vp.push_back({a, b, c});
+        else if (line[0] == 'v' && line[1] == 'n' && sscanf(line + 3, "%f %f %f", &a, &b, &c) == 3) vn.push_back({a, b, c});
+        else if (line[0] == 'v' && line[1] == 't' && sscanf(line + 3, "%f %f", &a, &b) >= 1) { vt.push_back(a); vt.push_back(b); }
+        else if (sscanf(line, " usemtl %511s", name) == 1) cur_mat = material(name);
+        else if (sscanf(line, " mtllib %511s", name) == 1) load_mtl(name);
+        else if (line[0] == 'f' && (line[1] == ' ' || line[1] == '\t')) {
+            std::vector<Corner> poly;
+            const char* q = line + 2;
+            while (*q) {
+                while (*q == ' ' || *q == '\t') ++q;
+                if (*q == '\0' || *q == '\n' || *q == '\r') break;
+                Corner cn = {0, 0, 0};
+                char* end;
+                cn.p = (int)strtol(q, &end, 10);
+                if (end == q) break;
+                q = end;
+                if (*q == '/') {
+                    ++q;
+                    if (*q != '/') { cn.t = (int)strtol(q, &end, 10); q = end; }
+                    if (*q == '/') { ++q; cn.n = (int)strtol(q, &end, 10); q = end; }
+                }
+                auto fix = [](int i, size_t n) { return i > 0 ? i - 1 : (i < 0 ? (int)n + i : -1); };
+                cn.p = fix(cn.p, vp.size()); cn.t = fix(cn.t, vt.size() / 2); cn.n = fix(cn.n, vn.size());
+                if (cn.p < 0 || cn.p >= (int)vp.size()) { fclose(fp); return failmsg("face references a missing vertex"); }
+                if (cn.t >= (int)(vt.size() / 2)) cn.t = -1;
+                if (cn.n >= (int)vn.size()) cn.n = -1;
+                poly.push_back(cn);
+            }
+            if (cur_mat < 0) cur_mat = material("(default)");
+            for (size_t k = 1; k + 1 < poly.size(); ++k) {          // aiProcess_Triangulate: fan
+                corners.push_back(poly[0]); corners.push_back(poly[k]); corners.push_back(poly[k + 1]);
+                tri_mat.push_back(cur_mat);
+            }
+        }
+    }
+    fclose(fp);
+    if (corners.empty()) return failmsg("no faces in the file");
+    // aiProcess_GenSmoothNormals for corners without a normal: area-weighted per position
+    std::vector<V3> smooth(vp.size(), V3{0, 0, 0});
+    for (size_t t = 0; t < tri_mat.size(); ++t) {
+        const V3 a = vp[(size_t)corners[3 * t].p], b = vp[(size_t)corners[3 * t + 1].p], c = vp[(size_t)corners[3 * t + 2].p];
+        const V3 fn = cross(b - a, c - a);
+        for (int k = 0; k < 3; ++k) smooth[(size_t)corners[3 * t + k].p] = smooth[(size_t)corners[3 * t + k].p] + fn;
+    }
+    vcth_scene* s = new vcth_scene();
+    s->materials = mats;
+    s->mat = tri_mat;
+    for (size_t t = 0; t < tri_mat.size(); ++t) {
+        const Corner* c = &corners[3 * t];
+        const V3 p0 = vp[(size_t)c[0].p], p1 = vp[(size_t)c[1].p], p2 = vp[(size_t)c[2].p];
+        // aiProcess_CalcTangentSpace: per-triangle tangent from the UV gradient when UVs exist
+        V3 tri_tan = {0, 0, 0};
+        if (c[0].t >= 0 && c[1].t >= 0 && c[2].t >= 0) {
+            const float du1 = vt[2 * (size_t)c[1].t] - vt[2 * (size_t)c[0].t], dv1 = vt[2 * (size_t)c[1].t + 1] - vt[2 * (size_t)c[0].t + 1];
+            const float du2 = vt[2 * (size_t)c[2].t] - vt[2 * (size_t)c[0].t], dv2 = vt[2 * (size_t)c[2].t + 1] - vt[2 * (size_t)c[0].t + 1];
+            const float det = du1 * dv2 - du2 * dv1;
+            if (fabsf(det) > 1e-20f) tri_tan = ((p1 - p0) * dv2 - (p2 - p0) * dv1) * (1.0f / det);
+        }
+        for (int k = 0; k < 3; ++k) {
+            const V3 pos = vp[(size_t)c[k].p];
+            V3 n = c[k].n >= 0 ? vn[(size_t)c[k].n] : smooth[(size_t)c[k].p];
+            n = normalize(n);
+            if (dot(n, n) == 0.0f) n = normalize(cross(p1 - p0, p2 - p0));
+            V3 tg = tri_tan - n * dot(n, tri_tan);                   // Gram-Schmidt against the normal
+            if (dot(tg, tg) < 1e-20f) {
+                const V3 hint = fabsf(n.y) < 0.9f ? V3{0, 1, 0} : V3{1, 0, 0};
+                tg = cross(hint, n);
+            }
+            tg = normalize(tg);
+            const V3 bt = cross(n, tg);
+            s->pos.insert(s->pos.end(), {pos.x, pos.y, pos.z});
+            s->nrm.insert(s->nrm.end(), {n.x, n.y, n.z});
+            s->tan.insert(s->tan.end(), {tg.x, tg.y, tg.z});
+            s->bit.insert(s->bit.end(), {bt.x, bt.y, bt.z});
+        }
+    }
     return s;
 }
 

@@ -39,6 +39,14 @@ void vcth_default_camera(vcth_camera* cam);
 /* kind: 0 = Cornell box (~40 tris), 1 = atrium (Sponza-class; `detail` scales tessellation,
  * detail = 1.0 gives ~262k triangles).  Model-space coordinates = world / 0.05 (VCT.h:183). */
 vcth_scene* vcth_scene_create(int kind, float detail, uint32_t seed);
+/* Wavefront OBJ (+ MTL) reader -- stands where the reference's assimp import stands (R/Model.h:39-61:
+ * triangulate, smooth normals, tangent space).  Reads v / vn / vt / f (polygons are fan-triangulated,
+ * negative indices allowed), usemtl + mtllib (Kd -> albedo, Ks -> specular, d -> albedo alpha); missing
+ * normals are generated area-weighted per position, tangents from the UVs when present else from the
+ * normal.  Textures are not read: materials are flat colours (SURVEY.md A.7 allows this).  Coordinates
+ * are taken as MODEL space (the orchestrator scales by 0.05, VCT.h:183).  Returns NULL on failure;
+ * `error` (optional, >= 256 bytes) receives the reason. */
+vcth_scene* vcth_scene_load_obj(const char* path, char* error);
 void vcth_scene_destroy(vcth_scene* s);
 int32_t vcth_scene_num_triangles(const vcth_scene* s);
 int32_t vcth_scene_num_materials(const vcth_scene* s);

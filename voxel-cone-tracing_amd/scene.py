@@ -23,6 +23,8 @@ class Camera(C.Structure):
 _lib.vcth_scene_create.restype = C.c_void_p
 _lib.vcth_scene_create.argtypes = [C.c_int, C.c_float, C.c_uint32]
 _lib.vcth_scene_destroy.argtypes = [C.c_void_p]
+_lib.vcth_scene_load_obj.restype = C.c_void_p
+_lib.vcth_scene_load_obj.argtypes = [C.c_char_p, C.c_char_p]
 _lib.vcth_scene_num_triangles.argtypes = [C.c_void_p]
 _lib.vcth_scene_num_materials.argtypes = [C.c_void_p]
 _lib.vcth_scene_get.argtypes = [C.c_void_p] * 5
@@ -65,9 +67,16 @@ def light_view_proj(light_dir):
 
 class Scene:
     def __init__(self, kind, detail=1.0, seed=1234):
-        self._h = _lib.vcth_scene_create(kind, float(detail), int(seed))
-        if not self._h:
-            raise ValueError("unknown scene kind")
+        """kind: CORNELL / ATRIUM (procedural) or the path of a Wavefront .obj file."""
+        if isinstance(kind, (str, bytes, os.PathLike)):
+            err = C.create_string_buffer(256)
+            self._h = _lib.vcth_scene_load_obj(os.fsencode(kind), err)
+            if not self._h:
+                raise ValueError(f"cannot load {kind}: {err.value.decode()}")
+        else:
+            self._h = _lib.vcth_scene_create(kind, float(detail), int(seed))
+            if not self._h:
+                raise ValueError("unknown scene kind")
         self.ntri = _lib.vcth_scene_num_triangles(self._h)
         self.nmat = _lib.vcth_scene_num_materials(self._h)
         self.pos = np.zeros((self.ntri, 9), np.float32)
