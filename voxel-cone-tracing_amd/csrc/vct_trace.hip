@@ -292,13 +292,17 @@ __constant__ float kConeDirs[18] = {0.0f, 0.0f, 1.0f,
                                     -0.823639f, 0.267617f, 0.5f};            // trace.fs:49-57
 __constant__ float kConeWeights[6] = {0.25f, 0.15f, 0.15f, 0.15f, 0.15f, 0.15f};   // trace.fs:48
 
-#define VCT_WAVES_PER_BLOCK 4
+// tiles (waves) per workgroup: single-wave workgroups dispatch with the finest granularity, which
+// balances the tail best (0.822 -> 0.800 ms against 4 waves; profiles/r01g_ab_waves_per_block.txt)
+#ifndef VCT_WAVES_PER_BLOCK
+#define VCT_WAVES_PER_BLOCK 1
+#endif
 #ifndef VCT_TRACE_MIN_WAVES
 #define VCT_TRACE_MIN_WAVES 6     // waves per SIMD the register allocator must leave room for (<= 80 VGPRs)
 #endif
 
-// One wave per tile, lane = pixel, the 7 cones in sequence; 4 horizontally adjacent tiles per
-// workgroup.  Workgroups are dealt to XCDs round-robin by the dispatcher (block b -> XCD b % 8), so
+// One wave per tile, lane = pixel, the 7 cones in sequence; VCT_WAVES_PER_BLOCK horizontally
+// adjacent tiles per workgroup.  Workgroups are dealt to XCDs round-robin by the dispatcher (block b -> XCD b % 8), so
 // the tile order is remapped to give every XCD one contiguous run of tiles: neighbouring tiles
 // march through neighbouring voxels and share that XCD's L2.
 template <bool WRAP, bool FASTDIV, bool COOP>
