@@ -316,8 +316,22 @@ k_trace_tile(const VctTraceParams p) {
     float4* blk = &lds_blk[wave][0][0];
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
-    const int per_xcd = gridDim.x >> 3;
+#ifndef VCT_XCD_MAP
+#define VCT_XCD_MAP 16   // measured: 0 (round-robin) 0.764 ms, 1 (contiguous) 0.797, 16: 0.756, 60: 0.779, 240: 0.758
+#endif
+#if VCT_XCD_MAP == 0
+    const int vb = blockIdx.x;                                   // tiles dealt round-robin to the XCDs
+#elif VCT_XCD_MAP == 1
+    const int per_xcd = gridDim.x >> 3;                          // one contiguous run of tiles per XCD
     const int vb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+#else
+    // runs of VCT_XCD_MAP consecutive blocks per XCD, dealt round-robin: locality inside a run,
+    // balance across the frame
+    const int run = VCT_XCD_MAP;
+    const int j = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    int vb = ((j / run) * 8 + xcd) * run + (j % run);
+    if (vb >= (int)gridDim.x) vb = blockIdx.x;                   // ragged tail: identity keeps it a bijection
+#endif
     const int ti = vb * VCT_WAVES_PER_BLOCK + wave;
     if (ti >= ntiles) return;
 
