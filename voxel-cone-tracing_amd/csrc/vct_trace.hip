@@ -327,10 +327,11 @@ k_trace_tile(const VctTraceParams p) {
 #else
     // runs of VCT_XCD_MAP consecutive blocks per XCD, dealt round-robin: locality inside a run,
     // balance across the frame
-    const int run = VCT_XCD_MAP;
-    const int j = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-    int vb = ((j / run) * 8 + xcd) * run + (j % run);
-    if (vb >= (int)gridDim.x) vb = blockIdx.x;                   // ragged tail: identity keeps it a bijection
+    // (a permutation inside every full group of 8*run blocks; the last partial group keeps identity)
+    const int run = VCT_XCD_MAP, group = 8 * run;
+    const int g = blockIdx.x / group, local = blockIdx.x - g * group;
+    const int vb = (g + 1) * group <= (int)gridDim.x ? g * group + (local & 7) * run + (local >> 3)
+                                                     : (int)blockIdx.x;
 #endif
     const int ti = vb * VCT_WAVES_PER_BLOCK + wave;
     if (ti >= ntiles) return;
