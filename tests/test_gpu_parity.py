@@ -343,3 +343,42 @@ def test_bounce_needs_attributes(vct):
         ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
         with pytest.raises(vct.VctError):
             ctx.bounce()
+
+
+def test_sparse_mips_and_bounce_track_changing_scenes(vct, oracle):
+    """The sparse resolve / mip build / bounce-chain updates keep no residue when the geometry under
+    them changes: voxelize scene A, then B (different bricks), then A again, with and without a
+    bounce, and compare every chain with a from-scratch oracle build."""
+    V = 32
+    scenes = [random_scene(120, seed=s) for s in (41, 42)]
+    p = oracle.default_params(V)
+    want = []
+    for pos, mat, alb in scenes:
+        sc = oracle.make_scene(pos, mat, alb)
+        l0, a, n = oracle.voxelize_conservative_attr(p, sc)
+        c0 = oracle.build_mips(l0)
+        l1, _ = oracle.bounce(p, c0, a, n, nthreads=8)
+        want.append((c0, oracle.build_mips(l1)))
+    assert not np.array_equal(want[0][0], want[1][0])
+    with make_ctx(vct, V, 8, 8, voxel_attributes=1) as ctx:
+        for which, do_bounce in ((0, True), (1, False), (0, False), (1, True), (1, True), (0, True)):
+            pos, mat, alb = scenes[which]
+            ctx.upload_triangles(pos, mat, alb)
+            ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+            assert np.array_equal(ctx.download_chain(), want[which][0]), (which, do_bounce, "bounce 0")
+            if do_bounce:
+                ctx.bounce()
+                assert np.array_equal(ctx.download_chain(), want[which][1]), (which, "bounce 1")
+        # an uploaded volume in between forces (and survives) the dense paths
+        junk = synth.noise_volume(V, seed=3, occupancy=0.3)
+        ctx.upload_volume(junk)
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), oracle.build_mips(junk))
+        with pytest.raises(vct.VctError):
+            ctx.bounce()
+        pos, mat, alb = scenes[1]
+        ctx.upload_triangles(pos, mat, alb)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), want[1][0])
+        ctx.bounce()
+        assert np.array_equal(ctx.download_chain(), want[1][1])

@@ -78,6 +78,13 @@ struct vct_ctx {
     uint32_t* plan = nullptr;          // [2] device counters used while planning
     uint32_t* brick_flags = nullptr;   // [V^3/512] touched in the pending pass
     uint32_t* brick_prev = nullptr;    // [V^3/512] touched in the pass level 0 currently shows
+    uint32_t* mip_seen = nullptr;      // [V^3/512] bricks non-empty when the chain's mips were last built
+    uint32_t* mip_seen_b = nullptr;    // same for the bounce chain
+    uint32_t* bounce_list = nullptr;   // occupied-voxel list of the bounce (+1 counter word in front)
+    uint32_t bounce_list_cap = 0;
+    uint32_t* brick_over = nullptr;
+    bool level0_sparse_ok = false;     // chain: untouched bricks have all-zero ancestors, mip_seen is current
+    bool level0_sparse_ok_next = false;
     bool acc_pending = false;          // accumulators hold an unresolved voxelize pass
     bool level0_dirty = false;         // level 0 was written by an upload: next resolve is dense
 };
@@ -371,7 +378,7 @@ void vct_destroy(vct_ctx* c) {
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
-                    c->brick_flags, c->brick_prev, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
+                    c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->vis, c->raster_big,
                     c->raster_big_count, c->raster_items};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -611,6 +618,8 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->brick_flags, 0, nbricks * sizeof(uint32_t), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->brick_prev, 0, nbricks * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMalloc(&c->mip_seen, nbricks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->mip_seen, 0, nbricks * sizeof(uint32_t), c->stream));
         if (c->cfg.voxel_attributes) {
             HIP_TRY(c, hipMalloc(&c->acc_attr, nvox * 24));
             HIP_TRY(c, hipMalloc(&c->attr_albedo, nvox * 4));
@@ -637,6 +646,10 @@ int vct_inject_light(vct_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, vct_launch_resolve(c->acc, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
                                   c->level0_dirty, c->acc_attr, c->attr_albedo, c->attr_normal, c->stream));
+    // after an upload the coarse levels may hold anything: one dense mip build re-establishes
+    // "untouched bricks have zero ancestors", then the sparse form is valid again
+    c->level0_sparse_ok = !c->level0_dirty && c->level0_sparse_ok_next;
+    c->level0_sparse_ok_next = true;
     c->acc_pending = false;
     c->level0_dirty = false;
     c->use_chain_b = false;
@@ -647,7 +660,13 @@ int vct_inject_light(vct_ctx* c) {
 int vct_build_mips(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, vct_launch_build_mips(c->chain, c->cfg.voxel_dim, c->stream));
+    const bool sparse = c->level0_sparse_ok && c->brick_prev && c->mip_seen;
+    if (!sparse && c->mip_seen && c->brick_prev)      // dense build: afterwards every brick is "seen" as it is now
+        HIP_TRY(c, hipMemcpyAsync(c->mip_seen, c->brick_prev,
+                                  ((size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512) * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, vct_launch_build_mips(c->chain, c->cfg.voxel_dim, sparse ? c->brick_prev : nullptr,
+                                     sparse ? c->mip_seen : nullptr, c->stream));
     c->mips_valid = true;
     c->use_chain_b = false;
     return VCT_OK;
@@ -659,25 +678,46 @@ int vct_bounce(vct_ctx* c) {
         return fail(c, VCT_ERR_INVALID, "vct_bounce: needs config.voxel_attributes = 1 and a voxelize + inject pass");
     if (c->acc_pending || !c->mips_valid)
         return fail(c, VCT_ERR_INVALID, "vct_bounce: call vct_inject_light and vct_build_mips first");
+    if (c->level0_dirty)
+        return fail(c, VCT_ERR_INVALID, "vct_bounce: level 0 was uploaded, not voxelized (no attributes for it)");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = refresh_steps(c);
     if (rc) return rc;
     const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
-    if (!c->chain_b) HIP_TRY(c, hipMalloc(&c->chain_b, c->chain_texels * 4));
-    // untouched voxels keep their bounce-0 value (zero where empty)
-    HIP_TRY(c, hipMemcpyAsync(c->chain_b, c->chain, nvox * 4, hipMemcpyDeviceToDevice, c->stream));
+    const size_t nbricks = nvox / 512;
+    bool b_sparse = c->chain_b != nullptr;
+    if (!c->chain_b) {
+        HIP_TRY(c, hipMalloc(&c->chain_b, c->chain_texels * 4));
+        HIP_TRY(c, hipMemsetAsync(c->chain_b, 0, c->chain_texels * 4, c->stream));
+        HIP_TRY(c, hipMalloc(&c->mip_seen_b, nbricks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->mip_seen_b, 0, nbricks * sizeof(uint32_t), c->stream));
+        b_sparse = true;     // zero-filled chain + empty "seen" set: the sparse form is valid from the start
+        // occupied-voxel list: surfaces occupy ~1 % of a grid; V^3/8 entries is a generous bound and
+        // bricks that do not fit are handled by the per-brick kernel
+        c->bounce_list_cap = (uint32_t)(nvox / 8);
+        HIP_TRY(c, hipMalloc(&c->bounce_list, ((size_t)c->bounce_list_cap + 1) * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->brick_over, nbricks * sizeof(uint32_t)));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->bounce_list, 0, sizeof(uint32_t), c->stream));        // the counter
+    HIP_TRY(c, hipMemsetAsync(c->bounce_list + 1, 0xff, (size_t)c->bounce_list_cap * sizeof(uint32_t), c->stream));
     VctTraceParams p;
     fill_march_params(c, p, c->chain);
     p.attr_albedo = c->attr_albedo;
     p.attr_normal = c->attr_normal;
     p.brick_prev = c->brick_prev;
+    p.bounce_seen = c->mip_seen_b;
     p.bounce_out = c->chain_b;
     p.nbricks = (uint32_t)(nvox / 512);
+    p.bounce_list_count = c->bounce_list;
+    p.bounce_list = c->bounce_list + 1;
+    p.bounce_list_cap = c->bounce_list_cap;
+    p.brick_over = c->brick_over;
     HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_bounce(p, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, c->stream));
+    HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
+                                     b_sparse ? c->mip_seen_b : nullptr, c->stream));
     c->use_chain_b = true;
     c->have_trace = true;      // step counter / event pair now describe the bounce launch
     return VCT_OK;
@@ -716,7 +756,9 @@ static int upload_levels(vct_ctx* c, const uint8_t* lin, int nlevels) {
     HIP_TRY(c, hipSetDevice(c->device));
     c->use_chain_b = false;
     c->mips_valid = nlevels > 1;
-    c->level0_dirty = true;     // level 0 no longer mirrors brick_prev: next resolve is dense
+    c->level0_dirty = true;
+    c->level0_sparse_ok = false;
+    c->level0_sparse_ok_next = false;     // level 0 no longer mirrors brick_prev: next resolve is dense
     int rc = ensure_staging(c);
     if (rc) return rc;
     const int V = c->cfg.voxel_dim;

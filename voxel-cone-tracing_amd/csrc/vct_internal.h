@@ -61,8 +61,13 @@ struct VctTraceParams {
     const uint32_t* attr_albedo;
     const uint32_t* attr_normal;
     const uint32_t* brick_prev;
+    const uint32_t* bounce_seen;        // bricks the bounce chain showed when its mips were last built
     uint32_t* bounce_out;
     uint32_t nbricks;
+    uint32_t* bounce_list;              // global list of occupied voxels (Morton indices), brick by brick
+    uint32_t* bounce_list_count;
+    uint32_t bounce_list_cap;
+    uint32_t* brick_over;               // bricks whose voxels did not fit the list
 };
 
 struct VctVoxParams {
@@ -116,7 +121,9 @@ hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s)
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s);
 hipError_t vct_launch_linear_to_morton(const uint32_t* lin, uint32_t* mor, int N, hipStream_t s);
 hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N, hipStream_t s);
-hipError_t vct_launch_build_mips(uint32_t* chain, int V, hipStream_t s);
+// bricks_now / bricks_seen (optional): per-8^3-brick occupancy flags of level 0 for the sparse form
+hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_now, uint32_t* bricks_seen,
+                                 hipStream_t s);
 hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
                                    hipStream_t s);
 hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* worklist,

@@ -473,83 +473,160 @@ __device__ __forceinline__ uint32_t to_unorm8_dev(float f) {     // [GL] float -
     return (uint32_t)(int)s;
 }
 
-// Second bounce (oracle/vct_oracle.h vcto_bounce): one wave per touched 8^3 brick.  The brick's
-// occupied voxels are compacted into an LDS list (ballot + popcount) and marched 64 at a time with
-// the same cone_march as the screen trace -- lanes = Morton-adjacent voxels, whose cones are
-// near-parallel wherever the surface is locally flat, so the cooperative sampler applies.
-template <bool WRAP, bool FASTDIV>
-__global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_TRACE_MIN_WAVES)
-k_bounce(const VctTraceParams p) {
-    __shared__ float4 lds_blk[VCT_WAVES_PER_BLOCK][2][64];
+// Second bounce (oracle/vct_oracle.h vcto_bounce), three kernels:
+//   k_bounce_list   one wave per touched 8^3 brick: copies the brick into the bounce chain (untouched
+//                   voxels keep their bounce-0 value), compacts its occupied voxels (ballot +
+//                   popcount through LDS) and appends them to a global voxel list -- bricks stay
+//                   contiguous in the list, so neighbouring entries are Morton-adjacent voxels;
+//   k_bounce_march  one wave per 64 list entries, lane = voxel, the 6 diffuse cones marched with the
+//                   same cone_march as the screen trace (voxels of a locally flat surface trace
+//                   near-parallel cones, so the cooperative sampler applies);
+//   k_bounce_bricks the same march per brick, only for bricks that did not fit the list.
+template <class March>
+__device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool alive, size_t vox,
+                                              float4* __restrict__ blk, const LaneBlock& lb, int& total_out,
+                                              March march) {
+    const uint32_t* __restrict__ level0 = p.chain;          // level 0 starts the chain
+    const float fV = (float)p.V;
+    const uint32_t src = level0[vox], nq = p.attr_normal[vox], aq = p.attr_albedo[vox];
+    const uint32_t mi = (uint32_t)vox;
+    const int i = (int)vct_compact3(mi), j = (int)vct_compact3(mi >> 1), k = (int)vct_compact3(mi >> 2);
+    const F3 P = f3((div_rn((float)i + 0.5f, fV) - 0.5f) * p.G, (div_rn((float)j + 0.5f, fV) - 0.5f) * p.G,
+                    (div_rn((float)k + 0.5f, fV) - 0.5f) * p.G);
+    const F3 nrm = normalize3(f3((float)((int)(nq & 0xffu) - 128), (float)((int)((nq >> 8) & 0xffu) - 128),
+                                 (float)((int)((nq >> 16) & 0xffu) - 128)));
+    const F3 helper = fabsf(nrm.y) < 0.9f ? f3(0.0f, 1.0f, 0.0f) : f3(1.0f, 0.0f, 0.0f);
+    const F3 t = normalize3(cross3(helper, nrm));
+    const F3 bt = cross3(nrm, t);
+    const F3 start = f3(P.x + nrm.x * p.vs, P.y + nrm.y * p.vs, P.z + nrm.z * p.vs);
+    float ind[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int total = 0;
+#pragma unroll 1
+    for (int c = 0; c < 6; ++c) {
+        const float ddx = kConeDirs[3 * c], ddy = kConeDirs[3 * c + 1], ddz = kConeDirs[3 * c + 2];
+        F3 dir = f3(t.x * ddx + bt.x * ddy + nrm.x * ddz, t.y * ddx + bt.y * ddy + nrm.y * ddz,
+                    t.z * ddx + bt.z * ddy + nrm.z * ddz);
+        dir = normalize3(dir);
+        int st;
+        const F4 cone = march(alive, start, dir, st);
+        total += st;
+        const float wgt = kConeWeights[c];
+        ind[0] = fmaf(wgt, cone.x, ind[0]);
+        ind[1] = fmaf(wgt, cone.y, ind[1]);
+        ind[2] = fmaf(wgt, cone.z, ind[2]);
+        ind[3] = fmaf(wgt, cone.w, ind[3]);
+    }
+    if (alive) {
+        const float occlusion = 1.0f - ind[3];
+        const uint32_t r = to_unorm8_dev(unorm8(src & 0xffu) + unorm8(aq & 0xffu) * (occlusion * ind[0]));
+        const uint32_t g = to_unorm8_dev(unorm8((src >> 8) & 0xffu) + unorm8((aq >> 8) & 0xffu) * (occlusion * ind[1]));
+        const uint32_t bl = to_unorm8_dev(unorm8((src >> 16) & 0xffu) + unorm8((aq >> 16) & 0xffu) * (occlusion * ind[2]));
+        p.bounce_out[vox] = r | (g << 8) | (bl << 16) | (src & 0xff000000u);
+    } else {
+        total = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    total_out = total;
+}
+
+#define VCT_BOUNCE_SETUP                                                     \
+    __shared__ float4 lds_blk[VCT_WAVES_PER_BLOCK][2][64];                   \
+    const int lane = threadIdx.x & 63;                                       \
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); \
+    float4* blk = &lds_blk[wave][0][0];                                      \
+    LaneBlock lb;                                                            \
+    lb.lane = lane;                                                          \
+    lb.sbx = vct_spread3((uint32_t)lane & 3u);                               \
+    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;                   \
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;
+
+// compaction of one brick into `list` (LDS); returns the number of occupied voxels
+__device__ __forceinline__ int compact_brick(const VctTraceParams& p, uint32_t b, int lane, uint16_t* list) {
+    int n = 0;
+    for (int it = 0; it < 8; ++it) {
+        const uint32_t v = (uint32_t)(it * 64 + lane);
+        const size_t vox = (size_t)b * 512 + v;
+        const uint32_t src0 = p.chain[vox];
+        p.bounce_out[vox] = src0;
+        const bool occ = (src0 >> 24) != 0u && (p.attr_normal[vox] & 0xffffffu) != 0x808080u;
+        const unsigned long long m = ballot64(occ);
+        if (occ) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)v;
+        n += __popcll(m);
+    }
+    return n;
+}
+
+__global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK)
+k_bounce_list(const VctTraceParams p) {
     __shared__ uint16_t lds_list[VCT_WAVES_PER_BLOCK][512];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float4* blk = &lds_blk[wave][0][0];
     uint16_t* list = &lds_list[wave][0];
-    LaneBlock lb;
-    lb.lane = lane;
-    lb.sbx = vct_spread3((uint32_t)lane & 3u);
-    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;
-    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;
-    const uint32_t* __restrict__ level0 = p.chain;          // level 0 starts the chain
-    const float fV = (float)p.V;
+    const uint32_t nwaves = gridDim.x * VCT_WAVES_PER_BLOCK;
+    for (uint32_t b = blockIdx.x * VCT_WAVES_PER_BLOCK + wave; b < p.nbricks; b += nwaves) {
+        p.brick_over[b] = 0u;
+        if (!p.brick_prev[b]) {
+            // nothing here now; if the bounce chain still shows an older pass, clear it
+            if (p.bounce_seen[b])
+                for (int it = 0; it < 8; ++it) p.bounce_out[(size_t)b * 512 + it * 64 + lane] = 0u;
+            continue;
+        }
+        const int n = compact_brick(p, b, lane, list);
+        wave_sync();
+        if (n == 0) continue;
+        uint32_t off = 0;
+        if (lane == 0) off = atomicAdd(p.bounce_list_count, (uint32_t)n);
+        off = __builtin_amdgcn_readfirstlane(off);
+        if (off + (uint32_t)n > p.bounce_list_cap) {      // does not fit: k_bounce_bricks takes this brick
+            if (lane == 0) p.brick_over[b] = 1u;
+        } else {
+            for (int i = lane; i < n; i += 64) p.bounce_list[off + i] = b * 512u + list[i];
+        }
+        wave_sync();
+    }
+}
+
+template <bool WRAP, bool FASTDIV>
+__global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_TRACE_MIN_WAVES)
+k_bounce_march(const VctTraceParams p) {
+    VCT_BOUNCE_SETUP
+    const uint32_t n = min(*p.bounce_list_count, p.bounce_list_cap);
+    const uint32_t nwaves = gridDim.x * VCT_WAVES_PER_BLOCK;
+    unsigned long long wave_steps = 0;
+    for (uint32_t w = blockIdx.x * VCT_WAVES_PER_BLOCK + wave; w * 64u < n; w += nwaves) {
+        const uint32_t e = w * 64u + lane < n ? p.bounce_list[w * 64u + lane] : 0xffffffffu;
+        const bool alive = e != 0xffffffffu;               // unwritten slots belong to overflowed bricks
+        const uint32_t first = __builtin_amdgcn_readfirstlane(e);
+        const size_t vox = alive ? e : (first != 0xffffffffu ? first : 0u);
+        int total;
+        bounce_voxels(p, alive, vox, blk, lb, total, [&](bool al, F3 start, F3 dir, int& st) {
+            return cone_march<WRAP, FASTDIV, true>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st);
+        });
+        wave_steps += (unsigned long long)total;
+    }
+    if (lane == 0 && wave_steps)
+        atomicAdd(p.step_counter + ((blockIdx.x * VCT_WAVES_PER_BLOCK + wave) & (VCT_STEP_COUNTERS - 1)), wave_steps);
+}
+
+template <bool WRAP, bool FASTDIV>
+__global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_TRACE_MIN_WAVES)
+k_bounce_bricks(const VctTraceParams p) {
+    VCT_BOUNCE_SETUP
+    __shared__ uint16_t lds_list[VCT_WAVES_PER_BLOCK][512];
+    uint16_t* list = &lds_list[wave][0];
     unsigned long long wave_steps = 0;
     const uint32_t nwaves = gridDim.x * VCT_WAVES_PER_BLOCK;
     for (uint32_t b = blockIdx.x * VCT_WAVES_PER_BLOCK + wave; b < p.nbricks; b += nwaves) {
-        if (!p.brick_prev[b]) continue;
-        // compact the occupied voxels with a usable normal
-        int n = 0;
-        for (int it = 0; it < 8; ++it) {
-            const uint32_t v = (uint32_t)(it * 64 + lane);
-            const size_t vox = (size_t)b * 512 + v;
-            const bool occ = (level0[vox] >> 24) != 0u && (p.attr_normal[vox] & 0xffffffu) != 0x808080u;
-            const unsigned long long m = ballot64(occ);
-            if (occ) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)v;
-            n += __popcll(m);
-        }
+        if (!p.brick_over[b]) continue;
+        const int n = compact_brick(p, b, lane, list);
         wave_sync();
         for (int base = 0; base < n; base += 64) {
             const bool alive = base + lane < n;
             const size_t vox = (size_t)b * 512 + (alive ? list[base + lane] : list[base]);
-            const uint32_t src = level0[vox], nq = p.attr_normal[vox], aq = p.attr_albedo[vox];
-            const uint32_t mi = (uint32_t)vox;
-            const int i = (int)vct_compact3(mi), j = (int)vct_compact3(mi >> 1), k = (int)vct_compact3(mi >> 2);
-            const F3 P = f3((div_rn((float)i + 0.5f, fV) - 0.5f) * p.G, (div_rn((float)j + 0.5f, fV) - 0.5f) * p.G,
-                            (div_rn((float)k + 0.5f, fV) - 0.5f) * p.G);
-            const F3 nrm = normalize3(f3((float)((int)(nq & 0xffu) - 128), (float)((int)((nq >> 8) & 0xffu) - 128),
-                                         (float)((int)((nq >> 16) & 0xffu) - 128)));
-            const F3 helper = fabsf(nrm.y) < 0.9f ? f3(0.0f, 1.0f, 0.0f) : f3(1.0f, 0.0f, 0.0f);
-            const F3 t = normalize3(cross3(helper, nrm));
-            const F3 bt = cross3(nrm, t);
-            const F3 start = f3(P.x + nrm.x * p.vs, P.y + nrm.y * p.vs, P.z + nrm.z * p.vs);
-            float ind[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            int total = 0;
-#pragma unroll 1
-            for (int c = 0; c < 6; ++c) {
-                const float ddx = kConeDirs[3 * c], ddy = kConeDirs[3 * c + 1], ddz = kConeDirs[3 * c + 2];
-                F3 dir = f3(t.x * ddx + bt.x * ddy + nrm.x * ddz, t.y * ddx + bt.y * ddy + nrm.y * ddz,
-                            t.z * ddx + bt.z * ddy + nrm.z * ddz);
-                dir = normalize3(dir);
-                int st;
-                const F4 cone = cone_march<WRAP, FASTDIV, true>(p, alive, start, dir, p.steps_diffuse,
-                                                                p.n_diffuse, blk, lb, st);
-                total += st;
-                const float wgt = kConeWeights[c];
-                ind[0] = fmaf(wgt, cone.x, ind[0]);
-                ind[1] = fmaf(wgt, cone.y, ind[1]);
-                ind[2] = fmaf(wgt, cone.z, ind[2]);
-                ind[3] = fmaf(wgt, cone.w, ind[3]);
-            }
-            if (alive) {
-                const float occlusion = 1.0f - ind[3];
-                const uint32_t r = to_unorm8_dev(unorm8(src & 0xffu) + unorm8(aq & 0xffu) * (occlusion * ind[0]));
-                const uint32_t g = to_unorm8_dev(unorm8((src >> 8) & 0xffu) + unorm8((aq >> 8) & 0xffu) * (occlusion * ind[1]));
-                const uint32_t bl = to_unorm8_dev(unorm8((src >> 16) & 0xffu) + unorm8((aq >> 16) & 0xffu) * (occlusion * ind[2]));
-                p.bounce_out[vox] = r | (g << 8) | (bl << 16) | (src & 0xff000000u);
-            } else {
-                total = 0;
-            }
-            for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+            int total;
+            bounce_voxels(p, alive, vox, blk, lb, total, [&](bool al, F3 start, F3 dir, int& st) {
+                return cone_march<WRAP, FASTDIV, true>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st);
+            });
             wave_steps += (unsigned long long)total;
         }
         wave_sync();
@@ -598,19 +675,25 @@ hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, h
     return hipGetLastError();
 }
 
+template <bool WRAP, bool FASTDIV>
+hipError_t launch_bounce(const VctTraceParams& p, hipStream_t s) {
+    uint32_t blocks = (p.nbricks + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
+    if (blocks > 256u * 64u) blocks = 256u * 64u;
+    const dim3 block(64 * VCT_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(k_bounce_list, dim3(blocks), block, 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_bounce_march<WRAP, FASTDIV>), dim3(256 * 24), block, 0, s, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_bounce_bricks<WRAP, FASTDIV>), dim3(blocks), block, 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t vct_launch_bounce(const VctTraceParams& p, hipStream_t s) {
     if (p.nbricks == 0) return hipSuccess;
-    uint32_t blocks = (p.nbricks + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
-    if (blocks > 256u * 16u) blocks = 256u * 16u;
-    const dim3 grid(blocks), block(64 * VCT_WAVES_PER_BLOCK);
-    if (p.wrap_repeat) {
-        if (p.fast_div) hipLaunchKernelGGL((k_bounce<true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_bounce<true, false>), grid, block, 0, s, p);
-    } else {
-        if (p.fast_div) hipLaunchKernelGGL((k_bounce<false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_bounce<false, false>), grid, block, 0, s, p);
-    }
-    return hipGetLastError();
+    if (p.wrap_repeat) return p.fast_div ? launch_bounce<true, true>(p, s) : launch_bounce<true, false>(p, s);
+    return p.fast_div ? launch_bounce<false, true>(p, s) : launch_bounce<false, false>(p, s);
 }
 
 // variant 0: cooperative sampler with per-lane fallback (default); 1: per-lane sampler only.

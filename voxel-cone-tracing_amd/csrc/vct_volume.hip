@@ -41,13 +41,23 @@ __device__ __forceinline__ uint32_t box8(uint32_t rb, uint32_t ga) {
 }
 
 // src: level L (count texels), dst1..3: levels L+1..L+3 (nout of them exist).
+// Sparse form (level 0 written by the voxelizer): wave w reduces exactly the 8^3 brick w, so bricks
+// that hold nothing now (`now`) and held nothing when the mips were last built (`seen`) are
+// skipped -- their three ancestors are already zero.
 __global__ void __launch_bounds__(256)
 k_mip3(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst1, uint32_t* __restrict__ dst2,
-       uint32_t* __restrict__ dst3, uint32_t count, int nout) {
+       uint32_t* __restrict__ dst3, uint32_t count, int nout, const uint32_t* __restrict__ now,
+       uint32_t* __restrict__ seen) {
     const uint32_t n1 = count >> 3;
     const uint32_t nthreads_needed = (n1 + 63u) & ~63u;   // whole waves so shuffles are defined
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nthreads_needed;
          t += gridDim.x * blockDim.x) {
+        if (now) {
+            const uint32_t b = t >> 6;
+            const uint32_t cur = now[b], old = seen[b];
+            if (!(cur | old)) continue;                  // wave-uniform
+            if ((t & 63u) == 0u) seen[b] = cur;
+        }
         uint32_t q = 0;
         if (t < n1) {
             const uint4* s4 = reinterpret_cast<const uint4*>(src) + 2 * (size_t)t;
@@ -122,7 +132,8 @@ hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N
     return hipGetLastError();
 }
 
-hipError_t vct_launch_build_mips(uint32_t* chain, int V, hipStream_t s) {
+hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_now, uint32_t* bricks_seen,
+                                 hipStream_t s) {
     const int nlev = vct_ilog2(V) + 1;
     for (int L = 0; L + 1 < nlev; L += 3) {
         const int nout = (nlev - 1 - L) < 3 ? (nlev - 1 - L) : 3;
@@ -133,8 +144,9 @@ hipError_t vct_launch_build_mips(uint32_t* chain, int V, hipStream_t s) {
         uint32_t* d2 = nout >= 2 ? chain + vct_level_offset(V, L + 2) : nullptr;
         uint32_t* d3 = nout >= 3 ? chain + vct_level_offset(V, L + 3) : nullptr;
         const size_t threads_needed = ((size_t)(count >> 3) + 63) & ~(size_t)63;
+        const bool sparse = L == 0 && bricks_now && bricks_seen && V >= 8;
         hipLaunchKernelGGL(k_mip3, dim3(grid_for(threads_needed, 256)), dim3(256), 0, s, src, d1,
-                           d2, d3, count, nout);
+                           d2, d3, count, nout, sparse ? bricks_now : nullptr, sparse ? bricks_seen : nullptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
