@@ -100,7 +100,13 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VCT_BENCH_FORCE_DIST=1: run the N-rank step loop (double-buffered slabs, comm stream, RCCL gather)
+    # with a 1-rank process group -- exercises that code path on a single-GPU box.
+    force_dist = world == 1 and os.environ.get("VCT_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -158,32 +164,51 @@ def main():
             gi = {"voxelize": None, "inject_resolve": None, "build_mips": e[0].elapsed_time(e[1])}
 
     # ---- slab of this rank (voxel-cone-tracing_amd/slabs.py) ----
-    fg = slabs.FrameGather(h, w, world, rank, f"cuda:{local_rank}")
+    # Two gather buffers: the kernel writes this rank's slab straight into one of them (full-frame
+    # addressing: the buffer's base minus the slab's first row -- no copies), and while the ONE
+    # gather of frame k runs on a communication stream, the trace of frame k+1 fills the other.
+    use_dist = world > 1 or force_dist
+    nbuf = 2 if use_dist else 1
+    fgs = [slabs.FrameGather(h, w, world, rank, f"cuda:{local_rank}") for _ in range(nbuf)]
+    fg = fgs[0]
     r0, r1 = slabs.partition(h, world)[rank]
     y0, y1 = fg.my_rows()
     slab_px = max(0, y1 - y0) * w
-
-    # first trace uploads + tiles the G-buffer; afterwards everything is resident in HBM.  The kernel
-    # writes this rank's slab straight into the gather buffer (full-frame addressing: the buffer's
-    # base minus the slab's first row), so a step is kernel + one gather, no copies.
-    base = fg.slab.data_ptr() - y0 * w * 8
-    ctx.set_frame_target(base)
+    bases = [f.slab.data_ptr() - y0 * w * 8 for f in fgs]
+    ctx.set_frame_target(bases[0])
     if inp["scene"] is None:
-        ctx.trace(inp["planes"], rows=(r0, r1), out_device_ptr=base)     # uploads the synthetic G-buffer
+        ctx.trace(inp["planes"], rows=(r0, r1), out_device_ptr=bases[0])  # uploads the synthetic G-buffer
     else:                                   # G-buffer already resident (vct_render_gbuffer)
         ctx.trace_gbuffer_rows(r0, r1)
     steps_slab = ctx.last_step_count()
 
+    comm_stream = torch.cuda.Stream(device=local_rank) if use_dist else None
+    traced = [torch.cuda.Event() for _ in range(nbuf)]
+    gathered = [torch.cuda.Event() for _ in range(nbuf)]
+    step_no = [0]
+
     def one_step():
-        ctx.trace_resident()                      # the trace kernel, on the context stream
-        if world > 1:
-            with torch.cuda.stream(ext_stream):   # ONE gather (RCCL), ordered after the kernel
-                fg.gather()
+        if not use_dist:
+            ctx.trace_resident()                  # the trace kernel, on the context stream
+            return
+        k = step_no[0] % nbuf
+        step_no[0] += 1
+        ext_stream.wait_event(gathered[k])        # buffer k is free once its previous gather is done
+        ctx.set_frame_target(bases[k])
+        ctx.trace_resident()
+        traced[k].record(ext_stream)
+        comm_stream.wait_event(traced[k])
+        with torch.cuda.stream(comm_stream):      # ONE gather per frame (RCCL)
+            fgs[k].gather(force_collective=force_dist)
+            gathered[k].record(comm_stream)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    for ev_ in gathered:                          # "previous gather" of the first use of each buffer
+        ev_.record(ext_stream)
 
     kernel_ms = []
     for _ in range(args.warmup):
@@ -196,6 +221,7 @@ def main():
     dt = time.perf_counter() - t0
     # per-launch device time of the trace kernel: HIP events on the context's stream, collected
     # in a second, untimed loop so the event reads do not serialise the timed region
+    fence()
     for _ in range(min(args.steps, 20)):
         ctx.trace_resident()
         kernel_ms.append(ctx.last_trace_ms())
@@ -214,10 +240,13 @@ def main():
     kernel_ms_avg = float(kmax.item())
 
     gather_ok = None
-    if world > 1:
+    if use_dist:
         # acceptance check of SURVEY.md 8e, untimed: the gathered frame is bit-identical to the frame
         # one GPU traces alone
-        full = fg.gather()
+        ctx.set_frame_target(bases[0])
+        ctx.trace_resident()
+        ctx.synchronize()
+        full = fg.gather(force_collective=force_dist)
         torch.cuda.synchronize()
         if rank == 0:
             ctx.set_frame_target(None)
@@ -271,7 +300,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, inp, ctx, vct)
         print(json.dumps(result), flush=True)
     ctx.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

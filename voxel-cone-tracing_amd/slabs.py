@@ -49,10 +49,11 @@ class FrameGather:
         """Pixel rows [y0, y1) of the frame this rank produces."""
         return slab_pixel_rows(self.height, self.world, self.rank)
 
-    def gather(self):
+    def gather(self, force_collective=False):
         """One collective: every rank contributes self.slab; root returns the [height,width,4] frame
-        (a view of its buffer), the others None."""
-        if self.world == 1:
+        (a view of its buffer), the others None.  A single rank only copies unless
+        `force_collective` (testing the collective path with a 1-rank group)."""
+        if self.world == 1 and not force_collective:
             self.frame[: self.rows].copy_(self.slab)
             return self.frame[: self.height]
         if self.slab.is_cuda and dist.get_backend(self.group) == "gloo":
