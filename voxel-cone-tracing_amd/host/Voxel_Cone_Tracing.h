@@ -178,6 +178,8 @@ struct Voxel_Cone_Tracing {
     bool ShowDiffuse = true, ShowIndirectDiffuse = true, ShowSpecular = true,
          ShowIndirectSpecular = true, ShowAmbientOcclusion = true;           // VCT.h:51 (never uploaded there either)
     float AmbientFactor = 0.1f;                                              // VCT.h:53
+    int Bounces = 1;    // 2 = re-inject the lit voxels once (the "2 bounces" of the reference's README.md:16,
+                        // which its code does not implement: VCT.h:138-139 injects once); set before init
 
     // what replaces the GL object names (Depth_FBO, Depth_Texture, VoxelTexture)
     vct_ctx* ctx = nullptr;
@@ -201,6 +203,7 @@ struct Voxel_Cone_Tracing {
         cfg.height = screen_height;
         cfg.shadow_map_size = (int32_t)ShadowMapSize;
         cfg.ambient_factor = AmbientFactor;
+        cfg.voxel_attributes = Bounces >= 2 ? 1 : 0;
         if (!check(vct_create(&cfg, &ctx), "vct_create")) return;
         if (!model.Load(model_path)) { last_status = VCT_ERR_INVALID; return; }
 
@@ -255,7 +258,8 @@ struct Voxel_Cone_Tracing {
         if (!ctx) return;
         if (!check(vct_voxelize(ctx, VCT_VOX_CONSERVATIVE_AVG), "vct_voxelize")) return;
         if (!check(vct_inject_light(ctx), "vct_inject_light")) return;
-        check(vct_build_mips(ctx), "vct_build_mips");                       // VCT.h:248
+        if (!check(vct_build_mips(ctx), "vct_build_mips")) return;          // VCT.h:248
+        if (Bounces >= 2) check(vct_bounce(ctx), "vct_bounce");
     }
 
     const uint16_t* Frame() const { return FrameRGBA16F.data(); }

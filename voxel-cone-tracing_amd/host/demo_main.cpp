@@ -5,7 +5,7 @@
 // optionally writes it as a tonemapped PPM.
 //
 //   vct_demo [--scene procedural:atrium|procedural:cornell] [--voxels 128] [--size 1280x720]
-//            [--shadow 4096] [--frames 3] [--ppm out.ppm]
+//            [--shadow 4096] [--frames 3] [--bounces 1|2] [--ppm out.ppm]
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,7 +25,7 @@ static float half_to_float(uint16_t h) {
 }
 
 int main(int argc, char** argv) {
-    int w = SCREEN_WIDTH, h = SCREEN_HEIGHT, frames = 3, voxels = 128, shadow = 4096;
+    int w = SCREEN_WIDTH, h = SCREEN_HEIGHT, frames = 3, voxels = 128, shadow = 4096, bounces = 1;
     const char* scene = "procedural:atrium";
     const char* ppm = nullptr;
     for (int i = 1; i + 1 < argc; i += 2) {
@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--size")) sscanf(argv[i + 1], "%dx%d", &w, &h);
         else if (!strcmp(argv[i], "--shadow")) shadow = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--frames")) frames = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--bounces")) bounces = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--ppm")) ppm = argv[i + 1];
     }
     GLFWwindow* window = nullptr;          // no window system on a compute node
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
     voxel_cone_tracing.VoxelDimensions = voxels;
     voxel_cone_tracing.ShadowMapSize = (unsigned)shadow;
     voxel_cone_tracing.model_path = scene;
+    voxel_cone_tracing.Bounces = bounces;
     voxel_cone_tracing.init_voxel_cone_tracing();           // R/main.cpp:68
     if (voxel_cone_tracing.last_status != VCT_OK) return 2;
 
