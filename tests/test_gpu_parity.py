@@ -206,7 +206,7 @@ def test_call_order_errors(vct):
         with pytest.raises(vct.VctError):
             ctx.trace_resident()                # nothing resident
         with pytest.raises(vct.VctError):
-            ctx.voxelize(vct.VOX_REFERENCE)
+            ctx.voxelize(7)                     # unknown mode
         bad = np.zeros((23, 4 * 4), np.float32)
         gb = vct.GBuffer()
         gb.planes, gb.width, gb.height, gb.layout, gb.location = bad.ctypes.data, 4, 4, 0, 0
@@ -382,3 +382,29 @@ def test_sparse_mips_and_bounce_track_changing_scenes(vct, oracle):
         assert np.array_equal(ctx.download_chain(), want[1][0])
         ctx.bounce()
         assert np.array_equal(ctx.download_chain(), want[1][1])
+
+
+@pytest.mark.parametrize("with_shadow", [False, True])
+def test_voxelize_reference_mode_matches_oracle(vct, oracle, with_shadow):
+    """VCT_VOX_REFERENCE: the reference's own voxelization (S/Voxelization.vs/.gs/.fs: dominant-axis
+    V x V raster at pixel centres, vox.fs:58-86 index, last triangle in submission order wins) is
+    bit-identical to the oracle's restatement, and switching modes on one context leaves no residue."""
+    V = 64
+    pos, mat, alb = random_scene(500, seed=77)
+    depth, vp = light_setup(256, 9) if with_shadow else (None, None)
+    p = oracle.default_params(V)
+    sc = oracle.make_scene(pos, mat, alb, shadow_depth=depth, light_vp=vp)
+    want_ref = oracle.build_mips(oracle.voxelize_reference(p, sc))
+    want_cons = oracle.build_mips(oracle.voxelize_conservative(p, sc))
+    occ_ref = (want_ref[: V ** 3, 3] > 0).mean()
+    assert 0.001 < occ_ref < (want_cons[: V ** 3, 3] > 0).mean()      # centre sampling covers less
+    with make_ctx(vct, V, 8, 8) as ctx:
+        ctx.upload_triangles(pos, mat, alb)
+        if with_shadow:
+            ctx.upload_shadow_map(depth, vp)
+        for mode, want in ((vct.VOX_REFERENCE, want_ref), (vct.VOX_CONSERVATIVE_AVG, want_cons),
+                           (vct.VOX_REFERENCE, want_ref), (vct.VOX_REFERENCE, want_ref)):
+            ctx.voxelize(mode)
+            ctx.inject_light()
+            ctx.build_mips()
+            assert np.array_equal(ctx.download_chain(), want), mode

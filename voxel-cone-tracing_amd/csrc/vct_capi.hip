@@ -86,6 +86,8 @@ struct vct_ctx {
     bool level0_sparse_ok = false;     // chain: untouched bricks have all-zero ancestors, mip_seen is current
     bool level0_sparse_ok_next = false;
     bool acc_pending = false;          // accumulators hold an unresolved voxelize pass
+    int acc_mode = 0;                  // vct_voxelize_mode of that pass
+    int32_t* ref_big = nullptr;        // reference mode: triangles left to the workgroup pass (+ counter)
     bool level0_dirty = false;         // level 0 was written by an upload: next resolve is dense
 };
 
@@ -107,6 +109,51 @@ int fail(vct_ctx* c, int code, const std::string& msg) {
     } while (0)
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// glm::ortho / glm::lookAt(eye, origin, up) / mat4 product as the reference builds ProjX/Y/Z
+// (VCT.h:128-134; glm defaults: right-handed, NDC z in [-1,1]); column-major, fp32, one rounding per
+// operation -- the same operation order as the oracle's restatement.
+void glm_ortho(float l, float r, float b, float t, float n, float f, float m[16]) {
+    memset(m, 0, 64);
+    m[0] = 2.0f / (r - l);
+    m[5] = 2.0f / (t - b);
+    m[10] = -2.0f / (f - n);
+    m[12] = -(r + l) / (r - l);
+    m[13] = -(t + b) / (t - b);
+    m[14] = -(f + n) / (f - n);
+    m[15] = 1.0f;
+}
+void glm_lookat_origin(const float eye[3], const float up[3], float m[16]) {
+    auto norm3 = [](float v[3]) {
+        const float l = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        v[0] = v[0] / l; v[1] = v[1] / l; v[2] = v[2] / l;
+    };
+    auto cross = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    auto dot = [](const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    float f[3] = {0.0f - eye[0], 0.0f - eye[1], 0.0f - eye[2]}, s[3], u[3];
+    norm3(f);
+    cross(f, up, s);
+    norm3(s);
+    cross(s, f, u);
+    memset(m, 0, 64);
+    m[0] = s[0]; m[4] = s[1]; m[8] = s[2];
+    m[1] = u[0]; m[5] = u[1]; m[9] = u[2];
+    m[2] = -f[0]; m[6] = -f[1]; m[10] = -f[2];
+    m[12] = -dot(s, eye); m[13] = -dot(u, eye); m[14] = dot(f, eye);
+    m[15] = 1.0f;
+}
+void mat_mul(const float a[16], const float b[16], float o[16]) {      // column-major o = a * b
+    float t[16];
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.0f;
+            for (int k = 0; k < 4; ++k) s += a[k * 4 + r] * b[c * 4 + k];
+            t[c * 4 + r] = s;
+        }
+    memcpy(o, t, sizeof(t));
+}
 
 // The step sequence of trace.fs:90-104, evaluated with the reference's operation order:
 //   dist = vs; while (dist < MAX) { diameter = max(vs, 2*t*dist); lod = log2(diameter/vs); ...
@@ -378,7 +425,7 @@ void vct_destroy(vct_ctx* c) {
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
-                    c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
+                    c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->vis, c->raster_big,
                     c->raster_big_count, c->raster_items};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -440,6 +487,7 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     if (c->big_list) { (void)hipFree(c->big_list); c->big_list = nullptr; }
     if (c->worklist) { (void)hipFree(c->worklist); c->worklist = nullptr; }
     if (c->raster_big) { (void)hipFree(c->raster_big); c->raster_big = nullptr; }   // sized by ntri
+    if (c->ref_big) { (void)hipFree(c->ref_big); c->ref_big = nullptr; }
     float** frames[3] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit};                   // belong to the old mesh
     for (float** f : frames) if (*f) { (void)hipFree(*f); *f = nullptr; }
     c->n_entries = 0;
@@ -605,8 +653,8 @@ int vct_download_gbuffer(vct_ctx* c, float* planes) {
 
 int vct_voxelize(vct_ctx* c, int32_t mode) {
     if (!c) return VCT_ERR_INVALID;
-    if (mode != VCT_VOX_CONSERVATIVE_AVG)
-        return fail(c, VCT_ERR_INVALID, "vct_voxelize: only VCT_VOX_CONSERVATIVE_AVG is implemented");
+    if (mode != VCT_VOX_CONSERVATIVE_AVG && mode != VCT_VOX_REFERENCE)
+        return fail(c, VCT_ERR_INVALID, "vct_voxelize: unknown mode");
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_voxelize: no triangles uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
@@ -635,8 +683,24 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
     }
     VctVoxParams p = vox_params(c);
     p.mode = mode;
-    HIP_TRY(c, vct_launch_voxelize(p, c->stream));
+    if (mode == VCT_VOX_REFERENCE) {
+        // VCT.h:128-134: ortho(-G/2, G/2, -G/2, G/2, G/2, 3G/2) * lookAt(+-G on the axis) per dominant axis
+        const float G = c->cfg.grid_world_size, h = G * 0.5f;
+        float o[16], v[16];
+        glm_ortho(-h, h, -h, h, h, G * 1.5f, o);
+        const float eye[3][3] = {{G, 0, 0}, {0, G, 0}, {0, 0, G}};
+        const float up[3][3] = {{0, 1, 0}, {0, 0, -1}, {0, 1, 0}};
+        for (int a = 0; a < 3; ++a) {
+            glm_lookat_origin(eye[a], up[a], v);
+            mat_mul(o, v, p.proj + 16 * a);
+        }
+        if (!c->ref_big) HIP_TRY(c, hipMalloc(&c->ref_big, ((size_t)c->ntri + 1) * sizeof(int32_t)));
+        HIP_TRY(c, vct_launch_voxelize_reference(p, c->ref_big + 1, c->ref_big, c->stream));
+    } else {
+        HIP_TRY(c, vct_launch_voxelize(p, c->stream));
+    }
     c->acc_pending = true;
+    c->acc_mode = mode;
     return VCT_OK;
 }
 
@@ -645,7 +709,8 @@ int vct_inject_light(vct_ctx* c) {
     if (!c->acc_pending) return fail(c, VCT_ERR_INVALID, "vct_inject_light: call vct_voxelize first");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, vct_launch_resolve(c->acc, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
-                                  c->level0_dirty, c->acc_attr, c->attr_albedo, c->attr_normal, c->stream));
+                                  c->level0_dirty, c->acc_attr, c->attr_albedo, c->attr_normal,
+                                  c->acc_mode == VCT_VOX_REFERENCE, c->stream));
     // after an upload the coarse levels may hold anything: one dense mip build re-establishes
     // "untouched bricks have zero ancestors", then the sparse form is valid again
     c->level0_sparse_ok = !c->level0_dirty && c->level0_sparse_ok_next;
@@ -678,8 +743,8 @@ int vct_bounce(vct_ctx* c) {
         return fail(c, VCT_ERR_INVALID, "vct_bounce: needs config.voxel_attributes = 1 and a voxelize + inject pass");
     if (c->acc_pending || !c->mips_valid)
         return fail(c, VCT_ERR_INVALID, "vct_bounce: call vct_inject_light and vct_build_mips first");
-    if (c->level0_dirty)
-        return fail(c, VCT_ERR_INVALID, "vct_bounce: level 0 was uploaded, not voxelized (no attributes for it)");
+    if (c->level0_dirty || c->acc_mode != VCT_VOX_CONSERVATIVE_AVG)
+        return fail(c, VCT_ERR_INVALID, "vct_bounce: level 0 must come from a VCT_VOX_CONSERVATIVE_AVG pass (voxel attributes)");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = refresh_steps(c);
     if (rc) return rc;

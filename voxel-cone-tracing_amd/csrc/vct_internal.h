@@ -87,6 +87,7 @@ struct VctVoxParams {
     int32_t n_big;
     uint32_t* brick_flags;     // [V^3 / 512] raised by fragments, consumed by the sparse resolve
     unsigned long long* acc_attr;   // [V^3][3]: (albR | albG<<32), (albB | nX<<32), (nY | nZ<<32) or null
+    float proj[48];            // ProjX, ProjY, ProjZ (VCT.h:128-134), column-major; reference mode only
     int32_t mode;
 };
 
@@ -131,7 +132,9 @@ hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* wor
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s);
 hipError_t vct_launch_resolve(unsigned long long* acc, uint32_t* level0, uint32_t* flags,
                               uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
-                              uint32_t* attr_albedo, uint32_t* attr_normal, hipStream_t s);
+                              uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, hipStream_t s);
+hipError_t vct_launch_voxelize_reference(const VctVoxParams& p, int32_t* big_list, int32_t* big_count,
+                                         hipStream_t s);
 hipError_t vct_launch_bounce(const VctTraceParams& p, hipStream_t s);
 
 #endif

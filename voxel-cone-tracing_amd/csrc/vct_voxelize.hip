@@ -360,6 +360,121 @@ k_voxelize_big(const VctVoxParams p) {
     }
 }
 
+// ---- reference mode (S/Voxelization.vs/.gs/.fs as written): dominant-axis projection, V x V raster
+// at pixel centres with the top-left rule, voxel index from (x, y, V*depth) (vox.fs:58-86), value
+// = unorm8(albedo * PCF/25), a = 1, and "imageStore: last writer wins".  The reference's store order
+// is a race; the deterministic reading the oracle uses -- the last triangle in submission order
+// wins -- is an order-independent 64-bit atomicMax on (triangle + 1) << 32 | rgb.
+struct RefSetup {
+    float wx[3], wy[3], wz[3];
+    F3 dc[3];
+    float area, sgn;
+    int x0, x1, y0, y1, axis;
+    float alb[3];
+    bool ok;
+};
+
+__device__ __forceinline__ void ref_setup(const VctVoxParams& p, int t, RefSetup& r) {
+    F3 w[3];
+    const float fV = (float)p.V;
+    for (int k = 0; k < 3; ++k) {
+        const float* q = p.pos + (size_t)t * 9 + 3 * k;
+        w[k] = {q[0] * p.model_scale, q[1] * p.model_scale, q[2] * p.model_scale};   // vox.vs:21
+        const F3 d = xform_point(p.light_vp, w[k]);                                  // vox.vs:18
+        r.dc[k] = {d.x * 0.5f + 0.5f, d.y * 0.5f + 0.5f, d.z * 0.5f + 0.5f};          // vox.vs:19
+    }
+    const F3 e1 = sub3(w[0], w[1]), e2 = sub3(w[2], w[0]);                            // vox.gs:24-25
+    const F3 nn = cross3(e1, e2);
+    const float len = __builtin_sqrtf(dot3(nn, nn));
+    const float nx = fabsf(__fdiv_rn(nn.x, len)), ny = fabsf(__fdiv_rn(nn.y, len)),
+                nz = fabsf(__fdiv_rn(nn.z, len));
+    if (nx >= ny && nx >= nz) r.axis = 1;                                             // vox.gs:34-39
+    else if (ny >= nx && ny >= nz) r.axis = 2;
+    else r.axis = 3;
+    const float* proj = p.proj + 16 * (r.axis - 1);
+    for (int k = 0; k < 3; ++k) {
+        const F3 ndc = xform_point(proj, w[k]);                                       // vox.gs:47 (w = 1)
+        r.wx[k] = (ndc.x * 0.5f + 0.5f) * fV;
+        r.wy[k] = (ndc.y * 0.5f + 0.5f) * fV;
+        r.wz[k] = ndc.z * 0.5f + 0.5f;
+    }
+    const float area = (r.wx[1] - r.wx[0]) * (r.wy[2] - r.wy[0]) - (r.wx[2] - r.wx[0]) * (r.wy[1] - r.wy[0]);
+    r.ok = !(area == 0.0f || area != area);
+    r.sgn = area > 0.0f ? 1.0f : -1.0f;
+    r.area = area * r.sgn;
+    r.x0 = max((int)floorf(fminf(fminf(r.wx[0], r.wx[1]), r.wx[2])), 0);
+    r.x1 = min((int)floorf(fmaxf(fmaxf(r.wx[0], r.wx[1]), r.wx[2])), p.V - 1);
+    r.y0 = max((int)floorf(fminf(fminf(r.wy[0], r.wy[1]), r.wy[2])), 0);
+    r.y1 = min((int)floorf(fmaxf(fmaxf(r.wy[0], r.wy[1]), r.wy[2])), p.V - 1);
+    const float* alb = p.albedo + 4 * (size_t)p.material[t];
+    r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
+}
+
+__device__ __forceinline__ void ref_fragment(const VctVoxParams& p, const RefSetup& r, int t, int px, int py) {
+    const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+    float e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;            // edge opposite vertex k
+        const float dx = (r.wx[b] - r.wx[a]) * r.sgn, dy = (r.wy[b] - r.wy[a]) * r.sgn;
+        e[k] = dx * (cy - r.wy[a]) - dy * (cx - r.wx[a]);
+        const bool top_left = (dy > 0.0f) || (dy == 0.0f && dx < 0.0f);              // [GL] fill rule
+        if (e[k] < 0.0f || (e[k] == 0.0f && !top_left)) return;
+    }
+    const float l0 = __fdiv_rn(e[0], r.area), l1 = __fdiv_rn(e[1], r.area), l2 = 1.0f - l0 - l1;
+    const float fz = l0 * r.wz[0] + l1 * r.wz[1] + l2 * r.wz[2];
+    const int V = p.V;
+    const int ix = (int)cx, iy = (int)cy, iz = (int)((float)V * fz);                  // vox.fs:58
+    int vx, vy, vz;
+    if (r.axis == 1) { vx = V - 1 - iz; vz = V - 1 - ix; vy = iy; }                   // vox.fs:70-75
+    else if (r.axis == 2) { vz = V - 1 - iy; vy = V - 1 - iz; vx = ix; }              // :76-81
+    else { vx = ix; vy = iy; vz = V - 1 - iz; }                                       // :82-86
+    if (vx < 0 || vy < 0 || vz < 0 || vx >= V || vy >= V || vz >= V) return;          // [GL] store dropped
+    float sh = 1.0f;
+    if (p.shadow) {
+        const F3 dc = {l0 * r.dc[0].x + l1 * r.dc[1].x + l2 * r.dc[2].x,
+                       l0 * r.dc[0].y + l1 * r.dc[1].y + l2 * r.dc[2].y,
+                       l0 * r.dc[0].z + l1 * r.dc[1].z + l2 * r.dc[2].z};
+        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_size, dc, 0.002f), 25.0f);    // vox.fs:46
+    }
+    const unsigned long long rgb = to_unorm8(r.alb[0] * sh) | (to_unorm8(r.alb[1] * sh) << 8) |
+                                   (to_unorm8(r.alb[2] * sh) << 16);                 // vox.fs:88
+    const uint32_t vox = vct_morton3((uint32_t)vx, (uint32_t)vy, (uint32_t)vz);
+    atomicMax(p.acc + 2 * (size_t)vox, ((unsigned long long)(uint32_t)(t + 1) << 32) | rgb);
+    p.brick_flags[vox >> 9] = 1u;
+}
+
+#define VCT_REF_SMALL 64
+
+__global__ void __launch_bounds__(256)
+k_voxelize_reference(const VctVoxParams p, int32_t* big_list, int32_t* big_count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.ntri) return;
+    RefSetup r;
+    ref_setup(p, t, r);
+    if (!r.ok || r.x1 < r.x0 || r.y1 < r.y0) return;
+    if ((long long)(r.x1 - r.x0 + 1) * (r.y1 - r.y0 + 1) > VCT_REF_SMALL) {
+        big_list[atomicAdd(big_count, 1)] = t;
+        return;
+    }
+    for (int py = r.y0; py <= r.y1; ++py)
+        for (int px = r.x0; px <= r.x1; ++px) ref_fragment(p, r, t, px, py);
+}
+
+__global__ void __launch_bounds__(256)
+k_voxelize_reference_big(const VctVoxParams p, const int32_t* big_list, const int32_t* big_count) {
+    const int nbig = *big_count;
+    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const int t = big_list[b];
+        RefSetup r;
+        ref_setup(p, t, r);
+        const int bw = r.x1 - r.x0 + 1;
+        const long long box = (long long)bw * (r.y1 - r.y0 + 1);
+        for (long long i = threadIdx.x; i < box; i += blockDim.x)
+            ref_fragment(p, r, t, r.x0 + (int)(i % bw), r.y0 + (int)(i / bw));
+    }
+}
+
 __device__ __forceinline__ uint32_t resolve_voxel(ulonglong2 a) {
     const uint32_t c = (uint32_t)(a.y >> 32);
     if (!c) return 0u;
@@ -376,7 +491,7 @@ __global__ void __launch_bounds__(256)
 k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ level0,
                  uint32_t* __restrict__ flags, uint32_t* __restrict__ prev, uint32_t nbricks,
                  uint32_t brick_voxels, int dense, unsigned long long* __restrict__ acc_attr,
-                 uint32_t* __restrict__ attr_albedo, uint32_t* __restrict__ attr_normal) {
+                 uint32_t* __restrict__ attr_albedo, uint32_t* __restrict__ attr_normal, int reference) {
     const int lane = threadIdx.x & 63;
     const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nbricks; b += waves) {
@@ -386,6 +501,11 @@ k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ le
         uint32_t* l0 = level0 + (size_t)b * brick_voxels;
         for (uint32_t v = lane; v < brick_voxels; v += 64) {
             const ulonglong2 a = a2[v];
+            if (reference) {        // (triangle + 1) << 32 | rgb of the last triangle that stored here
+                l0[v] = a.x ? ((uint32_t)a.x & 0xffffffu) | 0xff000000u : 0u;
+                if (a.x) a2[v] = make_ulonglong2(0ull, 0ull);
+                continue;
+            }
             l0[v] = resolve_voxel(a);
             if (a.y) a2[v] = make_ulonglong2(0ull, 0ull);
             if (acc_attr) {
@@ -421,6 +541,18 @@ hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* wor
     return hipGetLastError();
 }
 
+hipError_t vct_launch_voxelize_reference(const VctVoxParams& p, int32_t* big_list, int32_t* big_count,
+                                         hipStream_t s) {
+    if (p.ntri <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(big_count, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_voxelize_reference, dim3((p.ntri + 255) / 256), dim3(256), 0, s, p, big_list, big_count);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_voxelize_reference_big, dim3(256 * 8), dim3(256), 0, s, p, big_list, big_count);
+    return hipGetLastError();
+}
+
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
     if (p.n_entries > 0) {
         const size_t threads = (size_t)p.n_entries;
@@ -440,12 +572,13 @@ hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
 
 hipError_t vct_launch_resolve(unsigned long long* acc, uint32_t* level0, uint32_t* flags,
                               uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
-                              uint32_t* attr_albedo, uint32_t* attr_normal, hipStream_t s) {
+                              uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, hipStream_t s) {
     const uint32_t brick_voxels = V >= 8 ? 512u : (uint32_t)(V * V * V);
     const uint32_t nbricks = (uint32_t)(((size_t)V * V * V) / brick_voxels);
     size_t blocks = ((size_t)nbricks + 3) / 4;      // 4 waves per workgroup, one brick per wave
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)blocks), dim3(256), 0, s, acc, level0, flags,
-                       prev, nbricks, brick_voxels, dense ? 1 : 0, acc_attr, attr_albedo, attr_normal);
+                       prev, nbricks, brick_voxels, dense ? 1 : 0, reference ? nullptr : acc_attr, attr_albedo,
+                       attr_normal, reference ? 1 : 0);
     return hipGetLastError();
 }
