@@ -296,6 +296,21 @@ def main():
                                  "Cache resident and the kernel is VALU-issue bound (DESIGN.md 3.1), so "
                                  "frac against the HBM peak may exceed 1. " + traffic_note},
         }
+        if world == 1:
+            # BASELINE.json config 5's "glossy cones at 3 roughness levels": the specular aperture is a
+            # runtime parameter (trace.fs:218 uses 0.07 and mentions 0.105); same frame, same chain
+            sweep = []
+            for ts in (0.07, 0.105, 0.2):
+                ctx.set_cone_apertures(0.577, ts)
+                ms = []
+                for _ in range(5):
+                    ctx.trace_resident()
+                    ms.append(ctx.last_trace_ms())
+                sweep.append({"tan_specular": ts, "trace_kernel_ms": round(float(np.min(ms)), 4),
+                              "cone_steps": ctx.last_step_count(),
+                              "Mcones_per_s": round(cones / (float(np.min(ms)) * 1e-3) / 1e6, 1)})
+            ctx.set_cone_apertures(0.577, 0.07)
+            result["roughness_sweep"] = sweep
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(args, inp, ctx, vct)
         print(json.dumps(result), flush=True)
