@@ -58,7 +58,7 @@ def test_oracle_reproduces_golden_voxelization(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("path", TRACE_CASES, ids=os.path.basename)
 def test_hip_reproduces_golden_trace(path, variant):
     import vctpkg

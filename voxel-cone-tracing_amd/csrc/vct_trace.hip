@@ -292,6 +292,30 @@ __constant__ float kConeDirs[18] = {0.0f, 0.0f, 1.0f,
                                     -0.823639f, 0.267617f, 0.5f};            // trace.fs:49-57
 __constant__ float kConeWeights[6] = {0.25f, 0.15f, 0.15f, 0.15f, 0.15f, 0.15f};   // trace.fs:48
 
+#ifndef VCT_XCD_MAP
+#define VCT_XCD_MAP 16   // measured: 0 (round-robin) 0.764 ms, 1 (contiguous) 0.797, 16: 0.756, 60: 0.779, 240: 0.758
+#endif
+// Workgroups are dealt to XCDs round-robin by the dispatcher (block b -> XCD b % 8); the tile order is
+// remapped so that every XCD works on short runs of neighbouring tiles (neighbouring tiles march
+// through neighbouring voxels and share that XCD's L2) while the runs of all XCDs interleave over
+// the frame -- one long contiguous run per XCD loses more to imbalance between cheap and expensive
+// screen regions than it gains in locality (profiles/r01h_ab_xcd_map.txt).
+__device__ __forceinline__ int xcd_remap(int b, int nblocks) {
+#if VCT_XCD_MAP == 0
+    (void)nblocks;
+    return b;                                                    // tiles dealt round-robin to the XCDs
+#elif VCT_XCD_MAP == 1
+    const int per_xcd = nblocks >> 3;                            // one contiguous run of tiles per XCD
+    return (b & 7) * per_xcd + (b >> 3);
+#else
+    // runs of VCT_XCD_MAP consecutive blocks per XCD: a permutation inside every full group of
+    // 8*run blocks; the last partial group keeps identity
+    const int run = VCT_XCD_MAP, group = 8 * run;
+    const int g = b / group, local = b - g * group;
+    return (g + 1) * group <= nblocks ? g * group + (local & 7) * run + (local >> 3) : b;
+#endif
+}
+
 // tiles (waves) per workgroup: single-wave workgroups dispatch with the finest granularity, which
 // balances the tail best (0.822 -> 0.800 ms against 4 waves; profiles/r01g_ab_waves_per_block.txt)
 #ifndef VCT_WAVES_PER_BLOCK
@@ -316,23 +340,7 @@ k_trace_tile(const VctTraceParams p) {
     float4* blk = &lds_blk[wave][0][0];
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
-#ifndef VCT_XCD_MAP
-#define VCT_XCD_MAP 16   // measured: 0 (round-robin) 0.764 ms, 1 (contiguous) 0.797, 16: 0.756, 60: 0.779, 240: 0.758
-#endif
-#if VCT_XCD_MAP == 0
-    const int vb = blockIdx.x;                                   // tiles dealt round-robin to the XCDs
-#elif VCT_XCD_MAP == 1
-    const int per_xcd = gridDim.x >> 3;                          // one contiguous run of tiles per XCD
-    const int vb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-#else
-    // runs of VCT_XCD_MAP consecutive blocks per XCD, dealt round-robin: locality inside a run,
-    // balance across the frame
-    // (a permutation inside every full group of 8*run blocks; the last partial group keeps identity)
-    const int run = VCT_XCD_MAP, group = 8 * run;
-    const int g = blockIdx.x / group, local = blockIdx.x - g * group;
-    const int vb = (g + 1) * group <= (int)gridDim.x ? g * group + (local & 7) * run + (local >> 3)
-                                                     : (int)blockIdx.x;
-#endif
+    const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int ti = vb * VCT_WAVES_PER_BLOCK + wave;
     if (ti >= ntiles) return;
 
@@ -464,6 +472,165 @@ k_trace_tile(const VctTraceParams p) {
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
     if (lane == 0 && total)
         atomicAdd(p.step_counter + (ti & (VCT_STEP_COUNTERS - 1)), (unsigned long long)total);
+}
+
+// ---- the same trace with each tile split over 3 waves ------------------------------------------
+// A wave that marches all 71 steps of a tile lives ~140 us; at the end of a launch the GPU drains
+// for about half of that with ever fewer waves resident (measured: +55..66 us per launch, 7 % of a
+// 1080p frame but 37 % of the 0.15 ms slab an 8-GPU rank traces).  Here a tile is a workgroup of 3
+// waves -- diffuse cones 0-2, diffuse cones 3-5, the specular cone (21 / 21 / 29 steps) -- that
+// leave their raw cone vec4s in LDS and exit; the last one to arrive gathers them in the oracle's
+// order (the weighted sum is an fma chain over cones 0..5) and composites.  Same bits, waves one
+// third as long, no wave ever waits on another.
+#define VCT_SPLIT 3
+
+template <bool WRAP, bool FASTDIV>
+__global__ void __launch_bounds__(64 * VCT_SPLIT, VCT_TRACE_MIN_WAVES)
+k_trace_tile_split(const VctTraceParams p) {
+    __shared__ float4 lds_blk[VCT_SPLIT][2][64];
+    __shared__ float4 lds_cone[7][64];
+    __shared__ int lds_done;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float4* blk = &lds_blk[wave][0][0];
+    if (threadIdx.x == 0) lds_done = 0;
+    __syncthreads();
+
+    const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
+    const int ti = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (ti >= ntiles) return;
+
+    LaneBlock lb;
+    lb.lane = lane;
+    lb.sbx = vct_spread3((uint32_t)lane & 3u);
+    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;
+
+    const int tile = p.tile_row0 * p.tiles_x + ti;
+    const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto pixel_index = [&](int l) {
+        return (size_t)(ty * VCT_TILE + (l >> 3)) * p.width + (tx * VCT_TILE + (l & 7));
+    };
+    auto gbuf_ptr = [&](int l) {
+        return p.gbuf + (size_t)tile * (VCT_GB_NPLANES * VCT_TILE_PIX) + l;
+    };
+    const int x = tx * VCT_TILE + (lane & 7), y = ty * VCT_TILE + (lane >> 3);
+    const float* gb = gbuf_ptr(lane);
+#define VCT_GB(k) gb[(k) * VCT_TILE_PIX]
+    const bool in_frame = (x < p.width) && (y < p.height);
+    const bool alive = in_frame && !(VCT_GB(18) < 0.5f);            // trace.fs:171 discard
+    int total = 0;
+    if (wave < 2) {
+        F3 start, k0, k1, k2;
+        {
+            const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2)), Nw = f3(VCT_GB(3), VCT_GB(4), VCT_GB(5));
+            const F3 T = f3(VCT_GB(6), VCT_GB(7), VCT_GB(8)), B = f3(VCT_GB(9), VCT_GB(10), VCT_GB(11));
+            // trace.fs:175: inverse(transpose(mat3(T,B,N))) = columns (BxN, NxT, TxB) / det
+            const F3 c0 = cross3(B, Nw), c1 = cross3(Nw, T), c2 = cross3(T, B);
+            const float inv_det = div_rn(1.0f, dot3(T, c0));
+            k0 = f3(c0.x * inv_det, c0.y * inv_det, c0.z * inv_det);
+            k1 = f3(c1.x * inv_det, c1.y * inv_det, c1.z * inv_det);
+            k2 = f3(c2.x * inv_det, c2.y * inv_det, c2.z * inv_det);
+            start = f3(P.x + Nw.x * p.vs, P.y + Nw.y * p.vs, P.z + Nw.z * p.vs);       // :92
+        }
+#pragma unroll 1
+        for (int i = wave * 3; i < wave * 3 + 3; ++i) {                     // :196-199
+            const float ddx = kConeDirs[3 * i], ddy = kConeDirs[3 * i + 1], ddz = kConeDirs[3 * i + 2];
+            F3 dir = f3(k0.x * ddx + k1.x * ddy + k2.x * ddz, k0.y * ddx + k1.y * ddy + k2.y * ddz,
+                        k0.z * ddx + k1.z * ddy + k2.z * ddz);
+            dir = normalize3(dir);
+            int st;
+            const F4 c = cone_march<WRAP, FASTDIV, true>(p, alive, start, dir, p.steps_diffuse,
+                                                         p.n_diffuse, blk, lb, st);
+            total += st;
+            lds_cone[i][lane] = make_float4(c.x, c.y, c.z, c.w);
+            if (p.dbg_cones && alive) {
+                float* d = p.dbg_cones + pixel_index(fresh_lane()) * 28 + 4 * i;
+                d[0] = c.x; d[1] = c.y; d[2] = c.z; d[3] = c.w;
+            }
+            if (p.dbg_steps && in_frame) p.dbg_steps[pixel_index(fresh_lane()) * 7 + i] = (uint8_t)st;
+        }
+    } else {
+        // specular cone along reflect(-E, N) with the bump normal                 trace.fs:217-218
+        const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2)), Nw = f3(VCT_GB(3), VCT_GB(4), VCT_GB(5));
+        const F3 N = f3(VCT_GB(12), VCT_GB(13), VCT_GB(14));
+        const F3 start = f3(P.x + Nw.x * p.vs, P.y + Nw.y * p.vs, P.z + Nw.z * p.vs);
+        const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
+        const F3 Rd = normalize3(reflect3(f3(E.x * -1.0f, E.y * -1.0f, E.z * -1.0f), N));  // :217
+        int st6;
+        const F4 sc = cone_march<WRAP, FASTDIV, true>(p, alive, start, Rd, p.steps_specular, p.n_specular,
+                                                      blk, lb, st6);
+        total += st6;
+        lds_cone[6][lane] = make_float4(sc.x, sc.y, sc.z, sc.w);
+        if (p.dbg_cones && alive) {
+            float* d = p.dbg_cones + pixel_index(fresh_lane()) * 28 + 24;
+            d[0] = sc.x; d[1] = sc.y; d[2] = sc.z; d[3] = sc.w;
+        }
+        if (p.dbg_steps && in_frame) p.dbg_steps[pixel_index(fresh_lane()) * 7 + 6] = (uint8_t)st6;
+    }
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (lane == 0 && total)
+        atomicAdd(p.step_counter + ((ti * VCT_SPLIT + wave) & (VCT_STEP_COUNTERS - 1)), (unsigned long long)total);
+
+    // arrival: LDS operations of a wave are performed in order, so the cone values are in LDS before
+    // the count is raised; whoever raises it to VCT_SPLIT sees all of them
+    __threadfence_block();
+    int arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&lds_done, 1);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != VCT_SPLIT - 1) return;
+    __threadfence_block();
+
+    // composite by the last wave                                                   trace.fs:179-227
+    const float* gb3 = gbuf_ptr(fresh_lane());
+#undef VCT_GB
+#define VCT_GB(k) gb3[(k) * VCT_TILE_PIX]
+    if (in_frame) {
+        float ind[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float4 c = lds_cone[i][lane];
+            const float wgt = kConeWeights[i];
+            ind[0] = fmaf(wgt, c.x, ind[0]);
+            ind[1] = fmaf(wgt, c.y, ind[1]);
+            ind[2] = fmaf(wgt, c.z, ind[2]);
+            ind[3] = fmaf(wgt, c.w, ind[3]);
+        }
+        const float4 sc = lds_cone[6][lane];
+        const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2));
+        const F3 N = f3(VCT_GB(12), VCT_GB(13), VCT_GB(14));
+        const float alb_r = VCT_GB(15), alb_g = VCT_GB(16), alb_b = VCT_GB(17), alb_a = VCT_GB(18);
+        const float shadow = VCT_GB(22);
+        const F3 L = normalize3(f3(p.light[0], p.light[1], p.light[2]));        // :179
+        const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
+        const float cos_theta = fmaxf(dot3(N, L), 0.0f);                        // :188
+        const float direct_diffuse = shadow * cos_theta;                        // :192
+        const float occlusion = 1.0f - ind[3];                                  // :201
+        const float dr = (direct_diffuse + occlusion * ind[0]) * alb_r;         // :205
+        const float dg = (direct_diffuse + occlusion * ind[1]) * alb_g;
+        const float db = (direct_diffuse + occlusion * ind[2]) * alb_b;
+        const F3 R = normalize3(reflect3(f3(L.x * -1.0f, L.y * -1.0f, L.z * -1.0f), N));   // :212
+        const float spec = powf(fmaxf(dot3(E, R), 0.0f), p.shininess);          // :213
+        const float direct_spec = spec * shadow;                                // :214
+        const float spec_occ = 1.0f - sc.w;                                     // :221
+        const float sr = (sc.x + spec_occ * direct_spec) * VCT_GB(19);          // :223
+        const float sg = (sc.y + spec_occ * direct_spec) * VCT_GB(20);
+        const float sb = (sc.z + spec_occ * direct_spec) * VCT_GB(21);
+        const float ar = p.ambient * alb_r * occlusion;                         // :225
+        const float ag = p.ambient * alb_g * occlusion;
+        const float ab = p.ambient * alb_b * occlusion;
+        float o0 = ar + dr + sr, o1 = ag + dg + sg, o2 = ab + db + sb, o3 = alb_a;   // :227
+        if (!alive) {                                                           // VCT.h:156-159
+            const float cc = p.ambient < 0.5f ? 0.5f : 1.0f;
+            o0 = cc; o1 = cc; o2 = cc; o3 = 1.0f;
+        }
+        uint2 pk;
+        pk.x = pack_half2(o0, o1);
+        pk.y = pack_half2(o2, o3);
+        *reinterpret_cast<uint2*>(p.out + pixel_index(fresh_lane()) * 4) = pk;
+    }
+#undef VCT_GB
 }
 
 __device__ __forceinline__ uint32_t to_unorm8_dev(float f) {     // [GL] float -> unorm8, round to nearest
@@ -643,9 +810,15 @@ hipError_t launch(const VctTraceParams& p, int blocks, hipStream_t s) {
 }
 
 template <bool WRAP, bool FASTDIV>
-hipError_t launch_v(const VctTraceParams& p, int variant, int blocks, hipStream_t s) {
-    return variant == 1 ? launch<WRAP, FASTDIV, false>(p, blocks, s)
-                        : launch<WRAP, FASTDIV, true>(p, blocks, s);
+hipError_t launch_v(const VctTraceParams& p, int variant, int ntiles, hipStream_t s) {
+    if (variant == 1 || variant == 2) {
+        const int nblocks = (ntiles + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
+        const int blocks = ((nblocks + 7) / 8) * 8;     // whole rounds of the 8 XCDs
+        return variant == 1 ? launch<WRAP, FASTDIV, false>(p, blocks, s) : launch<WRAP, FASTDIV, true>(p, blocks, s);
+    }
+    const int blocks = ((ntiles + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+    return hipGetLastError();
 }
 
 // every fp32 bit pattern: div_const<true> against the IEEE divide
@@ -696,15 +869,14 @@ hipError_t vct_launch_bounce(const VctTraceParams& p, hipStream_t s) {
     return p.fast_div ? launch_bounce<false, true>(p, s) : launch_bounce<false, false>(p, s);
 }
 
-// variant 0: cooperative sampler with per-lane fallback (default); 1: per-lane sampler only.
+// variant 0 (default): cooperative sampler, each tile split over 3 waves; 2: cooperative sampler, one
+// wave per tile; 1: per-lane sampler only, one wave per tile.
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s) {
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
     if (ntiles <= 0) return hipSuccess;
-    const int nblocks = (ntiles + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
-    const int blocks = ((nblocks + 7) / 8) * 8;     // whole rounds of the 8 XCDs
     if (p.wrap_repeat)
-        return p.fast_div ? launch_v<true, true>(p, variant, blocks, s)
-                          : launch_v<true, false>(p, variant, blocks, s);
-    return p.fast_div ? launch_v<false, true>(p, variant, blocks, s)
-                      : launch_v<false, false>(p, variant, blocks, s);
+        return p.fast_div ? launch_v<true, true>(p, variant, ntiles, s)
+                          : launch_v<true, false>(p, variant, ntiles, s);
+    return p.fast_div ? launch_v<false, true>(p, variant, ntiles, s)
+                      : launch_v<false, false>(p, variant, ntiles, s);
 }
