@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--bounces", type=int, default=1, choices=[1, 2],
                     help="2 = re-inject lit voxels once before the screen trace (BASELINE config 3)")
+    ap.add_argument("--no-sweep", action="store_true",
+                    help="skip the 3-aperture roughness sweep (profiling runs: keeps every trace launch identical)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the oracle baseline sample (0 disables)")
     return ap.parse_args()
@@ -296,7 +298,7 @@ def main():
                                  "Cache resident and the kernel is VALU-issue bound (DESIGN.md 3.1), so "
                                  "frac against the HBM peak may exceed 1. " + traffic_note},
         }
-        if world == 1:
+        if world == 1 and not args.no_sweep:
             # BASELINE.json config 5's "glossy cones at 3 roughness levels": the specular aperture is a
             # runtime parameter (trace.fs:218 uses 0.07 and mentions 0.105); same frame, same chain
             sweep = []
