@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--bounces", type=int, default=1, choices=[1, 2],
                     help="2 = re-inject lit voxels once before the screen trace (BASELINE config 3)")
+    ap.add_argument("--anisotropic", action="store_true",
+                    help="six directional mip chains, direction-weighted sampling (north-star option)")
     ap.add_argument("--no-sweep", action="store_true",
                     help="skip the 3-aperture roughness sweep (profiling runs: keeps every trace launch identical)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -119,7 +121,8 @@ def main():
     inp = build_inputs(args, vct, sc)
     cfg = vct.default_config(voxel_dim=V, width=w, height=h, device=local_rank,
                              trace_variant=args.variant, shadow_map_size=args.shadow_size,
-                             voxel_attributes=1 if args.bounces == 2 else 0)
+                             voxel_attributes=1 if args.bounces == 2 else 0,
+                             anisotropic_mips=1 if args.anisotropic else 0)
     ctx = vct.Context(cfg)
     ctx.set_camera_position(inp["cam"])
     ctx.set_light_direction(inp["light"])
@@ -280,6 +283,7 @@ def main():
             "config": {"workload": f"{inp['label']}, {V}^3 RGBA8 brick chain, {w}x{h}, 6 diffuse + 1 "
                                    f"specular cone/px, trace of a resident (GPU-rasterised) G-buffer",
                        "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7, "bounces": args.bounces,
+                       "anisotropic_mips": bool(args.anisotropic),
                        "parallelism": "single GPU" if world == 1 else
                        f"{world} screen-tile slabs + 1 RCCL gather" +
                        ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]"),
@@ -345,7 +349,10 @@ def cpu_baseline(args, inp, ctx, vct):
     from oracle import pyoracle
     w, h, V = args.width, args.height, args.voxel_dim
     chain = ctx.download_chain()                       # the GPU-built chain, linear layout
+    aniso = ctx.download_aniso() if args.anisotropic else None
     p = pyoracle.default_params(V, camera_pos=inp["cam"], light_dir=inp["light"])
+    otrace = (lambda pp, ch, pl, nthreads: pyoracle.trace_aniso(pp, ch, aniso, pl, nthreads=nthreads)) \
+        if args.anisotropic else pyoracle.trace
     planes = inp["planes"]
     tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
     cores = os.cpu_count() or 1
@@ -358,7 +365,7 @@ def cpu_baseline(args, inp, ctx, vct):
     # probe: 1/256 of the tiles on one thread
     idx = sample(256)
     t = time.perf_counter()
-    r = pyoracle.trace(p, chain, planes[:, idx], nthreads=1)
+    r = otrace(p, chain, planes[:, idx], nthreads=1)
     t1 = time.perf_counter() - t
     rate_1t = len(idx) * 7 / t1 / 1e6
     # all-thread sample sized for ~cpu_seconds
@@ -366,7 +373,7 @@ def cpu_baseline(args, inp, ctx, vct):
     every = int(min(256, max(1, 2 ** int(np.ceil(np.log2(max(est_full / args.cpu_seconds, 1.0)))))))
     idx = sample(every)
     t = time.perf_counter()
-    r = pyoracle.trace(p, chain, planes[:, idx], nthreads=cores)
+    r = otrace(p, chain, planes[:, idx], nthreads=cores)
     tn = time.perf_counter() - t
     rate = len(idx) * 7 / tn / 1e6
     # parity of the GPU frame on the sampled pixels

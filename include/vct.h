@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 2
+#define VCT_ABI_VERSION 3
 
 typedef enum vct_status {
     VCT_OK = 0,
@@ -88,6 +88,10 @@ typedef struct vct_config {
     int32_t trace_variant;     /* 0 = default kernel; others select experimental variants */
     int32_t voxel_attributes;  /* 1 = the voxelizer also keeps per-voxel mean albedo + face normal
                                   (needed by vct_bounce; 24 B/voxel of extra accumulators) */
+    int32_t anisotropic_mips;  /* 1 = also keep six directional (pre-integrated) mip chains and sample
+                                  levels >= 1 from them by cone direction (north-star option; the
+                                  reference has one isotropic chain -- VCT.h:248 -- so the default 0 is
+                                  what matches the shader transliteration) */
 } vct_config;
 
 typedef struct vct_ctx vct_ctx;
@@ -168,6 +172,10 @@ int vct_download_voxel_attributes(vct_ctx* ctx, uint8_t* albedo, uint8_t* normal
 int vct_upload_volume_rgba8(vct_ctx* ctx, const uint8_t* level0_linear);
 int vct_upload_chain_rgba8(vct_ctx* ctx, const uint8_t* chain_linear);
 int vct_download_chain_rgba8(vct_ctx* ctx, uint8_t* chain_linear);
+/* config.anisotropic_mips = 1: the six directional chains built by the last vct_build_mips / vct_bounce,
+ * [6][chain_texels - V^3][4] bytes, direction = 2*axis + (0: towards +axis, 1: towards -axis), level k
+ * of a direction at texel offset level_offset(k) - V^3, linear layout. */
+int vct_download_aniso_rgba8(vct_ctx* ctx, uint8_t* aniso_linear);
 size_t vct_chain_texels(int32_t voxel_dim);
 
 /* Render (VCT.h:146-190) -> trace.fs:165-228.  Traces the G-buffer through the brick chain and

@@ -78,6 +78,10 @@ def lib():
                                          C.c_void_p]
         L.vcto_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vcto_trace_aniso.restype = C.c_uint64
+        L.vcto_trace_aniso.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vcto_build_mips_aniso.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vcto_bounce.restype = C.c_uint64
         L.vcto_bounce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vcto_voxelize_conservative_attr.argtypes = [C.c_void_p] * 6
@@ -262,3 +266,24 @@ def bounce(p, chain0, attr_albedo, attr_normal, nthreads=1):
     n = np.ascontiguousarray(attr_normal, np.uint8)
     steps = lib().vcto_bounce(C.byref(p), _ptr(chain0), _ptr(a), _ptr(n), _ptr(out), int(nthreads))
     return out, int(steps)
+
+
+def build_mips_aniso(l0):
+    """Directional chains of level 0: uint8 [6, chain_texels - V^3, 4] (levels 1.. of each direction)."""
+    l0 = np.ascontiguousarray(l0, np.uint8)
+    V = l0.shape[0]
+    out = np.zeros((6, chain_texels(V) - V ** 3, 4), np.uint8)
+    lib().vcto_build_mips_aniso(_ptr(l0), V, _ptr(out))
+    return out
+
+
+def trace_aniso(p, chain, aniso, planes, nthreads=1, want_cones=False):
+    planes = np.ascontiguousarray(planes, np.float32)
+    npix = planes.shape[1]
+    o32 = np.zeros((npix, 4), np.float32)
+    o16 = np.zeros((npix, 4), np.uint16)
+    steps = np.zeros((npix, 7), np.uint8)
+    cones = np.zeros((npix, 7, 4), np.float32) if want_cones else None
+    total = lib().vcto_trace_aniso(C.byref(p), _ptr(chain), _ptr(aniso), _ptr(planes), npix, _ptr(o32),
+                                   _ptr(o16), _ptr(steps), _ptr(cones), int(nthreads))
+    return dict(rgba32f=o32, rgba16f=o16, steps=steps, cones=cones, total_steps=int(total))

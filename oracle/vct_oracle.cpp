@@ -49,11 +49,12 @@ inline uint8_t to_unorm8(float f) {
 }
 
 // [GL] A.2 tri(level): trilinear with texel centres at (i+0.5)/N, GL_REPEAT (or clamp-to-edge).
+// `chain` points at texel 0 of a buffer in which level `level` starts at (level_offset - skip)
 void tri_sample(const vcto_params* p, const uint8_t* chain, int level, float ux, float uy, float uz,
-                float out[4]) {
+                float out[4], size_t skip = 0) {
     const int V = p->V;
     const int N = V >> level;
-    const uint8_t* base = chain + 4 * vcto_level_offset_texels(V, level);
+    const uint8_t* base = chain + 4 * (vcto_level_offset_texels(V, level) - skip);
     const float fN = (float)N;
     const float u = ux * fN - 0.5f, v = uy * fN - 0.5f, w = uz * fN - 0.5f;
     const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
@@ -85,8 +86,28 @@ void tri_sample(const vcto_params* p, const uint8_t* chain, int level, float ux,
 }
 
 // [GL] A.2 textureLod, LINEAR_MIPMAP_LINEAR min / LINEAR mag, no bias.
+// Directional sample of a level >= 1 (vct_oracle.h, anisotropic mip volumes)
+void tri_sample_aniso(const vcto_params* p, const uint8_t* aniso, int level, float ux, float uy, float uz,
+                      V3 dir, float out[4]) {
+    const size_t V3n = (size_t)p->V * p->V * p->V;
+    const size_t stride = 4 * (vcto_chain_texels(p->V) - V3n);
+    const float w[3] = {dir.x * dir.x, dir.y * dir.y, dir.z * dir.z};
+    const float comp[3] = {dir.x, dir.y, dir.z};
+    float t[3][4];
+    for (int a = 0; a < 3; ++a) {
+        const int d = 2 * a + (comp[a] >= 0.0f ? 0 : 1);
+        tri_sample(p, aniso + (size_t)d * stride, level, ux, uy, uz, t[a], V3n);
+    }
+    for (int ch = 0; ch < 4; ++ch) {
+        float r = w[0] * t[0][ch];
+        r = fmaf(w[1], t[1][ch], r);
+        r = fmaf(w[2], t[2][ch], r);
+        out[ch] = r;
+    }
+}
+
 void texture_lod(const vcto_params* p, const uint8_t* chain, float ux, float uy, float uz, float lod,
-                 float out[4]) {
+                 float out[4], const uint8_t* aniso = nullptr, V3 dir = V3{0, 0, 0}) {
     const int maxl = ilog2(p->V);
     float lam = lod;
     if (!(lam > 0.0f)) {  // magnification (and NaN): level 0 only
@@ -99,25 +120,28 @@ void texture_lod(const vcto_params* p, const uint8_t* chain, float ux, float uy,
     const int d2 = d1 + 1 > maxl ? maxl : d1 + 1;
     const float f = lam - fl;
     float t1[4], t2[4];
-    tri_sample(p, chain, d1, ux, uy, uz, t1);
-    tri_sample(p, chain, d2, ux, uy, uz, t2);
+    if (aniso && d1 >= 1) tri_sample_aniso(p, aniso, d1, ux, uy, uz, dir, t1);
+    else tri_sample(p, chain, d1, ux, uy, uz, t1);
+    if (aniso && d2 >= 1) tri_sample_aniso(p, aniso, d2, ux, uy, uz, dir, t2);
+    else tri_sample(p, chain, d2, ux, uy, uz, t2);
     const float g = 1.0f - f;
     for (int ch = 0; ch < 4; ++ch) out[ch] = fmaf(f, t2[ch], g * t1[ch]);
 }
 
 // trace.fs:59-66
-void sample_voxels(const vcto_params* p, const uint8_t* chain, V3 pos, float lod, float out[4]) {
+void sample_voxels(const vcto_params* p, const uint8_t* chain, V3 pos, float lod, float out[4],
+                   const uint8_t* aniso = nullptr, V3 dir = V3{0, 0, 0}) {
     const float half = p->G * 0.5f;
     float ux = pos.x / half, uy = pos.y / half, uz = pos.z / half;
     ux = ux * 0.5f + 0.5f;
     uy = uy * 0.5f + 0.5f;
     uz = uz * 0.5f + 0.5f;
-    texture_lod(p, chain, ux, uy, uz, lod, out);
+    texture_lod(p, chain, ux, uy, uz, lod, out, aniso, dir);
 }
 
 // trace.fs:82-107
 int cone_trace(const vcto_params* p, const uint8_t* chain, V3 P, V3 Nw, V3 dir, float tan_half,
-               float out[4]) {
+               float out[4], const uint8_t* aniso = nullptr) {
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     float alpha = 0.0f, occlusion = 0.0f;
     const float vs = p->G / (float)p->V;                 // trace.fs:90
@@ -128,7 +152,7 @@ int cone_trace(const vcto_params* p, const uint8_t* chain, V3 P, V3 Nw, V3 dir, 
         const float diameter = fmaxf(vs, 2.0f * tan_half * dist);   // :96
         const float lod = log2f(diameter / vs);                     // :97
         float vc[4];
-        sample_voxels(p, chain, add(start, mul(dir, dist)), lod, vc);   // :98
+        sample_voxels(p, chain, add(start, mul(dir, dist)), lod, vc, aniso, dir);   // :98
         const float oma = 1.0f - alpha;
         cr = fmaf(oma, vc[0], cr);                                  // :100
         cg = fmaf(oma, vc[1], cg);
@@ -204,6 +228,48 @@ void vcto_build_mips(uint8_t* chain, int V) {
     }
 }
 
+void vcto_build_mips_aniso(const uint8_t* level0, int V, uint8_t* aniso) {
+    const int nl = vcto_num_levels(V);
+    const size_t V3n = (size_t)V * V * V;
+    const size_t stride = 4 * (vcto_chain_texels(V) - V3n);
+    for (int d = 0; d < 6; ++d) {
+        const int axis = d >> 1;
+        const bool toward_plus = (d & 1) == 0;
+        uint8_t* chain_d = aniso + (size_t)d * stride;
+        for (int l = 1; l < nl; ++l) {
+            const int Ns = V >> (l - 1), Nd = V >> l;
+            const uint8_t* src = l == 1 ? level0 : chain_d + 4 * (vcto_level_offset_texels(V, l - 1) - V3n);
+            uint8_t* dst = chain_d + 4 * (vcto_level_offset_texels(V, l) - V3n);
+            const int oa = axis == 0 ? 1 : 0, ob = axis == 2 ? 1 : 2;     // the two other axes, lower first
+            for (int z = 0; z < Nd; ++z)
+                for (int y = 0; y < Nd; ++y)
+                    for (int x = 0; x < Nd; ++x) {
+                        float acc[4] = {0, 0, 0, 0};
+                        for (int pr = 0; pr < 4; ++pr) {
+                            int c[3] = {0, 0, 0};
+                            c[oa] = pr & 1;
+                            c[ob] = pr >> 1;
+                            float F[4], B[4];
+                            for (int side = 0; side < 2; ++side) {
+                                c[axis] = side;
+                                const size_t sx = 2 * (size_t)x + c[0], sy = 2 * (size_t)y + c[1], sz = 2 * (size_t)z + c[2];
+                                const uint8_t* t = src + 4 * ((sz * Ns + sy) * Ns + sx);
+                                float* o = (side == 0) == toward_plus ? F : B;     // lower coordinate first when travelling +
+                                for (int ch = 0; ch < 4; ++ch) o[ch] = unorm8(t[ch]);
+                            }
+                            const float oma = 1.0f - F[3];
+                            for (int ch = 0; ch < 4; ++ch) {
+                                const float comp = fmaf(oma, B[ch], F[ch]);
+                                acc[ch] = pr == 0 ? comp : acc[ch] + comp;
+                            }
+                        }
+                        uint8_t* o = dst + 4 * (((size_t)z * Nd + y) * Nd + x);
+                        for (int ch = 0; ch < 4; ++ch) o[ch] = to_unorm8(acc[ch] * 0.25f);
+                    }
+        }
+    }
+}
+
 void vcto_sample(const vcto_params* p, const uint8_t* chain, const float pos[3], float lod,
                  float out[4]) {
     sample_voxels(p, chain, v3(pos), lod, out);
@@ -233,8 +299,11 @@ int vcto_max_steps(const vcto_params* p, float tan_half, float* last_lod) {
     return steps;
 }
 
-int vcto_shade_pixel(const vcto_params* p, const uint8_t* chain, const float gb[23], float out[4],
-                     uint8_t steps[7], float cones[28]) {
+}  // extern "C" (reopened below)
+
+namespace {
+int shade_pixel(const vcto_params* p, const uint8_t* chain, const uint8_t* aniso, const float gb[23],
+                float out[4], uint8_t steps[7], float cones[28]) {
     const float* alb = gb + VCTO_GB_ALBEDO;
     uint8_t st[7] = {0, 0, 0, 0, 0, 0, 0};
     float cn[28];
@@ -270,7 +339,7 @@ int vcto_shade_pixel(const vcto_params* p, const uint8_t* chain, const float gb[
                   k0.z * d[0] + k1.z * d[1] + k2.z * d[2]};
         dir = normalize(dir);
         float c[4];
-        st[i] = (uint8_t)cone_trace(p, chain, P, Nw, dir, p->tan_diffuse, c);
+        st[i] = (uint8_t)cone_trace(p, chain, P, Nw, dir, p->tan_diffuse, c, aniso);
         for (int ch = 0; ch < 4; ++ch) {
             cn[4 * i + ch] = c[ch];
             ind[ch] = fmaf(kConeWeights[i], c[ch], ind[ch]);
@@ -287,7 +356,7 @@ int vcto_shade_pixel(const vcto_params* p, const uint8_t* chain, const float gb[
     const float direct_spec = spec * shadow;                               // :214
     const V3 Rd = normalize(reflect(mul(E, -1.0f), N));                    // :217
     float s[4];
-    st[6] = (uint8_t)cone_trace(p, chain, P, Nw, Rd, p->tan_specular, s);  // :218
+    st[6] = (uint8_t)cone_trace(p, chain, P, Nw, Rd, p->tan_specular, s, aniso);  // :218
     for (int ch = 0; ch < 4; ++ch) cn[24 + ch] = s[ch];
     const float spec_occ = 1.0f - s[3];                                    // :221
     const float sr = (s[0] + spec_occ * direct_spec) * sc[0];              // :223
@@ -305,6 +374,14 @@ int vcto_shade_pixel(const vcto_params* p, const uint8_t* chain, const float gb[
     if (steps) memcpy(steps, st, 7);
     if (cones) memcpy(cones, cn, sizeof(cn));
     return 1;
+}
+}  // namespace
+
+extern "C" {
+
+int vcto_shade_pixel(const vcto_params* p, const uint8_t* chain, const float gb[23], float out[4],
+                     uint8_t steps[7], float cones[28]) {
+    return shade_pixel(p, chain, nullptr, gb, out, steps, cones);
 }
 
 uint16_t vcto_f32_to_f16(float f) {
@@ -345,13 +422,19 @@ float vcto_f16_to_f32(uint16_t h) {
 
 uint64_t vcto_trace(const vcto_params* p, const uint8_t* chain, const float* planes, size_t npix,
                     float* out32f, uint16_t* out16f, uint8_t* steps, float* cones, int nthreads) {
+    return vcto_trace_aniso(p, chain, nullptr, planes, npix, out32f, out16f, steps, cones, nthreads);
+}
+
+uint64_t vcto_trace_aniso(const vcto_params* p, const uint8_t* chain, const uint8_t* aniso,
+                          const float* planes, size_t npix, float* out32f, uint16_t* out16f,
+                          uint8_t* steps, float* cones, int nthreads) {
     auto work = [&](size_t lo, size_t hi, uint64_t* total) {
         uint64_t t = 0;
         for (size_t i = lo; i < hi; ++i) {
             float gb[23], o[4], cn[28];
             uint8_t st[7];
             for (int k = 0; k < 23; ++k) gb[k] = planes[(size_t)k * npix + i];
-            vcto_shade_pixel(p, chain, gb, o, st, cn);
+            shade_pixel(p, chain, aniso, gb, o, st, cn);
             for (int k = 0; k < 7; ++k) t += st[k];
             if (out32f) memcpy(out32f + 4 * i, o, 16);
             if (out16f) for (int k = 0; k < 4; ++k) out16f[4 * i + k] = vcto_f32_to_f16(o[k]);

@@ -177,6 +177,29 @@ void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, 
 uint64_t vcto_bounce(const vcto_params* p, const uint8_t* chain0, const uint8_t* attr_albedo,
                      const uint8_t* attr_normal, uint8_t* out_l0, int nthreads);
 
+/* ---- anisotropic (directional) mip volumes -- north-star option, no reference code -----------
+ * BASELINE.json north_star names "the anisotropic mip-filter downsample" as one of the kernels; the
+ * reference has a single isotropic chain (glGenerateMipmap, VCT.h:248), so this is an OPTION and the
+ * definition is the build's own (directional pre-integration as in Crassin et al. 2011):
+ *   six chains, direction index = 2*axis + (0: travelling towards +axis, 1: towards -axis), levels
+ *   1..log2 V only (level 0 is the shared isotropic level 0).  A parent texel of direction d is built
+ *   from its 8 children of the same direction (of level 0 for level 1): the 2x2x2 block is four
+ *   pairs along the axis; per pair  comp = F + (1 - F.a) * B  (front F = the child met first when
+ *   travelling in direction d, per channel, fp32 on unorm8-decoded values, comp = fmaf(1-F.a, B, F));
+ *   parent = unorm8(((c0 + c1) + c2 + c3) * 0.25) with the pairs in (lower, higher) order of the two
+ *   other coordinates (first varying fastest = the lower axis).
+ *   Sampling a level l >= 1 for a unit cone direction dir:  T(l) = dir.x^2 * tri(chain[x, sign]) +
+ *   dir.y^2 * tri(chain[y, sign]) + dir.z^2 * tri(chain[z, sign])  (r = wx*tx; r = fma(wy,ty,r);
+ *   r = fma(wz,tz,r)), sign = 0 if the component is >= 0; level 0 is the isotropic trilinear
+ *   sample.  The two-level blend and the march are unchanged.
+ * aniso: [6][chain_texels(V) - V^3][4] bytes (level k of a direction at texel offset
+ * level_offset(k) - V^3, linear layout). */
+void vcto_build_mips_aniso(const uint8_t* level0, int V, uint8_t* aniso);
+/* Like vcto_trace, sampling levels >= 1 from the directional chains. */
+uint64_t vcto_trace_aniso(const vcto_params* p, const uint8_t* chain, const uint8_t* aniso,
+                          const float* planes, size_t npix, float* out32f, uint16_t* out16f,
+                          uint8_t* steps, float* cones, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,12 @@ def main():
     # 3. clamp-to-edge wrap mode + a wider specular aperture (config 5 roughness sweep)
     np.savez_compressed(os.path.join(HERE, "trace_v16_8x8_clamp_glossy.npz"),
                         **trace_case(16, 8, 8, 12, 7, 0.2, False, wrap_repeat=0, tan_specular=0.2))
+    # 3b. anisotropic option: directional chains + the trace through them
+    c = trace_case(16, 8, 8, 13, 5, 0.2, True)
+    an = pyoracle.build_mips_aniso(c["level0"])
+    ra = pyoracle.trace_aniso(pyoracle.default_params(16), c["chain"], an, c["planes"], want_cones=True)
+    np.savez_compressed(os.path.join(HERE, "aniso_v16_8x8.npz"), V=16, w=8, h=8, level0=c["level0"],
+                        planes=c["planes"], aniso=an, rgba16f=ra["rgba16f"], steps=ra["steps"], cones=ra["cones"])
     # 4. voxelization (conservative + integer average) + mip chain of a small triangle soup
     V = 32
     pos, mat, alb = small_scene()

@@ -22,7 +22,7 @@ def _params_kw(g):
 
 
 def test_fixture_set_is_complete():
-    assert len(TRACE_CASES) == 3
+    assert len(TRACE_CASES) == 3 and os.path.exists(os.path.join(GOLDEN, "aniso_v16_8x8.npz"))
     assert os.path.exists(os.path.join(GOLDEN, "voxelize_v32.npz"))
 
 
@@ -97,3 +97,28 @@ def test_hip_reproduces_golden_voxelization():
         ctx.bounce()
         assert ctx.last_step_count() == int(g["bounce_steps"])
         assert np.array_equal(ctx.download_chain(), g["bounce_chain"])
+
+
+def test_oracle_reproduces_golden_aniso(oracle):
+    g = np.load(os.path.join(GOLDEN, "aniso_v16_8x8.npz"))
+    an = oracle.build_mips_aniso(g["level0"])
+    assert np.array_equal(an, g["aniso"])
+    r = oracle.trace_aniso(oracle.default_params(16), oracle.build_mips(g["level0"]), an, g["planes"], want_cones=True)
+    assert np.array_equal(r["steps"], g["steps"]) and np.array_equal(r["rgba16f"], g["rgba16f"])
+    assert np.array_equal(r["cones"].view(np.uint32), g["cones"].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_aniso():
+    import vctpkg
+    vct = vctpkg.load()
+    g = np.load(os.path.join(GOLDEN, "aniso_v16_8x8.npz"))
+    with vct.Context(vct.default_config(voxel_dim=16, width=8, height=8, debug_outputs=1,
+                                        anisotropic_mips=1)) as ctx:
+        ctx.upload_volume(g["level0"])
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_aniso(), g["aniso"])
+        out = ctx.trace(g["planes"])
+        assert np.array_equal(ctx.steps(), g["steps"])
+        assert np.array_equal(ctx.cones().view(np.uint32), g["cones"].view(np.uint32))
+        assert (out.reshape(-1, 4) == g["rgba16f"]).mean() > 0.995

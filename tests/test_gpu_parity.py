@@ -408,3 +408,35 @@ def test_voxelize_reference_mode_matches_oracle(vct, oracle, with_shadow):
             ctx.inject_light()
             ctx.build_mips()
             assert np.array_equal(ctx.download_chain(), want), mode
+
+
+def test_anisotropic_mips_option_matches_oracle(vct, oracle):
+    """config.anisotropic_mips = 1 (north-star option, no reference code): the six directional
+    chains and the direction-weighted trace through them are bit-identical to the oracle's; the
+    default isotropic path is untouched."""
+    V, w, h = 32, 40, 24
+    l0 = synth.noise_volume(V, seed=5, occupancy=0.2)
+    chain = oracle.build_mips(l0)
+    want_aniso = oracle.build_mips_aniso(l0)
+    p = oracle.default_params(V)
+    for planes in (synth.coherent_gbuffer(w, h), synth.random_gbuffer(w * h, seed=8, discard_frac=0.1)):
+        ref = oracle.trace_aniso(p, chain, want_aniso, planes, nthreads=8, want_cones=True)
+        iso = oracle.trace(p, chain, planes, nthreads=8)
+        assert not np.array_equal(ref["rgba16f"], iso["rgba16f"])
+        with make_ctx(vct, V, w, h, anisotropic_mips=1) as ctx:
+            ctx.upload_volume(l0)
+            ctx.build_mips()
+            assert np.array_equal(ctx.download_chain(), chain)
+            assert np.array_equal(ctx.download_aniso(), want_aniso)
+            out = ctx.trace(planes)
+            assert np.array_equal(ctx.steps(), ref["steps"])
+            assert np.array_equal(ctx.cones().view(np.uint32), ref["cones"].view(np.uint32))
+            assert ctx.last_step_count() == ref["total_steps"]
+            assert (out.reshape(-1, 4) == ref["rgba16f"]).mean() > 0.999
+            ctx.upload_chain(chain)                      # full-chain upload rebuilds the directional chains too
+            assert np.array_equal(ctx.download_aniso(), want_aniso)
+        with make_ctx(vct, V, w, h) as ctx:
+            ctx.upload_chain(chain)
+            check_frame(vct, oracle, ctx, chain, planes, w, h)
+            with pytest.raises(vct.VctError):
+                ctx.download_aniso()

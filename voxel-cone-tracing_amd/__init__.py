@@ -25,7 +25,7 @@ GB_PLANES = 23
 GB_LINEAR, GB_TILED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 VOX_CONSERVATIVE_AVG, VOX_REFERENCE = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/vct.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "vct_trace_resident", "vct_synchronize", "vct_download_steps", "vct_download_cones",
     "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream", "vct_get_frame_device",
     "vct_selftest_const_divide", "vct_set_frame_target", "vct_bounce",
-    "vct_download_voxel_attributes", "vct_upload_mesh_attributes", "vct_render_shadow_map",
+    "vct_download_voxel_attributes", "vct_download_aniso_rgba8", "vct_upload_mesh_attributes", "vct_render_shadow_map",
     "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer", "vct_trace_current", "vct_trace_resident_rows",
 ]
 
@@ -50,7 +50,7 @@ class Config(C.Structure):
         ("ambient_factor", C.c_float), ("shininess", C.c_float), ("max_distance", C.c_float),
         ("max_alpha", C.c_float), ("tan_diffuse", C.c_float), ("tan_specular", C.c_float),
         ("wrap_repeat", C.c_int32), ("debug_outputs", C.c_int32), ("trace_variant", C.c_int32),
-        ("voxel_attributes", C.c_int32),
+        ("voxel_attributes", C.c_int32), ("anisotropic_mips", C.c_int32),
     ]
 
 
@@ -77,7 +77,7 @@ _lib.vct_destroy.restype = None
 _lib.vct_destroy.argtypes = [C.c_void_p]
 _lib.vct_create.argtypes = [C.c_void_p, C.c_void_p]
 for _n in ("vct_set_camera_position", "vct_set_light_direction", "vct_upload_volume_rgba8",
-           "vct_upload_chain_rgba8", "vct_download_chain_rgba8", "vct_download_steps",
+           "vct_upload_chain_rgba8", "vct_download_chain_rgba8", "vct_download_aniso_rgba8", "vct_download_steps",
            "vct_download_cones", "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream",
            "vct_get_config"):
     getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p]
@@ -255,6 +255,12 @@ class Context:
         chain = np.ascontiguousarray(chain, np.uint8)
         assert chain.size == chain_texels(self.cfg.voxel_dim) * 4
         self._ck(_lib.vct_upload_chain_rgba8(self._h, _ptr(chain)), "vct_upload_chain_rgba8")
+
+    def download_aniso(self):
+        V = self.cfg.voxel_dim
+        out = np.zeros((6, chain_texels(V) - V ** 3, 4), np.uint8)
+        self._ck(_lib.vct_download_aniso_rgba8(self._h, _ptr(out)), "vct_download_aniso_rgba8")
+        return out
 
     def download_chain(self):
         out = np.zeros((chain_texels(self.cfg.voxel_dim), 4), np.uint8)

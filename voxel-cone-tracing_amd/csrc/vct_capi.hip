@@ -27,6 +27,7 @@ struct vct_ctx {
     uint32_t* attr_albedo = nullptr;  // [V^3] resolved mean albedo, Morton order
     uint32_t* attr_normal = nullptr;  // [V^3] resolved mean normal (biased), Morton order
     bool mips_valid = false;
+    uint32_t* aniso = nullptr;        // [6][chain_texels - V^3] directional chains (cfg.anisotropic_mips)
     size_t chain_texels = 0;
     uint32_t* staging = nullptr;      // linear staging for up/downloads (size of level 0)
     int nlev = 0;
@@ -288,6 +289,8 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.tile_row1 = row1;
     const int variant = c->cfg.trace_variant;
     p.gbuf = c->gb_current;
+    p.aniso = c->cfg.anisotropic_mips ? c->aniso : nullptr;
+    p.aniso_stride = (uint32_t)(c->chain_texels - (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim);
     p.out = c->frame_target ? c->frame_target : c->frame;
     p.dbg_steps = c->cfg.debug_outputs ? c->dbg_steps : nullptr;
     p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
@@ -350,6 +353,7 @@ int vct_default_config(vct_config* cfg) {
     cfg->debug_outputs = 0;
     cfg->trace_variant = 0;
     cfg->voxel_attributes = 0;
+    cfg->anisotropic_mips = 0;
     return VCT_OK;
 }
 
@@ -399,6 +403,11 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     const size_t npix = (size_t)cfg->width * cfg->height;
     CREATE_TRY(hipMalloc(&c->gb_tiled, gb_tiled_floats(c) * sizeof(float)));
     CREATE_TRY(hipMemsetAsync(c->gb_tiled, 0, gb_tiled_floats(c) * sizeof(float), c->stream));
+    if (cfg->anisotropic_mips) {
+        const size_t n = 6 * (c->chain_texels - (size_t)V * V * V);
+        CREATE_TRY(hipMalloc(&c->aniso, n * 4));
+        CREATE_TRY(hipMemsetAsync(c->aniso, 0, n * 4, c->stream));
+    }
     CREATE_TRY(hipMalloc(&c->frame, npix * 8));
     CREATE_TRY(hipMemsetAsync(c->frame, 0, npix * 8, c->stream));
     CREATE_TRY(hipMalloc(&c->step_counter, VCT_STEP_COUNTERS * sizeof(unsigned long long)));
@@ -425,7 +434,7 @@ void vct_destroy(vct_ctx* c) {
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
-                    c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
+                    c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->vis, c->raster_big,
                     c->raster_big_count, c->raster_items};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -732,6 +741,7 @@ int vct_build_mips(vct_ctx* c) {
                                   hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, vct_launch_build_mips(c->chain, c->cfg.voxel_dim, sparse ? c->brick_prev : nullptr,
                                      sparse ? c->mip_seen : nullptr, c->stream));
+    if (c->aniso) HIP_TRY(c, vct_launch_build_mips_aniso(c->chain, c->aniso, c->cfg.voxel_dim, c->stream));
     c->mips_valid = true;
     c->use_chain_b = false;
     return VCT_OK;
@@ -783,6 +793,9 @@ int vct_bounce(vct_ctx* c) {
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
                                      b_sparse ? c->mip_seen_b : nullptr, c->stream));
+    // the directional chains always describe the chain the trace reads (the bounce itself gathers
+    // from the isotropic bounce-0 chain, like the oracle's vcto_bounce)
+    if (c->aniso) HIP_TRY(c, vct_launch_build_mips_aniso(c->chain_b, c->aniso, c->cfg.voxel_dim, c->stream));
     c->use_chain_b = true;
     c->have_trace = true;      // step counter / event pair now describe the bounce launch
     return VCT_OK;
@@ -846,7 +859,29 @@ int vct_upload_volume_rgba8(vct_ctx* c, const uint8_t* l0) {
 int vct_upload_chain_rgba8(vct_ctx* c, const uint8_t* chain) {
     if (!c) return VCT_ERR_INVALID;
     if (!chain) return fail(c, VCT_ERR_INVALID, "vct_upload_chain_rgba8: null chain");
-    return upload_levels(c, chain, c->nlev);
+    int rc = upload_levels(c, chain, c->nlev);
+    if (rc) return rc;
+    if (c->aniso) HIP_TRY(c, vct_launch_build_mips_aniso(c->chain, c->aniso, c->cfg.voxel_dim, c->stream));
+    return VCT_OK;
+}
+
+int vct_download_aniso_rgba8(vct_ctx* c, uint8_t* out) {
+    if (!c || !out) return VCT_ERR_INVALID;
+    if (!c->aniso) return fail(c, VCT_ERR_INVALID, "context created without anisotropic_mips");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc) return rc;
+    const int V = c->cfg.voxel_dim;
+    const size_t V3 = (size_t)V * V * V, stride = c->chain_texels - V3;
+    for (int d = 0; d < 6; ++d)
+        for (int l = 1; l < c->nlev; ++l) {
+            const int N = V >> l;
+            const size_t off = (size_t)vct_level_offset(V, l) - V3, n = (size_t)N * N * N;
+            HIP_TRY(c, vct_launch_morton_to_linear(c->aniso + d * stride + off, c->staging, N, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(out + (d * stride + off) * 4, c->staging, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    return VCT_OK;
 }
 
 int vct_download_chain_rgba8(vct_ctx* c, uint8_t* chain) {

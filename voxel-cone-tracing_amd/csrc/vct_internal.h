@@ -7,6 +7,22 @@
 
 #include "vct_layout.h"
 
+#if defined(__HIPCC__)
+// unorm8 -> float, bit-identical to (float)c / 255.0f for every c in [0,255]: c * RN(1/255) misses for
+// 126 of the 256 bytes; the two-term product below never does (tests/test_abi.py).
+__device__ __forceinline__ float vct_unorm8_to_float(uint32_t c) {
+    const float f = (float)c;
+    return fmaf(f, 0x1.010102p-8f, f * -0x1.fdfdfep-33f);
+}
+// [GL] float -> unorm8, round to nearest
+__device__ __forceinline__ uint32_t vct_float_to_unorm8(float f) {
+    const float s = f * 255.0f + 0.5f;
+    if (!(s > 0.0f)) return 0u;
+    if (s >= 255.0f) return 255u;
+    return (uint32_t)(int)s;
+}
+#endif
+
 #define VCT_TILE 8
 #define VCT_TILE_PIX 64
 #define VCT_GB_NPLANES 23
@@ -64,6 +80,10 @@ struct VctTraceParams {
     const uint32_t* bounce_seen;        // bricks the bounce chain showed when its mips were last built
     uint32_t* bounce_out;
     uint32_t nbricks;
+    // anisotropic option: six directional chains (levels >= 1), Morton per level, each
+    // `aniso_stride` texels; level k of a direction at texel offset level_off[k] - level_off[1]
+    const uint32_t* aniso;
+    uint32_t aniso_stride;
     uint32_t* bounce_list;              // global list of occupied voxels (Morton indices), brick by brick
     uint32_t* bounce_list_count;
     uint32_t bounce_list_cap;
@@ -125,6 +145,7 @@ hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N
 // bricks_now / bricks_seen (optional): per-8^3-brick occupancy flags of level 0 for the sparse form
 hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_now, uint32_t* bricks_seen,
                                  hipStream_t s);
+hipError_t vct_launch_build_mips_aniso(const uint32_t* level0, uint32_t* aniso, int V, hipStream_t s);
 hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
                                    hipStream_t s);
 hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* worklist,

@@ -84,10 +84,7 @@ __device__ __forceinline__ float div_const(float x, float d, float r) {
 // unorm8 -> float, bit-identical to (float)c / 255.0f for every c in [0,255]:
 // c * RN(1/255) misses for 126 of the 256 bytes; the two-term product below never does
 // (checked exhaustively in tests/test_abi.py::test_unorm8_decode_exact).
-__device__ __forceinline__ float unorm8(uint32_t c) {
-    const float f = (float)c;
-    return fmaf(f, 0x1.010102p-8f, f * -0x1.fdfdfep-33f);
-}
+__device__ __forceinline__ float unorm8(uint32_t c) { return vct_unorm8_to_float(c); }
 
 // LDS operations of one wave execute in order, so a slab written and then read by the lanes of
 // the same wave needs no s_barrier -- only the compiler must not reorder across this point.
@@ -219,6 +216,39 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
     return r;
 }
 
+// Anisotropic option (oracle/vct_oracle.h "anisotropic (directional) mip volumes"): a level >= 1 is
+// sampled from the three directional chains the cone direction faces, weighted by dir^2.  The chain
+// of an axis depends on the sign of that direction component, which is per lane: when the live
+// lanes disagree the axis is sampled once per sign with the lanes split by mask (rare: a tile's
+// cones are near-parallel), so sample_level always sees a wave-uniform chain.
+struct AnisoCone {
+    float wx, wy, wz;       // dir.x^2, dir.y^2, dir.z^2
+    bool nx, ny, nz;        // component not >= 0: the chain pre-integrated towards -axis
+};
+
+template <bool WRAP, bool COOP>
+__device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLevelRef lv, float ux,
+                                           float uy, float uz, bool act, float4* __restrict__ blk,
+                                           const LaneBlock& lb, const AnisoCone& ac) {
+    // chain pointer of direction d such that (pointer + lv.off) is the level's first texel
+    auto chain_of = [&](int d) { return p.aniso + (size_t)d * p.aniso_stride - p.level_off[1]; };
+    auto axis_sample = [&](int axis, bool neg) -> F4 {
+        const unsigned long long m = ballot64(act), mn = ballot64(act && neg);
+        if (mn == 0ull) return sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act, blk, lb);
+        if (mn == m) return sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act, blk, lb);
+        const F4 a = sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act && !neg, blk, lb);
+        const F4 b = sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act && neg, blk, lb);
+        return neg ? b : a;
+    };
+    const F4 tx = axis_sample(0, ac.nx), ty = axis_sample(1, ac.ny), tz = axis_sample(2, ac.nz);
+    F4 r;
+    r.x = ac.wx * tx.x; r.x = fmaf(ac.wy, ty.x, r.x); r.x = fmaf(ac.wz, tz.x, r.x);
+    r.y = ac.wx * tx.y; r.y = fmaf(ac.wy, ty.y, r.y); r.y = fmaf(ac.wz, tz.y, r.y);
+    r.z = ac.wx * tx.z; r.z = fmaf(ac.wy, ty.z, r.z); r.z = fmaf(ac.wz, tz.z, r.z);
+    r.w = ac.wx * tx.w; r.w = fmaf(ac.wy, ty.w, r.w); r.w = fmaf(ac.wz, tz.w, r.w);
+    return r;
+}
+
 // trace.fs:82-107 with the pixel-independent step sequence read from `tab`.
 // The step table is read through the constant address space: a wave-uniform index then becomes one
 // scalar s_load_dwordx16 instead of vector loads + v_readfirstlane, and the entry of step k+1 is
@@ -234,7 +264,7 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
     return s;
 }
 
-template <bool WRAP, bool FASTDIV, bool COOP>
+template <bool WRAP, bool FASTDIV, bool COOP, bool ANISO = false>
 __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3 start, F3 dir,
                                          const VctStep* tab_global, int n,
                                          float4* __restrict__ blk, const LaneBlock& lb,
@@ -242,6 +272,11 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
     const StepTable tab = (StepTable)tab_global;
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, alpha = 0.0f, occ = 0.0f;
     int steps = 0;
+    AnisoCone ac = {0.0f, 0.0f, 0.0f, false, false, false};
+    if (ANISO) {
+        ac.wx = dir.x * dir.x; ac.wy = dir.y * dir.y; ac.wz = dir.z * dir.z;
+        ac.nx = !(dir.x >= 0.0f); ac.ny = !(dir.y >= 0.0f); ac.nz = !(dir.z >= 0.0f);
+    }
     VctStep nxt = load_step(tab, 0);
     for (int k = 0; k < n; ++k) {
         const bool act = alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
@@ -256,9 +291,11 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
         const float ux = fmaf(div_const<FASTDIV>(px, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
         const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
         const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        F4 vc = sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, blk, lb);
+        F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, blk, lb, ac)
+                                         : sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, blk, lb);
         if (st.two_levels) {
-            const F4 t2 = sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, blk + 64, lb);
+            const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, blk + 64, lb, ac)
+                                : sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, blk + 64, lb);
             const float g = 1.0f - st.frac;
             vc.x = fmaf(st.frac, t2.x, g * vc.x);
             vc.y = fmaf(st.frac, t2.y, g * vc.y);
@@ -484,7 +521,7 @@ k_trace_tile(const VctTraceParams p) {
 // third as long, no wave ever waits on another.
 #define VCT_SPLIT 3
 
-template <bool WRAP, bool FASTDIV>
+template <bool WRAP, bool FASTDIV, bool ANISO>
 __global__ void __launch_bounds__(64 * VCT_SPLIT, VCT_TRACE_MIN_WAVES)
 k_trace_tile_split(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_SPLIT][2][64];
@@ -541,8 +578,8 @@ k_trace_tile_split(const VctTraceParams p) {
                         k0.z * ddx + k1.z * ddy + k2.z * ddz);
             dir = normalize3(dir);
             int st;
-            const F4 c = cone_march<WRAP, FASTDIV, true>(p, alive, start, dir, p.steps_diffuse,
-                                                         p.n_diffuse, blk, lb, st);
+            const F4 c = cone_march<WRAP, FASTDIV, true, ANISO>(p, alive, start, dir, p.steps_diffuse,
+                                                                p.n_diffuse, blk, lb, st);
             total += st;
             lds_cone[i][lane] = make_float4(c.x, c.y, c.z, c.w);
             if (p.dbg_cones && alive) {
@@ -559,8 +596,8 @@ k_trace_tile_split(const VctTraceParams p) {
         const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
         const F3 Rd = normalize3(reflect3(f3(E.x * -1.0f, E.y * -1.0f, E.z * -1.0f), N));  // :217
         int st6;
-        const F4 sc = cone_march<WRAP, FASTDIV, true>(p, alive, start, Rd, p.steps_specular, p.n_specular,
-                                                      blk, lb, st6);
+        const F4 sc = cone_march<WRAP, FASTDIV, true, ANISO>(p, alive, start, Rd, p.steps_specular,
+                                                             p.n_specular, blk, lb, st6);
         total += st6;
         lds_cone[6][lane] = make_float4(sc.x, sc.y, sc.z, sc.w);
         if (p.dbg_cones && alive) {
@@ -811,13 +848,14 @@ hipError_t launch(const VctTraceParams& p, int blocks, hipStream_t s) {
 
 template <bool WRAP, bool FASTDIV>
 hipError_t launch_v(const VctTraceParams& p, int variant, int ntiles, hipStream_t s) {
-    if (variant == 1 || variant == 2) {
+    if (!p.aniso && (variant == 1 || variant == 2)) {      // the anisotropic option exists in the default kernel only
         const int nblocks = (ntiles + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
         const int blocks = ((nblocks + 7) / 8) * 8;     // whole rounds of the 8 XCDs
         return variant == 1 ? launch<WRAP, FASTDIV, false>(p, blocks, s) : launch<WRAP, FASTDIV, true>(p, blocks, s);
     }
     const int blocks = ((ntiles + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+    if (p.aniso) hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+    else hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     return hipGetLastError();
 }
 

@@ -90,6 +90,44 @@ k_mip3(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst1, uint32_t* 
     }
 }
 
+// Directional (anisotropic) mip level: one thread per (parent texel, direction).  Definition:
+// oracle/vct_oracle.h "anisotropic (directional) mip volumes".  In Morton order the 8 children of
+// parent m are src[8m .. 8m+7], child t at (x,y,z) = (t&1, (t>>1)&1, t>>2).
+__global__ void __launch_bounds__(256)
+k_mip_aniso(const uint32_t* __restrict__ level0, uint32_t* __restrict__ aniso, uint32_t stride,
+            uint32_t src_off, uint32_t dst_off, uint32_t nparents, int from_level0) {
+    const uint32_t total = nparents * 6u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t d = i / nparents, m = i - d * nparents;
+        const int axis = (int)(d >> 1);
+        const bool toward_plus = (d & 1u) == 0u;
+        const uint32_t* src = from_level0 ? level0 + 8 * (size_t)m
+                                          : aniso + (size_t)d * stride + src_off + 8 * (size_t)m;
+        uint32_t c[8];
+        const uint4 lo = reinterpret_cast<const uint4*>(src)[0], hi = reinterpret_cast<const uint4*>(src)[1];
+        c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+        const int oa = axis == 0 ? 1 : 0, ob = axis == 2 ? 1 : 2;       // the two other axes, lower first
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const int base = ((pr & 1) << oa) | ((pr >> 1) << ob);
+            const uint32_t t0 = c[base], t1 = c[base | (1 << axis)];    // lower / higher along the axis
+            const uint32_t F = toward_plus ? t0 : t1, B = toward_plus ? t1 : t0;
+            const float oma = 1.0f - vct_unorm8_to_float(F >> 24);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const float comp = fmaf(oma, vct_unorm8_to_float((B >> (8 * ch)) & 0xffu),
+                                        vct_unorm8_to_float((F >> (8 * ch)) & 0xffu));
+                acc[ch] = pr == 0 ? comp : acc[ch] + comp;
+            }
+        }
+        uint32_t out = 0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) out |= vct_float_to_unorm8(acc[ch] * 0.25f) << (8 * ch);
+        aniso[(size_t)d * stride + dst_off + m] = out;
+    }
+}
+
 // planes [23][h*w] -> tiled [tile][23][64]; pixels outside the frame are zero (albedo.a = 0).
 __global__ void k_tile_gbuffer(const float* __restrict__ planes, float* __restrict__ tiled, int w,
                                int h, int tiles_x, int tiles_y) {
@@ -147,6 +185,23 @@ hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_
         const bool sparse = L == 0 && bricks_now && bricks_seen && V >= 8;
         hipLaunchKernelGGL(k_mip3, dim3(grid_for(threads_needed, 256)), dim3(256), 0, s, src, d1,
                            d2, d3, count, nout, sparse ? bricks_now : nullptr, sparse ? bricks_seen : nullptr);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t vct_launch_build_mips_aniso(const uint32_t* level0, uint32_t* aniso, int V, hipStream_t s) {
+    const int nlev = vct_ilog2(V) + 1;
+    const uint32_t V3 = (uint32_t)vct_level_offset(V, 1);
+    const uint32_t stride = (uint32_t)vct_level_offset(V, nlev) - V3;
+    for (int l = 1; l < nlev; ++l) {
+        const uint32_t n = (uint32_t)(V >> l);
+        const uint32_t nparents = n * n * n;
+        const uint32_t dst_off = (uint32_t)vct_level_offset(V, l) - V3;
+        const uint32_t src_off = l == 1 ? 0u : (uint32_t)vct_level_offset(V, l - 1) - V3;
+        hipLaunchKernelGGL(k_mip_aniso, dim3(grid_for((size_t)nparents * 6, 256)), dim3(256), 0, s, level0,
+                           aniso, stride, src_off, dst_off, nparents, l == 1 ? 1 : 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
