@@ -82,3 +82,26 @@ def test_null_handles_are_rejected(vct):
     assert L.vct_voxelize(None, 0) != 0
     assert L.vct_trace(None, None, None, 0) != 0
     assert L.vct_default_config(None) != 0
+
+
+def test_host_library_exports_every_declared_symbol(vct):
+    import ctypes
+    hdr = open(os.path.join(ROOT, "voxel-cone-tracing_amd", "host", "vct_host.h")).read()
+    declared = set(re.findall(r"\b(vcth_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 11
+    lib = ctypes.CDLL(os.path.join(ROOT, "voxel-cone-tracing_amd", "libvct_host.so"))
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} not exported by libvct_host.so"
+
+
+def test_facade_header_keeps_the_reference_surface():
+    """The names main.cpp uses (R/main.cpp:64-68,90,117-142) and the public fields of the reference's
+    orchestrator (VCT.h:14-53) exist in the facade header."""
+    hdr = open(os.path.join(ROOT, "voxel-cone-tracing_amd", "host", "Voxel_Cone_Tracing.h")).read()
+    for name in ("struct Voxel_Cone_Tracing", "void init_voxel_cone_tracing()", "void Render()",
+                 "void DrawDepthTexture()", "void DrawVoxelTexture()", "lightDirection", "VoxelDimensions",
+                 "VoxelGridWorldSize", "screen_width", "screen_height", "ShadowMapSize",
+                 "DepthViewProjectionMatrix", "ProjX", "ProjY", "ProjZ", "AmbientFactor", "ShowDiffuse",
+                 "Camera camera(vec3(0.0f, 4.0f, 0.0f))", "MovementSpeed", "MouseSensitivity",
+                 "ProcessKeyBoard", "ProcessMouseMovement", "ProcessMouseScroll", "GetViewMatrix"):
+        assert name in hdr, name

@@ -440,3 +440,28 @@ def test_anisotropic_mips_option_matches_oracle(vct, oracle):
             check_frame(vct, oracle, ctx, chain, planes, w, h)
             with pytest.raises(vct.VctError):
                 ctx.download_aniso()
+
+
+def test_device_resident_tiled_gbuffer_is_traced_in_place(vct, oracle):
+    """vct_gbuffer with layout = TILED, location = DEVICE: the kernel reads the caller's HBM buffer
+    (no copy) and produces the frame of the host-linear path."""
+    import torch
+    V, w, h = 32, 37, 21
+    chain = oracle.build_mips(synth.noise_volume(V, seed=9, occupancy=0.1))
+    planes = synth.random_gbuffer(w * h, seed=1, discard_frac=0.2)
+    tx, ty = (w + 7) // 8, (h + 7) // 8
+    tiled = np.zeros((ty, tx, 23, 64), np.float32)
+    img = planes.reshape(23, h, w)
+    for y in range(h):
+        for x in range(w):
+            tiled[y // 8, x // 8, :, (y % 8) * 8 + (x % 8)] = img[:, y, x]
+    dev = torch.from_numpy(tiled).cuda()
+    with make_ctx(vct, V, w, h) as ctx:
+        ctx.upload_chain(chain)
+        want = ctx.trace(planes)
+        got = ctx.trace(dev.data_ptr(), layout=vct.GB_TILED)
+        assert np.array_equal(got, want)
+        dev.zero_()                                     # the context holds no copy of it
+        torch.cuda.synchronize()
+        blank = ctx.trace(dev.data_ptr(), layout=vct.GB_TILED)
+        assert not np.array_equal(blank, want)
