@@ -49,6 +49,37 @@ def trace_case(V, w, h, vol_seed, gb_seed, occupancy, coherent, **params):
                                 np.float32))
 
 
+def fnv1a(u16):
+    h = 1469598103934665603
+    for v in np.asarray(u16, np.uint16).reshape(-1).tolist():
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def config1_cornell():
+    """Procedural Cornell box -> CPU shadow map + G-buffer raster (host/vct_host.cpp) -> oracle
+    voxelization (conservative, shadowed) -> oracle mips -> oracle trace.  Small outputs only."""
+    import vctpkg
+    vctpkg.load()
+    from voxel_cone_tracing_amd import scene as sc
+    V, w, h, S = 64, 128, 128, 512
+    light, cam_pos = (0.0, 1.0, 0.25), (0.0, 0.0, 58.0)
+    scene = sc.Scene(sc.CORNELL)
+    depth, lvp_row = scene.shadow_map(light, S)
+    planes = scene.gbuffer(sc.default_camera(position=cam_pos), w, h, depth, lvp_row)
+    p = pyoracle.default_params(V, camera_pos=cam_pos, light_dir=light)
+    l0 = pyoracle.voxelize_conservative(p, pyoracle.make_scene(scene.pos, scene.material, scene.albedo,
+                                                               shadow_depth=depth, light_vp=lvp_row))
+    chain = pyoracle.build_mips(l0)
+    r = pyoracle.trace(p, chain, planes, nthreads=8)
+    img = r["rgba32f"].reshape(h, w, 4)
+    small = img.reshape(16, 8, 16, 8, 4).mean((1, 3)).astype(np.float32)
+    return dict(V=V, w=w, h=h, S=S, total_steps=np.int64(r["total_steps"]),
+                frame_fnv1a=np.uint64(fnv1a(r["rgba16f"])), chain_fnv1a=np.uint64(fnv1a(chain.view(np.uint16))),
+                covered=np.float32((planes[18] >= 0.5).mean()), image16=small,
+                steps_hist=np.bincount(r["steps"].reshape(-1), minlength=32).astype(np.int64))
+
+
 def main():
     # 1. SURVEY.md 8c suggestion: 16^3 volume + 8x8 G-buffer -> 64 RGBA fp32 + 64x7 step counts
     np.savez_compressed(os.path.join(HERE, "trace_v16_8x8_random.npz"),
@@ -80,6 +111,8 @@ def main():
                         level0=l0, count=acc[..., 3].astype(np.uint16), chain=chain0,
                         attr_albedo=attr_alb, attr_normal=attr_nrm, bounce_level0=l1,
                         bounce_steps=np.int64(bounce_steps), bounce_chain=pyoracle.build_mips(l1))
+    # 5. BASELINE.json configs[0]: Cornell box, 64^3, 128x128, the scalar CPU path end to end
+    np.savez_compressed(os.path.join(HERE, "config1_cornell_v64_128.npz"), **config1_cornell())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -122,3 +122,58 @@ def test_hip_reproduces_golden_aniso():
         assert np.array_equal(ctx.steps(), g["steps"])
         assert np.array_equal(ctx.cones().view(np.uint32), g["cones"].view(np.uint32))
         assert (out.reshape(-1, 4) == g["rgba16f"]).mean() > 0.995
+
+
+def _config1_inputs():
+    import vctpkg
+    vctpkg.load()
+    from voxel_cone_tracing_amd import scene as sc
+    light, cam_pos = (0.0, 1.0, 0.25), (0.0, 0.0, 58.0)
+    scene = sc.Scene(sc.CORNELL)
+    return sc, scene, light, cam_pos
+
+
+def test_config1_cornell_scalar_path(oracle):
+    """BASELINE.json configs[0]: Cornell box, 64^3, 128x128 through the scalar CPU path (host
+    rasterisers + oracle), pinned by the committed hashes."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_golden
+    g = np.load(os.path.join(GOLDEN, "config1_cornell_v64_128.npz"))
+    got = make_golden.config1_cornell()
+    assert int(got["total_steps"]) == int(g["total_steps"])
+    assert int(got["frame_fnv1a"]) == int(g["frame_fnv1a"]) and int(got["chain_fnv1a"]) == int(g["chain_fnv1a"])
+    assert np.array_equal(got["steps_hist"], g["steps_hist"])
+    assert np.allclose(got["image16"], g["image16"], atol=0) and 0.5 < float(g["covered"]) <= 1.0
+    img = g["image16"]
+    assert img[..., :3].max() < 4.0 and img[..., :3].min() >= 0.0         # composite stays bounded
+    # colour bleeding: the part of the floor next to the red (left) wall is redder than the part next
+    # to the green (right) wall
+    floor = img[2:5]
+    left, right = floor[:, 2:5].mean((0, 1)), floor[:, 11:14].mean((0, 1))
+    assert left[0] - left[1] > right[0] - right[1]
+
+
+@pytest.mark.gpu
+def test_config1_cornell_on_the_gpu_matches_the_scalar_path():
+    import sys
+    import vctpkg
+    sys.path.insert(0, GOLDEN)
+    import make_golden
+    vct = vctpkg.load()
+    g = np.load(os.path.join(GOLDEN, "config1_cornell_v64_128.npz"))
+    sc, scene, light, cam_pos = _config1_inputs()
+    V, w, h, S = int(g["V"]), int(g["w"]), int(g["h"]), int(g["S"])
+    with vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=S)) as ctx:
+        ctx.set_camera_position(cam_pos); ctx.set_light_direction(light)
+        ctx.upload_triangles(scene.pos, scene.material, scene.albedo)
+        ctx.upload_mesh_attributes(*scene.frames(), scene.specular)
+        ctx.render_shadow_map(sc.light_view_proj(light))
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        assert make_golden.fnv1a(ctx.download_chain().view(np.uint16)) == int(g["chain_fnv1a"])
+        ctx.render_gbuffer(sc.camera_view_proj(sc.default_camera(position=cam_pos), w, h))
+        frame = ctx.trace_current()
+        assert ctx.last_step_count() == int(g["total_steps"])
+        img = vct.half_to_float(frame.reshape(-1, 4)).reshape(h, w, 4)
+        small = img.reshape(16, 8, 16, 8, 4).mean((1, 3))
+        assert synth.rel_l2(small, g["image16"]) <= REL_L2_TOL
