@@ -268,7 +268,8 @@ def main():
         achieved = alg_bytes / (float(np.mean(kernel_ms)) * 1e-3) / 1e9
         traffic, traffic_note = pmc_traffic(args, world, float(np.mean(kernel_ms)))
         result = {
-            "metric": "Mcones/s (+ ms per GI pass), Sponza-class 256^3 @1080p",
+            "metric": "Mcones/s (+ ms per GI pass), Sponza-class 256^3 @1080p" if (V, w, h) == (256, 1920, 1080)
+            else f"Mcones/s (+ ms per GI pass), Sponza-class {V}^3 @{w}x{h}",
             "value": round(value, 1),
             "unit": "Mcones/s",
             "n_gpus": world,
