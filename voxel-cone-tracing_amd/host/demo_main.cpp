@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+
 #include "Voxel_Cone_Tracing.h"
 
 static const int SCREEN_WIDTH = 1280;
@@ -57,11 +59,15 @@ int main(int argc, char** argv) {
     if (voxel_cone_tracing.last_status != VCT_OK) return 2;
 
     float delta_time = 0.05f;
+    auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; ++f) {                      // R/main.cpp:77-94
+        if (f == 1) t0 = std::chrono::steady_clock::now();  // frame 0 pays first-launch costs
         if (f > 0) camera.ProcessKeyBoard(FORWARD, delta_time);
         voxel_cone_tracing.Render();
         if (voxel_cone_tracing.last_status != VCT_OK) return 3;
     }
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (frames > 1) printf("Render(): %.3f ms per frame (wall, %d frames, frame 0 excluded)\n", wall_ms / (frames - 1), frames - 1);
     const uint16_t* fr = voxel_cone_tracing.Frame();
     const size_t n = (size_t)w * h * 4;
     uint64_t sum = 1469598103934665603ull;                  // FNV-1a over the RGBA16F halves
