@@ -465,3 +465,33 @@ def test_device_resident_tiled_gbuffer_is_traced_in_place(vct, oracle):
         torch.cuda.synchronize()
         blank = ctx.trace(dev.data_ptr(), layout=vct.GB_TILED)
         assert not np.array_equal(blank, want)
+
+
+def test_contexts_release_all_hbm(vct):
+    """vct_destroy frees every buffer a context acquired along the way (accumulators, attribute and
+    directional chains, work lists, raster buffers, bounce chain, ...)."""
+    import torch
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(sc.CORNELL)
+
+    def exercise():
+        with vct.Context(vct.default_config(voxel_dim=64, width=64, height=48, shadow_map_size=256,
+                                            voxel_attributes=1, anisotropic_mips=1, debug_outputs=1)) as ctx:
+            ctx.upload_triangles(scene.pos, scene.material, scene.albedo)
+            ctx.upload_mesh_attributes(*scene.frames(), scene.specular)
+            ctx.render_shadow_map(sc.light_view_proj((0.0, 1.0, 0.25)))
+            ctx.voxelize(vct.VOX_REFERENCE); ctx.inject_light(); ctx.build_mips()
+            ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+            ctx.bounce()
+            ctx.render_gbuffer(sc.camera_view_proj(sc.default_camera(position=(0.0, 0.0, 58.0)), 64, 48))
+            ctx.trace_current()
+            ctx.download_chain(); ctx.download_gbuffer(); ctx.download_aniso()
+
+    exercise()                                   # first use may grow runtime-internal pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        exercise()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)     # nothing accumulates (a context here holds > 100 MB)
