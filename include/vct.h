@@ -85,7 +85,8 @@ typedef struct vct_config {
     float tan_specular;        /* 0.07                                         trace.fs:218 */
     int32_t wrap_repeat;       /* 1 = GL_REPEAT (VCT.h:110-113 leaves the GL default) */
     int32_t debug_outputs;     /* 1 = also keep per-cone step counts and raw cone vec4s */
-    int32_t trace_variant;     /* 0 = default kernel; others select experimental variants */
+    int32_t trace_variant;     /* 0 = default (cooperative sampler, tile split over 3 waves); A/B variants with
+                                  identical results: 1 = per-lane sampler, 2 = one wave per tile */
     int32_t voxel_attributes;  /* 1 = the voxelizer also keeps per-voxel mean albedo + face normal
                                   (needed by vct_bounce; 24 B/voxel of extra accumulators) */
     int32_t anisotropic_mips;  /* 1 = also keep six directional (pre-integrated) mip chains and sample
