@@ -495,3 +495,33 @@ def test_contexts_release_all_hbm(vct):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)     # nothing accumulates (a context here holds > 100 MB)
+
+
+def test_extreme_sizes(vct, oracle):
+    """Smallest grid (8^3: one brick, 4 levels), 1x1 and 1xN frames, all pixels discarded."""
+    V = 8
+    l0 = synth.noise_volume(V, seed=2, occupancy=0.3)
+    chain = oracle.build_mips(l0)
+    for w, h in ((1, 1), (1, 9), (9, 1), (8, 8)):
+        planes = synth.random_gbuffer(w * h, seed=w * 31 + h)
+        with make_ctx(vct, V, w, h) as ctx:
+            ctx.upload_volume(l0)
+            ctx.build_mips()
+            assert np.array_equal(ctx.download_chain(), chain)
+            check_frame(vct, oracle, ctx, chain, planes, w, h)
+            dead = planes.copy()
+            dead[18] = 0.0
+            out = ctx.trace(dead)
+            assert ctx.last_step_count() == 0
+            assert np.all(out == np.array([0x3800, 0x3800, 0x3800, 0x3c00], np.uint16))   # clear colour 0.5,0.5,0.5,1
+    pos, mat, alb = random_scene(40, seed=3)
+    with make_ctx(vct, V, 8, 8, voxel_attributes=1) as ctx:
+        ctx.upload_triangles(pos, mat, alb)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        p = oracle.default_params(V)
+        l0v, a, n = oracle.voxelize_conservative_attr(p, oracle.make_scene(pos, mat, alb))
+        c0 = oracle.build_mips(l0v)
+        assert np.array_equal(ctx.download_chain(), c0)
+        ctx.bounce()
+        l1, _ = oracle.bounce(p, c0, a, n)
+        assert np.array_equal(ctx.download_chain(), oracle.build_mips(l1))
