@@ -9,6 +9,7 @@ from oracle import pyoracle as oracle
 from voxel_cone_tracing_amd import scene as sc
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+BIG = len(sys.argv) > 2 and sys.argv[2] == "big"      # larger grids / frames, fewer cases per second
 t_end = time.time() + budget
 counts = {"trace": 0, "voxelize": 0, "raster": 0, "bounce": 0, "aniso": 0}
 
@@ -33,7 +34,8 @@ while time.time() < t_end:
     seed += 1
     r = np.random.default_rng(seed)
     # ---- trace ----
-    V = int(r.choice([16, 32, 64])); w = int(r.integers(1, 70)); h = int(r.integers(1, 50))
+    V = int(r.choice([64, 128] if BIG else [16, 32, 64]))
+    w = int(r.integers(1, 260 if BIG else 70)); h = int(r.integers(1, 140 if BIG else 50))
     l0 = synth.noise_volume(V, seed=seed, occupancy=float(r.uniform(0.02, 0.4)))
     chain = oracle.build_mips(l0)
     planes = synth.coherent_gbuffer(w, h, seed=seed) if r.random() < 0.5 else \
@@ -63,7 +65,7 @@ while time.time() < t_end:
         if (out.reshape(-1, 4) == ref["rgba16f"]).mean() < 0.995: fail("frame", seed)
         counts["trace"] += 1
     # ---- voxelize (+ bounce) ----
-    V = int(r.choice([32, 64])); ntri = int(r.integers(50, 700))
+    V = int(r.choice([64, 128] if BIG else [32, 64])); ntri = int(r.integers(50, 3000 if BIG else 700))
     pos, mat, alb = rnd_scene(r, ntri)
     S = 128
     yy, xx = np.meshgrid(np.arange(S), np.arange(S), indexing="ij")
@@ -91,8 +93,9 @@ while time.time() < t_end:
                 fail("bounce", seed)
             counts["bounce"] += 1
     # ---- raster stages ----
-    kind = int(r.integers(0, 2)); w = int(r.integers(8, 200)); h = int(r.integers(8, 120)); S = int(r.choice([64, 256]))
-    scene = sc.Scene(kind, 0.1, seed)
+    kind = int(r.integers(0, 2)); w = int(r.integers(8, 640 if BIG else 200)); h = int(r.integers(8, 360 if BIG else 120))
+    S = int(r.choice([256, 1024] if BIG else [64, 256]))
+    scene = sc.Scene(kind, 0.3 if BIG else 0.1, seed)
     lightd = tuple(np.abs(r.normal(size=3)) + 0.1)
     cam = sc.default_camera(position=tuple(r.uniform(-40, 40, 3)), yaw=float(r.uniform(-180, 180)),
                             pitch=float(r.uniform(-60, 60)), zoom=float(r.uniform(20, 45)))
