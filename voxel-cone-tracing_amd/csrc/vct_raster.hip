@@ -57,6 +57,13 @@ __device__ __forceinline__ void clip_near(const RVert in[3], ClipPoly& p) {
     }
 }
 
+// true when no vertex is behind the near plane: the polygon is the triangle itself.  Almost every
+// triangle takes this path, which never indexes a vertex array at run time (a run-time index forces
+// the whole ClipPoly into scratch memory).
+__device__ __forceinline__ bool unclipped(const RVert in[3]) {
+    return in[0].c[2] + in[0].c[3] >= 0.0f && in[1].c[2] + in[1].c[3] >= 0.0f && in[2].c[2] + in[2].c[3] >= 0.0f;
+}
+
 struct SubTri {
     double sx[3], sy[3], area, sgn;
     float sz[3], iw[3];
@@ -178,12 +185,17 @@ k_raster_vis(const RasterParams p) {
     if (t >= p.ntri) return;
     RVert in[3];
     load_clip_tri(p, t, in);
+    const bool whole = unclipped(in);
     ClipPoly poly;
-    clip_near(in, poly);
-    if (poly.n < 3) return;
+    poly.n = 3;
+    if (!whole) {
+        clip_near(in, poly);
+        if (poly.n < 3) return;
+    }
     for (int f = 1; f + 1 < poly.n; ++f) {
         SubTri s;
-        setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
+        if (whole) setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, s);
+        else setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
         if (!s.ok) continue;
         const unsigned long long id = (unsigned long long)(uint32_t)(t * 2 + (f - 1));
         const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
@@ -201,6 +213,10 @@ __device__ __forceinline__ bool rebuild_subtri(const RasterParams& p, int id, Su
     const int t = id >> 1, f = (id & 1) + 1;
     RVert in[3];
     load_clip_tri(p, t, in);
+    if (unclipped(in)) {
+        setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, s);
+        return s.ok;
+    }
     ClipPoly poly;
     clip_near(in, poly);
     setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
@@ -314,10 +330,15 @@ k_gbuffer_shade(const ShadeParams p) {
         const int t = id >> 1, f = (id & 1) + 1;
         RVert in[3];
         load_clip_tri(p.r, t, in);
+        const bool whole = unclipped(in);
         ClipPoly poly;
-        clip_near(in, poly);
         SubTri s;
-        setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], W, H, s);
+        if (whole) {
+            setup_subtri(&in[0], &in[1], &in[2], W, H, s);
+        } else {
+            clip_near(in, poly);
+            setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], W, H, s);
+        }
         float b0, b1, b2, z;
         cover(s, px, py, b0, b1, b2, z);
         // perspective-correct interpolation of the 12 varyings (trace.vs:27,31-33)
@@ -327,16 +348,20 @@ k_gbuffer_shade(const ShadeParams p) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             float var[3];
+            auto attr = [&](int vert) -> float {
+                const size_t o = (size_t)t * 9 + 3 * vert + (i % 3);
+                const float* src = i < 3 ? p.r.pos : (i < 6 ? p.nrm : (i < 9 ? p.tan : p.bit));
+                return src[o] * p.r.model_scale;
+            };
+            if (whole) {
+                var[0] = attr(0); var[1] = attr(1); var[2] = attr(2);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int pi = pv[k];
-                auto attr = [&](int vert) -> float {
-                    const size_t o = (size_t)t * 9 + 3 * vert + (i % 3);
-                    const float* src = i < 3 ? p.r.pos : (i < 6 ? p.nrm : (i < 9 ? p.tan : p.bit));
-                    return src[o] * p.r.model_scale;
-                };
-                const float va = attr(poly.src_a[pi]);
-                var[k] = poly.src_b[pi] < 0 ? va : va + (attr(poly.src_b[pi]) - va) * poly.t[pi];
+                for (int k = 0; k < 3; ++k) {
+                    const int pi = pv[k];
+                    const float va = attr(poly.src_a[pi]);
+                    var[k] = poly.src_b[pi] < 0 ? va : va + (attr(poly.src_b[pi]) - va) * poly.t[pi];
+                }
             }
             g[i] = (q0 * var[0] + q1 * var[1] + q2 * var[2]) * qs;
         }
