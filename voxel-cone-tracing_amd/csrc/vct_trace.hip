@@ -687,8 +687,7 @@ __device__ __forceinline__ uint32_t to_unorm8_dev(float f) {     // [GL] float -
 //                   near-parallel cones, so the cooperative sampler applies);
 //   k_bounce_bricks the same march per brick, only for bricks that did not fit the list.
 template <class March>
-__device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool alive, size_t vox,
-                                              float4* __restrict__ blk, const LaneBlock& lb, int& total_out,
+__device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool alive, size_t vox, int& total_out,
                                               March march) {
     const uint32_t* __restrict__ level0 = p.chain;          // level 0 starts the chain
     const float fV = (float)p.V;
@@ -803,7 +802,7 @@ k_bounce_march(const VctTraceParams p) {
         const uint32_t first = __builtin_amdgcn_readfirstlane(e);
         const size_t vox = alive ? e : (first != 0xffffffffu ? first : 0u);
         int total;
-        bounce_voxels(p, alive, vox, blk, lb, total, [&](bool al, F3 start, F3 dir, int& st) {
+        bounce_voxels(p, alive, vox, total, [&](bool al, F3 start, F3 dir, int& st) {
             return cone_march<WRAP, FASTDIV, true>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st);
         });
         wave_steps += (unsigned long long)total;
@@ -828,7 +827,7 @@ k_bounce_bricks(const VctTraceParams p) {
             const bool alive = base + lane < n;
             const size_t vox = (size_t)b * 512 + (alive ? list[base + lane] : list[base]);
             int total;
-            bounce_voxels(p, alive, vox, blk, lb, total, [&](bool al, F3 start, F3 dir, int& st) {
+            bounce_voxels(p, alive, vox, total, [&](bool al, F3 start, F3 dir, int& st) {
                 return cone_march<WRAP, FASTDIV, true>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st);
             });
             wave_steps += (unsigned long long)total;
