@@ -41,11 +41,14 @@ while time.time() < t_end:
     planes = synth.coherent_gbuffer(w, h, seed=seed) if r.random() < 0.5 else \
         synth.random_gbuffer(w * h, seed=seed, discard_frac=float(r.uniform(0, 0.3)))
     kw = dict(wrap_repeat=int(r.random() < 0.8), tan_specular=float(r.choice([0.07, 0.105, 0.2, 0.33])),
-              tan_diffuse=float(r.choice([0.577, 0.4])))
+              tan_diffuse=float(r.choice([0.577, 0.4])), max_distance=float(r.choice([75.0, 75.0, 40.0, 111.0])),
+              max_alpha=float(r.choice([0.95, 0.95, 0.7, 0.999])), ambient_factor=float(r.choice([0.1, 0.6])),
+              shininess=float(r.choice([20.0, 5.0])))
+    G = float(r.choice([150.0, 150.0, 100.0, 317.3]))
     cam = tuple(r.uniform(-60, 60, 3)); light = tuple(r.normal(size=3))
-    p = oracle.default_params(V, camera_pos=cam, light_dir=light, **kw)
+    p = oracle.default_params(V, camera_pos=cam, light_dir=light, G=G, **kw)
     aniso_on = r.random() < 0.25
-    with vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, debug_outputs=1,
+    with vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, debug_outputs=1, grid_world_size=G,
                                         trace_variant=int(r.choice([0, 0, 1, 2])),
                                         anisotropic_mips=int(aniso_on), **kw)) as ctx:
         ctx.set_camera_position(cam); ctx.set_light_direction(light)
