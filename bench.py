@@ -29,6 +29,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+VALU_INFO = None
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_STEP = 64            # 2 levels x 8 texels x 4 B
 BYTES_PER_PIXEL = 100          # 92 B G-buffer in + 8 B RGBA16F out
@@ -266,7 +267,7 @@ def main():
         # roofline of the dominant kernel (trace) on this rank's launch
         alg_bytes = steps_slab * BYTES_PER_STEP + slab_px * BYTES_PER_PIXEL
         achieved = alg_bytes / (float(np.mean(kernel_ms)) * 1e-3) / 1e9
-        traffic, traffic_note = pmc_traffic(args, world, float(np.mean(kernel_ms)))
+        traffic, traffic_note = pmc_traffic(args, world, float(np.mean(kernel_ms)), steps_slab)
         result = {
             "metric": "Mcones/s (+ ms per GI pass), Sponza-class 256^3 @1080p" if (V, w, h) == (256, 1920, 1080)
             else f"Mcones/s (+ ms per GI pass), Sponza-class {V}^3 @{w}x{h}",
@@ -290,6 +291,7 @@ def main():
                        ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]"),
                        "trace_variant": args.variant},
             "cone_steps_per_frame": total_steps,
+            "valu_issue": VALU_INFO,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
             "trace_kernel_ms": round(kernel_ms_avg, 4),
             "gi_pass_ms": {k: (None if v is None else round(v, 4)) for k, v in gi.items()}
@@ -327,7 +329,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args, world, kernel_ms):
+def pmc_traffic(args, world, kernel_ms, cone_steps):
     """HBM GB/s actually moved by the trace kernel: PMC bytes per launch from the committed rocprofv3
     counter passes of this same command (profiles/trace_traffic.json, written by
     tools/summarize_prof.py with the FETCH_SIZE x2 correction calibrated on this box) / this run's
@@ -340,6 +342,16 @@ def pmc_traffic(args, world, kernel_ms):
     with open(path) as fh:
         t = json.load(fh)
     gbs = t["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+    global VALU_INFO
+    wi = t.get("wave_instructions_per_launch") or {}
+    if wi.get("valu"):
+        # what actually bounds the kernel: VALU issue.  Peak = 1024 SIMDs x 2.4 GHz / 2 cycles per
+        # wave64 instruction (fp32 fma/mul/add, plain logic; conversions and 3-operand integer ops take
+        # 4 -- tools/valu_bench.hip), so this fraction is a lower bound of the issue utilisation.
+        rate = wi["valu"] / (kernel_ms * 1e-3)
+        VALU_INFO = {"valu_wave_instructions_per_launch": int(wi["valu"]), "valu_wave_instructions_per_64_cone_steps": round(wi["valu"] * 64 / max(cone_steps, 1), 1),
+                     "issue_rate_G_per_s": round(rate / 1e9, 1), "peak_2cycle_G_per_s": 1228.8,
+                     "frac_of_2cycle_peak": round(rate / 1.2288e12, 3), "source": t["source"]}
     return round(gbs, 1), (f"traffic = PMC HBM bytes per launch ({t['hbm_bytes_per_launch'] / 1e6:.0f} MB, "
                            f"{t['source']}: (2*FETCH_SIZE+WRITE_SIZE)*1024) / kernel time, GB/s.")
 

@@ -44,9 +44,11 @@ def main():
         for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for r in csv.DictReader(fh):
-                    if "k_trace_tile" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    if "k_trace_tile" in r["Kernel_Name"] and r["Counter_Name"] in (
+                            "FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                            "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"):
                         traffic.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    if len(traffic) == 2 and len(sys.argv) > 3:
+    if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic and len(sys.argv) > 3:
         import json
         fetch = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
         write = sum(traffic["WRITE_SIZE"]) / len(traffic["WRITE_SIZE"])
@@ -54,6 +56,10 @@ def main():
             json.dump({"kernel": "k_trace_tile", "source": os.path.basename(dst),
                        "fetch_size_kib": fetch, "write_size_kib": write,
                        "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+                       "wave_instructions_per_launch": {k[9:].lower(): sum(v) / len(v) for k, v in traffic.items()
+                                                        if k.startswith("SQ_INSTS_")},
+                       "gpu_cycles_per_launch": (sum(traffic["GRBM_GUI_ACTIVE"]) / len(traffic["GRBM_GUI_ACTIVE"]) / 8.0
+                                                 if "GRBM_GUI_ACTIVE" in traffic else None),
                        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, calibrated with tools/fetch_calib.hip"}, fh, indent=1)
         lines.append(f"== trace kernel HBM bytes per launch (corrected): {(2.0 * fetch + write) * 1024.0:.4g} ==")
     if os.path.exists(os.path.join(src, "passes.txt")):
