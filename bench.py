@@ -356,6 +356,29 @@ def pmc_traffic(args, world, kernel_ms, cone_steps):
                            f"{t['source']}: (2*FETCH_SIZE+WRITE_SIZE)*1024) / kernel time, GB/s.")
 
 
+def usable_cpus():
+    """Host threads this process can really keep busy: the affinity mask, capped by the cgroup CPU
+    quota (the GPU box shows 256 hardware threads but grants its container 16 CPUs of time)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2
+            q, per = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                                            # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(np.ceil(quota))))
+    return n, quota
+
+
 def cpu_baseline(args, inp, ctx, vct):
     """The scalar oracle (a port of the reference shader, oracle/vct_oracle.cpp) timed on the host
     cores on a bounded tile sample of the same frame, against the same volume the GPU traced."""
@@ -368,7 +391,7 @@ def cpu_baseline(args, inp, ctx, vct):
         if args.anisotropic else pyoracle.trace
     planes = inp["planes"]
     tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cpus()
 
     def sample(every):
         ys, xs = np.divmod(np.arange(w * h), w)
@@ -403,6 +426,7 @@ def cpu_baseline(args, inp, ctx, vct):
                        f"every {every}th 8x8 tile of the same {w}x{h} frame") +
                       f" ({len(idx)} px, {r['total_steps']} cone steps), {reps} passes of {tn:.2f} s on {cores} threads "
                       f"({reps * tn * cores:.0f} core-seconds)",
+            "host_threads_visible": os.cpu_count(), "cgroup_cpu_quota": quota,
             "value_1thread": round(rate_1t, 3), "gpu_vs_oracle_rel_l2": err,
             "ms_per_frame_extrapolated": round(w * h * 7 / rate / 1e3, 1)}
 
