@@ -296,6 +296,10 @@ def main():
             "trace_kernel_ms": round(kernel_ms_avg, 4),
             "gi_pass_ms": {k: (None if v is None else round(v, 4)) for k, v in gi.items()}
             | {"trace": round(kernel_ms_avg, 4)},
+            # one full GI pass = every stage once (moving light + moving camera): raster inputs,
+            # voxelize, inject, mips, (bounce,) trace
+            "gi_pass_total_ms": round(sum(v for k, v in gi.items() if v is not None and k != "bounce_cone_steps")
+                                      + kernel_ms_avg, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
