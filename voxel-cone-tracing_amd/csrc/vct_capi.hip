@@ -290,6 +290,7 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     const int variant = c->cfg.trace_variant;
     p.gbuf = c->gb_current;
     p.aniso = c->cfg.anisotropic_mips ? c->aniso : nullptr;
+    p.aniso_alt_slab = 128;     // k_trace_tile_split<ANISO>: slabs [level 1][level 2][-axis of 1][-axis of 2]
     p.aniso_stride = (uint32_t)(c->chain_texels - (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim);
     p.out = c->frame_target ? c->frame_target : c->frame;
     p.dbg_steps = c->cfg.debug_outputs ? c->dbg_steps : nullptr;

@@ -84,6 +84,7 @@ struct VctTraceParams {
     // `aniso_stride` texels; level k of a direction at texel offset level_off[k] - level_off[1]
     const uint32_t* aniso;
     uint32_t aniso_stride;
+    uint32_t aniso_alt_slab;            // float4 offset from a level's LDS slab to its second ("-axis") slab
     uint32_t* bounce_list;              // global list of occupied voxels (Morton indices), brick by brick
     uint32_t* bounce_list_count;
     uint32_t bounce_list_cap;

@@ -232,15 +232,95 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
                                            const LaneBlock& lb, const AnisoCone& ac) {
     // chain pointer of direction d such that (pointer + lv.off) is the level's first texel
     auto chain_of = [&](int d) { return p.aniso + (size_t)d * p.aniso_stride - p.level_off[1]; };
-    auto axis_sample = [&](int axis, bool neg) -> F4 {
-        const unsigned long long m = ballot64(act), mn = ballot64(act && neg);
-        if (mn == 0ull) return sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act, blk, lb);
-        if (mn == m) return sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act, blk, lb);
-        const F4 a = sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act && !neg, blk, lb);
-        const F4 b = sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act && neg, blk, lb);
-        return neg ? b : a;
-    };
-    const F4 tx = axis_sample(0, ac.nx), ty = axis_sample(1, ac.ny), tz = axis_sample(2, ac.nz);
+    const unsigned long long m = ballot64(act);
+    const unsigned long long mx = ballot64(act && ac.nx), my = ballot64(act && ac.ny), mz = ballot64(act && ac.nz);
+    F4 tx, ty, tz;
+    bool done = false;
+    if (COOP && WRAP) {
+        // The six directional chains have the same geometry, so coordinates, anchor, cooperative
+        // test, Morton index, LDS slot and trilinear weights are computed once for all of them; only
+        // the texel, its decode and the 8-texel gather are per chain.  An axis whose live lanes
+        // disagree on the sign (cones along a coordinate axis have components ~0 of either sign)
+        // fetches both of its chains into two slabs and every lane gathers from the one its sign
+        // selects.
+        const int mm = lv.m;
+        const float fN = lv.fN;
+        const float u = fmaf(ux, fN, -0.5f), v = fmaf(uy, fN, -0.5f), w = fmaf(uz, fN, -0.5f);
+        const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+        const float a = u - fu, b = v - fv, c = w - fw;
+        const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
+        const int src = ((m >> 27) & 1ull) ? 27 : (int)__ffsll((long long)m) - 1;
+        const int ax = __builtin_amdgcn_readlane(i0, src) - 1;
+        const int ay = __builtin_amdgcn_readlane(j0, src) - 1;
+        const int az = __builtin_amdgcn_readlane(k0, src) - 1;
+        const int dx = i0 - ax, dy = j0 - ay, dz = k0 - az;
+        const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
+        if (ballot64(act && far > 2u) == 0ull) {
+            done = true;
+            const uint32_t MX = lv.mask_x, MY = MX << 1, MZ = MX << 2;
+            const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)mm);
+            const uint32_t say = vct_spread3((uint32_t)ay & (uint32_t)mm) << 1;
+            const uint32_t saz = vct_spread3((uint32_t)az & (uint32_t)mm) << 2;
+            const uint32_t idx = (((sax | ~MX) + lb.sbx) & MX) | (((say | ~MY) + lb.sby) & MY) |
+                                 (((saz | ~MZ) + lb.sbz) & MZ);
+            const unsigned long long mneg[3] = {mx, my, mz};
+            const bool lneg[3] = {ac.nx, ac.ny, ac.nz};
+            uint32_t tpos[3], tneg[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {          // all block loads first (up to 6 in flight)
+                tpos[k] = mneg[k] != m ? (chain_of(2 * k) + lv.off)[idx] : 0u;          // some lane is >= 0
+                tneg[k] = mneg[k] != 0ull ? (chain_of(2 * k + 1) + lv.off)[idx] : 0u;   // some lane is < 0
+            }
+            const int slot = act ? (dz * 4 + dy) * 4 + dx : 0;
+            const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
+            const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
+            const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
+            const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
+            float4* alt = p.aniso_alt_slab ? blk + p.aniso_alt_slab : blk;      // slab of the "towards -axis" chain
+            F4 out3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                F4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (ballot64((tpos[k] | tneg[k]) != 0u) != 0ull) {
+                    auto dec = [](uint32_t t) {
+                        float4 d;
+                        d.x = unorm8(t & 0xffu); d.y = unorm8((t >> 8) & 0xffu);
+                        d.z = unorm8((t >> 16) & 0xffu); d.w = unorm8(t >> 24);
+                        return d;
+                    };
+                    if (mneg[k] != m) blk[lb.lane] = dec(tpos[k]);
+                    if (mneg[k] != 0ull) alt[lb.lane] = dec(tneg[k]);
+                    wave_sync();
+                    const float4* q = (lneg[k] ? alt : blk) + slot;
+                    const float4 t0 = q[0], t1 = q[1], t2 = q[4], t3v = q[5];
+                    const float4 t4 = q[16], t5 = q[17], t6 = q[20], t7 = q[21];
+                    wave_sync();
+#define VCT_ACC(ch)                                                                            \
+    r.ch = w0 * t0.ch;                                                                         \
+    r.ch = fmaf(w1, t1.ch, r.ch); r.ch = fmaf(w2, t2.ch, r.ch); r.ch = fmaf(w3, t3v.ch, r.ch); \
+    r.ch = fmaf(w4, t4.ch, r.ch); r.ch = fmaf(w5, t5.ch, r.ch); r.ch = fmaf(w6, t6.ch, r.ch);  \
+    r.ch = fmaf(w7, t7.ch, r.ch);
+                    VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+                }
+                out3[k] = r;
+            }
+            tx = out3[0]; ty = out3[1]; tz = out3[2];
+        }
+    }
+    if (!done) {
+        // per axis: lanes that disagree on the sign are served in two masked passes
+        auto axis_sample = [&](int axis, bool neg, unsigned long long mn) -> F4 {
+            if (mn == 0ull) return sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act, blk, lb);
+            if (mn == m) return sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act, blk, lb);
+            const F4 a = sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act && !neg, blk, lb);
+            const F4 b = sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act && neg, blk, lb);
+            return neg ? b : a;
+        };
+        tx = axis_sample(0, ac.nx, mx);
+        ty = axis_sample(1, ac.ny, my);
+        tz = axis_sample(2, ac.nz, mz);
+    }
     F4 r;
     r.x = ac.wx * tx.x; r.x = fmaf(ac.wy, ty.x, r.x); r.x = fmaf(ac.wz, tz.x, r.x);
     r.y = ac.wx * tx.y; r.y = fmaf(ac.wy, ty.y, r.y); r.y = fmaf(ac.wz, tz.y, r.y);
@@ -521,10 +601,12 @@ k_trace_tile(const VctTraceParams p) {
 // third as long, no wave ever waits on another.
 #define VCT_SPLIT 3
 
+// (the anisotropic instantiation carries three samples' worth of state: it gets 128 VGPRs instead of
+// spilling under the 80 of the default kernel)
 template <bool WRAP, bool FASTDIV, bool ANISO>
-__global__ void __launch_bounds__(64 * VCT_SPLIT, VCT_TRACE_MIN_WAVES)
+__global__ void __launch_bounds__(64 * VCT_SPLIT, ANISO ? 4 : VCT_TRACE_MIN_WAVES)
 k_trace_tile_split(const VctTraceParams p) {
-    __shared__ float4 lds_blk[VCT_SPLIT][2][64];
+    __shared__ float4 lds_blk[VCT_SPLIT][ANISO ? 4 : 2][64];   // per wave: level-1 slab, level-2 slab (+ their "-axis" slabs)
     __shared__ float4 lds_cone[7][64];
     __shared__ int lds_done;
     const int lane = threadIdx.x & 63;
