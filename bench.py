@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell", "noise"])
+    ap.add_argument("--scene-detail", type=float, default=1.0,
+                    help="tessellation scale of the procedural atrium (1.0 = 257k triangles, ~3.3 = Bistro-class 2.8M)")
     ap.add_argument("--shadow-size", type=int, default=4096)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--bounces", type=int, default=1, choices=[1, 2],
@@ -68,7 +70,7 @@ def build_inputs(args, vct, sc):
                     label="noise volume (seed 7) + coherent G-buffer")
     light = (0.0, 1.0, 0.25)                                     # VCT.h:14
     if args.scene == "atrium":
-        scene = sc.Scene(sc.ATRIUM, 1.0, 1234)
+        scene = sc.Scene(sc.ATRIUM, args.scene_detail, 1234)
         cam = sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
         label = f"procedural atrium (Sponza-class, {scene.ntri} tris, seed 1234)"
     else:
