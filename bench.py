@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell", "noise"])
+    ap.add_argument("--obj", default=None, metavar="PATH",
+                    help="Wavefront .obj (+ .mtl) to use instead of a procedural scene, e.g. the real Sponza; model "
+                         "units like the reference's (world = 0.05 * model, VCT.h:183)")
+    ap.add_argument("--cam", type=float, nargs=5, default=None, metavar=("X", "Y", "Z", "YAW", "PITCH"),
+                    help="camera position (world units) and yaw/pitch in degrees (default: the scene's preset)")
     ap.add_argument("--scene-detail", type=float, default=1.0,
                     help="tessellation scale of the procedural atrium (1.0 = 257k triangles, ~3.3 = Bistro-class 2.8M)")
     ap.add_argument("--shadow-size", type=int, default=4096)
@@ -69,7 +74,11 @@ def build_inputs(args, vct, sc):
                     cam=(0.0, 4.0, 0.0), light=(0.0, 1.0, 0.25), scene=None,
                     label="noise volume (seed 7) + coherent G-buffer")
     light = (0.0, 1.0, 0.25)                                     # VCT.h:14
-    if args.scene == "atrium":
+    if args.obj:
+        scene = sc.Scene(args.obj)
+        cam = sc.default_camera()                                # VCT.h:8: (0,4,0), yaw -90
+        label = f"{os.path.basename(args.obj)} ({scene.ntri} tris)"
+    elif args.scene == "atrium":
         scene = sc.Scene(sc.ATRIUM, args.scene_detail, 1234)
         cam = sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
         label = f"procedural atrium (Sponza-class, {scene.ntri} tris, seed 1234)"
@@ -77,6 +86,8 @@ def build_inputs(args, vct, sc):
         scene = sc.Scene(sc.CORNELL)
         cam = sc.default_camera(position=(0.0, 0.0, 58.0), yaw=-90.0)
         label = f"procedural Cornell box ({scene.ntri} tris)"
+    if args.cam:
+        cam = sc.default_camera(position=tuple(args.cam[:3]), yaw=args.cam[3], pitch=args.cam[4])
     return dict(scene=scene, camera=cam, light_vp=sc.light_view_proj(light),
                 view_proj=sc.camera_view_proj(cam, w, h), planes=None,
                 cam=tuple(cam.position), light=light, label=label)
@@ -283,7 +294,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.obj else "user-supplied mesh (flat per-material colours)",
             "config": {"workload": f"{inp['label']}, {V}^3 RGBA8 brick chain, {w}x{h}, 6 diffuse + 1 "
                                    f"specular cone/px, trace of a resident (GPU-rasterised) G-buffer",
                        "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7, "bounces": args.bounces,
