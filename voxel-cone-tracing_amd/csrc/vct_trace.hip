@@ -9,7 +9,11 @@
 // fmaf only where the oracle has one or where the fused form is provably the same bits), so
 // per-cone step counts and the raw cone vec4s are bit-identical; compile with -ffp-contract=off.
 //
-// Mapping: one wavefront per 8x8 screen tile, lane = pixel, the 7 cones in sequence.  The kernel
+// Kernels in this file: k_trace_tile_split (default: an 8x8 screen tile = 3 waves -- cones 0-2, cones
+// 3-5, specular -- with an LDS hand-off and a last-arriver composite), k_trace_tile (one wave per
+// tile; A/B variants), k_bounce_list/_march/_bricks (second bounce, same march), k_divide_selftest.
+//
+// Mapping: lane = pixel of the tile, a wave marches its cones one after the other.  The kernel
 // is VALU-issue bound (profiles/r01a: 995 M VALU wave-instructions per 1080p frame, half of the
 // wave cycles spent waiting to issue, 12 % waiting on memory), and on gfx950 only fp32
 // fma/mul/add and plain logic ops issue in 2 cycles per wave -- conversions, floor, bit-field,
