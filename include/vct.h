@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 3
+#define VCT_ABI_VERSION 4
 
 typedef enum vct_status {
     VCT_OK = 0,
@@ -93,6 +93,10 @@ typedef struct vct_config {
                                   levels >= 1 from them by cone direction (north-star option; the
                                   reference has one isotropic chain -- VCT.h:248 -- so the default 0 is
                                   what matches the shader transliteration) */
+    int32_t decoded_chain;     /* 1 (default) = also keep the chain decoded to fp32 (exact byte/255, 16 B per
+                                  texel: 4x the RGBA8 chain, e.g. 292 MiB at 256^3, 18.3 GiB at 1024^3) so the
+                                  tracer streams texel blocks HBM -> LDS without decoding them per sample;
+                                  0 = trace from the RGBA8 chain only (same results, ~15 % slower) */
 } vct_config;
 
 typedef struct vct_ctx vct_ctx;
@@ -199,6 +203,9 @@ int vct_trace_resident_rows(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
  * rank passes its gather buffer minus the slab's first row so the kernel writes the gather buffer
  * directly (no device-to-device copy per frame).  The caller keeps the memory alive. */
 int vct_set_frame_target(vct_ctx* ctx, void* rgba16f_dev);
+/* Host copy of the frame the trace kernels write (the context-owned frame, or the target set above with
+ * full-frame addressing): width*height*4 halves.  Rows no trace has written keep their old content. */
+int vct_download_frame(vct_ctx* ctx, void* out_rgba16f_host);
 int vct_synchronize(vct_ctx* ctx);
 
 /* Debug outputs of the last trace (config.debug_outputs = 1): steps [npix][7] uint8, cones
@@ -207,6 +214,12 @@ int vct_download_steps(vct_ctx* ctx, uint8_t* steps);
 int vct_download_cones(vct_ctx* ctx, float* cones);
 /* Executed cone steps of the last trace (always counted). */
 int vct_last_step_count(vct_ctx* ctx, uint64_t* steps);
+/* Wave-level statistics of the last trace launch -- instrumented builds only (-DVCT_STATS=1; the
+ * production library returns VCT_ERR_INVALID): [0] march-loop iterations executed by waves, [1] live
+ * lanes summed over them (= executed cone steps), [2] level samples whose cooperative 4x4x4 block was
+ * all zero (skipped), [3] served through the cooperative block, [4] served by the per-lane gather,
+ * [5] live lanes in [4], [6] level samples skipped by the brick-occupancy pre-test, [7] reserved. */
+int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[8]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);
 /* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the

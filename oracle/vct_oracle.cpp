@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -723,28 +724,37 @@ void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8
     vcto_voxelize_conservative_attr(p, s, l0, acc_out, nullptr, nullptr);
 }
 
+namespace {
+// one conservative fragment: voxel (linear index), vox.fs:88 value, and the triangle's attributes
+struct ConsFrag {
+    uint64_t vox;
+    uint8_t rgb[3];
+    uint8_t attr[6];     // albedo rgb (unorm8), biased face normal xyz
+};
+}  // namespace
+
+// Fragments are collected per triangle range (one std::thread each -- the per-fragment arithmetic is the
+// scalar restatement; integer sums make the result independent of the order), sorted by voxel and
+// reduced, so memory scales with the surface (fragments), not with V^3: a 1024^3 grid needs no 16 GiB
+// accumulator on the checker side either.
 void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
                                      uint32_t* acc_out, uint8_t* attr_albedo, uint8_t* attr_normal) {
     const int V = p->V;
     const float fV = (float)V;
     const size_t nvox = (size_t)V * V * V;
-    std::vector<uint32_t> local;
-    uint32_t* acc = acc_out;
-    if (!acc) { local.assign(nvox * 4, 0u); acc = local.data(); }
-    else memset(acc, 0, nvox * 16);
     const bool want_attr = attr_albedo || attr_normal;
-    std::vector<uint32_t> asum;      // [nvox][6]: albedo rgb sums, biased normal xyz sums
-    if (want_attr) asum.assign(nvox * 6, 0u);
-    for (int t = 0; t < s->ntri; ++t) {
+    auto work = [&](int t0, int t1, std::vector<ConsFrag>* out) {
+      for (int t = t0; t < t1; ++t) {
         const TriSetup ts = setup_tri(s, t);
-        uint32_t fa[6] = {0, 0, 0, 0, 0, 0};
+        ConsFrag f;
+        memset(&f, 0, sizeof(f));
         if (want_attr) {
             const float* alb = s->albedo + 4 * (size_t)s->material[t];
             const V3 fn = normalize(cross(sub(ts.w[1], ts.w[0]), sub(ts.w[2], ts.w[0])));
             const float fc[3] = {fn.x, fn.y, fn.z};
             for (int c = 0; c < 3; ++c) {
-                fa[c] = to_unorm8(alb[c]);
-                fa[3 + c] = (uint32_t)((int)floorf(fc[c] * 127.0f + 0.5f) + 128);
+                f.attr[c] = to_unorm8(alb[c]);
+                f.attr[3 + c] = (uint8_t)((int)floorf(fc[c] * 127.0f + 0.5f) + 128);
             }
         }
         V3 g[3];
@@ -783,36 +793,66 @@ void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, 
                     const V3 dc = {b0 * ts.dc[0].x + b1 * ts.dc[1].x + b2 * ts.dc[2].x,
                                    b0 * ts.dc[0].y + b1 * ts.dc[1].y + b2 * ts.dc[2].y,
                                    b0 * ts.dc[0].z + b1 * ts.dc[1].z + b2 * ts.dc[2].z};
-                    uint8_t rgb[3];
-                    frag_value(s, t, dc, rgb);
-                    uint32_t* a = acc + 4 * (((size_t)k * V + j) * V + i);
-                    a[0] += rgb[0]; a[1] += rgb[1]; a[2] += rgb[2]; a[3] += 1u;
-                    if (want_attr) {
-                        uint32_t* q = asum.data() + 6 * (((size_t)k * V + j) * V + i);
-                        for (int c = 0; c < 6; ++c) q[c] += fa[c];
-                    }
+                    frag_value(s, t, dc, f.rgb);
+                    f.vox = ((uint64_t)k * V + j) * V + i;
+                    out->push_back(f);
                 }
+      }
+    };
+    int nthreads = s->ntri >= 20000 ? (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    std::vector<std::vector<ConsFrag>> parts((size_t)nthreads);
+    if (nthreads == 1) {
+        work(0, s->ntri, &parts[0]);
+    } else {
+        // dynamic chunks: large triangles (floors, walls) cluster in the triangle list
+        std::atomic<int> next(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t)
+            th.emplace_back([&, t]() {
+                for (;;) {
+                    const int t0 = next.fetch_add(64);
+                    if (t0 >= s->ntri) break;
+                    work(t0, std::min(s->ntri, t0 + 64), &parts[(size_t)t]);
+                }
+            });
+        for (auto& x : th) x.join();
     }
-    if (want_attr)
-        for (size_t v = 0; v < nvox; ++v) {
-            const uint32_t c = acc[4 * v + 3], h = c >> 1;
-            const uint32_t* q = asum.data() + 6 * v;
-            for (int k = 0; k < 3; ++k) {
-                if (attr_albedo) attr_albedo[4 * v + k] = c ? (uint8_t)((q[k] + h) / c) : 0;
-                if (attr_normal) attr_normal[4 * v + k] = c ? (uint8_t)((q[3 + k] + h) / c) : 0;
-            }
-            if (attr_albedo) attr_albedo[4 * v + 3] = c ? 255 : 0;
-            if (attr_normal) attr_normal[4 * v + 3] = c ? 255 : 0;
+    std::vector<ConsFrag> frags;
+    {
+        size_t n = 0;
+        for (auto& v : parts) n += v.size();
+        frags.reserve(n);
+        for (auto& v : parts) { frags.insert(frags.end(), v.begin(), v.end()); std::vector<ConsFrag>().swap(v); }
+    }
+    std::sort(frags.begin(), frags.end(), [](const ConsFrag& a, const ConsFrag& b) { return a.vox < b.vox; });
+
+    memset(l0, 0, nvox * 4);
+    if (acc_out) memset(acc_out, 0, nvox * 16);
+    if (attr_albedo) memset(attr_albedo, 0, nvox * 4);
+    if (attr_normal) memset(attr_normal, 0, nvox * 4);
+    for (size_t b = 0; b < frags.size();) {
+        size_t e = b;
+        uint32_t a[3] = {0, 0, 0}, q[6] = {0, 0, 0, 0, 0, 0}, c = 0;
+        for (; e < frags.size() && frags[e].vox == frags[b].vox; ++e) {
+            for (int k = 0; k < 3; ++k) a[k] += frags[e].rgb[k];
+            for (int k = 0; k < 6; ++k) q[k] += frags[e].attr[k];
+            ++c;
         }
-    for (size_t v = 0; v < nvox; ++v) {
-        const uint32_t* a = acc + 4 * v;
+        const size_t v = (size_t)frags[b].vox;
+        const uint32_t h = c >> 1;                        // rounded integer mean
         uint8_t* d = l0 + 4 * v;
-        if (a[3] == 0u) { d[0] = d[1] = d[2] = d[3] = 0; continue; }
-        const uint32_t c = a[3], h = c >> 1;
         d[0] = (uint8_t)((a[0] + h) / c);
         d[1] = (uint8_t)((a[1] + h) / c);
         d[2] = (uint8_t)((a[2] + h) / c);
         d[3] = 255;
+        if (acc_out) { uint32_t* o = acc_out + 4 * v; o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = c; }
+        for (int k = 0; k < 3; ++k) {
+            if (attr_albedo) attr_albedo[4 * v + k] = (uint8_t)((q[k] + h) / c);
+            if (attr_normal) attr_normal[4 * v + k] = (uint8_t)((q[3 + k] + h) / c);
+        }
+        if (attr_albedo) attr_albedo[4 * v + 3] = 255;
+        if (attr_normal) attr_normal[4 * v + 3] = 255;
+        b = e;
     }
 }
 

@@ -1,0 +1,233 @@
+"""BASELINE.json configurations at their FULL sizes on the GPU, every stage against the oracle.
+
+  config 2 (configs[1]): Sponza-class atrium (257k triangles), 256^3, 1920x1080, 6+1 cones
+  config 3 (configs[2]): the same scene at 512^3, 3840x2160, two bounces (vct_bounce)
+  config 5 (configs[4]): Bistro-class scene (2.75 M triangles), 1024^3, 3840x2160, specular cone at
+                         three apertures (tan 0.07 / 0.105 / 0.2)
+(config 1 is the golden fixture of tests/test_golden.py, config 4 is config 2 cut into slabs:
+tests/test_gpu_fullsize.py, tests/test_slabs_gloo.py, tests/test_gpu_multi.py.)
+
+Per configuration: shadow map and G-buffer rasterised on the GPU and compared bit for bit with the CPU
+rasterisers; voxelize + inject + mips (+ bounce) compared bit for bit with the oracle's chain; the
+trace compared with the oracle over the whole frame (config 2, 3) or a tile sample (config 5):
+identical per-cone step counts, RGBA16F frame within 1e-3 relative L2 (north-star tolerance); plus
+the size-independent properties (step counter == sum of per-cone counts, idempotence, slab union ==
+frame, empty-volume known answers of SURVEY.md section 4).  The reference shader lines restated:
+S/VoxelConeTracing.fs:82-107 (march), :196-199 (diffuse gather), :217-218 (specular cone).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+import vctpkg
+
+pytestmark = pytest.mark.gpu
+
+LIGHT = (0.0, 1.0, 0.25)                                   # VCT.h:14
+CAM = dict(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)   # the bench camera
+
+
+def host_threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 16))
+
+
+def mem_available_gib():
+    try:
+        with open("/proc/meminfo") as fh:
+            for ln in fh:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.fixture(scope="module")
+def vct():
+    import torch
+    assert torch.cuda.is_available()
+    return vctpkg.load()
+
+
+class Pipeline:
+    """Scene + context with every input stage on the GPU, each checked against its CPU counterpart."""
+
+    def __init__(self, vct, oracle, detail, V, w, h, attrs=0, S=4096):
+        from voxel_cone_tracing_amd import scene as sc
+        self.vct, self.oracle, self.sc = vct, oracle, sc
+        self.V, self.w, self.h, self.S = V, w, h, S
+        self.scene = sc.Scene(sc.ATRIUM, detail, 1234)
+        self.cam = sc.default_camera(**CAM)
+        self.ctx = vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=S,
+                                                  debug_outputs=1, voxel_attributes=attrs))
+        self.ctx.set_camera_position(tuple(self.cam.position))
+        self.ctx.set_light_direction(LIGHT)
+        self.ctx.upload_triangles(self.scene.pos, self.scene.material, self.scene.albedo)
+        self.ctx.upload_mesh_attributes(*self.scene.frames(), self.scene.specular)
+        self.params = oracle.default_params(V, camera_pos=tuple(self.cam.position), light_dir=LIGHT)
+
+    def shadow_map(self):
+        """DrawDepthTexture on the GPU == the CPU rasteriser, bit for bit (f2 at full size)."""
+        self.depth, self.light_vp_row = self.scene.shadow_map(LIGHT, self.S)
+        self.ctx.render_shadow_map(self.sc.light_view_proj(LIGHT))
+        got = self.ctx.download_shadow_map()
+        assert np.array_equal(got.view(np.uint32), self.depth.view(np.uint32))
+
+    def gbuffer(self):
+        """Raster part of Render() on the GPU == the CPU rasteriser, bit for bit (f1 at full size)."""
+        want = self.scene.gbuffer(self.cam, self.w, self.h, self.depth, self.light_vp_row)
+        self.ctx.render_gbuffer(self.sc.camera_view_proj(self.cam, self.w, self.h))
+        self.planes = self.ctx.download_gbuffer()
+        bad = np.nonzero((self.planes.view(np.uint32) != want.view(np.uint32)).any(0))[0]
+        assert bad.size == 0, (bad[:10], self.planes[:, bad[:1]].ravel(), want[:, bad[:1]].ravel())
+        assert 0.5 < (self.planes[18] >= 0.5).mean() <= 1.0
+        return self.planes
+
+    def oracle_scene(self):
+        return self.oracle.make_scene(self.scene.pos, self.scene.material, self.scene.albedo,
+                                      shadow_depth=self.depth, light_vp=self.light_vp_row)
+
+    def check_frame(self, frame, steps, chain, sel=None, tag=""):
+        """GPU frame + per-cone step counts against the oracle on pixels `sel` (None = all)."""
+        planes = self.planes if sel is None else np.ascontiguousarray(self.planes[:, sel])
+        ref = self.oracle.trace(self.params, chain, planes, nthreads=host_threads())
+        got16 = frame.reshape(-1, 4) if sel is None else frame.reshape(-1, 4)[sel]
+        gst = steps if sel is None else steps[sel]
+        assert np.array_equal(gst, ref["steps"]), tag
+        assert (got16 == ref["rgba16f"]).mean() > 0.999, tag
+        err = synth.rel_l2(self.vct.half_to_float(got16), ref["rgba32f"])
+        assert err <= 1e-3, (tag, err)               # north-star tolerance (fp32 path, RGBA16F output)
+        return ref
+
+    def tile_sample(self, every):
+        ys, xs = np.divmod(np.arange(self.w * self.h), self.w)
+        tiles_x = (self.w + 7) // 8
+        return np.nonzero(((ys // 8) * tiles_x + xs // 8) % every == 0)[0]
+
+    def close(self):
+        self.ctx.close()
+
+
+def test_config2_atrium_256_1080p(vct, oracle):
+    """configs[1]: every stage of the bench workload, full size, against the oracle."""
+    V, w, h = 256, 1920, 1080
+    pl = Pipeline(vct, oracle, 1.0, V, w, h)
+    ctx = pl.ctx
+    assert pl.scene.ntri > 250000
+    pl.shadow_map()
+    # voxelize (conservative, atomic integer average) + inject + mips: the whole chain, bit for bit
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    chain = ctx.download_chain()
+    l0 = oracle.voxelize_conservative(pl.params, pl.oracle_scene())
+    assert 100000 < int((l0[..., 3] > 0).sum()) < V ** 3 // 20
+    want_chain = oracle.build_mips(l0)
+    assert np.array_equal(chain, want_chain)
+    # reference-mode voxelization (Voxelization.vs/.gs/.fs as written) at full size
+    ctx.voxelize(vct.VOX_REFERENCE); ctx.inject_light(); ctx.build_mips()
+    ref_l0 = oracle.voxelize_reference(pl.params, pl.oracle_scene())
+    assert np.array_equal(ctx.download_chain(), oracle.build_mips(ref_l0))
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    assert np.array_equal(ctx.download_chain(), want_chain)         # and back: same bits
+    pl.gbuffer()
+    frame = ctx.trace_current()
+    steps = ctx.steps()
+    total = ctx.last_step_count()
+    assert total == int(steps.astype(np.int64).sum())
+    ref = pl.check_frame(frame, steps, want_chain, tag="config 2")      # the WHOLE 1080p frame
+    assert ref["total_steps"] == total
+    assert np.array_equal(ctx.trace_current(), frame)                   # idempotent
+    pl.close()
+
+
+def test_config3_512_4k_two_bounces(vct, oracle):
+    """configs[2]: 512^3, 3840x2160, voxel attributes + vct_bounce, then the screen trace."""
+    V, w, h = 512, 3840, 2160
+    pl = Pipeline(vct, oracle, 1.0, V, w, h, attrs=1)
+    ctx = pl.ctx
+    pl.shadow_map()
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    l0, alb, nrm = oracle.voxelize_conservative_attr(pl.params, pl.oracle_scene())
+    chain0 = oracle.build_mips(l0)
+    assert np.array_equal(ctx.download_chain(), chain0)
+    galb, gnrm = ctx.voxel_attributes()
+    assert np.array_equal(galb, alb) and np.array_equal(gnrm, nrm)
+    del galb, gnrm, l0
+    # second bounce: level 0', its step count and the re-mipped chain
+    ctx.bounce()
+    bounce_steps = ctx.last_step_count()
+    l0b, want_steps = oracle.bounce(pl.params, chain0, alb, nrm, nthreads=host_threads())
+    assert bounce_steps == want_steps and want_steps > 10_000_000
+    chain1 = oracle.build_mips(l0b)
+    assert not np.array_equal(chain1[: V ** 3], chain0[: V ** 3])       # the bounce added light
+    assert np.array_equal(ctx.download_chain(), chain1)
+    del l0b, alb, nrm, chain0
+    pl.gbuffer()
+    frame = ctx.trace_current()
+    steps = ctx.steps()
+    total = ctx.last_step_count()
+    assert total == int(steps.astype(np.int64).sum())
+    ref = pl.check_frame(frame, steps, chain1, tag="config 3")          # the WHOLE 4K frame
+    assert ref["total_steps"] == total
+    # 8 slabs like an 8-GPU node: union == frame, step counts add up
+    from voxel_cone_tracing_amd import slabs
+    parts = np.zeros_like(frame)
+    seen = 0
+    for r0, r1 in slabs.partition(h, 8):
+        ctx.trace_gbuffer_rows(r0, r1)
+        seen += ctx.last_step_count()
+        buf = ctx.download_frame()
+        parts[r0 * 8:min(r1 * 8, h)] = buf[r0 * 8:min(r1 * 8, h)]
+    assert seen == total and np.array_equal(parts, frame)
+    pl.close()
+
+
+def test_config5_1024_4k_three_apertures(vct, oracle):
+    """configs[4]: 2.75 M triangles, 1024^3 (4.57 GiB chain), 3840x2160, specular tan 0.07 / 0.105 / 0.2."""
+    V, w, h = 1024, 3840, 2160
+    apertures = (0.07, 0.105, 0.2)
+    pl = Pipeline(vct, oracle, 3.5, V, w, h)
+    ctx = pl.ctx
+    assert pl.scene.ntri > 2_500_000
+    pl.shadow_map()
+    pl.gbuffer()
+    alive = pl.planes[18] >= 0.5
+    # known answers on the EMPTY volume: 9 diffuse steps, 39 specular steps at
+    # tan 0.07 for V = 1024; the other apertures from the oracle's step recurrence (trace.fs:90-104)
+    for ts in apertures:
+        ctx.set_cone_apertures(0.577, ts)
+        n_d, _ = oracle.max_steps(pl.params, 0.577)
+        n_s, _ = oracle.max_steps(pl.params, ts)
+        if ts == 0.07:
+            assert (n_d, n_s) == (9, 39)
+        ctx.trace_current()
+        st = ctx.steps()
+        assert (st[alive, :6] == n_d).all() and (st[alive, 6] == n_s).all() and (st[~alive] == 0).all()
+        assert ctx.last_step_count() == int(alive.sum()) * (6 * n_d + n_s)
+    # the 1024^3 chain, bit for bit against the oracle (host memory permitting: ~14 GiB of arrays)
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    chain = ctx.download_chain()
+    if mem_available_gib() > 24.0:
+        l0 = oracle.voxelize_conservative(pl.params, pl.oracle_scene())
+        assert int((l0[..., 3] > 0).sum()) > 2_000_000
+        want = oracle.build_mips(l0)
+        del l0
+        assert np.array_equal(chain, want)
+        del want
+    else:                                           # small host: level 0 of the first 64 z-slices + mips from the GPU level 0
+        pytest.skip("host too small for the 1024^3 oracle chain")
+    sel = pl.tile_sample(16)
+    frames = []
+    for ts in apertures:
+        ctx.set_cone_apertures(0.577, ts)
+        pl.params.tan_specular = ts
+        frame = ctx.trace_current()
+        steps = ctx.steps()
+        assert ctx.last_step_count() == int(steps.astype(np.int64).sum())
+        pl.check_frame(frame, steps, chain, sel=sel, tag=f"config 5 tan {ts}")
+        assert np.array_equal(ctx.trace_current(), frame)               # idempotent
+        frames.append(frame)
+    assert not np.array_equal(frames[0], frames[2])                     # the aperture matters
+    pl.close()

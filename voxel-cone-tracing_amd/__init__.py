@@ -25,7 +25,7 @@ GB_PLANES = 23
 GB_LINEAR, GB_TILED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 VOX_CONSERVATIVE_AVG, VOX_REFERENCE = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/vct.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "vct_selftest_const_divide", "vct_set_frame_target", "vct_bounce",
     "vct_download_voxel_attributes", "vct_download_aniso_rgba8", "vct_upload_mesh_attributes", "vct_render_shadow_map",
     "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer", "vct_trace_current", "vct_trace_resident_rows",
+    "vct_last_trace_stats", "vct_download_frame",
 ]
 
 
@@ -50,7 +51,7 @@ class Config(C.Structure):
         ("ambient_factor", C.c_float), ("shininess", C.c_float), ("max_distance", C.c_float),
         ("max_alpha", C.c_float), ("tan_diffuse", C.c_float), ("tan_specular", C.c_float),
         ("wrap_repeat", C.c_int32), ("debug_outputs", C.c_int32), ("trace_variant", C.c_int32),
-        ("voxel_attributes", C.c_int32), ("anisotropic_mips", C.c_int32),
+        ("voxel_attributes", C.c_int32), ("anisotropic_mips", C.c_int32), ("decoded_chain", C.c_int32),
     ]
 
 
@@ -78,7 +79,7 @@ _lib.vct_destroy.argtypes = [C.c_void_p]
 _lib.vct_create.argtypes = [C.c_void_p, C.c_void_p]
 for _n in ("vct_set_camera_position", "vct_set_light_direction", "vct_upload_volume_rgba8",
            "vct_upload_chain_rgba8", "vct_download_chain_rgba8", "vct_download_aniso_rgba8", "vct_download_steps",
-           "vct_download_cones", "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream",
+           "vct_download_cones", "vct_last_step_count", "vct_last_trace_ms", "vct_last_trace_stats", "vct_get_stream",
            "vct_get_config"):
     getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_set_ambient_factor.argtypes = [C.c_void_p, C.c_float]
@@ -89,7 +90,8 @@ _lib.vct_upload_shadow_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_vo
 _lib.vct_voxelize.argtypes = [C.c_void_p, C.c_int32]
 _lib.vct_download_voxel_attributes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.vct_upload_mesh_attributes.argtypes = [C.c_void_p] * 5
-for _n in ("vct_render_shadow_map", "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer"):
+for _n in ("vct_render_shadow_map", "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer",
+           "vct_download_frame"):
     getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_trace_current.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 _lib.vct_trace_resident_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
@@ -295,6 +297,11 @@ class Context:
                      "vct_trace_slab")
         return out
 
+    def download_frame(self):
+        out = np.zeros((self.cfg.height, self.cfg.width, 4), np.uint16)
+        self._ck(_lib.vct_download_frame(self._h, _ptr(out)), "vct_download_frame")
+        return out
+
     def set_frame_target(self, dev_ptr):
         """Kernel output goes to caller-owned HBM (full-frame addressing); None restores the default."""
         self._ck(_lib.vct_set_frame_target(self._h, C.c_void_p(dev_ptr) if dev_ptr else None),
@@ -320,6 +327,13 @@ class Context:
         v = C.c_uint64()
         self._ck(_lib.vct_last_step_count(self._h, C.byref(v)), "vct_last_step_count")
         return v.value
+
+    def last_trace_stats(self):
+        """Instrumented builds (-DVCT_STATS=1) only: dict of wave-level march counters."""
+        v = (C.c_uint64 * 8)()
+        self._ck(_lib.vct_last_trace_stats(self._h, v), "vct_last_trace_stats")
+        keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes", "brick_skip")
+        return dict(zip(keys, (int(x) for x in v)))
 
     def last_trace_ms(self):
         v = C.c_float()

@@ -21,12 +21,14 @@ struct vct_ctx {
     std::string err;
 
     uint32_t* chain = nullptr;        // Morton chain (bounce 0: direct light)
+    float4* chain_f = nullptr;        // decoded fp32 copy of `chain` (cfg.decoded_chain), kept current by vct_build_mips
+    float4* chain_bf = nullptr;       // same for chain_b
     uint32_t* chain_b = nullptr;      // second chain (bounce 1), allocated by vct_bounce
     bool use_chain_b = false;         // the trace reads chain_b until the next vct_inject_light
     unsigned long long* acc_attr = nullptr;   // [V^3][3] attribute accumulators (cfg.voxel_attributes)
     uint32_t* attr_albedo = nullptr;  // [V^3] resolved mean albedo, Morton order
     uint32_t* attr_normal = nullptr;  // [V^3] resolved mean normal (biased), Morton order
-    bool mips_valid = false;
+    bool mips_valid = true;           // levels >= 1 (and the decoded copy) describe level 0; a fresh chain is all zero
     uint32_t* aniso = nullptr;        // [6][chain_texels - V^3] directional chains (cfg.anisotropic_mips)
     size_t chain_texels = 0;
     uint32_t* staging = nullptr;      // linear staging for up/downloads (size of level 0)
@@ -40,6 +42,7 @@ struct vct_ctx {
     uint8_t* dbg_steps = nullptr;
     float* dbg_cones = nullptr;
     unsigned long long* step_counter = nullptr;
+    unsigned long long* stats = nullptr;      // [8] march statistics of instrumented builds (VCT_STATS)
     VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
     int n_diffuse = 0, n_specular = 0;
     bool steps_dirty = true;
@@ -84,8 +87,8 @@ struct vct_ctx {
     uint32_t* bounce_list = nullptr;   // occupied-voxel list of the bounce (+1 counter word in front)
     uint32_t bounce_list_cap = 0;
     uint32_t* brick_over = nullptr;
-    bool level0_sparse_ok = false;     // chain: untouched bricks have all-zero ancestors, mip_seen is current
-    bool level0_sparse_ok_next = false;
+    bool chain_sparse_ready = true;    // bricks outside mip_seen have all-zero ancestors (true for a fresh, zero-filled
+                                       // chain; an upload clears it until a dense mip build over a resolved level 0)
     bool acc_pending = false;          // accumulators hold an unresolved voxelize pass
     int acc_mode = 0;                  // vct_voxelize_mode of that pass
     int32_t* ref_big = nullptr;        // reference mode: triangles left to the workgroup pass (+ counter)
@@ -256,6 +259,7 @@ size_t gb_tiled_floats(const vct_ctx* c) {
 void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chain) {
     memset(&p, 0, sizeof(p));
     p.chain = chain;
+    p.chain_f = chain == c->chain ? c->chain_f : c->chain_bf;
     for (int l = 0; l < c->nlev; ++l) p.level_off[l] = (uint32_t)vct_level_offset(c->cfg.voxel_dim, l);
     p.V = c->cfg.voxel_dim;
     p.nlev = c->nlev;
@@ -271,9 +275,16 @@ void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chai
     p.n_diffuse = c->n_diffuse;
     p.n_specular = c->n_specular;
     p.step_counter = c->step_counter;
+#if defined(VCT_STATS) && VCT_STATS
+    p.stats = c->stats;
+#endif
 }
 
 int launch_trace(vct_ctx* c, int row0, int row1) {
+    // the reference rebuilds the mips right after every voxelization (VCT.h:248); tracing a chain whose
+    // coarse levels describe an older level 0 would return wrong GI without any sign of it
+    if (!c->mips_valid)
+        return fail(c, VCT_ERR_INVALID, "trace: level 0 changed since the last vct_build_mips (call it first)");
     int rc = refresh_steps(c);
     if (rc) return rc;
     VctTraceParams p;
@@ -297,6 +308,7 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
     HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long),
                               c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -355,6 +367,7 @@ int vct_default_config(vct_config* cfg) {
     cfg->trace_variant = 0;
     cfg->voxel_attributes = 0;
     cfg->anisotropic_mips = 0;
+    cfg->decoded_chain = 1;
     return VCT_OK;
 }
 
@@ -401,6 +414,10 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     c->chain_texels = vct_chain_texels(V);
     CREATE_TRY(hipMalloc(&c->chain, c->chain_texels * 4));
     CREATE_TRY(hipMemsetAsync(c->chain, 0, c->chain_texels * 4, c->stream));   // VCT.h:115-119
+    if (cfg->decoded_chain && !cfg->anisotropic_mips) {      // (the directional chains are sampled as RGBA8)
+        CREATE_TRY(hipMalloc(&c->chain_f, c->chain_texels * sizeof(float4)));
+        CREATE_TRY(hipMemsetAsync(c->chain_f, 0, c->chain_texels * sizeof(float4), c->stream));
+    }
     const size_t npix = (size_t)cfg->width * cfg->height;
     CREATE_TRY(hipMalloc(&c->gb_tiled, gb_tiled_floats(c) * sizeof(float)));
     CREATE_TRY(hipMemsetAsync(c->gb_tiled, 0, gb_tiled_floats(c) * sizeof(float), c->stream));
@@ -412,6 +429,8 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     CREATE_TRY(hipMalloc(&c->frame, npix * 8));
     CREATE_TRY(hipMemsetAsync(c->frame, 0, npix * 8, c->stream));
     CREATE_TRY(hipMalloc(&c->step_counter, VCT_STEP_COUNTERS * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&c->stats, 8 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(c->stats, 0, 8 * sizeof(unsigned long long), c->stream));
     CREATE_TRY(hipMalloc(&c->steps_dev, 2 * VCT_MAX_STEPS * sizeof(VctStep)));
     if (cfg->debug_outputs) {
         CREATE_TRY(hipMalloc(&c->dbg_steps, npix * 7));
@@ -432,8 +451,8 @@ void vct_destroy(vct_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
-                    c->dbg_cones, c->step_counter, c->steps_dev, c->tri_pos,
+    void* bufs[] = {c->chain, c->chain_f, c->chain_bf, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
+                    c->dbg_cones, c->step_counter, c->stats, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->vis, c->raster_big,
@@ -721,10 +740,6 @@ int vct_inject_light(vct_ctx* c) {
     HIP_TRY(c, vct_launch_resolve(c->acc, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
                                   c->level0_dirty, c->acc_attr, c->attr_albedo, c->attr_normal,
                                   c->acc_mode == VCT_VOX_REFERENCE, c->stream));
-    // after an upload the coarse levels may hold anything: one dense mip build re-establishes
-    // "untouched bricks have zero ancestors", then the sparse form is valid again
-    c->level0_sparse_ok = !c->level0_dirty && c->level0_sparse_ok_next;
-    c->level0_sparse_ok_next = true;
     c->acc_pending = false;
     c->level0_dirty = false;
     c->use_chain_b = false;
@@ -735,13 +750,19 @@ int vct_inject_light(vct_ctx* c) {
 int vct_build_mips(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    const bool sparse = c->level0_sparse_ok && c->brick_prev && c->mip_seen;
+    // Sparse form: only bricks that hold something now (brick_prev) or held something when the mips were
+    // last built (mip_seen) are reduced.  Valid while level 0 is the output of a resolve (not an upload)
+    // and every other brick has all-zero ancestors -- which an upload destroys until ONE dense build has
+    // run over a resolved level 0.
+    const bool tracked = c->brick_prev && c->mip_seen && !c->level0_dirty;
+    const bool sparse = tracked && c->chain_sparse_ready;
     if (!sparse && c->mip_seen && c->brick_prev)      // dense build: afterwards every brick is "seen" as it is now
         HIP_TRY(c, hipMemcpyAsync(c->mip_seen, c->brick_prev,
                                   ((size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512) * sizeof(uint32_t),
                                   hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, vct_launch_build_mips(c->chain, c->cfg.voxel_dim, sparse ? c->brick_prev : nullptr,
+    HIP_TRY(c, vct_launch_build_mips(c->chain, c->chain_f, c->cfg.voxel_dim, sparse ? c->brick_prev : nullptr,
                                      sparse ? c->mip_seen : nullptr, c->stream));
+    if (!sparse) c->chain_sparse_ready = tracked;
     if (c->aniso) HIP_TRY(c, vct_launch_build_mips_aniso(c->chain, c->aniso, c->cfg.voxel_dim, c->stream));
     c->mips_valid = true;
     c->use_chain_b = false;
@@ -765,6 +786,10 @@ int vct_bounce(vct_ctx* c) {
     if (!c->chain_b) {
         HIP_TRY(c, hipMalloc(&c->chain_b, c->chain_texels * 4));
         HIP_TRY(c, hipMemsetAsync(c->chain_b, 0, c->chain_texels * 4, c->stream));
+        if (c->chain_f) {
+            HIP_TRY(c, hipMalloc(&c->chain_bf, c->chain_texels * sizeof(float4)));
+            HIP_TRY(c, hipMemsetAsync(c->chain_bf, 0, c->chain_texels * sizeof(float4), c->stream));
+        }
         HIP_TRY(c, hipMalloc(&c->mip_seen_b, nbricks * sizeof(uint32_t)));
         HIP_TRY(c, hipMemsetAsync(c->mip_seen_b, 0, nbricks * sizeof(uint32_t), c->stream));
         b_sparse = true;     // zero-filled chain + empty "seen" set: the sparse form is valid from the start
@@ -792,7 +817,7 @@ int vct_bounce(vct_ctx* c) {
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_bounce(p, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
+    HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->chain_bf, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
                                      b_sparse ? c->mip_seen_b : nullptr, c->stream));
     // the directional chains always describe the chain the trace reads (the bounce itself gathers
     // from the isotropic bounce-0 chain, like the oracle's vcto_bounce)
@@ -836,8 +861,7 @@ static int upload_levels(vct_ctx* c, const uint8_t* lin, int nlevels) {
     c->use_chain_b = false;
     c->mips_valid = nlevels > 1;
     c->level0_dirty = true;
-    c->level0_sparse_ok = false;
-    c->level0_sparse_ok_next = false;     // level 0 no longer mirrors brick_prev: next resolve is dense
+    c->chain_sparse_ready = false;        // level 0 no longer mirrors brick_prev: next resolve and mip build are dense
     int rc = ensure_staging(c);
     if (rc) return rc;
     const int V = c->cfg.voxel_dim;
@@ -848,6 +872,8 @@ static int upload_levels(vct_ctx* c, const uint8_t* lin, int nlevels) {
         HIP_TRY(c, vct_launch_linear_to_morton(c->staging, c->chain + off, N, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    if (nlevels > 1 && c->chain_f)        // whole chain uploaded: refresh the decoded copy (a level-0 upload is
+        HIP_TRY(c, vct_launch_decode_chain(c->chain, c->chain_f, c->chain_texels, c->stream));   // decoded by the mip build)
     return VCT_OK;
 }
 
@@ -997,6 +1023,15 @@ int vct_trace_resident(vct_ctx* c) {
     return launch_trace(c, c->last_row0, c->last_row1);
 }
 
+int vct_download_frame(vct_ctx* c, void* out) {
+    if (!c || !out) return VCT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const char* src = (const char*)(c->frame_target ? c->frame_target : c->frame);
+    HIP_TRY(c, hipMemcpyAsync(out, src, (size_t)c->cfg.width * c->cfg.height * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCT_OK;
+}
+
 int vct_set_frame_target(vct_ctx* c, void* dev) {
     if (!c) return VCT_ERR_INVALID;
     c->frame_target = (uint16_t*)dev;
@@ -1037,6 +1072,19 @@ int vct_last_step_count(vct_ctx* c, uint64_t* steps) {
     for (int i = 0; i < VCT_STEP_COUNTERS; ++i) sum += v[i];
     *steps = sum;
     return VCT_OK;
+}
+
+int vct_last_trace_stats(vct_ctx* c, uint64_t out[8]) {
+    if (!c || !out) return VCT_ERR_INVALID;
+#if defined(VCT_STATS) && VCT_STATS
+    if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return VCT_OK;
+#else
+    return fail(c, VCT_ERR_INVALID, "vct_last_trace_stats: this library was built without -DVCT_STATS=1 "
+                                    "(tools/build_ab.sh stats \"-DVCT_STATS=1\")");
+#endif
 }
 
 int vct_last_trace_ms(vct_ctx* c, float* ms) {

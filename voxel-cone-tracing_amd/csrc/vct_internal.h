@@ -54,6 +54,7 @@ struct VctStep {       // 64 B: one s_load_dwordx16 per march step
 
 struct VctTraceParams {
     const uint32_t* chain;              // Morton chain, RGBA8 packed
+    const float4* chain_f;              // the same chain decoded to fp32 (exact c/255 per channel), or null
     uint32_t level_off[VCT_MAX_LEVELS]; // texel offsets
     int32_t V, nlev;
     float G, half_G, vs;
@@ -73,6 +74,7 @@ struct VctTraceParams {
     uint8_t* dbg_steps;                 // [npix][7] or null
     float* dbg_cones;                   // [npix][7][4] or null
     unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] partial sums of executed steps
+    unsigned long long* stats;          // [8] wave-level march counters (builds with -DVCT_STATS=1 only)
     // second bounce (k_bounce): per-voxel attributes (Morton order), touched-brick flags, output level 0
     const uint32_t* attr_albedo;
     const uint32_t* attr_normal;
@@ -144,8 +146,11 @@ hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, h
 hipError_t vct_launch_linear_to_morton(const uint32_t* lin, uint32_t* mor, int N, hipStream_t s);
 hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N, hipStream_t s);
 // bricks_now / bricks_seen (optional): per-8^3-brick occupancy flags of level 0 for the sparse form
-hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_now, uint32_t* bricks_seen,
-                                 hipStream_t s);
+// chain_f (optional): the decoded fp32 copy of the chain, refreshed for exactly the texels this build
+// reads (level 0) or writes (levels >= 1)
+hipError_t vct_launch_build_mips(uint32_t* chain, float4* chain_f, int V, const uint32_t* bricks_now,
+                                 uint32_t* bricks_seen, hipStream_t s);
+hipError_t vct_launch_decode_chain(const uint32_t* chain, float4* chain_f, size_t ntexels, hipStream_t s);
 hipError_t vct_launch_build_mips_aniso(const uint32_t* level0, uint32_t* aniso, int V, hipStream_t s);
 hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
                                    hipStream_t s);
