@@ -6,7 +6,7 @@ CSRC := $(PKG)/csrc
 # -fno-slp-vectorize: packed fp32 (v_pk_fma_f32 ...) issues at half rate on gfx950, so SLP packing buys
 #   nothing and costs v_mov shuffles (trace kernel 1.01 -> 0.87 ms, profiles/r01c).
 HIPFLAGS := -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function
-OBJS := $(CSRC)/vct_capi.o $(CSRC)/vct_trace.o $(CSRC)/vct_volume.o $(CSRC)/vct_voxelize.o $(CSRC)/vct_raster.o
+OBJS := $(CSRC)/vct_capi.o $(CSRC)/vct_trace.o $(CSRC)/vct_volume.o $(CSRC)/vct_voxelize.o $(CSRC)/vct_raster.o $(CSRC)/vct_multi.o
 LIB := $(PKG)/libvct_amd.so
 
 HOSTLIB := $(PKG)/libvct_host.so
@@ -27,11 +27,11 @@ $(DEMO): $(PKG)/host/demo_main.cpp $(PKG)/host/Voxel_Cone_Tracing.h include/vct.
 	g++ -O2 -std=c++17 -Wall -Wextra -o $@ $(PKG)/host/demo_main.cpp -L$(PKG) -lvct_amd -lvct_host \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vct_internal.h $(CSRC)/vct_layout.h include/vct.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vct_internal.h $(CSRC)/vct_layout.h $(CSRC)/vct_ctx.h include/vct.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -29,8 +29,9 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-VALU_INFO = None
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GINSTR = 1228.8      # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide:
+                               # "v_fma_f32 (wave64) 2 cyc"); conversions / 3-operand integer ops take 4
 BYTES_PER_STEP = 64            # 2 levels x 8 texels x 4 B
 BYTES_PER_PIXEL = 100          # 92 B G-buffer in + 8 B RGBA16F out
 
@@ -112,24 +113,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the voxel-cone-tracing path has no CPU fallback")
-    # VCT_BENCH_BACKEND=gloo: functional test of the N-rank control flow on a box with fewer GPUs
-    # than ranks (ranks share devices, the gather is staged on the host) -- never a measurement.
+    # Data path of N ranks: the library's native step (vct_frame_step: slab trace -> ONE ncclGather, RCCL called
+    # directly from C++).  torch.distributed only carries the control plane (unique id, barrier, timing
+    # reductions) over gloo.  VCT_BENCH_BACKEND=gloo: functional test of the N-rank flow on a box with fewer
+    # GPUs than ranks (ranks share devices, Python-paced step, gather staged on the host) -- never a measurement.
     backend = os.environ.get("VCT_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # VCT_BENCH_FORCE_DIST=1: run the N-rank step loop (double-buffered slabs, comm stream, RCCL gather)
-    # with a 1-rank process group -- exercises that code path on a single-GPU box.
+    # with a 1-rank communicator -- exercises that code path on a single-GPU box.
     force_dist = world == 1 and os.environ.get("VCT_BENCH_FORCE_DIST") == "1"
     if force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
     if world > 1 or force_dist:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    native = (world > 1 or force_dist) and backend == "nccl"
 
     w, h, V = args.width, args.height, args.voxel_dim
     inp = build_inputs(args, vct, sc)
@@ -182,46 +182,61 @@ def main():
             ctx.synchronize()
             gi = {"voxelize": None, "inject_resolve": None, "build_mips": e[0].elapsed_time(e[1])}
 
-    # ---- slab of this rank (voxel-cone-tracing_amd/slabs.py) ----
-    # Two gather buffers: the kernel writes this rank's slab straight into one of them (full-frame
-    # addressing: the buffer's base minus the slab's first row -- no copies), and while the ONE
-    # gather of frame k runs on a communication stream, the trace of frame k+1 fills the other.
+    # ---- slab of this rank ----
+    # native (default for N > 1): vct_comm_init allocates two gather buffers per rank; vct_frame_step makes the
+    # kernel write this rank's slab straight into one of them (full-frame addressing, no copies) and issues
+    # the ONE gather of the frame on a communication stream while the next frame's trace fills the other.
     use_dist = world > 1 or force_dist
-    nbuf = 2 if use_dist else 1
-    fgs = [slabs.FrameGather(h, w, world, rank, f"cuda:{local_rank}") for _ in range(nbuf)]
-    fg = fgs[0]
-    r0, r1 = slabs.partition(h, world)[rank]
-    y0, y1 = fg.my_rows()
+    r0, r1, _per = vct.slab_partition(h, world, rank)
+    y0, y1 = r0 * 8, min(r1 * 8, h)
     slab_px = max(0, y1 - y0) * w
-    bases = [f.slab.data_ptr() - y0 * w * 8 for f in fgs]
-    ctx.set_frame_target(bases[0])
+    fgs = []
+    if native:
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(vct.comm_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(idt, src=0)
+        ctx.comm_init(bytes(idt.numpy().tobytes()), rank, world)
+        assert ctx.comm_slab() == (r0, r1)
+        if inp["scene"] is not None and world > 1:
+            ctx.render_gbuffer_rows(inp["view_proj"], r0, r1)   # each rank rasterises only its slab from now on
+    else:
+        nbuf = 2 if use_dist else 1
+        fgs = [slabs.FrameGather(h, w, world, rank, f"cuda:{local_rank}") for _ in range(nbuf)]
+        bases = [f.slab.data_ptr() - y0 * w * 8 for f in fgs]
+        ctx.set_frame_target(bases[0])
     if inp["scene"] is None:
-        ctx.trace(inp["planes"], rows=(r0, r1), out_device_ptr=bases[0])  # uploads the synthetic G-buffer
+        ctx.trace(inp["planes"], rows=(r0, r1))             # uploads the synthetic G-buffer
     else:                                   # G-buffer already resident (vct_render_gbuffer)
         ctx.trace_gbuffer_rows(r0, r1)
     steps_slab = ctx.last_step_count()
 
-    comm_stream = torch.cuda.Stream(device=local_rank) if use_dist else None
-    traced = [torch.cuda.Event() for _ in range(nbuf)]
-    gathered = [torch.cuda.Event() for _ in range(nbuf)]
+    comm_stream = torch.cuda.Stream(device=local_rank) if (use_dist and not native) else None
+    traced = [torch.cuda.Event() for _ in range(len(fgs))]
+    gathered = [torch.cuda.Event() for _ in range(len(fgs))]
     step_no = [0]
 
     def one_step():
         if not use_dist:
             ctx.trace_resident()                  # the trace kernel, on the context stream
             return
-        k = step_no[0] % nbuf
+        if native:
+            ctx.frame_step()                      # slab trace + ONE ncclGather, issued from C++
+            return
+        k = step_no[0] % len(fgs)
         step_no[0] += 1
         ext_stream.wait_event(gathered[k])        # buffer k is free once its previous gather is done
         ctx.set_frame_target(bases[k])
         ctx.trace_resident()
         traced[k].record(ext_stream)
         comm_stream.wait_event(traced[k])
-        with torch.cuda.stream(comm_stream):      # ONE gather per frame (RCCL)
-            fgs[k].gather(force_collective=force_dist)
+        with torch.cuda.stream(comm_stream):      # functional path: gather staged through the host
+            fgs[k].gather()
             gathered[k].record(comm_stream)
 
     def fence():
+        if native:
+            ctx.comm_sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -236,6 +251,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    t_issue = time.perf_counter() - t0            # host time to ISSUE the steps (pacing overhead)
     fence()
     dt = time.perf_counter() - t0
     # per-launch device time of the trace kernel: HIP events on the context's stream, collected
@@ -246,7 +262,7 @@ def main():
         kernel_ms.append(ctx.last_trace_ms())
     fence()
 
-    red_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
+    red_dev = "cpu"                               # control plane over gloo
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     steps_all = torch.tensor([steps_slab], dtype=torch.float64, device=red_dev)
     kmax = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=red_dev)
@@ -262,15 +278,26 @@ def main():
     if use_dist:
         # acceptance check of SURVEY.md 8e, untimed: the gathered frame is bit-identical to the frame
         # one GPU traces alone
-        ctx.set_frame_target(bases[0])
-        ctx.trace_resident()
-        ctx.synchronize()
-        full = fg.gather(force_collective=force_dist)
-        torch.cuda.synchronize()
-        if rank == 0:
+        if native:
+            ctx.frame_step()
+            ctx.comm_sync()
+            full = ctx.comm_download_frame() if rank == 0 else None
+            ctx.comm_destroy()                    # restores the context-owned frame target
+        else:
+            ctx.set_frame_target(bases[0])
+            ctx.trace_resident()
+            ctx.synchronize()
+            full = fgs[0].gather()
+            torch.cuda.synchronize()
+            full = full.cpu().numpy().view(np.uint16) if rank == 0 else None
             ctx.set_frame_target(None)
-            alone = ctx.trace(inp["planes"])
-            gather_ok = bool(np.array_equal(full.cpu().numpy().view(np.uint16), alone))
+        if rank == 0:
+            if inp["scene"] is not None:
+                ctx.render_gbuffer(inp["view_proj"])          # the whole G-buffer again (ranks kept only slabs)
+                alone = ctx.trace_current()
+            else:
+                alone = ctx.trace(inp["planes"])
+            gather_ok = bool(np.array_equal(full, alone))
 
     if rank == 0:
         npix = w * h
@@ -279,8 +306,9 @@ def main():
         value = cones / (dt / args.steps) / 1e6
         # roofline of the dominant kernel (trace) on this rank's launch
         alg_bytes = steps_slab * BYTES_PER_STEP + slab_px * BYTES_PER_PIXEL
-        achieved = alg_bytes / (float(np.mean(kernel_ms)) * 1e-3) / 1e9
-        traffic, traffic_note = pmc_traffic(args, world, float(np.mean(kernel_ms)), steps_slab)
+        k_ms = float(np.mean(kernel_ms))
+        alg_gbs = alg_bytes / (k_ms * 1e-3) / 1e9
+        prof = pmc_profile(args, world)
         result = {
             "metric": "Mcones/s (+ ms per GI pass), Sponza-class 256^3 @1080p" if (V, w, h) == (256, 1920, 1080)
             else f"Mcones/s (+ ms per GI pass), Sponza-class {V}^3 @{w}x{h}",
@@ -300,12 +328,12 @@ def main():
                        "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7, "bounces": args.bounces,
                        "anisotropic_mips": bool(args.anisotropic),
                        "parallelism": "single GPU" if world == 1 else
-                       f"{world} screen-tile slabs + 1 RCCL gather" +
+                       f"{world} screen-tile slabs + 1 RCCL gather (native vct_frame_step)" +
                        ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]"),
                        "trace_variant": args.variant},
             "cone_steps_per_frame": total_steps,
-            "valu_issue": VALU_INFO,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
+            "host_issue_us_per_step": round(t_issue / args.steps * 1e6, 2),
             "trace_kernel_ms": round(kernel_ms_avg, 4),
             "gi_pass_ms": {k: (None if v is None else round(v, 4)) for k, v in gi.items()}
             | {"trace": round(kernel_ms_avg, 4)},
@@ -313,14 +341,7 @@ def main():
             # voxelize, inject, mips, (bounce,) trace
             "gi_pass_total_ms": round(sum(v for k, v in gi.items() if v is not None and k != "bounce_cone_steps")
                                       + kernel_ms_avg, 4),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": "achieved = (cone steps*64 B + px*100 B) per launch / HIP-event kernel "
-                                 "time on the context stream. At 256^3 the 73 MiB chain is L2/Infinity-"
-                                 "Cache resident and the kernel is VALU-issue bound (DESIGN.md 3.1), so "
-                                 "frac against the HBM peak may exceed 1. " + traffic_note},
+            "roofline": roofline_block(prof, k_ms, steps_slab, alg_bytes, alg_gbs),
         }
         if world == 1 and not args.no_sweep:
             # BASELINE.json config 5's "glossy cones at 3 roughness levels": the specular aperture is a
@@ -332,9 +353,9 @@ def main():
                 for _ in range(5):
                     ctx.trace_resident()
                     ms.append(ctx.last_trace_ms())
-                sweep.append({"tan_specular": ts, "trace_kernel_ms": round(float(np.min(ms)), 4),
+                sweep.append({"tan_specular": ts, "trace_kernel_ms": round(float(np.mean(ms)), 4),
                               "cone_steps": ctx.last_step_count(),
-                              "Mcones_per_s": round(cones / (float(np.min(ms)) * 1e-3) / 1e6, 1)})
+                              "Mcones_per_s": round(cones / (float(np.mean(ms)) * 1e-3) / 1e6, 1)})
             ctx.set_cone_apertures(0.577, 0.07)
             result["roughness_sweep"] = sweep
         if world == 1 and args.cpu_seconds > 0:
@@ -346,31 +367,75 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args, world, kernel_ms, cone_steps):
-    """HBM GB/s actually moved by the trace kernel: PMC bytes per launch from the committed rocprofv3
-    counter passes of this same command (profiles/trace_traffic.json, written by
-    tools/summarize_prof.py with the FETCH_SIZE x2 correction calibrated on this box) / this run's
-    kernel time.  Only valid for the default single-GPU workload."""
+def kernel_source_sha():
+    """sha256 over the sources the trace kernel is compiled from: ties a committed PMC profile to the
+    binary that is being benchmarked (the .so itself is git-ignored and rebuilt per box)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "voxel-cone-tracing_amd", "csrc")
+    for f in ("vct_trace.hip", "vct_internal.h", "vct_layout.h"):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(ROOT, "Makefile"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(args, world):
+    """Per-launch PMC figures of the trace kernel (profiles/trace_traffic.json, written by
+    tools/summarize_prof.py from separate rocprofv3 --pmc passes of this same command).  Counters cannot be
+    read from inside the timed process, so they are REPLAYED from that file -- and only when the file was
+    recorded for the default workload with exactly the kernel sources being benchmarked (sha match)."""
     path = os.path.join(ROOT, "profiles", "trace_traffic.json")
     default = (world == 1 and args.voxel_dim == 256 and args.width == 1920 and args.height == 1080
-               and args.scene == "atrium" and args.variant == 0)
-    if not default or not os.path.exists(path):
-        return None, "traffic: no PMC pass for this configuration."
+               and args.scene == "atrium" and args.variant == 0 and not args.obj and args.bounces == 1
+               and not args.anisotropic and args.scene_detail == 1.0)
+    if not default:
+        return {"ok": False, "why": "no PMC profile for this configuration"}
+    if not os.path.exists(path):
+        return {"ok": False, "why": "profiles/trace_traffic.json missing"}
     with open(path) as fh:
         t = json.load(fh)
-    gbs = t["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
-    global VALU_INFO
-    wi = t.get("wave_instructions_per_launch") or {}
-    if wi.get("valu"):
-        # what actually bounds the kernel: VALU issue.  Peak = 1024 SIMDs x 2.4 GHz / 2 cycles per
-        # wave64 instruction (fp32 fma/mul/add, plain logic; conversions and 3-operand integer ops take
-        # 4 -- tools/valu_bench.hip), so this fraction is a lower bound of the issue utilisation.
-        rate = wi["valu"] / (kernel_ms * 1e-3)
-        VALU_INFO = {"valu_wave_instructions_per_launch": int(wi["valu"]), "valu_wave_instructions_per_64_cone_steps": round(wi["valu"] * 64 / max(cone_steps, 1), 1),
-                     "issue_rate_G_per_s": round(rate / 1e9, 1), "peak_2cycle_G_per_s": 1228.8,
-                     "frac_of_2cycle_peak": round(rate / 1.2288e12, 3), "source": t["source"]}
-    return round(gbs, 1), (f"traffic = PMC HBM bytes per launch ({t['hbm_bytes_per_launch'] / 1e6:.0f} MB, "
-                           f"{t['source']}: (2*FETCH_SIZE+WRITE_SIZE)*1024) / kernel time, GB/s.")
+    sha = kernel_source_sha()
+    if t.get("kernel_source_sha16") != sha:
+        return {"ok": False, "why": f"profiles/trace_traffic.json was recorded for kernel sources "
+                                    f"{t.get('kernel_source_sha16')}, this build is {sha}: re-run tools/profile_gpu.sh"}
+    t["ok"] = True
+    return t
+
+
+def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
+    """The bound that actually binds the trace kernel is VALU issue (at every BASELINE size
+    the chain's working set is L2 / Infinity-Cache resident and a cooperative 4x4x4 block fetch moves 4 B per
+    lane-step where the per-texel figure of SURVEY.md 8d counts 64 B), so `frac` is the VALU issue rate
+    against 1024 SIMDs x 2.4 GHz / 2 cycles -- a LOWER bound of pipe utilisation, since a third of the
+    kernel's instructions are 4-cycle ops.  The HBM-side numbers are kept next to it."""
+    r = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
+         "frac": None, "traffic": None,
+         "hbm_algorithmic": {"bytes_per_launch": int(alg_bytes), "GBps": round(alg_gbs, 1),
+                             "frac_of_8TBps": round(alg_gbs / HBM_PEAK_GBS, 4),
+                             "definition": "SURVEY.md 8d: cone steps * 64 B + px * 100 B per launch / HIP-event "
+                                           "kernel time; NOT a bound of this kernel (can exceed 1)"}}
+    if not prof.get("ok"):
+        r["note"] = "VALU instruction count / HBM traffic not reported: " + prof["why"]
+        return r
+    wi = prof.get("wave_instructions_per_launch") or {}
+    valu = wi.get("valu")
+    if valu:
+        rate = valu / (kernel_ms * 1e-3) / 1e9
+        r["achieved"] = round(rate, 1)
+        r["frac"] = round(rate / VALU_PEAK_GINSTR, 4)
+        r["valu_wave_instructions_per_launch"] = int(valu)
+        r["valu_wave_instructions_per_64_cone_steps"] = round(valu * 64 / max(cone_steps, 1), 1)
+    hbm = prof.get("hbm_bytes_per_launch")
+    if hbm:
+        r["traffic"] = round(hbm / (kernel_ms * 1e-3) / 1e9, 1)
+        r["traffic_unit"] = "GB/s of HBM (PMC bytes per launch / this run's kernel time)"
+        r["traffic_bytes_per_launch"] = int(hbm)
+    r["note"] = (f"instruction and byte counts per launch replayed from {prof.get('source')} (rocprofv3 --pmc "
+                 f"passes of this command, kernel sources {prof.get('kernel_source_sha16')} = this build); "
+                 f"kernel time measured live with HIP events on the context stream")
+    return r
 
 
 def usable_cpus():

@@ -93,10 +93,6 @@ typedef struct vct_config {
                                   levels >= 1 from them by cone direction (north-star option; the
                                   reference has one isotropic chain -- VCT.h:248 -- so the default 0 is
                                   what matches the shader transliteration) */
-    int32_t decoded_chain;     /* 1 (default) = also keep the chain decoded to fp32 (exact byte/255, 16 B per
-                                  texel: 4x the RGBA8 chain, e.g. 292 MiB at 256^3, 18.3 GiB at 1024^3) so the
-                                  tracer streams texel blocks HBM -> LDS without decoding them per sample;
-                                  0 = trace from the RGBA8 chain only (same results, ~15 % slower) */
 } vct_config;
 
 typedef struct vct_ctx vct_ctx;
@@ -147,6 +143,9 @@ int vct_download_shadow_map(vct_ctx* ctx, float* depth);
  * the column-major view-projection matrix (VCT.h:161-163).  Follow with vct_trace_resident or
  * vct_trace_current. */
 int vct_render_gbuffer(vct_ctx* ctx, const float view_proj[16]);
+/* The same for tile rows [tile_row0, tile_row1) only (scissored raster + shading of those tiles): what a
+ * multi-GPU rank runs for its slab.  Other rows of the resident G-buffer keep their old content. */
+int vct_render_gbuffer_rows(vct_ctx* ctx, const float view_proj[16], int32_t tile_row0, int32_t tile_row1);
 /* Linear planes [23][h*w] of the resident G-buffer. */
 int vct_download_gbuffer(vct_ctx* ctx, float* planes);
 /* Trace the resident G-buffer (vct_render_gbuffer, or the last vct_trace upload) and return the frame
@@ -208,6 +207,31 @@ int vct_set_frame_target(vct_ctx* ctx, void* rgba16f_dev);
 int vct_download_frame(vct_ctx* ctx, void* out_rgba16f_host);
 int vct_synchronize(vct_ctx* ctx);
 
+/* ---- multi-GPU: screen-tile slabs + ONE RCCL gather per frame (BASELINE.json config 4) -------------
+ * No reference counterpart (R/main.cpp:77-94 drives one GL context).  One process and one context per
+ * GPU; every rank holds the whole scene + chain (voxelize / inject / mips are replicated: cheaper than
+ * broadcasting the chain), rasterises and traces only its slab of 8-pixel tile rows, and rank 0 receives
+ * the frame through a single ncclGather of padded equal slabs (RCCL over xGMI; rccl.h ncclGather, in
+ * place on the root).  Slab r = tile rows [r*per, min((r+1)*per, tiles_y)), per = ceil(tiles_y / world). */
+#define VCT_COMM_ID_BYTES 128
+int vct_slab_partition(int32_t height, int32_t world, int32_t rank, int32_t* tile_row0, int32_t* tile_row1,
+                       int32_t* rows_per_rank);
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to every rank out of band (file, pipe, MPI ...). */
+int vct_comm_get_unique_id(void* id128);
+/* ncclCommInitRank on the context's device; allocates the two gather buffers (the root's are whole
+ * frames), a communication stream and events.  Collective: every rank must call it. */
+int vct_comm_init(vct_ctx* ctx, const void* id128, int32_t rank, int32_t world);
+int vct_comm_destroy(vct_ctx* ctx);
+int vct_comm_slab(vct_ctx* ctx, int32_t* tile_row0, int32_t* tile_row1);
+/* One frame, asynchronous: trace this rank's slab of the resident G-buffer straight into gather buffer k
+ * (k alternates), then ONE ncclGather on the communication stream; the gather of frame k overlaps the
+ * trace of frame k+1.  Collective: every rank calls it once per frame. */
+int vct_frame_step(vct_ctx* ctx);
+int vct_comm_sync(vct_ctx* ctx);
+/* Root only: the last gathered frame (device pointer valid until the next-but-one vct_frame_step) / a host copy. */
+int vct_comm_frame(vct_ctx* ctx, void** rgba16f_dev, size_t* bytes);
+int vct_comm_download_frame(vct_ctx* ctx, void* out_rgba16f_host);
+
 /* Debug outputs of the last trace (config.debug_outputs = 1): steps [npix][7] uint8, cones
  * [npix][7][4] fp32, linear pixel order. */
 int vct_download_steps(vct_ctx* ctx, uint8_t* steps);
@@ -218,7 +242,7 @@ int vct_last_step_count(vct_ctx* ctx, uint64_t* steps);
  * production library returns VCT_ERR_INVALID): [0] march-loop iterations executed by waves, [1] live
  * lanes summed over them (= executed cone steps), [2] level samples whose cooperative 4x4x4 block was
  * all zero (skipped), [3] served through the cooperative block, [4] served by the per-lane gather,
- * [5] live lanes in [4], [6] level samples skipped by the brick-occupancy pre-test, [7] reserved. */
+ * [5] live lanes in [4], [6..7] reserved. */
 int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[8]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);

@@ -1,0 +1,134 @@
+"""Multi-GPU path (BASELINE.json config 4) on the ONE GPU the test box has.
+
+  * the native step (vct_comm_init / vct_frame_step: slab trace -> ncclGather called from C++) with a 1-rank
+    RCCL communicator: the gathered frame equals the frame the plain single-GPU calls produce, frame after
+    frame through both gather buffers;
+  * slab-restricted G-buffer raster (vct_render_gbuffer_rows) == the same rows of the full raster;
+  * two RANKS sharing the GPU (RCCL refuses two ranks on one device, so the gather is staged through the
+    host over gloo): vct_trace_resident_rows + vct_set_frame_target across processes, gathered frame
+    bit-equal to the single-context frame -- the whole bench.py N-rank flow;
+  * the C++ caller: vct_demo --gpus 1 re-launches itself as a rank process and gathers through RCCL.
+There is no reference counterpart (R/main.cpp:77-94 drives a single GL context).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import vctpkg
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def vct():
+    import torch
+    assert torch.cuda.is_available()
+    return vctpkg.load()
+
+
+def small_pipeline(vct, w=200, h=120, V=64):
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(sc.ATRIUM, 0.15, 1234)
+    cam = sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
+    ctx = vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=512))
+    ctx.set_camera_position(tuple(cam.position))
+    ctx.set_light_direction((0.0, 1.0, 0.25))
+    ctx.upload_triangles(scene.pos, scene.material, scene.albedo)
+    ctx.upload_mesh_attributes(*scene.frames(), scene.specular)
+    ctx.render_shadow_map(sc.light_view_proj((0.0, 1.0, 0.25)))
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    return ctx, sc.camera_view_proj(cam, w, h)
+
+
+def test_slab_partition_matches_survey(vct):
+    rows = [vct.slab_partition(1080, 8, r) for r in range(8)]          # 135 tile rows -> 17 x 7 + 16
+    assert [r1 - r0 for r0, r1, _ in rows] == [17] * 7 + [16] and all(p == 17 for _, _, p in rows)
+    assert rows[0][0] == 0 and rows[-1][1] == 135
+    assert all(rows[i][1] == rows[i + 1][0] for i in range(7))
+    assert vct.slab_partition(16, 8, 7)[:2] == (2, 2)                  # more ranks than tile rows: empty slabs
+
+
+def test_native_frame_step_one_rank_communicator(vct):
+    ctx, vp = small_pipeline(vct)
+    ctx.render_gbuffer(vp)
+    want = ctx.trace_current()
+    ctx.comm_init(vct.comm_unique_id(), 0, 1)
+    assert ctx.comm_slab() == (0, 15)
+    for _ in range(3):                          # both gather buffers, reuse of the first
+        ctx.frame_step()
+    ctx.comm_sync()
+    assert np.array_equal(ctx.comm_download_frame(), want)
+    with pytest.raises(vct.VctError):
+        ctx.comm_init(vct.comm_unique_id(), 0, 1)       # already initialised
+    ctx.comm_destroy()
+    assert np.array_equal(ctx.trace_current(), want)     # the context-owned frame target is back
+    with pytest.raises(vct.VctError):
+        ctx.frame_step()
+    ctx.close()
+
+
+def test_slab_raster_equals_rows_of_full_raster(vct):
+    ctx, vp = small_pipeline(vct, w=203, h=117)          # ragged size
+    ctx.render_gbuffer(vp)
+    full = ctx.download_gbuffer()
+    frame = ctx.trace_current()
+    h, w = 117, 203
+    got = np.zeros_like(full)
+    parts = np.zeros_like(frame)
+    for rank in range(4):
+        r0, r1, _ = vct.slab_partition(h, 4, rank)
+        ctx.render_gbuffer_rows(vp, r0, r1)
+        g = ctx.download_gbuffer().reshape(23, h, w)
+        got.reshape(23, h, w)[:, r0 * 8:min(r1 * 8, h)] = g[:, r0 * 8:min(r1 * 8, h)]
+        ctx.trace_gbuffer_rows(r0, r1)
+        parts[r0 * 8:min(r1 * 8, h)] = ctx.download_frame()[r0 * 8:min(r1 * 8, h)]
+    assert np.array_equal(got.view(np.uint32), full.view(np.uint32))
+    assert np.array_equal(parts, frame)
+    ctx.close()
+
+
+def test_two_ranks_sharing_the_gpu_gather_the_single_gpu_frame():
+    env = dict(os.environ, VCT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "320", "--height", "180",
+           "--voxel-dim", "64", "--scene-detail", "0.15", "--shadow-size", "512", "--cpu-seconds", "0", "--no-sweep"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["gathered_frame_equals_single_gpu_frame"] is True
+    assert d["cone_steps_per_frame"] > 0
+
+
+def test_native_bench_loop_with_forced_one_rank_group():
+    """The pipelined native step loop of bench.py (what N > 1 runs) with a 1-rank RCCL communicator."""
+    env = dict(os.environ, VCT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--width", "320",
+           "--height", "180", "--voxel-dim", "64", "--scene-detail", "0.15", "--shadow-size", "512",
+           "--cpu-seconds", "0", "--no-sweep"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["gathered_frame_equals_single_gpu_frame"] is True and d["host_issue_us_per_step"] > 0
+
+
+def test_cpp_caller_multi_gpu_launcher(vct):
+    """vct_demo --gpus 1: the C++ caller re-launches itself as rank 0 of a 1-rank RCCL communicator; its frame
+    checksum equals the plain single-GPU run's."""
+    demo = os.path.join(ROOT, "voxel-cone-tracing_amd", "vct_demo")
+    args = ["--scene", "procedural:cornell", "--voxels", "32", "--size", "96x64", "--shadow", "256", "--frames", "2"]
+    one = subprocess.run([demo] + args, capture_output=True, text=True, timeout=300)
+    multi = subprocess.run([demo] + args + ["--gpus", "1"], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    assert multi.returncode == 0, multi.stdout + multi.stderr
+
+    def fnv(txt):
+        return [t for t in txt.split() if t.startswith("fnv1a=")][-1]
+    assert "gpus=1" in multi.stdout and fnv(one.stdout) == fnv(multi.stdout)

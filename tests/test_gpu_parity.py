@@ -215,6 +215,38 @@ def test_call_order_errors(vct):
         assert b"size differs" in vct.lib().vct_last_error(ctx._h)
 
 
+def test_stale_mips_are_refused_and_upload_then_sparse_builds_stay_correct(vct, oracle):
+    """Call orders around vct_build_mips: a trace over a chain whose level 0 changed since the last mip
+    build is an error (the reference rebuilds its mips right after every voxelization, VCT.h:248); after
+    an uploaded volume, voxelize + inject twice and ONE mip build must leave no ancestor of the uploaded
+    content behind (the sparse mip build may only skip bricks whose ancestors are known to be zero)."""
+    V, w, h = 32, 16, 8
+    pos, mat, alb = random_scene(200, seed=12)
+    p = oracle.default_params(V)
+    want = oracle.build_mips(oracle.voxelize_conservative(p, oracle.make_scene(pos, mat, alb)))
+    planes = synth.random_gbuffer(w * h, seed=2)
+    with make_ctx(vct, V, w, h) as ctx:
+        junk = np.random.default_rng(5).integers(0, 256, (V, V, V, 4), dtype=np.uint8)
+        ctx.upload_volume(junk)
+        with pytest.raises(vct.VctError):
+            ctx.trace(planes)                       # level 0 uploaded, mips not rebuilt
+        ctx.upload_chain(oracle.build_mips(junk))   # a full chain is consistent by definition
+        ctx.trace(planes)
+        ctx.upload_triangles(pos, mat, alb)
+        ctx.voxelize(); ctx.inject_light()
+        with pytest.raises(vct.VctError):
+            ctx.trace(planes)                       # injected, mips stale
+        ctx.voxelize(); ctx.inject_light()          # second pass before any mip build
+        ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), want)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()      # and the sparse form afterwards
+        assert np.array_equal(ctx.download_chain(), want)
+        check_frame(vct, oracle, ctx, want, planes, w, h)
+        steps = ctx.last_step_count()
+        assert ctx.selftest_const_divide(75.0) == 0
+        assert ctx.last_step_count() == steps       # the self-test does not disturb the step counters
+
+
 def test_const_divide_exhaustive(vct):
     """The trace kernel's x/d (two FMA correction rounds) equals the IEEE divide for EVERY finite
     fp32 x, for the divisors the default configs use: half_G = 75 and the per-step occlusion

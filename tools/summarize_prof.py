@@ -53,7 +53,10 @@ def main():
         fetch = sum(traffic["FETCH_SIZE"]) / len(traffic["FETCH_SIZE"])
         write = sum(traffic["WRITE_SIZE"]) / len(traffic["WRITE_SIZE"])
         with open(sys.argv[3], "w") as fh:
-            json.dump({"kernel": "k_trace_tile", "source": os.path.basename(dst),
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+            import bench
+            json.dump({"kernel": "k_trace_tile_split<true, true, false>", "source": os.path.basename(dst),
+                       "kernel_source_sha16": bench.kernel_source_sha(),
                        "fetch_size_kib": fetch, "write_size_kib": write,
                        "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
                        "wave_instructions_per_launch": {k[9:].lower(): sum(v) / len(v) for k, v in traffic.items()

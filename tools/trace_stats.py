@@ -6,8 +6,7 @@ then  VCT_AMD_LIB=$PWD/build/ab/stats.so python tools/trace_stats.py [bench.py s
 
 Reports, for one launch of the trace kernel: march-loop iterations executed by waves, the mean fraction
 of live lanes per executed iteration (the lane utilisation of the lane-per-pixel mapping), and how the
-level samples were served (cooperative block all zero / cooperative gather / per-lane gather / skipped
-by the brick-occupancy pre-test).
+level samples were served (cooperative block all zero / cooperative gather / per-lane gather).
 """
 import json
 import os
@@ -50,7 +49,7 @@ def main():
         ctx.trace_resident()
         ctx.synchronize()
         st = ctx.last_trace_stats()
-        samples = st["coop_zero"] + st["coop_hit"] + st["fallback"] + st["brick_skip"]
+        samples = st["coop_zero"] + st["coop_hit"] + st["fallback"]
         st.update({
             "tan_specular": ts,
             "cone_steps": ctx.last_step_count(),
@@ -60,7 +59,6 @@ def main():
             "frac_coop_zero": round(st["coop_zero"] / max(samples, 1), 4),
             "frac_coop_gather": round(st["coop_hit"] / max(samples, 1), 4),
             "frac_per_lane": round(st["fallback"] / max(samples, 1), 4),
-            "frac_brick_skip": round(st["brick_skip"] / max(samples, 1), 4),
             "per_lane_mean_live_lanes": round(st["fallback_lanes"] / max(st["fallback"], 1), 2),
         })
         out["launches"].append(st)

@@ -39,7 +39,9 @@ ABI_SYMBOLS = [
     "vct_selftest_const_divide", "vct_set_frame_target", "vct_bounce",
     "vct_download_voxel_attributes", "vct_download_aniso_rgba8", "vct_upload_mesh_attributes", "vct_render_shadow_map",
     "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer", "vct_trace_current", "vct_trace_resident_rows",
-    "vct_last_trace_stats", "vct_download_frame",
+    "vct_last_trace_stats", "vct_download_frame", "vct_render_gbuffer_rows",
+    "vct_slab_partition", "vct_comm_get_unique_id", "vct_comm_init", "vct_comm_destroy", "vct_comm_slab",
+    "vct_frame_step", "vct_comm_sync", "vct_comm_frame", "vct_comm_download_frame",
 ]
 
 
@@ -51,7 +53,7 @@ class Config(C.Structure):
         ("ambient_factor", C.c_float), ("shininess", C.c_float), ("max_distance", C.c_float),
         ("max_alpha", C.c_float), ("tan_diffuse", C.c_float), ("tan_specular", C.c_float),
         ("wrap_repeat", C.c_int32), ("debug_outputs", C.c_int32), ("trace_variant", C.c_int32),
-        ("voxel_attributes", C.c_int32), ("anisotropic_mips", C.c_int32), ("decoded_chain", C.c_int32),
+        ("voxel_attributes", C.c_int32), ("anisotropic_mips", C.c_int32),
     ]
 
 
@@ -102,6 +104,16 @@ _lib.vct_trace_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.
 _lib.vct_get_frame_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.vct_set_frame_target.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_selftest_const_divide.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+_lib.vct_render_gbuffer_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+_lib.vct_slab_partition.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.vct_comm_get_unique_id.argtypes = [C.c_void_p]
+_lib.vct_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+_lib.vct_comm_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.vct_comm_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.vct_comm_download_frame.argtypes = [C.c_void_p, C.c_void_p]
+for _n in ("vct_comm_destroy", "vct_frame_step", "vct_comm_sync"):
+    getattr(_lib, _n).argtypes = [C.c_void_p]
+COMM_ID_BYTES = 128
 
 
 def lib():
@@ -114,6 +126,23 @@ def default_config(**kw):
     for k, v in kw.items():
         setattr(cfg, k, v)
     return cfg
+
+
+def slab_partition(height, world, rank):
+    """(tile_row0, tile_row1, rows_per_rank) of rank's slab: equal padded slabs of ceil(tile_rows / world)."""
+    r0, r1, per = C.c_int32(), C.c_int32(), C.c_int32()
+    if _lib.vct_slab_partition(height, world, rank, C.byref(r0), C.byref(r1), C.byref(per)) != 0:
+        raise VctError("vct_slab_partition: bad arguments")
+    return r0.value, r1.value, per.value
+
+
+def comm_unique_id():
+    """ncclGetUniqueId as 128 bytes (rank 0 creates it, every rank passes it to Context.comm_init)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = _lib.vct_comm_get_unique_id(buf)
+    if rc != 0:
+        raise VctError(f"vct_comm_get_unique_id failed ({rc}): {_lib.vct_last_error(None).decode()}")
+    return bytes(buf)
 
 
 def chain_texels(V):
@@ -222,6 +251,34 @@ class Context:
     def render_gbuffer(self, view_proj_colmajor):
         m = np.ascontiguousarray(view_proj_colmajor, np.float32).reshape(16)
         self._ck(_lib.vct_render_gbuffer(self._h, _ptr(m)), "vct_render_gbuffer")
+
+    def render_gbuffer_rows(self, view_proj_colmajor, row0, row1):
+        m = np.ascontiguousarray(view_proj_colmajor, np.float32).reshape(16)
+        self._ck(_lib.vct_render_gbuffer_rows(self._h, _ptr(m), row0, row1), "vct_render_gbuffer_rows")
+
+    # --- multi-GPU slabs + one RCCL gather per frame
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._ck(_lib.vct_comm_init(self._h, buf, rank, world), "vct_comm_init")
+
+    def comm_destroy(self):
+        self._ck(_lib.vct_comm_destroy(self._h), "vct_comm_destroy")
+
+    def comm_slab(self):
+        r0, r1 = C.c_int32(), C.c_int32()
+        self._ck(_lib.vct_comm_slab(self._h, C.byref(r0), C.byref(r1)), "vct_comm_slab")
+        return r0.value, r1.value
+
+    def frame_step(self):
+        self._ck(_lib.vct_frame_step(self._h), "vct_frame_step")
+
+    def comm_sync(self):
+        self._ck(_lib.vct_comm_sync(self._h), "vct_comm_sync")
+
+    def comm_download_frame(self):
+        out = np.zeros((self.cfg.height, self.cfg.width, 4), np.uint16)
+        self._ck(_lib.vct_comm_download_frame(self._h, _ptr(out)), "vct_comm_download_frame")
+        return out
 
     def download_gbuffer(self):
         out = np.zeros((GB_PLANES, self.cfg.width * self.cfg.height), np.float32)
@@ -332,7 +389,7 @@ class Context:
         """Instrumented builds (-DVCT_STATS=1) only: dict of wave-level march counters."""
         v = (C.c_uint64 * 8)()
         self._ck(_lib.vct_last_trace_stats(self._h, v), "vct_last_trace_stats")
-        keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes", "brick_skip")
+        keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes")
         return dict(zip(keys, (int(x) for x in v)))
 
     def last_trace_ms(self):

@@ -10,90 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/vct.h"
-#include "vct_internal.h"
-
-struct vct_ctx {
-    vct_config cfg;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::string err;
-
-    uint32_t* chain = nullptr;        // Morton chain (bounce 0: direct light)
-    float4* chain_f = nullptr;        // decoded fp32 copy of `chain` (cfg.decoded_chain), kept current by vct_build_mips
-    float4* chain_bf = nullptr;       // same for chain_b
-    uint32_t* chain_b = nullptr;      // second chain (bounce 1), allocated by vct_bounce
-    bool use_chain_b = false;         // the trace reads chain_b until the next vct_inject_light
-    unsigned long long* acc_attr = nullptr;   // [V^3][3] attribute accumulators (cfg.voxel_attributes)
-    uint32_t* attr_albedo = nullptr;  // [V^3] resolved mean albedo, Morton order
-    uint32_t* attr_normal = nullptr;  // [V^3] resolved mean normal (biased), Morton order
-    bool mips_valid = true;           // levels >= 1 (and the decoded copy) describe level 0; a fresh chain is all zero
-    uint32_t* aniso = nullptr;        // [6][chain_texels - V^3] directional chains (cfg.anisotropic_mips)
-    size_t chain_texels = 0;
-    uint32_t* staging = nullptr;      // linear staging for up/downloads (size of level 0)
-    int nlev = 0;
-
-    float* gb_linear = nullptr;       // [23][w*h] staging
-    float* gb_tiled = nullptr;        // [tiles][23][64]
-    const float* gb_current = nullptr;   // tiled buffer the next resident trace reads
-    uint16_t* frame = nullptr;        // RGBA16F [h][w][4]
-    uint16_t* frame_target = nullptr; // caller-owned output (vct_set_frame_target) or null
-    uint8_t* dbg_steps = nullptr;
-    float* dbg_cones = nullptr;
-    unsigned long long* step_counter = nullptr;
-    unsigned long long* stats = nullptr;      // [8] march statistics of instrumented builds (VCT_STATS)
-    VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
-    int n_diffuse = 0, n_specular = 0;
-    bool steps_dirty = true;
-    bool fast_div = false;            // set by refresh_steps: constant divisors admit the FMA division
-    int last_row0 = 0, last_row1 = 0;
-    bool have_trace = false;
-    bool have_gbuffer = false;        // a G-buffer is resident (uploaded by vct_trace or rendered)
-
-    float cam[3] = {0.0f, 4.0f, 0.0f};        // VCT.h:8
-    float light[3] = {0.0f, 1.0f, 0.25f};     // VCT.h:14
-
-    // scene
-    float* tri_pos = nullptr;
-    int32_t* tri_mat = nullptr;
-    float* mat_albedo = nullptr;
-    int32_t ntri = 0, nmat = 0;
-    float* shadow = nullptr;
-    int32_t shadow_size = 0;
-    // raster input stages
-    float* tri_nrm = nullptr;
-    float* tri_tan = nullptr;
-    float* tri_bit = nullptr;
-    float* mat_specular = nullptr;
-    unsigned long long* vis = nullptr;
-    size_t vis_words = 0;
-    int32_t* raster_big = nullptr;
-    int32_t* raster_big_count = nullptr;      // [0] huge sub-triangles, [1] tile work items, [2] wave list
-    uint2* raster_items = nullptr;
-    uint32_t raster_item_capacity = 0;
-    float light_vp[16];
-    unsigned long long* acc = nullptr;
-    // voxelization plan (geometry only; built by vct_upload_triangles) and sparse-resolve state
-    uint2* worklist = nullptr;
-    uint32_t n_entries = 0;
-    int32_t* big_list = nullptr;
-    int32_t n_big = 0;
-    uint32_t* plan = nullptr;          // [2] device counters used while planning
-    uint32_t* brick_flags = nullptr;   // [V^3/512] touched in the pending pass
-    uint32_t* brick_prev = nullptr;    // [V^3/512] touched in the pass level 0 currently shows
-    uint32_t* mip_seen = nullptr;      // [V^3/512] bricks non-empty when the chain's mips were last built
-    uint32_t* mip_seen_b = nullptr;    // same for the bounce chain
-    uint32_t* bounce_list = nullptr;   // occupied-voxel list of the bounce (+1 counter word in front)
-    uint32_t bounce_list_cap = 0;
-    uint32_t* brick_over = nullptr;
-    bool chain_sparse_ready = true;    // bricks outside mip_seen have all-zero ancestors (true for a fresh, zero-filled
-                                       // chain; an upload clears it until a dense mip build over a resolved level 0)
-    bool acc_pending = false;          // accumulators hold an unresolved voxelize pass
-    int acc_mode = 0;                  // vct_voxelize_mode of that pass
-    int32_t* ref_big = nullptr;        // reference mode: triangles left to the workgroup pass (+ counter)
-    bool level0_dirty = false;         // level 0 was written by an upload: next resolve is dense
-};
+#include "vct_ctx.h"
 
 namespace {
 
@@ -103,14 +20,6 @@ int fail(vct_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg; else g_create_error = msg;
     return code;
 }
-
-#define HIP_TRY(c, expr)                                                                     \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail((c), e_ == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE,     \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
-    } while (0)
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -259,7 +168,6 @@ size_t gb_tiled_floats(const vct_ctx* c) {
 void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chain) {
     memset(&p, 0, sizeof(p));
     p.chain = chain;
-    p.chain_f = chain == c->chain ? c->chain_f : c->chain_bf;
     for (int l = 0; l < c->nlev; ++l) p.level_off[l] = (uint32_t)vct_level_offset(c->cfg.voxel_dim, l);
     p.V = c->cfg.voxel_dim;
     p.nlev = c->nlev;
@@ -287,6 +195,8 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
         return fail(c, VCT_ERR_INVALID, "trace: level 0 changed since the last vct_build_mips (call it first)");
     int rc = refresh_steps(c);
     if (rc) return rc;
+    if (c->cfg.debug_outputs && (c->n_diffuse > 255 || c->n_specular > 255))
+        return fail(c, VCT_ERR_INVALID, "debug_outputs keeps per-cone step counts as uint8: this aperture needs more than 255 steps");
     VctTraceParams p;
     fill_march_params(c, p, c->use_chain_b ? c->chain_b : c->chain);
     for (int i = 0; i < 3; ++i) { p.cam[i] = c->cam[i]; p.light[i] = c->light[i]; }
@@ -308,7 +218,9 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
     HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long),
                               c->stream));
+#if defined(VCT_STATS) && VCT_STATS
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(unsigned long long), c->stream));
+#endif
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -343,6 +255,12 @@ VctVoxParams vox_params(const vct_ctx* c) {
 
 }  // namespace
 
+int vct_fail(vct_ctx* c, int code, const std::string& msg) { return fail(c, code, msg); }
+int vct_launch_trace_rows(vct_ctx* c, int row0, int row1) { return launch_trace(c, row0, row1); }
+int vct_tiles_x(const vct_ctx* c) { return tiles_x(c); }
+int vct_tiles_y(const vct_ctx* c) { return tiles_y(c); }
+void vct_comm_release(vct_ctx* c);      // vct_multi.hip
+
 extern "C" {
 
 int vct_default_config(vct_config* cfg) {
@@ -367,7 +285,6 @@ int vct_default_config(vct_config* cfg) {
     cfg->trace_variant = 0;
     cfg->voxel_attributes = 0;
     cfg->anisotropic_mips = 0;
-    cfg->decoded_chain = 1;
     return VCT_OK;
 }
 
@@ -414,10 +331,6 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     c->chain_texels = vct_chain_texels(V);
     CREATE_TRY(hipMalloc(&c->chain, c->chain_texels * 4));
     CREATE_TRY(hipMemsetAsync(c->chain, 0, c->chain_texels * 4, c->stream));   // VCT.h:115-119
-    if (cfg->decoded_chain && !cfg->anisotropic_mips) {      // (the directional chains are sampled as RGBA8)
-        CREATE_TRY(hipMalloc(&c->chain_f, c->chain_texels * sizeof(float4)));
-        CREATE_TRY(hipMemsetAsync(c->chain_f, 0, c->chain_texels * sizeof(float4), c->stream));
-    }
     const size_t npix = (size_t)cfg->width * cfg->height;
     CREATE_TRY(hipMalloc(&c->gb_tiled, gb_tiled_floats(c) * sizeof(float)));
     CREATE_TRY(hipMemsetAsync(c->gb_tiled, 0, gb_tiled_floats(c) * sizeof(float), c->stream));
@@ -450,8 +363,9 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
 void vct_destroy(vct_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    vct_comm_release(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->chain, c->chain_f, c->chain_bf, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
+    void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->stats, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
@@ -652,21 +566,28 @@ int vct_download_shadow_map(vct_ctx* c, float* depth) {
     return VCT_OK;
 }
 
-int vct_render_gbuffer(vct_ctx* c, const float view_proj[16]) {
+int vct_render_gbuffer_rows(vct_ctx* c, const float view_proj[16], int32_t row0, int32_t row1) {
     if (!c) return VCT_ERR_INVALID;
     if (!view_proj) return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer: null matrix");
     if (!c->tri_nrm) return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer: call vct_upload_mesh_attributes first");
+    if (row0 < 0 || row1 > tiles_y(c) || row0 > row1)
+        return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer_rows: tile-row range outside the frame");
     HIP_TRY(c, hipSetDevice(c->device));
     VctRasterArgs a;
     int rc = raster_args(c, (size_t)c->cfg.width * c->cfg.height, a);
     if (rc) return rc;
-    HIP_TRY(c, vct_launch_gbuffer_raster(a, view_proj, c->cfg.width, c->cfg.height, c->shadow,
+    HIP_TRY(c, vct_launch_gbuffer_raster(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow,
                                          c->shadow_size, c->light_vp, c->gb_tiled, c->stream));
     c->gb_current = c->gb_tiled;
-    c->last_row0 = 0;
-    c->last_row1 = tiles_y(c);
+    c->last_row0 = row0;
+    c->last_row1 = row1;
     c->have_gbuffer = true;
     return VCT_OK;
+}
+
+int vct_render_gbuffer(vct_ctx* c, const float view_proj[16]) {
+    if (!c) return VCT_ERR_INVALID;
+    return vct_render_gbuffer_rows(c, view_proj, 0, tiles_y(c));
 }
 
 int vct_download_gbuffer(vct_ctx* c, float* planes) {
@@ -760,7 +681,7 @@ int vct_build_mips(vct_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(c->mip_seen, c->brick_prev,
                                   ((size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512) * sizeof(uint32_t),
                                   hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, vct_launch_build_mips(c->chain, c->chain_f, c->cfg.voxel_dim, sparse ? c->brick_prev : nullptr,
+    HIP_TRY(c, vct_launch_build_mips(c->chain, c->cfg.voxel_dim, sparse ? c->brick_prev : nullptr,
                                      sparse ? c->mip_seen : nullptr, c->stream));
     if (!sparse) c->chain_sparse_ready = tracked;
     if (c->aniso) HIP_TRY(c, vct_launch_build_mips_aniso(c->chain, c->aniso, c->cfg.voxel_dim, c->stream));
@@ -786,10 +707,6 @@ int vct_bounce(vct_ctx* c) {
     if (!c->chain_b) {
         HIP_TRY(c, hipMalloc(&c->chain_b, c->chain_texels * 4));
         HIP_TRY(c, hipMemsetAsync(c->chain_b, 0, c->chain_texels * 4, c->stream));
-        if (c->chain_f) {
-            HIP_TRY(c, hipMalloc(&c->chain_bf, c->chain_texels * sizeof(float4)));
-            HIP_TRY(c, hipMemsetAsync(c->chain_bf, 0, c->chain_texels * sizeof(float4), c->stream));
-        }
         HIP_TRY(c, hipMalloc(&c->mip_seen_b, nbricks * sizeof(uint32_t)));
         HIP_TRY(c, hipMemsetAsync(c->mip_seen_b, 0, nbricks * sizeof(uint32_t), c->stream));
         b_sparse = true;     // zero-filled chain + empty "seen" set: the sparse form is valid from the start
@@ -817,7 +734,7 @@ int vct_bounce(vct_ctx* c) {
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_bounce(p, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->chain_bf, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
+    HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
                                      b_sparse ? c->mip_seen_b : nullptr, c->stream));
     // the directional chains always describe the chain the trace reads (the bounce itself gathers
     // from the isotropic bounce-0 chain, like the oracle's vcto_bounce)
@@ -872,8 +789,6 @@ static int upload_levels(vct_ctx* c, const uint8_t* lin, int nlevels) {
         HIP_TRY(c, vct_launch_linear_to_morton(c->staging, c->chain + off, N, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (nlevels > 1 && c->chain_f)        // whole chain uploaded: refresh the decoded copy (a level-0 upload is
-        HIP_TRY(c, vct_launch_decode_chain(c->chain, c->chain_f, c->chain_texels, c->stream));   // decoded by the mip build)
     return VCT_OK;
 }
 
@@ -1099,10 +1014,11 @@ int vct_selftest_const_divide(vct_ctx* c, float d, uint64_t* mismatches) {
     if (!c || !mismatches) return VCT_ERR_INVALID;
     if (!divisor_ok(d)) return fail(c, VCT_ERR_INVALID, "divisor outside the set the FMA division is proven for");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, 2 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, vct_launch_divide_selftest(d, c->step_counter, c->stream));
+    // scratch = the statistics words (never the step-counter bank: vct_last_step_count sums that)
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, vct_launch_divide_selftest(d, c->stats, c->stream));
     unsigned long long v[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(v, c->step_counter, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(v, c->stats, sizeof(v), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *mismatches = v[0];
     if (v[0]) {      // not a failure of the call: leave one offending x readable for diagnosis

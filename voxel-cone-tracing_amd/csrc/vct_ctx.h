@@ -1,0 +1,107 @@
+// vct_ctx.h -- the context behind the C ABI (private to the library's translation units).
+#ifndef VCT_CTX_H_
+#define VCT_CTX_H_
+
+#include <string>
+
+#include "../../include/vct.h"
+#include "vct_internal.h"
+
+struct vct_comm;      // multi-GPU state (vct_multi.hip)
+
+struct vct_ctx {
+    vct_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    uint32_t* chain = nullptr;        // Morton chain (bounce 0: direct light)
+    uint32_t* chain_b = nullptr;      // second chain (bounce 1), allocated by vct_bounce
+    bool use_chain_b = false;         // the trace reads chain_b until the next vct_inject_light
+    unsigned long long* acc_attr = nullptr;   // [V^3][3] attribute accumulators (cfg.voxel_attributes)
+    uint32_t* attr_albedo = nullptr;  // [V^3] resolved mean albedo, Morton order
+    uint32_t* attr_normal = nullptr;  // [V^3] resolved mean normal (biased), Morton order
+    bool mips_valid = true;           // levels >= 1 describe level 0 (a fresh chain is all zero)
+    uint32_t* aniso = nullptr;        // [6][chain_texels - V^3] directional chains (cfg.anisotropic_mips)
+    size_t chain_texels = 0;
+    uint32_t* staging = nullptr;      // linear staging for up/downloads (size of level 0)
+    int nlev = 0;
+
+    float* gb_linear = nullptr;       // [23][w*h] staging
+    float* gb_tiled = nullptr;        // [tiles][23][64]
+    const float* gb_current = nullptr;   // tiled buffer the next resident trace reads
+    uint16_t* frame = nullptr;        // RGBA16F [h][w][4]
+    uint16_t* frame_target = nullptr; // caller-owned output (vct_set_frame_target) or null
+    uint8_t* dbg_steps = nullptr;
+    float* dbg_cones = nullptr;
+    unsigned long long* step_counter = nullptr;
+    unsigned long long* stats = nullptr;      // [8] march statistics of instrumented builds (VCT_STATS)
+    VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
+    int n_diffuse = 0, n_specular = 0;
+    bool steps_dirty = true;
+    bool fast_div = false;            // set by refresh_steps: constant divisors admit the FMA division
+    int last_row0 = 0, last_row1 = 0;
+    bool have_trace = false;
+    bool have_gbuffer = false;        // a G-buffer is resident (uploaded by vct_trace or rendered)
+
+    float cam[3] = {0.0f, 4.0f, 0.0f};        // VCT.h:8
+    float light[3] = {0.0f, 1.0f, 0.25f};     // VCT.h:14
+
+    // scene
+    float* tri_pos = nullptr;
+    int32_t* tri_mat = nullptr;
+    float* mat_albedo = nullptr;
+    int32_t ntri = 0, nmat = 0;
+    float* shadow = nullptr;
+    int32_t shadow_size = 0;
+    // raster input stages
+    float* tri_nrm = nullptr;
+    float* tri_tan = nullptr;
+    float* tri_bit = nullptr;
+    float* mat_specular = nullptr;
+    unsigned long long* vis = nullptr;
+    size_t vis_words = 0;
+    int32_t* raster_big = nullptr;
+    int32_t* raster_big_count = nullptr;      // [0] huge sub-triangles, [1] tile work items, [2] wave list
+    uint2* raster_items = nullptr;
+    uint32_t raster_item_capacity = 0;
+    float light_vp[16];
+    unsigned long long* acc = nullptr;
+    // voxelization plan (geometry only; built by vct_upload_triangles) and sparse-resolve state
+    uint2* worklist = nullptr;
+    uint32_t n_entries = 0;
+    int32_t* big_list = nullptr;
+    int32_t n_big = 0;
+    uint32_t* plan = nullptr;          // [2] device counters used while planning
+    uint32_t* brick_flags = nullptr;   // [V^3/512] touched in the pending pass
+    uint32_t* brick_prev = nullptr;    // [V^3/512] touched in the pass level 0 currently shows
+    uint32_t* mip_seen = nullptr;      // [V^3/512] bricks non-empty when the chain's mips were last built
+    uint32_t* mip_seen_b = nullptr;    // same for the bounce chain
+    uint32_t* bounce_list = nullptr;   // occupied-voxel list of the bounce (+1 counter word in front)
+    uint32_t bounce_list_cap = 0;
+    uint32_t* brick_over = nullptr;
+    bool chain_sparse_ready = true;    // bricks outside mip_seen have all-zero ancestors (true for a fresh, zero-filled
+                                       // chain; an upload clears it until a dense mip build over a resolved level 0)
+    bool acc_pending = false;          // accumulators hold an unresolved voxelize pass
+    int acc_mode = 0;                  // vct_voxelize_mode of that pass
+    int32_t* ref_big = nullptr;        // reference mode: triangles left to the workgroup pass (+ counter)
+    bool level0_dirty = false;         // level 0 was written by an upload: next resolve is dense
+    vct_comm* comm = nullptr;          // multi-GPU slabs + gather (vct_comm_init)
+};
+
+// shared helpers (vct_capi.hip)
+int vct_fail(vct_ctx* c, int code, const std::string& msg);
+int vct_launch_trace_rows(vct_ctx* c, int row0, int row1);      // memset counters + trace kernel, asynchronous
+int vct_tiles_x(const vct_ctx* c);
+int vct_tiles_y(const vct_ctx* c);
+
+#define HIP_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return vct_fail((c), e_ == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE, \
+                            std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+#endif

@@ -54,7 +54,6 @@ struct VctStep {       // 64 B: one s_load_dwordx16 per march step
 
 struct VctTraceParams {
     const uint32_t* chain;              // Morton chain, RGBA8 packed
-    const float4* chain_f;              // the same chain decoded to fp32 (exact c/255 per channel), or null
     uint32_t level_off[VCT_MAX_LEVELS]; // texel offsets
     int32_t V, nlev;
     float G, half_G, vs;
@@ -137,20 +136,18 @@ struct VctRasterArgs {
 
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
                                     hipStream_t s);
+// tile rows [row0, row1) only (whole frame: 0 .. ceil(H/8))
 hipError_t vct_launch_gbuffer_raster(const VctRasterArgs& a, const float view_proj[16], int W, int H,
-                                     const float* shadow, int shadow_size, const float light_vp[16],
-                                     float* tiled, hipStream_t s);
+                                     int row0, int row1, const float* shadow, int shadow_size,
+                                     const float light_vp[16], float* tiled, hipStream_t s);
 hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s);
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s);
 hipError_t vct_launch_linear_to_morton(const uint32_t* lin, uint32_t* mor, int N, hipStream_t s);
 hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N, hipStream_t s);
 // bricks_now / bricks_seen (optional): per-8^3-brick occupancy flags of level 0 for the sparse form
-// chain_f (optional): the decoded fp32 copy of the chain, refreshed for exactly the texels this build
-// reads (level 0) or writes (levels >= 1)
-hipError_t vct_launch_build_mips(uint32_t* chain, float4* chain_f, int V, const uint32_t* bricks_now,
-                                 uint32_t* bricks_seen, hipStream_t s);
-hipError_t vct_launch_decode_chain(const uint32_t* chain, float4* chain_f, size_t ntexels, hipStream_t s);
+hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_now, uint32_t* bricks_seen,
+                                 hipStream_t s);
 hipError_t vct_launch_build_mips_aniso(const uint32_t* level0, uint32_t* aniso, int V, hipStream_t s);
 hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
                                    hipStream_t s);

@@ -71,8 +71,9 @@ struct SubTri {
     bool ok;
 };
 
+// [ys0, ys1): scissor in pixel rows (a multi-GPU rank rasterises only its slab; the whole frame is [0, H))
 __device__ __forceinline__ void setup_subtri(const RVert* v0, const RVert* v1, const RVert* v2, int W,
-                                             int H, SubTri& s) {
+                                             int H, int ys0, int ys1, SubTri& s) {
     const RVert* v[3] = {v0, v1, v2};
     s.ok = false;
 #pragma unroll
@@ -90,8 +91,8 @@ __device__ __forceinline__ void setup_subtri(const RVert* v0, const RVert* v1, c
     s.area = area;
     s.x0 = max(0, (int)floor(fmin(fmin(s.sx[0], s.sx[1]), s.sx[2])));
     s.x1 = min(W - 1, (int)floor(fmax(fmax(s.sx[0], s.sx[1]), s.sx[2])));
-    s.y0 = max(0, (int)floor(fmin(fmin(s.sy[0], s.sy[1]), s.sy[2])));
-    s.y1 = min(H - 1, (int)floor(fmax(fmax(s.sy[0], s.sy[1]), s.sy[2])));
+    s.y0 = max(ys0, (int)floor(fmin(fmin(s.sy[0], s.sy[1]), s.sy[2])));
+    s.y1 = min(ys1 - 1, (int)floor(fmax(fmax(s.sy[0], s.sy[1]), s.sy[2])));
     s.ok = s.x1 >= s.x0 && s.y1 >= s.y0;
 }
 
@@ -123,6 +124,7 @@ struct RasterParams {
     float model_scale;
     float vp[16];                // column-major view-projection applied to world positions
     int32_t W, H;
+    int32_t ys0, ys1;            // scissor: pixel rows [ys0, ys1)
     unsigned long long* vis;     // [H][W] (depth bits << 32) | (tri * 2 + sub); ~0 = empty
     int32_t* wave_list;          // (tri * 2 + sub) of medium sub-triangles (one wave each)
     uint32_t* wave_count;
@@ -194,8 +196,8 @@ k_raster_vis(const RasterParams p) {
     }
     for (int f = 1; f + 1 < poly.n; ++f) {
         SubTri s;
-        if (whole) setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, s);
-        else setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
+        if (whole) setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, p.ys0, p.ys1, s);
+        else setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, p.ys0, p.ys1, s);
         if (!s.ok) continue;
         const unsigned long long id = (unsigned long long)(uint32_t)(t * 2 + (f - 1));
         const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
@@ -214,12 +216,12 @@ __device__ __forceinline__ bool rebuild_subtri(const RasterParams& p, int id, Su
     RVert in[3];
     load_clip_tri(p, t, in);
     if (unclipped(in)) {
-        setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, s);
+        setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, p.ys0, p.ys1, s);
         return s.ok;
     }
     ClipPoly poly;
     clip_near(in, poly);
-    setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, s);
+    setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, p.ys0, p.ys1, s);
     return s.ok;
 }
 
@@ -295,6 +297,7 @@ struct ShadeParams {
     float light_vp[16];
     float* tiled;                // [tile][23][64]
     int32_t tiles_x;
+    int32_t tile0, tile1;        // tiles [tile0, tile1) are shaded (whole tile rows)
 };
 
 // [GL] bilinear clamp-to-edge fetch with the operation order of host/vct_host.cpp shadow_fetch
@@ -314,10 +317,10 @@ __device__ __forceinline__ float shadow_fetch(const float* __restrict__ depth, i
 __global__ void __launch_bounds__(256)
 k_gbuffer_shade(const ShadeParams p) {
     const int W = p.r.W, H = p.r.H;
-    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tile = p.tile0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    if (ty * VCT_TILE >= H) return;
+    if (tile >= p.tile1 || ty * VCT_TILE >= H) return;
     const int px = tx * VCT_TILE + (lane & 7), py = ty * VCT_TILE + (lane >> 3);
     float* out = p.tiled + (size_t)tile * (VCT_GB_NPLANES * VCT_TILE_PIX) + lane;
     float g[VCT_GB_NPLANES];
@@ -334,10 +337,10 @@ k_gbuffer_shade(const ShadeParams p) {
         ClipPoly poly;
         SubTri s;
         if (whole) {
-            setup_subtri(&in[0], &in[1], &in[2], W, H, s);
+            setup_subtri(&in[0], &in[1], &in[2], W, H, 0, H, s);
         } else {
             clip_near(in, poly);
-            setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], W, H, s);
+            setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], W, H, 0, H, s);
         }
         float b0, b1, b2, z;
         cover(s, px, py, b0, b1, b2, z);
@@ -465,8 +468,10 @@ __global__ void k_untile_gbuffer(const float* __restrict__ tiled, float* __restr
     }
 }
 
-RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int H) {
+RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int H, int ys0, int ys1) {
     RasterParams r;
+    r.ys0 = ys0 < 0 ? 0 : ys0;
+    r.ys1 = ys1 > H ? H : ys1;
     r.pos = a.pos;
     r.ntri = a.ntri;
     r.model_scale = a.model_scale;
@@ -485,7 +490,9 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
 }
 
 hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(r.vis, 0xff, (size_t)r.W * r.H * sizeof(unsigned long long), s);
+    if (r.ys1 <= r.ys0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(r.vis + (size_t)r.ys0 * r.W, 0xff,
+                                  (size_t)r.W * (r.ys1 - r.ys0) * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(r.big_count, 0, 3 * sizeof(int32_t), s);     // big, item and wave counters
     if (e != hipSuccess) return e;
@@ -507,7 +514,7 @@ hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
 
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
                                     hipStream_t s) {
-    const RasterParams r = make_raster(a, light_vp, S, S);
+    const RasterParams r = make_raster(a, light_vp, S, S, 0, S);
     hipError_t e = run_visibility(r, s);
     if (e != hipSuccess) return e;
     const size_t n = (size_t)S * S;
@@ -516,10 +523,10 @@ hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp
 }
 
 hipError_t vct_launch_gbuffer_raster(const VctRasterArgs& a, const float view_proj[16], int W, int H,
-                                     const float* shadow, int shadow_size, const float light_vp[16],
-                                     float* tiled, hipStream_t s) {
+                                     int row0, int row1, const float* shadow, int shadow_size,
+                                     const float light_vp[16], float* tiled, hipStream_t s) {
     ShadeParams p;
-    p.r = make_raster(a, view_proj, W, H);
+    p.r = make_raster(a, view_proj, W, H, row0 * VCT_TILE, row1 * VCT_TILE);
     hipError_t e = run_visibility(p.r, s);
     if (e != hipSuccess) return e;
     p.nrm = a.nrm; p.tan = a.tan; p.bit = a.bit;
@@ -528,7 +535,10 @@ hipError_t vct_launch_gbuffer_raster(const VctRasterArgs& a, const float view_pr
     for (int i = 0; i < 16; ++i) p.light_vp[i] = light_vp[i];
     p.tiled = tiled;
     p.tiles_x = (W + VCT_TILE - 1) / VCT_TILE;
-    const int tiles = p.tiles_x * ((H + VCT_TILE - 1) / VCT_TILE);
+    p.tile0 = row0 * p.tiles_x;
+    p.tile1 = row1 * p.tiles_x;
+    const int tiles = p.tile1 - p.tile0;
+    if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_gbuffer_shade, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -113,12 +113,6 @@ struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
 #ifndef VCT_STATS
 #define VCT_STATS 0
 #endif
-// Ablation builds (tools/ablate.sh; results are WRONG by construction, timing only): bit 0 never take the
-// per-lane path, 1 no LDS gather, 2 no global loads in the cooperative path, 3 no interpolation, 4 one
-// level per step, 5 treat every cooperative block as empty, 6 cones never terminate on alpha (fixed work).
-#ifndef VCT_ABLATE
-#define VCT_ABLATE 0
-#endif
 struct MarchStats {
     uint32_t wave_steps;       // march-loop iterations executed by the wave
     uint32_t lane_steps;       // sum over those iterations of the live lanes (== executed cone steps)
@@ -126,26 +120,15 @@ struct MarchStats {
     uint32_t coop_hit;         // level samples served by the cooperative block, gathered through LDS
     uint32_t fallback;         // level samples that took the per-lane gather
     uint32_t fallback_lanes;   // live lanes in those
-    uint32_t brick_skip;       // level samples skipped by the occupancy pre-test
-    uint32_t pad;
 };
 
 // [GL] tri(level): trilinear, texel centres, REPEAT (or clamp).  `level` is wave-uniform; must be
 // called in wave-uniform control flow with at least one lane `act`.  Lanes without `act` help
 // fetch the block and return garbage-free zeros / unused values.
-//
-// FCHAIN: texel values come from the decoded fp32 copy of the chain (`fchain`, exact byte/255 per
-// channel, written by the mip build): the cooperative block goes from L2/HBM straight into the wave's
-// LDS slab with one global_load_lds_dwordx4 per lane (LDS destination = slab base + lane * 16, exactly
-// the slab layout) -- no VGPR round trip, no decode, no ds_write; the RGBA8 texel is still fetched, only
-// for the all-zero test.  The per-lane gather loads float4 texels directly.  Same bits either way.
-typedef __attribute__((address_space(3))) void* LdsPtr;
-
-template <bool WRAP, bool COOP, bool FCHAIN = false>
+template <bool WRAP, bool COOP>
 __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, const VctLevelRef lv,
                                            float ux, float uy, float uz, bool act,
-                                           float4* __restrict__ blk, const LaneBlock& lb, MarchStats& ms,
-                                           const float4* __restrict__ fchain = nullptr) {
+                                           float4* __restrict__ blk, const LaneBlock& lb, MarchStats& ms) {
     const int m = lv.m;
     const float fN = lv.fN;
     // ux * fN is exact (power of two), so the fused form is the oracle's (ux*fN) - 0.5f bit for bit
@@ -169,7 +152,6 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         dx = i0 - ax; dy = j0 - ay; dz = k0 - az;
         const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
         coop = ballot64(act && far > 2u) == 0ull;
-        if (VCT_ABLATE & 1) { coop = true; dx &= 1; dy &= 1; dz &= 1; }
     }
     if (COOP && coop) {
         uint32_t idx;
@@ -186,37 +168,22 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             const int z = min(max(az + (lb.lane >> 4), 0), m);
             idx = vct_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
         }
-        if (FCHAIN && !(VCT_ABLATE & 4))      // issued first: the DMA flies while the zero test below waits for its own load
-            __builtin_amdgcn_global_load_lds((const void*)(fchain + lv.off + idx), (LdsPtr)blk, 16, 0, 0);
-        const uint32_t t = (VCT_ABLATE & 4) ? idx | 1u : base[idx];
-        const bool any_texel = (VCT_ABLATE & 32) ? false : ballot64(t != 0u) != 0ull;
+        const uint32_t t = base[idx];
+        const bool any_texel = ballot64(t != 0u) != 0ull;
         if (VCT_STATS) { if (any_texel) ++ms.coop_hit; else ++ms.coop_zero; }
         if (any_texel) {     // all 64 texels zero: every footprint sums to exactly +0
-            if (FCHAIN) {
-                // loads return in order, so the zero test's wait already covered the DMA; the explicit
-                // wait keeps that true whatever the compiler schedules around the builtin
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                float4 d;
-                d.x = unorm8(t & 0xffu);
-                d.y = unorm8((t >> 8) & 0xffu);
-                d.z = unorm8((t >> 16) & 0xffu);
-                d.w = unorm8(t >> 24);
-                blk[lb.lane] = d;
-            }
+            float4 d;
+            d.x = unorm8(t & 0xffu);
+            d.y = unorm8((t >> 8) & 0xffu);
+            d.z = unorm8((t >> 16) & 0xffu);
+            d.w = unorm8(t >> 24);
+            blk[lb.lane] = d;
             wave_sync();
             const int slot = act ? (dz * 4 + dy) * 4 + dx : 0;
             const float4* q = blk + slot;
-            float4 t0, t1, t2, t3, t4, t5, t6, t7;
-            if (VCT_ABLATE & 2) {
-                t0 = make_float4(a, b, c, u); t1 = make_float4(b, c, a, v); t2 = make_float4(c, a, b, w); t3 = t0;
-                t4 = t1; t5 = t2; t6 = t0; t7 = t1;
-            } else {
-                t0 = q[0]; t1 = q[1]; t2 = q[4]; t3 = q[5];
-                t4 = q[16]; t5 = q[17]; t6 = q[20]; t7 = q[21];
-            }
+            const float4 t0 = q[0], t1 = q[1], t2 = q[4], t3 = q[5];
+            const float4 t4 = q[16], t5 = q[17], t6 = q[20], t7 = q[21];
             wave_sync();
-            if (VCT_ABLATE & 8) { r.x = t0.x + t7.y; r.y = t1.y + t6.x; r.z = t2.z + t5.w; r.w = t3.w * 0.01f + t4.x * 0.01f; return r; }
             const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
             const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
             const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
@@ -248,30 +215,14 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             my0 = vct_spread3((uint32_t)cj0) << 1; my1 = vct_spread3((uint32_t)cj1) << 1;
             mz0 = vct_spread3((uint32_t)ck0) << 2; mz1 = vct_spread3((uint32_t)ck1) << 2;
         }
-        const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
-        const float wg[8] = {(a0 * b0) * c0, (a * b0) * c0, (a0 * b) * c0, (a * b) * c0,
-                             (a0 * b0) * c,  (a * b0) * c,  (a0 * b) * c,  (a * b) * c};
-        if (FCHAIN) {
-            const float4* __restrict__ fb = fchain + lv.off;
-            float4 f[8];
-            f[0] = fb[mx0 | my0 | mz0]; f[1] = fb[mx1 | my0 | mz0];
-            f[2] = fb[mx0 | my1 | mz0]; f[3] = fb[mx1 | my1 | mz0];
-            f[4] = fb[mx0 | my0 | mz1]; f[5] = fb[mx1 | my0 | mz1];
-            f[6] = fb[mx0 | my1 | mz1]; f[7] = fb[mx1 | my1 | mz1];
-            r.x = wg[0] * f[0].x; r.y = wg[0] * f[0].y; r.z = wg[0] * f[0].z; r.w = wg[0] * f[0].w;
-#pragma unroll
-            for (int i = 1; i < 8; ++i) {
-                r.x = fmaf(wg[i], f[i].x, r.x);
-                r.y = fmaf(wg[i], f[i].y, r.y);
-                r.z = fmaf(wg[i], f[i].z, r.z);
-                r.w = fmaf(wg[i], f[i].w, r.w);
-            }
-        } else {
         uint32_t t[8];
         t[0] = base[mx0 | my0 | mz0]; t[1] = base[mx1 | my0 | mz0];
         t[2] = base[mx0 | my1 | mz0]; t[3] = base[mx1 | my1 | mz0];
         t[4] = base[mx0 | my0 | mz1]; t[5] = base[mx1 | my0 | mz1];
         t[6] = base[mx0 | my1 | mz1]; t[7] = base[mx1 | my1 | mz1];
+        const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
+        const float wg[8] = {(a0 * b0) * c0, (a * b0) * c0, (a0 * b) * c0, (a * b) * c0,
+                             (a0 * b0) * c,  (a * b0) * c,  (a0 * b) * c,  (a * b) * c};
         r.x = wg[0] * unorm8(t[0] & 0xffu);
         r.y = wg[0] * unorm8((t[0] >> 8) & 0xffu);
         r.z = wg[0] * unorm8((t[0] >> 16) & 0xffu);
@@ -282,7 +233,6 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             r.y = fmaf(wg[i], unorm8((t[i] >> 8) & 0xffu), r.y);
             r.z = fmaf(wg[i], unorm8((t[i] >> 16) & 0xffu), r.z);
             r.w = fmaf(wg[i], unorm8(t[i] >> 24), r.w);
-        }
         }
       }
     }
@@ -417,7 +367,7 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
     return s;
 }
 
-template <bool WRAP, bool FASTDIV, bool COOP, bool ANISO = false, bool FCHAIN = false>
+template <bool WRAP, bool FASTDIV, bool COOP, bool ANISO = false>
 __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3 start, F3 dir,
                                          const VctStep* tab_global, int n,
                                          float4* __restrict__ blk, const LaneBlock& lb,
@@ -432,7 +382,7 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
     }
     VctStep nxt = load_step(tab, 0);
     for (int k = 0; k < n; ++k) {
-        const bool act = (VCT_ABLATE & 64) ? alive : alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
+        const bool act = alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
         const unsigned long long live = ballot64(act);
         if (live == 0ull) break;
         if (VCT_STATS) { ++ms.wave_steps; ms.lane_steps += (uint32_t)__popcll(live); }
@@ -447,266 +397,16 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
         const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
         const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
         F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, blk, lb, ac, ms)
-                                         : sample_level<WRAP, COOP, FCHAIN>(p.chain, st.l1, ux, uy, uz, act, blk, lb, ms, p.chain_f);
-        if (st.two_levels && !(VCT_ABLATE & 16)) {
-            const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, blk + 64, lb, ac, ms)
-                                : sample_level<WRAP, COOP, FCHAIN>(p.chain, st.l2, ux, uy, uz, act, blk + 64, lb, ms, p.chain_f);
-            const float g = 1.0f - st.frac;
-            vc.x = fmaf(st.frac, t2.x, g * vc.x);
-            vc.y = fmaf(st.frac, t2.y, g * vc.y);
-            vc.z = fmaf(st.frac, t2.z, g * vc.z);
-            vc.w = fmaf(st.frac, t2.w, g * vc.w);
-        }
-        if (act) {
-            const float oma = 1.0f - alpha;
-            cr = fmaf(oma, vc.x, cr);                                                  // :100
-            cg = fmaf(oma, vc.y, cg);
-            cb = fmaf(oma, vc.z, cb);
-            occ = occ + div_const<FASTDIV>(oma * vc.w, st.occ_den, st.occ_rcp);        // :101
-            alpha = fmaf(oma, vc.w, alpha);                                            // :102
-            ++steps;
-        }
-    }
-    steps_out = steps;
-    return {cr, cg, cb, occ};
-}
-
-// ---- software-pipelined march over the decoded chain ----------------------------------------------
-// Ablation (profiles/r02c_ablation.txt) shows the march is bound by the latency of its texel loads, not
-// by VALU issue: with the cooperative block's loads removed and every other instruction kept, the kernel
-// runs 42 % faster.  A wave's chain per step is load -> wait -> gather -> interpolate, twice (two mip
-// levels), and 6 waves per SIMD do not cover two dependent L2/Infinity-Cache round trips per step.
-// The texel addresses of step k+1 depend only on the pixel and the step table -- not on what step k
-// samples -- so this march issues the block loads of step k+1 (LDS-DMA straight into a second pair of
-// LDS slabs: no VGPRs are held by loads in flight) BEFORE it gathers and interpolates step k.  What is
-// kept per lane for a prefetched level is its slot inside the block and its three filter fractions.
-// The anchor of a prefetched block is chosen among the lanes live at step k (a superset of the lanes
-// live at step k+1), which can only make the "every footprint inside the block" test more conservative;
-// any block that contains a lane's footprint returns the same eight texels, so results are unchanged.
-// Levels whose footprints do not fit one block are sampled per lane when the step is consumed.
-typedef __attribute__((address_space(3))) char* LdsBytes;
-
-// one 16-byte-per-lane LDS-DMA: LDS destination = lds_dst + lane * 16 (M0 carries the wave-uniform base;
-// the compiler does not model M0 across an asm statement, so it is saved and restored inside it)
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-struct LevelState {        // a prefetched level, per lane (coop flag is wave-uniform)
-    float a, b, c;         // trilinear fractions
-    int slot;              // first texel of the lane's footprint inside the 4x4x4 block
-};
-
-// coordinates + anchor + cooperative test; if the block covers every live footprint, issue its DMA
-template <bool WRAP>
-__device__ __forceinline__ bool prefetch_level(const VctTraceParams& p, const VctLevelRef lv, float ux, float uy,
-                                               float uz, unsigned long long am, bool act, uint32_t lds_dst,
-                                               const LaneBlock& lb, LevelState& ls) {
-    const int m = lv.m;
-    const float fN = lv.fN;
-    const float u = fmaf(ux, fN, -0.5f), v = fmaf(uy, fN, -0.5f), w = fmaf(uz, fN, -0.5f);
-    const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
-    ls.a = u - fu; ls.b = v - fv; ls.c = w - fw;
-    const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
-    const int src = ((am >> 27) & 1ull) ? 27 : (int)__ffsll((long long)am) - 1;
-    const int ax = __builtin_amdgcn_readlane(i0, src) - 1;
-    const int ay = __builtin_amdgcn_readlane(j0, src) - 1;
-    const int az = __builtin_amdgcn_readlane(k0, src) - 1;
-    const int dx = i0 - ax, dy = j0 - ay, dz = k0 - az;
-    const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
-    bool coop = ballot64(act && far > 2u) == 0ull;
-    int dxx = dx, dyy = dy, dzz = dz;
-    if (VCT_ABLATE & 1) { coop = true; dxx &= 1; dyy &= 1; dzz &= 1; }
-    if (coop) {
-        const uint32_t MX = lv.mask_x, MY = MX << 1, MZ = MX << 2;
-        uint32_t idx;
-        if (WRAP) {
-            const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)m);
-            const uint32_t say = vct_spread3((uint32_t)ay & (uint32_t)m) << 1;
-            const uint32_t saz = vct_spread3((uint32_t)az & (uint32_t)m) << 2;
-            idx = (((sax | ~MX) + lb.sbx) & MX) | (((say | ~MY) + lb.sby) & MY) |
-                  (((saz | ~MZ) + lb.sbz) & MZ);
-        } else {
-            const int x = min(max(ax + (lb.lane & 3), 0), m);
-            const int y = min(max(ay + ((lb.lane >> 2) & 3), 0), m);
-            const int z = min(max(az + (lb.lane >> 4), 0), m);
-            idx = vct_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
-        }
-        if (!(VCT_ABLATE & 4)) glds16(p.chain_f + lv.off + idx, lds_dst);
-        ls.slot = act ? (dzz * 4 + dyy) * 4 + dxx : 0;
-    }
-    return coop;
-}
-
-// gather + trilinear interpolation of a prefetched level (its DMA has landed)
-__device__ __forceinline__ F4 consume_level(const float4* __restrict__ blk, const LevelState& ls) {
-    const float4* q = blk + ls.slot;
-    const float a = ls.a, b = ls.b, c = ls.c;
-    float4 t0, t1, t2, t3, t4, t5, t6, t7;
-    if (VCT_ABLATE & 2) {
-        t0 = make_float4(a, b, c, a); t1 = make_float4(b, c, a, b); t2 = make_float4(c, a, b, c); t3 = t0;
-        t4 = t1; t5 = t2; t6 = t0; t7 = t1;
-    } else {
-        t0 = q[0]; t1 = q[1]; t2 = q[4]; t3 = q[5];
-        t4 = q[16]; t5 = q[17]; t6 = q[20]; t7 = q[21];
-    }
-    const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
-    const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
-    const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
-    const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
-    F4 r;
-#define VCT_ACC(ch)                                                                           \
-    r.ch = w0 * t0.ch;                                                                        \
-    r.ch = fmaf(w1, t1.ch, r.ch); r.ch = fmaf(w2, t2.ch, r.ch); r.ch = fmaf(w3, t3.ch, r.ch); \
-    r.ch = fmaf(w4, t4.ch, r.ch); r.ch = fmaf(w5, t5.ch, r.ch); r.ch = fmaf(w6, t6.ch, r.ch); \
-    r.ch = fmaf(w7, t7.ch, r.ch);
-    VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
-#undef VCT_ACC
-    return r;
-}
-
-template <bool WRAP, bool FASTDIV>
-__device__ __forceinline__ F4 cone_march_pipe(const VctTraceParams& p, bool alive, F3 start, F3 dir,
-                                              const VctStep* tab_global, int n,
-                                              float4* __restrict__ blk /* [2 buffers][2 levels][64] */,
-                                              const LaneBlock& lb, int& steps_out, MarchStats& ms) {
-    const StepTable tab = (StepTable)tab_global;
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f, alpha = 0.0f, occ = 0.0f;
-    int steps = 0;
-    const uint32_t lds0 = (uint32_t)(unsigned long)(LdsBytes)blk;
-    auto coords = [&](float dist, float& ux, float& uy, float& uz) {
-        // trace.fs:98 + :61-63 (see cone_march)
-        const float px = start.x + dir.x * dist;
-        const float py = start.y + dir.y * dist;
-        const float pz = start.z + dir.z * dist;
-        ux = fmaf(div_const<FASTDIV>(px, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-    };
-    VctStep st = load_step(tab, 0);
-    LevelState s1 = {0.0f, 0.0f, 0.0f, 0}, s2 = {0.0f, 0.0f, 0.0f, 0};
-    bool coop1 = false, coop2 = false;
-    unsigned long long live = ballot64(alive);
-    if (live != 0ull) {                                    // prologue: the loads of step 0
-        float ux, uy, uz;
-        coords(st.dist, ux, uy, uz);
-        coop1 = prefetch_level<WRAP>(p, st.l1, ux, uy, uz, live, alive, lds0, lb, s1);
-        if (st.two_levels) coop2 = prefetch_level<WRAP>(p, st.l2, ux, uy, uz, live, alive, lds0 + 1024u, lb, s2);
-    }
-    for (int k = 0; k < n; ++k) {
-        const bool act = (VCT_ABLATE & 64) ? alive : alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
-        live = ballot64(act);
-        if (live == 0ull) break;
-        if (VCT_STATS) { ++ms.wave_steps; ms.lane_steps += (uint32_t)__popcll(live); }
-        const VctStep cur = st;
-        const LevelState c1 = s1, c2 = s2;
-        const bool cc1 = coop1, cc2 = coop2;
-        // ---- issue the loads of step k+1 (buffer (k+1)&1) ----
-        int issued = 0;
-        if (k + 1 < n) {
-            st = load_step(tab, k + 1);
-            const uint32_t dst = lds0 + (((uint32_t)(k + 1) & 1u) << 11);
-            float ux, uy, uz;
-            coords(st.dist, ux, uy, uz);
-            coop1 = prefetch_level<WRAP>(p, st.l1, ux, uy, uz, live, act, dst, lb, s1);
-            issued = coop1 ? 1 : 0;
-            coop2 = false;
-            if (st.two_levels) {
-                coop2 = prefetch_level<WRAP>(p, st.l2, ux, uy, uz, live, act, dst + 1024u, lb, s2);
-                issued += coop2 ? 1 : 0;
-            }
-        }
-        // ---- the loads of step k have landed once at most `issued` younger ones are outstanding ----
-        if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (issued == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync();
-        const float4* cb0 = blk + (((uint32_t)k & 1u) << 7);
-        float fx = 0.0f, fy = 0.0f, fz = 0.0f;
-        if (!(cc1 && (cc2 || !cur.two_levels))) coords(cur.dist, fx, fy, fz);   // a level needs the per-lane path
-        F4 vc;
-        if (cc1) { vc = consume_level(cb0, c1); if (VCT_STATS) ++ms.coop_hit; }
-        else vc = sample_level<WRAP, false, true>(p.chain, cur.l1, fx, fy, fz, act, nullptr, lb, ms, p.chain_f);
-        if (cur.two_levels) {
-            F4 t2;
-            if (cc2) { t2 = consume_level(cb0 + 64, c2); if (VCT_STATS) ++ms.coop_hit; }
-            else t2 = sample_level<WRAP, false, true>(p.chain, cur.l2, fx, fy, fz, act, nullptr, lb, ms, p.chain_f);
-            const float g = 1.0f - cur.frac;
-            vc.x = fmaf(cur.frac, t2.x, g * vc.x);
-            vc.y = fmaf(cur.frac, t2.y, g * vc.y);
-            vc.z = fmaf(cur.frac, t2.z, g * vc.z);
-            vc.w = fmaf(cur.frac, t2.w, g * vc.w);
-        }
-        wave_sync();            // the gathers above are done before a later DMA may overwrite this buffer
-        if (act) {
-            const float oma = 1.0f - alpha;
-            cr = fmaf(oma, vc.x, cr);                                                  // :100
-            cg = fmaf(oma, vc.y, cg);
-            cb = fmaf(oma, vc.z, cb);
-            occ = occ + div_const<FASTDIV>(oma * vc.w, cur.occ_den, cur.occ_rcp);      // :101
-            alpha = fmaf(oma, vc.w, alpha);                                            // :102
-            ++steps;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA of this cone outlives it
-    steps_out = steps;
-    return {cr, cg, cb, occ};
-}
-
-// Intra-step variant: both levels' block DMAs of a step are issued before either is consumed (halves the
-// exposed load latency per step, no state carried across steps, no speculation).
-template <bool WRAP, bool FASTDIV>
-__device__ __forceinline__ F4 cone_march_dual(const VctTraceParams& p, bool alive, F3 start, F3 dir,
-                                              const VctStep* tab_global, int n,
-                                              float4* __restrict__ blk /* [2 levels][64] */,
-                                              const LaneBlock& lb, int& steps_out, MarchStats& ms) {
-    const StepTable tab = (StepTable)tab_global;
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f, alpha = 0.0f, occ = 0.0f;
-    int steps = 0;
-    const uint32_t lds0 = (uint32_t)(unsigned long)(LdsBytes)blk;
-    VctStep nxt = load_step(tab, 0);
-    for (int k = 0; k < n; ++k) {
-        const bool act = (VCT_ABLATE & 64) ? alive : alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
-        const unsigned long long live = ballot64(act);
-        if (live == 0ull) break;
-        if (VCT_STATS) { ++ms.wave_steps; ms.lane_steps += (uint32_t)__popcll(live); }
-        const VctStep st = nxt;
-        nxt = load_step(tab, k + 1 < n ? k + 1 : k);
-        const float px = start.x + dir.x * st.dist;
-        const float py = start.y + dir.y * st.dist;
-        const float pz = start.z + dir.z * st.dist;
-        const float ux = fmaf(div_const<FASTDIV>(px, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        LevelState s1, s2;
-        const bool c1 = prefetch_level<WRAP>(p, st.l1, ux, uy, uz, live, act, lds0, lb, s1);
-        bool c2 = false;
-        if (st.two_levels) c2 = prefetch_level<WRAP>(p, st.l2, ux, uy, uz, live, act, lds0 + 1024u, lb, s2);
-        if (c1 && c2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync();
-        F4 vc;
-        if (c1) { vc = consume_level(blk, s1); if (VCT_STATS) ++ms.coop_hit; }
-        else vc = sample_level<WRAP, false, true>(p.chain, st.l1, ux, uy, uz, act, nullptr, lb, ms, p.chain_f);
+                                         : sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, blk, lb, ms);
         if (st.two_levels) {
-            F4 t2;
-            if (c2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wave_sync();
-                t2 = consume_level(blk + 64, s2);
-                if (VCT_STATS) ++ms.coop_hit;
-            } else {
-                t2 = sample_level<WRAP, false, true>(p.chain, st.l2, ux, uy, uz, act, nullptr, lb, ms, p.chain_f);
-            }
+            const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, blk + 64, lb, ac, ms)
+                                : sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, blk + 64, lb, ms);
             const float g = 1.0f - st.frac;
             vc.x = fmaf(st.frac, t2.x, g * vc.x);
             vc.y = fmaf(st.frac, t2.y, g * vc.y);
             vc.z = fmaf(st.frac, t2.z, g * vc.z);
             vc.w = fmaf(st.frac, t2.w, g * vc.w);
         }
-        wave_sync();
         if (act) {
             const float oma = 1.0f - alpha;
             cr = fmaf(oma, vc.x, cr);                                                  // :100
@@ -728,9 +428,9 @@ __device__ __forceinline__ uint32_t pack_half2(float a, float b) {
 
 __device__ __forceinline__ void flush_stats(const VctTraceParams& p, const MarchStats& ms, int lane) {
     if (VCT_STATS && p.stats && lane == 0) {
-        const uint32_t v[7] = {ms.wave_steps, ms.lane_steps, ms.coop_zero, ms.coop_hit, ms.fallback,
-                               ms.fallback_lanes, ms.brick_skip};
-        for (int i = 0; i < 7; ++i)
+        const uint32_t v[6] = {ms.wave_steps, ms.lane_steps, ms.coop_zero, ms.coop_hit, ms.fallback,
+                               ms.fallback_lanes};
+        for (int i = 0; i < 6; ++i)
             if (v[i]) atomicAdd(p.stats + i, (unsigned long long)v[i]);
     }
 }
@@ -771,12 +471,6 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
 // balances the tail best (0.822 -> 0.800 ms against 4 waves; profiles/r01g_ab_waves_per_block.txt)
 #ifndef VCT_WAVES_PER_BLOCK
 #define VCT_WAVES_PER_BLOCK 1
-#endif
-#ifndef VCT_PIPE
-#define VCT_PIPE 1                // 1: software-pipelined march over the decoded chain (cone_march_pipe)
-#endif
-#ifndef VCT_PIPE_MIN_WAVES
-#define VCT_PIPE_MIN_WAVES 5      // the pipelined march keeps a prefetched step's state live: no spills inside the loop
 #endif
 #ifndef VCT_TRACE_MIN_WAVES
 #define VCT_TRACE_MIN_WAVES 6     // waves per SIMD the register allocator must leave room for (<= 80 VGPRs)
@@ -945,12 +639,10 @@ k_trace_tile(const VctTraceParams p) {
 
 // (the anisotropic instantiation carries three samples' worth of state: it gets 128 VGPRs instead of
 // spilling under the 80 of the default kernel)
-template <bool WRAP, bool FASTDIV, bool ANISO, bool FCHAIN>
-__global__ void __launch_bounds__(64 * VCT_SPLIT, ANISO ? 4 : ((FCHAIN && VCT_PIPE) ? VCT_PIPE_MIN_WAVES : VCT_TRACE_MIN_WAVES))
+template <bool WRAP, bool FASTDIV, bool ANISO>
+__global__ void __launch_bounds__(64 * VCT_SPLIT, ANISO ? 4 : VCT_TRACE_MIN_WAVES)
 k_trace_tile_split(const VctTraceParams p) {
-    // per wave: level-1 slab, level-2 slab; + their "-axis" slabs (ANISO) or the second buffer of the
-    // software-pipelined march (FCHAIN)
-    __shared__ float4 lds_blk[VCT_SPLIT][(ANISO || FCHAIN) ? 4 : 2][64];
+    __shared__ float4 lds_blk[VCT_SPLIT][ANISO ? 4 : 2][64];   // per wave: level-1 slab, level-2 slab (+ their "-axis" slabs)
     __shared__ float4 lds_cone[7][64];
     __shared__ int lds_done;
     const int lane = threadIdx.x & 63;
@@ -1005,12 +697,8 @@ k_trace_tile_split(const VctTraceParams p) {
                         k0.z * ddx + k1.z * ddy + k2.z * ddz);
             dir = normalize3(dir);
             int st;
-            const F4 c = (FCHAIN && VCT_PIPE == 2) ? cone_march_dual<WRAP, FASTDIV>(p, alive, start, dir, p.steps_diffuse, p.n_diffuse,
-                                                                 blk, lb, st, ms)
-                       : (FCHAIN && VCT_PIPE) ? cone_march_pipe<WRAP, FASTDIV>(p, alive, start, dir, p.steps_diffuse, p.n_diffuse,
-                                                                 blk, lb, st, ms)
-                                : cone_march<WRAP, FASTDIV, true, ANISO, FCHAIN>(p, alive, start, dir, p.steps_diffuse,
-                                                                                 p.n_diffuse, blk, lb, st, ms);
+            const F4 c = cone_march<WRAP, FASTDIV, true, ANISO>(p, alive, start, dir, p.steps_diffuse,
+                                                                p.n_diffuse, blk, lb, st, ms);
             total += st;
             lds_cone[i][lane] = make_float4(c.x, c.y, c.z, c.w);
             if (p.dbg_cones && alive) {
@@ -1027,12 +715,8 @@ k_trace_tile_split(const VctTraceParams p) {
         const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
         const F3 Rd = normalize3(reflect3(f3(E.x * -1.0f, E.y * -1.0f, E.z * -1.0f), N));  // :217
         int st6;
-        const F4 sc = (FCHAIN && VCT_PIPE == 2) ? cone_march_dual<WRAP, FASTDIV>(p, alive, start, Rd, p.steps_specular, p.n_specular,
-                                                              blk, lb, st6, ms)
-                        : (FCHAIN && VCT_PIPE) ? cone_march_pipe<WRAP, FASTDIV>(p, alive, start, Rd, p.steps_specular, p.n_specular,
-                                                              blk, lb, st6, ms)
-                             : cone_march<WRAP, FASTDIV, true, ANISO, FCHAIN>(p, alive, start, Rd, p.steps_specular,
-                                                                              p.n_specular, blk, lb, st6, ms);
+        const F4 sc = cone_march<WRAP, FASTDIV, true, ANISO>(p, alive, start, Rd, p.steps_specular,
+                                                             p.n_specular, blk, lb, st6, ms);
         total += st6;
         lds_cone[6][lane] = make_float4(sc.x, sc.y, sc.z, sc.w);
         if (p.dbg_cones && alive) {
@@ -1177,7 +861,7 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
     lb.lane = lane;                                                          \
     lb.sbx = vct_spread3((uint32_t)lane & 3u);                               \
     lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;                   \
-    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;                   \
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;                          \
     MarchStats ms = {};
 
 // compaction of one brick into `list` (LDS); returns the number of occupied voxels
@@ -1229,7 +913,7 @@ k_bounce_list(const VctTraceParams p) {
 #ifndef VCT_BOUNCE_MIN_WAVES
 #define VCT_BOUNCE_MIN_WAVES 4     // the per-voxel frame + attribute state spills under the trace kernel's 80 VGPRs (0.551 -> 0.539 ms at 512^3)
 #endif
-template <bool WRAP, bool FASTDIV, bool FCHAIN>
+template <bool WRAP, bool FASTDIV>
 __global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_BOUNCE_MIN_WAVES)
 k_bounce_march(const VctTraceParams p) {
     VCT_BOUNCE_SETUP
@@ -1243,7 +927,7 @@ k_bounce_march(const VctTraceParams p) {
         const size_t vox = alive ? e : (first != 0xffffffffu ? first : 0u);
         int total;
         bounce_voxels(p, alive, vox, total, [&](bool al, F3 start, F3 dir, int& st) {
-            return cone_march<WRAP, FASTDIV, true, false, FCHAIN>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st, ms);
+            return cone_march<WRAP, FASTDIV, true>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st, ms);
         });
         wave_steps += (unsigned long long)total;
     }
@@ -1251,7 +935,7 @@ k_bounce_march(const VctTraceParams p) {
         atomicAdd(p.step_counter + ((blockIdx.x * VCT_WAVES_PER_BLOCK + wave) & (VCT_STEP_COUNTERS - 1)), wave_steps);
 }
 
-template <bool WRAP, bool FASTDIV, bool FCHAIN>
+template <bool WRAP, bool FASTDIV>
 __global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_BOUNCE_MIN_WAVES)
 k_bounce_bricks(const VctTraceParams p) {
     VCT_BOUNCE_SETUP
@@ -1268,7 +952,7 @@ k_bounce_bricks(const VctTraceParams p) {
             const size_t vox = (size_t)b * 512 + (alive ? list[base + lane] : list[base]);
             int total;
             bounce_voxels(p, alive, vox, total, [&](bool al, F3 start, F3 dir, int& st) {
-                return cone_march<WRAP, FASTDIV, true, false, FCHAIN>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st, ms);
+                return cone_march<WRAP, FASTDIV, true>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st, ms);
             });
             wave_steps += (unsigned long long)total;
         }
@@ -1293,9 +977,8 @@ hipError_t launch_v(const VctTraceParams& p, int variant, int ntiles, hipStream_
         return variant == 1 ? launch<WRAP, FASTDIV, false>(p, blocks, s) : launch<WRAP, FASTDIV, true>(p, blocks, s);
     }
     const int blocks = ((ntiles + 7) / 8) * 8;
-    if (p.aniso) hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, true, false>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
-    else if (p.chain_f) hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
-    else hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false, false>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+    if (p.aniso) hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+    else hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     return hipGetLastError();
 }
 
@@ -1326,7 +1009,7 @@ hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, h
     return hipGetLastError();
 }
 
-template <bool WRAP, bool FASTDIV, bool FCHAIN>
+template <bool WRAP, bool FASTDIV>
 hipError_t launch_bounce(const VctTraceParams& p, hipStream_t s) {
     uint32_t blocks = (p.nbricks + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
     if (blocks > 256u * 64u) blocks = 256u * 64u;
@@ -1334,21 +1017,17 @@ hipError_t launch_bounce(const VctTraceParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_bounce_list, dim3(blocks), block, 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_bounce_march<WRAP, FASTDIV, FCHAIN>), dim3(256 * 24), block, 0, s, p);
+    hipLaunchKernelGGL((k_bounce_march<WRAP, FASTDIV>), dim3(256 * 24), block, 0, s, p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_bounce_bricks<WRAP, FASTDIV, FCHAIN>), dim3(blocks), block, 0, s, p);
+    hipLaunchKernelGGL((k_bounce_bricks<WRAP, FASTDIV>), dim3(blocks), block, 0, s, p);
     return hipGetLastError();
 }
 
 hipError_t vct_launch_bounce(const VctTraceParams& p, hipStream_t s) {
     if (p.nbricks == 0) return hipSuccess;
-    if (p.chain_f) {
-        if (p.wrap_repeat) return p.fast_div ? launch_bounce<true, true, true>(p, s) : launch_bounce<true, false, true>(p, s);
-        return p.fast_div ? launch_bounce<false, true, true>(p, s) : launch_bounce<false, false, true>(p, s);
-    }
-    if (p.wrap_repeat) return p.fast_div ? launch_bounce<true, true, false>(p, s) : launch_bounce<true, false, false>(p, s);
-    return p.fast_div ? launch_bounce<false, true, false>(p, s) : launch_bounce<false, false, false>(p, s);
+    if (p.wrap_repeat) return p.fast_div ? launch_bounce<true, true>(p, s) : launch_bounce<true, false>(p, s);
+    return p.fast_div ? launch_bounce<false, true>(p, s) : launch_bounce<false, false>(p, s);
 }
 
 // variant 0 (default): cooperative sampler, each tile split over 3 waves; 2: cooperative sampler, one

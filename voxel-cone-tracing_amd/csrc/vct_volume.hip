@@ -40,36 +40,14 @@ __device__ __forceinline__ uint32_t box8(uint32_t rb, uint32_t ga) {
     return rb | (ga << 8);
 }
 
-__device__ __forceinline__ float4 decode_texel(uint32_t t) {
-    float4 d;
-    d.x = vct_unorm8_to_float(t & 0xffu);
-    d.y = vct_unorm8_to_float((t >> 8) & 0xffu);
-    d.z = vct_unorm8_to_float((t >> 16) & 0xffu);
-    d.w = vct_unorm8_to_float(t >> 24);
-    return d;
-}
-
-// The tracer reads a decoded fp32 copy of the chain (exact byte/255 per channel, 16 B per texel) so
-// that a cooperative 4x4x4 block goes from HBM/L2 straight into LDS (global_load_lds_dwordx4) with no
-// per-sample decode.  Dense form for uploads; the mip build below refreshes the copy for exactly the
-// texels it reads or writes.
-__global__ void __launch_bounds__(256)
-k_decode_chain(const uint32_t* __restrict__ src, float4* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = decode_texel(src[i]);
-}
-
 // src: level L (count texels), dst1..3: levels L+1..L+3 (nout of them exist).
-// fsrc / f1..f3 (optional): decoded copies of the same levels; fsrc is refreshed for the texels read
-// (first launch of a chain only: later launches read what the previous one wrote and decoded).
 // Sparse form (level 0 written by the voxelizer): wave w reduces exactly the 8^3 brick w, so bricks
 // that hold nothing now (`now`) and held nothing when the mips were last built (`seen`) are
 // skipped -- their three ancestors are already zero.
 __global__ void __launch_bounds__(256)
 k_mip3(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst1, uint32_t* __restrict__ dst2,
        uint32_t* __restrict__ dst3, uint32_t count, int nout, const uint32_t* __restrict__ now,
-       uint32_t* __restrict__ seen, float4* __restrict__ fsrc, float4* __restrict__ f1,
-       float4* __restrict__ f2, float4* __restrict__ f3) {
+       uint32_t* __restrict__ seen) {
     const uint32_t n1 = count >> 3;
     const uint32_t nthreads_needed = (n1 + 63u) & ~63u;   // whole waves so shuffles are defined
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nthreads_needed;
@@ -93,11 +71,6 @@ k_mip3(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst1, uint32_t* 
             }
             q = box8(rb, ga);
             dst1[t] = q;
-            if (f1) f1[t] = decode_texel(q);
-            if (fsrc) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) fsrc[8 * (size_t)t + i] = decode_texel(v[i]);
-            }
         }
         if (nout < 2) continue;
         uint32_t rb = q & 0x00ff00ffu, ga = (q >> 8) & 0x00ff00ffu;
@@ -106,21 +79,14 @@ k_mip3(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst1, uint32_t* 
         rb += __shfl_xor(rb, 4); ga += __shfl_xor(ga, 4);
         const uint32_t q2 = box8(rb, ga);
         const uint32_t n2 = n1 >> 3;
-        if ((t & 7u) == 0u && (t >> 3) < n2) {
-            dst2[t >> 3] = q2;
-            if (f2) f2[t >> 3] = decode_texel(q2);
-        }
+        if ((t & 7u) == 0u && (t >> 3) < n2) dst2[t >> 3] = q2;
         if (nout < 3) continue;
         rb = q2 & 0x00ff00ffu; ga = (q2 >> 8) & 0x00ff00ffu;
         rb += __shfl_xor(rb, 8); ga += __shfl_xor(ga, 8);
         rb += __shfl_xor(rb, 16); ga += __shfl_xor(ga, 16);
         rb += __shfl_xor(rb, 32); ga += __shfl_xor(ga, 32);
         const uint32_t n3 = n2 >> 3;
-        if ((t & 63u) == 0u && (t >> 6) < n3) {
-            const uint32_t q3 = box8(rb, ga);
-            dst3[t >> 6] = q3;
-            if (f3) f3[t >> 6] = decode_texel(q3);
-        }
+        if ((t & 63u) == 0u && (t >> 6) < n3) dst3[t >> 6] = box8(rb, ga);
     }
 }
 
@@ -204,15 +170,9 @@ hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N
     return hipGetLastError();
 }
 
-hipError_t vct_launch_decode_chain(const uint32_t* chain, float4* chain_f, size_t ntexels, hipStream_t s) {
-    hipLaunchKernelGGL(k_decode_chain, dim3(grid_for(ntexels, 256)), dim3(256), 0, s, chain, chain_f, ntexels);
-    return hipGetLastError();
-}
-
-hipError_t vct_launch_build_mips(uint32_t* chain, float4* chain_f, int V, const uint32_t* bricks_now,
-                                 uint32_t* bricks_seen, hipStream_t s) {
+hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_now, uint32_t* bricks_seen,
+                                 hipStream_t s) {
     const int nlev = vct_ilog2(V) + 1;
-    if (nlev == 1 && chain_f) return vct_launch_decode_chain(chain, chain_f, 1, s);
     for (int L = 0; L + 1 < nlev; L += 3) {
         const int nout = (nlev - 1 - L) < 3 ? (nlev - 1 - L) : 3;
         const uint32_t n = (uint32_t)(V >> L);
@@ -223,13 +183,8 @@ hipError_t vct_launch_build_mips(uint32_t* chain, float4* chain_f, int V, const 
         uint32_t* d3 = nout >= 3 ? chain + vct_level_offset(V, L + 3) : nullptr;
         const size_t threads_needed = ((size_t)(count >> 3) + 63) & ~(size_t)63;
         const bool sparse = L == 0 && bricks_now && bricks_seen && V >= 8;
-        float4* fs = chain_f && L == 0 ? chain_f : nullptr;
-        float4* f1 = chain_f ? chain_f + vct_level_offset(V, L + 1) : nullptr;
-        float4* f2 = chain_f && nout >= 2 ? chain_f + vct_level_offset(V, L + 2) : nullptr;
-        float4* f3 = chain_f && nout >= 3 ? chain_f + vct_level_offset(V, L + 3) : nullptr;
         hipLaunchKernelGGL(k_mip3, dim3(grid_for(threads_needed, 256)), dim3(256), 0, s, src, d1,
-                           d2, d3, count, nout, sparse ? bricks_now : nullptr, sparse ? bricks_seen : nullptr,
-                           fs, f1, f2, f3);
+                           d2, d3, count, nout, sparse ? bricks_now : nullptr, sparse ? bricks_seen : nullptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

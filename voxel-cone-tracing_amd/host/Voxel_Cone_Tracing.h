@@ -178,6 +178,12 @@ struct Voxel_Cone_Tracing {
     bool ShowDiffuse = true, ShowIndirectDiffuse = true, ShowSpecular = true,
          ShowIndirectSpecular = true, ShowAmbientOcclusion = true;           // VCT.h:51 (never uploaded there either)
     float AmbientFactor = 0.1f;                                              // VCT.h:53
+    // Multi-GPU (no reference counterpart, R/main.cpp drives one GL context): one process per GPU, each with
+    // its own Voxel_Cone_Tracing; set Rank / World / Device and the 128-byte RCCL id (vct_comm_get_unique_id
+    // on rank 0, shared out of band) before init.  Render() then rasterises and traces only this rank's
+    // slab of tile rows and rank 0's Frame() receives the whole frame through ONE ncclGather.
+    int Rank = 0, World = 1, Device = -1;
+    unsigned char CommId[VCT_COMM_ID_BYTES] = {0};
     int Bounces = 1;    // 2 = re-inject the lit voxels once (the "2 bounces" of the reference's README.md:16,
                         // which its code does not implement: VCT.h:138-139 injects once); set before init
 
@@ -204,7 +210,10 @@ struct Voxel_Cone_Tracing {
         cfg.shadow_map_size = (int32_t)ShadowMapSize;
         cfg.ambient_factor = AmbientFactor;
         cfg.voxel_attributes = Bounces >= 2 ? 1 : 0;
+        cfg.device = Device;
         if (!check(vct_create(&cfg, &ctx), "vct_create")) return;
+        if (World > 1 || Rank != 0 || CommId[0] || CommId[1])
+            if (!check(vct_comm_init(ctx, CommId, Rank, World), "vct_comm_init")) return;
         if (!model.Load(model_path)) { last_status = VCT_ERR_INVALID; return; }
 
         // VCT.h:84-86 and :128-134 (the projections are kept as public data; the HIP voxelizer maps
@@ -244,6 +253,18 @@ struct Voxel_Cone_Tracing {
         hc.z_near = 0.1f; hc.z_far = 1000.0f;                                              // VCT.h:162
         float vp[16];
         vcth_camera_view_proj(&hc, screen_width, screen_height, vp);                       // VCT.h:161-163
+        int32_t row0 = 0, row1 = 0;
+        if (vct_comm_slab(ctx, &row0, &row1) == VCT_OK) {       // multi-GPU: this rank's slab, one gather
+            if (!check(vct_render_gbuffer_rows(ctx, vp, row0, row1), "vct_render_gbuffer_rows")) return;
+            if (!check(vct_frame_step(ctx), "vct_frame_step")) return;
+            if (Rank == 0) {
+                FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
+                check(vct_comm_download_frame(ctx, FrameRGBA16F.data()), "vct_comm_download_frame");
+            } else {
+                check(vct_comm_sync(ctx), "vct_comm_sync");
+            }
+            return;
+        }
         if (!check(vct_render_gbuffer(ctx, vp), "vct_render_gbuffer")) return;
         FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
         check(vct_trace_current(ctx, FrameRGBA16F.data(), VCT_MEM_HOST), "vct_trace_current");

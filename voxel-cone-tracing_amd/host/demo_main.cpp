@@ -5,12 +5,22 @@
 // optionally writes it as a tonemapped PPM.
 //
 //   vct_demo [--scene procedural:atrium|procedural:cornell] [--voxels 128] [--size 1280x720]
-//            [--shadow 4096] [--frames 3] [--bounces 1|2] [--ppm out.ppm]
+//            [--shadow 4096] [--frames 3] [--bounces 1|2] [--ppm out.ppm] [--gpus N]
+//
+// --gpus N: the frame is cut into N screen-tile slabs, one process per GPU (this program re-launches
+// itself N times BEFORE anything touches a GPU; rank r uses device r), each rank rasterises and traces its
+// slab, rank 0 receives the frame through one ncclGather per frame and prints / writes it.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <chrono>
+#include <string>
+#include <vector>
 
 #include "Voxel_Cone_Tracing.h"
 
@@ -26,10 +36,50 @@ static float half_to_float(uint16_t h) {
     return s ? -f : f;
 }
 
+// parent of a multi-GPU run: start one child per rank (fork + exec of this binary; the parent never
+// initialises a GPU) and wait for them
+static int launch_ranks(int gpus, int argc, char** argv) {
+    char idfile[64];
+    snprintf(idfile, sizeof(idfile), "/tmp/vct_demo_id_%d", (int)getpid());
+    unlink(idfile);
+    std::vector<pid_t> kids;
+    for (int r = 0; r < gpus; ++r) {
+        pid_t pid = fork();
+        if (pid == 0) {
+            std::vector<std::string> a(argv, argv + argc);
+            a.push_back("--rank"); a.push_back(std::to_string(r));
+            a.push_back("--idfile"); a.push_back(idfile);
+            std::vector<char*> av;
+            for (auto& x : a) av.push_back(const_cast<char*>(x.c_str()));
+            av.push_back(nullptr);
+            execv("/proc/self/exe", av.data());
+            perror("execv");
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t k : kids) {
+        int st = 0;
+        waitpid(k, &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 5;
+    }
+    unlink(idfile);
+    return rc;
+}
+
 int main(int argc, char** argv) {
     int w = SCREEN_WIDTH, h = SCREEN_HEIGHT, frames = 3, voxels = 128, shadow = 4096, bounces = 1;
+    int gpus = 0, rank = -1;
     const char* scene = "procedural:atrium";
     const char* ppm = nullptr;
+    const char* idfile = nullptr;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--gpus")) gpus = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--rank")) rank = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--idfile")) idfile = argv[i + 1];
+    }
+    if (gpus > 0 && rank < 0) return launch_ranks(gpus, argc, argv);
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--scene")) scene = argv[i + 1];
         else if (!strcmp(argv[i], "--voxels")) voxels = atoi(argv[i + 1]);
@@ -55,6 +105,24 @@ int main(int argc, char** argv) {
     voxel_cone_tracing.ShadowMapSize = (unsigned)shadow;
     voxel_cone_tracing.model_path = scene;
     voxel_cone_tracing.Bounces = bounces;
+    if (gpus > 0) {                                         // a rank of a multi-GPU run
+        voxel_cone_tracing.Rank = rank;
+        voxel_cone_tracing.World = gpus;
+        voxel_cone_tracing.Device = rank;
+        const std::string tmp = std::string(idfile) + ".tmp";
+        if (rank == 0) {                                    // create the RCCL id, publish it atomically
+            if (vct_comm_get_unique_id(voxel_cone_tracing.CommId) != VCT_OK) { printf("%s\n", vct_last_error(nullptr)); return 6; }
+            FILE* fp = fopen(tmp.c_str(), "wb");
+            if (!fp || fwrite(voxel_cone_tracing.CommId, 1, VCT_COMM_ID_BYTES, fp) != VCT_COMM_ID_BYTES) return 6;
+            fclose(fp);
+            rename(tmp.c_str(), idfile);
+        } else {
+            FILE* fp = nullptr;
+            for (int tries = 0; tries < 6000 && !(fp = fopen(idfile, "rb")); ++tries) usleep(10000);
+            if (!fp || fread(voxel_cone_tracing.CommId, 1, VCT_COMM_ID_BYTES, fp) != VCT_COMM_ID_BYTES) return 6;
+            fclose(fp);
+        }
+    }
     voxel_cone_tracing.init_voxel_cone_tracing();           // R/main.cpp:68
     if (voxel_cone_tracing.last_status != VCT_OK) return 2;
 
@@ -67,6 +135,8 @@ int main(int argc, char** argv) {
         if (voxel_cone_tracing.last_status != VCT_OK) return 3;
     }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (gpus > 0 && rank != 0) return 0;                    // the frame lives on rank 0
+    if (gpus > 0) printf("gpus=%d (screen-tile slabs + one ncclGather per frame)\n", gpus);
     if (frames > 1) printf("Render(): %.3f ms per frame (wall, %d frames, frame 0 excluded)\n", wall_ms / (frames - 1), frames - 1);
     const uint16_t* fr = voxel_cone_tracing.Frame();
     const size_t n = (size_t)w * h * 4;
