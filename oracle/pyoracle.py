@@ -32,6 +32,10 @@ class Params(C.Structure):
     ]
 
 
+class Texture(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 class Scene(C.Structure):
     _fields_ = [
         ("pos", C.c_void_p),
@@ -43,6 +47,19 @@ class Scene(C.Structure):
         ("shadow_depth", C.c_void_p),
         ("shadow_size", C.c_int32),
         ("light_vp", C.c_float * 16),
+        ("uv", C.c_void_p),
+        ("mat_tex", C.c_void_p),
+        ("textures", C.c_void_p),
+        ("ntex", C.c_int32),
+    ]
+
+
+class Mesh(C.Structure):
+    _fields_ = [
+        ("pos", C.c_void_p), ("nrm", C.c_void_p), ("tan", C.c_void_p), ("bit", C.c_void_p),
+        ("uv", C.c_void_p), ("material", C.c_void_p), ("albedo", C.c_void_p), ("specular", C.c_void_p),
+        ("mat_tex", C.c_void_p), ("textures", C.c_void_p),
+        ("ntri", C.c_int32), ("nmat", C.c_int32), ("ntex", C.c_int32), ("model_scale", C.c_float),
     ]
 
 
@@ -85,6 +102,10 @@ def lib():
         L.vcto_bounce.restype = C.c_uint64
         L.vcto_bounce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vcto_voxelize_conservative_attr.argtypes = [C.c_void_p] * 6
+        L.vcto_tex_sample.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.vcto_render_shadow_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.vcto_render_gbuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                          C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -210,7 +231,79 @@ def pcf25(depth, coord, bias=0.002):
     return lib().vcto_pcf25(_ptr(depth), depth.shape[0], _ptr(c), float(bias))
 
 
-def make_scene(pos, material, albedo, model_scale=0.05, shadow_depth=None, light_vp=None):
+def _texture_table(textures, keep):
+    """textures: list of uint8 [h, w, 4] arrays -> (ctypes array of Texture, count)."""
+    if not textures:
+        return None, 0
+    arr = (Texture * len(textures))()
+    for i, t in enumerate(textures):
+        t = np.ascontiguousarray(t, np.uint8)
+        assert t.ndim == 3 and t.shape[2] == 4
+        keep.append(t)
+        arr[i].rgba, arr[i].height, arr[i].width = _ptr(t), t.shape[0], t.shape[1]
+    keep.append(arr)
+    return arr, len(textures)
+
+
+def tex_sample(texture, u, v):
+    keep = []
+    arr, _ = _texture_table([texture], keep)
+    out = np.zeros(4, np.float32)
+    lib().vcto_tex_sample(C.byref(arr[0]), float(u), float(v), _ptr(out))
+    return out
+
+
+def make_mesh(pos, material, albedo, specular=None, frames=None, uv=None, mat_tex=None, textures=None,
+              model_scale=0.05):
+    """Input of the raster oracles (render_shadow_map / render_gbuffer).  frames = (normal, tangent, bitangent)."""
+    m = Mesh()
+    k = m._keep = []
+
+    def arr(a, dt, shape):
+        a = np.ascontiguousarray(a, dt).reshape(shape)
+        k.append(a)
+        return _ptr(a)
+    m.pos = arr(pos, np.float32, (-1, 9))
+    m.ntri = k[-1].shape[0]
+    m.material = arr(material, np.int32, (-1,))
+    m.albedo = arr(albedo, np.float32, (-1, 4))
+    m.nmat = k[-1].shape[0]
+    m.specular = arr(specular if specular is not None else np.zeros((m.nmat, 3)), np.float32, (-1, 3))
+    if frames is not None:
+        m.nrm, m.tan, m.bit = (arr(f, np.float32, (-1, 9)) for f in frames)
+    m.uv = arr(uv, np.float32, (-1, 6)) if uv is not None else None
+    m.mat_tex = arr(mat_tex, np.int32, (-1, 3)) if mat_tex is not None else None
+    tab, n = _texture_table(textures, k)
+    m.textures = C.cast(tab, C.c_void_p) if tab is not None else None
+    m.ntex = n
+    m.model_scale = model_scale
+    return m
+
+
+def render_shadow_map(mesh, light_vp_colmajor, size):
+    """DrawDepthTexture on the CPU: depth [size, size] fp32."""
+    vp = np.ascontiguousarray(light_vp_colmajor, np.float32).reshape(16)
+    depth = np.zeros((size, size), np.float32)
+    lib().vcto_render_shadow_map(C.byref(mesh), _ptr(vp), size, _ptr(depth))
+    return depth
+
+
+def render_gbuffer(mesh, view_proj_colmajor, w, h, shadow_depth=None, light_vp_colmajor=None):
+    """The raster + non-cone fragment work of Render() on the CPU: planes float32 [23, w*h]."""
+    vp = np.ascontiguousarray(view_proj_colmajor, np.float32).reshape(16)
+    planes = np.zeros((GB_PLANES, w * h), np.float32)
+    if shadow_depth is not None:
+        sd = np.ascontiguousarray(shadow_depth, np.float32)
+        lvp = np.ascontiguousarray(light_vp_colmajor, np.float32).reshape(16)
+        lib().vcto_render_gbuffer(C.byref(mesh), _ptr(vp), w, h, _ptr(sd), sd.shape[0], _ptr(lvp), _ptr(planes))
+    else:
+        lvp = np.eye(4, dtype=np.float32).reshape(16)
+        lib().vcto_render_gbuffer(C.byref(mesh), _ptr(vp), w, h, None, 0, _ptr(lvp), _ptr(planes))
+    return planes
+
+
+def make_scene(pos, material, albedo, model_scale=0.05, shadow_depth=None, light_vp=None, uv=None, mat_tex=None,
+               textures=None):
     """Keeps references to the numpy arrays alive on the returned struct."""
     s = Scene()
     s._keep = [np.ascontiguousarray(pos, np.float32).reshape(-1, 9),
@@ -230,6 +323,14 @@ def make_scene(pos, material, albedo, model_scale=0.05, shadow_depth=None, light
         s.shadow_size = 0
     lv = np.eye(4, dtype=np.float32) if light_vp is None else np.asarray(light_vp, np.float32)
     s.light_vp[:] = list(lv.T.reshape(-1))   # row-major in -> column-major struct
+    s.uv, s.mat_tex, s.textures, s.ntex = None, None, None, 0
+    if uv is not None and mat_tex is not None and textures:
+        a = np.ascontiguousarray(uv, np.float32).reshape(-1, 6)
+        b = np.ascontiguousarray(mat_tex, np.int32).reshape(-1, 3)
+        s._keep += [a, b]
+        s.uv, s.mat_tex = _ptr(a), _ptr(b)
+        tab, n = _texture_table(textures, s._keep)
+        s.textures, s.ntex = C.cast(tab, C.c_void_p), n
     return s
 
 

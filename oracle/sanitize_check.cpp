@@ -17,7 +17,7 @@ int main() {
     vcto_default_params(&p);
     p.V = V;
     // scenes + host stages
-    for (int kind = 0; kind < 2; ++kind) {
+    for (int kind = 0; kind < 3; ++kind) {      // Cornell, atrium, textured atrium
         vcth_scene* s = vcth_scene_create(kind, 0.05f, 7u);
         const int ntri = vcth_scene_num_triangles(s), nmat = vcth_scene_num_materials(s);
         std::vector<float> pos((size_t)ntri * 9), alb((size_t)nmat * 4), spec((size_t)nmat * 3);
@@ -25,16 +25,36 @@ int main() {
         std::vector<int32_t> mat((size_t)ntri);
         vcth_scene_get(s, pos.data(), mat.data(), alb.data(), spec.data());
         vcth_scene_get_frames(s, nrm.data(), tan.data(), bit.data());
+        std::vector<float> uv((size_t)ntri * 6);
+        std::vector<int32_t> mat_tex((size_t)nmat * 3);
+        vcth_scene_get_uvs(s, uv.data());
+        vcth_scene_get_material_textures(s, mat_tex.data());
+        const int ntex = vcth_scene_num_textures(s);
+        std::vector<std::vector<uint8_t>> texels((size_t)ntex);
+        std::vector<vcto_texture> tex((size_t)ntex);
+        for (int i = 0; i < ntex; ++i) {
+            int32_t tw, th;
+            vcth_scene_texture_info(s, i, &tw, &th);
+            texels[(size_t)i].resize((size_t)tw * th * 4);
+            vcth_scene_get_texture(s, i, texels[(size_t)i].data());
+            tex[(size_t)i] = {texels[(size_t)i].data(), tw, th};
+        }
+        vcto_mesh mesh;
+        memset(&mesh, 0, sizeof(mesh));
+        mesh.pos = pos.data(); mesh.nrm = nrm.data(); mesh.tan = tan.data(); mesh.bit = bit.data();
+        mesh.uv = uv.data(); mesh.material = mat.data(); mesh.albedo = alb.data(); mesh.specular = spec.data();
+        mesh.mat_tex = mat_tex.data(); mesh.textures = tex.data();
+        mesh.ntri = ntri; mesh.nmat = nmat; mesh.ntex = ntex; mesh.model_scale = 0.05f;
         const float L[3] = {0.0f, 1.0f, 0.25f};
         float lvp[16], vp[16];
         vcth_light_view_proj(L, lvp);
         std::vector<float> depth((size_t)S * S), planes((size_t)23 * w * h);
-        vcth_render_shadow_map(s, 0.05f, lvp, S, depth.data());
+        vcto_render_shadow_map(&mesh, lvp, S, depth.data());
         vcth_camera cam;
         vcth_default_camera(&cam);
         cam.position[2] = kind == 0 ? 58.0f : 2.0f;
         vcth_camera_view_proj(&cam, w, h, vp);
-        vcth_render_gbuffer(s, 0.05f, &cam, w, h, depth.data(), S, lvp, planes.data());
+        vcto_render_gbuffer(&mesh, vp, w, h, depth.data(), S, lvp, planes.data());
         // oracle: voxelize (both modes, attributes), mips, aniso, bounce, trace
         vcto_scene sc;
         memset(&sc, 0, sizeof(sc));
@@ -42,6 +62,7 @@ int main() {
         sc.ntri = ntri; sc.nmat = nmat; sc.model_scale = 0.05f;
         sc.shadow_depth = depth.data(); sc.shadow_size = S;
         memcpy(sc.light_vp, lvp, sizeof(lvp));
+        sc.uv = uv.data(); sc.mat_tex = mat_tex.data(); sc.textures = tex.data(); sc.ntex = ntex;
         const size_t nvox = (size_t)V * V * V, nchain = vcto_chain_texels(V);
         std::vector<uint8_t> l0(nvox * 4, 0), lref(nvox * 4, 0), a_alb(nvox * 4), a_nrm(nvox * 4), l1(nvox * 4);
         std::vector<uint32_t> acc(nvox * 4);

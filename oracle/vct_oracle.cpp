@@ -572,6 +572,8 @@ namespace {
 struct TriSetup {
     V3 w[3];    // world-space vertices  (ModelMatrix * position, vox.vs:21)
     V3 dc[3];   // DepthCoord.xyz*0.5+0.5 per vertex (vox.vs:18-19)
+    float uv[3][2];   // TexCoord per vertex (vox.vs:17)
+    int tex;    // diffuse texture of the triangle's material or -1
     int axis;
 };
 
@@ -588,6 +590,13 @@ TriSetup setup_tri(const vcto_scene* s, int t) {
         r.w[k] = {q[0] * s->model_scale, q[1] * s->model_scale, q[2] * s->model_scale};
         const V3 d = xform_point(s->light_vp, r.w[k]);
         r.dc[k] = {d.x * 0.5f + 0.5f, d.y * 0.5f + 0.5f, d.z * 0.5f + 0.5f};
+        r.uv[k][0] = s->uv ? s->uv[(size_t)t * 6 + 2 * k] : 0.0f;
+        r.uv[k][1] = s->uv ? s->uv[(size_t)t * 6 + 2 * k + 1] : 0.0f;
+    }
+    r.tex = -1;
+    if (s->uv && s->mat_tex && s->textures) {
+        const int ti = s->mat_tex[3 * (size_t)s->material[t]];
+        if (ti >= 0 && ti < s->ntex) r.tex = ti;
     }
     const float a[3] = {r.w[0].x, r.w[0].y, r.w[0].z}, b[3] = {r.w[1].x, r.w[1].y, r.w[1].z},
                 c[3] = {r.w[2].x, r.w[2].y, r.w[2].z};
@@ -595,9 +604,19 @@ TriSetup setup_tri(const vcto_scene* s, int t) {
     return r;
 }
 
-// vox.fs:88 value: unorm8(albedo.rgb * PCF/25), a = 1.
-inline void frag_value(const vcto_scene* s, int t, V3 dc, uint8_t out[3]) {
+// vox.fs:56,88 value: unorm8(texture(DiffuseTexture, uv).rgb * PCF/25), a = 1 (flat material colour when the
+// material has no diffuse texture).  b0..b2: the fragment's barycentrics; alb_out (optional): the albedo used.
+inline void frag_value(const vcto_scene* s, int t, const TriSetup& ts, float b0, float b1, float b2, V3 dc,
+                       uint8_t out[3], float* alb_out = nullptr) {
+    float texel[4];
     const float* alb = s->albedo + 4 * (size_t)s->material[t];
+    if (ts.tex >= 0) {
+        const float u = b0 * ts.uv[0][0] + b1 * ts.uv[1][0] + b2 * ts.uv[2][0];
+        const float v = b0 * ts.uv[0][1] + b1 * ts.uv[1][1] + b2 * ts.uv[2][1];
+        vcto_tex_sample(&s->textures[ts.tex], u, v, texel);
+        alb = texel;
+    }
+    if (alb_out) { alb_out[0] = alb[0]; alb_out[1] = alb[1]; alb_out[2] = alb[2]; }
     float sh = 1.0f;
     if (s->shadow_depth) {
         const float c[3] = {dc.x, dc.y, dc.z};
@@ -661,7 +680,7 @@ void vcto_voxelize_reference(const vcto_params* p, const vcto_scene* s, uint8_t*
                 if (vp[0] < 0 || vp[1] < 0 || vp[2] < 0 || vp[0] >= V || vp[1] >= V || vp[2] >= V)
                     continue;   // [GL] out-of-bounds imageStore is discarded
                 uint8_t rgb[3];
-                frag_value(s, t, dc, rgb);
+                frag_value(s, t, ts, l0b, l1b, l2b, dc, rgb);
                 uint8_t* d = l0 + 4 * (((size_t)vp[2] * V + vp[1]) * V + vp[0]);
                 d[0] = rgb[0]; d[1] = rgb[1]; d[2] = rgb[2]; d[3] = 255;   // last writer wins
             }
@@ -749,13 +768,9 @@ void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, 
         ConsFrag f;
         memset(&f, 0, sizeof(f));
         if (want_attr) {
-            const float* alb = s->albedo + 4 * (size_t)s->material[t];
             const V3 fn = normalize(cross(sub(ts.w[1], ts.w[0]), sub(ts.w[2], ts.w[0])));
             const float fc[3] = {fn.x, fn.y, fn.z};
-            for (int c = 0; c < 3; ++c) {
-                f.attr[c] = to_unorm8(alb[c]);
-                f.attr[3 + c] = (uint8_t)((int)floorf(fc[c] * 127.0f + 0.5f) + 128);
-            }
+            for (int c = 0; c < 3; ++c) f.attr[3 + c] = (uint8_t)((int)floorf(fc[c] * 127.0f + 0.5f) + 128);
         }
         V3 g[3];
         for (int k = 0; k < 3; ++k)
@@ -793,7 +808,10 @@ void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, 
                     const V3 dc = {b0 * ts.dc[0].x + b1 * ts.dc[1].x + b2 * ts.dc[2].x,
                                    b0 * ts.dc[0].y + b1 * ts.dc[1].y + b2 * ts.dc[2].y,
                                    b0 * ts.dc[0].z + b1 * ts.dc[1].z + b2 * ts.dc[2].z};
-                    frag_value(s, t, dc, f.rgb);
+                    float alb[3];
+                    frag_value(s, t, ts, b0, b1, b2, dc, f.rgb, alb);
+                    if (want_attr)
+                        for (int c = 0; c < 3; ++c) f.attr[c] = to_unorm8(alb[c]);      // the fragment's albedo
                     f.vox = ((uint64_t)k * V + j) * V + i;
                     out->push_back(f);
                 }

@@ -128,6 +128,18 @@ void vcto_frag_to_voxel(int V, int axis, float fx, float fy, float fz, int32_t o
  * the texture fetch at vox.fs:56).  model_scale = 0.05 (VCT.h:240).  light_vp: column-major
  * DepthViewProjectionMatrix (VCT.h:84-86) applied to WORLD positions (the reference applies
  * DepthVP*Model to model positions: the same point).  shadow may be NULL (PCF = 1). */
+/* Material textures (R/Model.h:126-136,141-226 loads them, R/Mesh.h:91-108 binds them).  RGBA8, row 0 at
+ * v = 0, texel = byte/255.  Sampling restates texture(sampler2D, uv) as LEVEL 0, BILINEAR, GL_REPEAT:
+ *   x = u*W - 0.5, i0 = floor(x), a = x - i0, indices wrapped mod W (same for v), per channel
+ *   ((1-a)*(1-b))*t00 + (a*(1-b))*t10 + ((1-a)*b)*t01 + (a*b)*t11 in that order, fp32.
+ * (The reference samples a mip-mapped texture with implicit derivatives, R/Model.h:172-175; SURVEY.md A.7
+ * allows level 0 for the restatement and asks that it be said: this is where.) */
+typedef struct vcto_texture {
+    const uint8_t* rgba;      /* [height*width*4] */
+    int32_t width, height;
+} vcto_texture;
+void vcto_tex_sample(const vcto_texture* t, float u, float v, float out[4]);
+
 typedef struct vcto_scene {
     const float* pos;         /* [ntri*9] */
     const int32_t* material;  /* [ntri] */
@@ -137,6 +149,13 @@ typedef struct vcto_scene {
     const float* shadow_depth; /* [S*S] or NULL */
     int32_t shadow_size;
     float light_vp[16];
+    /* optional (NULL / 0: flat per-material colours): texture coordinates and diffuse textures.  A
+     * fragment of a material with a diffuse texture takes albedo = texture(DiffuseTexture, uv) (vox.fs:56),
+     * uv interpolated with the barycentrics the fragment's shadow coordinate is interpolated with. */
+    const float* uv;           /* [ntri*6] */
+    const int32_t* mat_tex;    /* [nmat*3]: diffuse, specular, height texture index or -1 */
+    const vcto_texture* textures;
+    int32_t ntex;
 } vcto_scene;
 
 /* Reference mode (A.7): dominant-axis VxV raster at pixel centres, top-left rule, value =
@@ -150,6 +169,37 @@ void vcto_voxelize_reference(const vcto_params* p, const vcto_scene* s, uint8_t*
  * (sum r, sum g, sum b, count). */
 void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
                                 uint32_t* acc);
+
+/* ---- raster input stages -- the checkers of csrc/vct_raster.hip ---------------
+ * GL rules restated once: near-plane clip (z >= -w), window coordinates snapped to 1/256 pixel, edge
+ * functions in double (exact on snapped inputs: shared edges are watertight), pixel-centre sampling,
+ * top-left fill rule, CCW front faces with back faces culled (R/main.cpp:55-58), depth test LESS in
+ * triangle order, perspective-correct varyings. */
+typedef struct vcto_mesh {
+    const float* pos;          /* [ntri*9] model space                      R/Mesh.h:12-19 */
+    const float* nrm;          /* [ntri*9] per-vertex normal   (G-buffer only; may be NULL for the shadow pass) */
+    const float* tan;          /* [ntri*9] tangent */
+    const float* bit;          /* [ntri*9] bitangent */
+    const float* uv;           /* [ntri*6] texture coordinates or NULL */
+    const int32_t* material;   /* [ntri] */
+    const float* albedo;       /* [nmat*4] flat colour of materials without a diffuse texture */
+    const float* specular;     /* [nmat*3] same for the specular colour */
+    const int32_t* mat_tex;    /* [nmat*3] diffuse / specular / height texture index or -1; NULL = none */
+    const vcto_texture* textures;
+    int32_t ntri, nmat, ntex;
+    float model_scale;         /* ModelMatrix = scale(0.05)                 VCT.h:183,204 */
+} vcto_mesh;
+/* DrawDepthTexture (VCT.h:192-211, S/Shadow.vs/.fs): depth [S*S] in [0,1], cleared to 1, quantised to
+ * DEPTH_COMPONENT24.  No alpha test (Shadow.fs has none). */
+void vcto_render_shadow_map(const vcto_mesh* m, const float light_vp[16], int32_t S, float* depth);
+/* The vertex + fixed-function part of Render (VCT.h:161-189, S/VoxelConeTracing.vs) and the non-cone
+ * fragment work of S/VoxelConeTracing.fs: matColor fetch + alpha test (:167-172; a discarded fragment
+ * writes neither colour nor depth), CalcBumpNormal from three HeightTexture taps (:110-128), specColor
+ * with the .rrra rule (:209-210), PCF x 0.111 (:132-163).  planes: [23][W*H] (include/vct.h VCT_GB_*);
+ * pixels without a fragment keep albedo.a = 0.  Row 0 = bottom row of the GL window. */
+void vcto_render_gbuffer(const vcto_mesh* m, const float view_proj[16], int32_t W, int32_t H,
+                         const float* shadow_depth, int32_t shadow_size, const float light_vp[16],
+                         float* planes);
 
 /* ---- second bounce (north-star; BASELINE.json config 3) ---------------------------------------
  * The reference has NO code for this: its README claims "2 bounces" (README.md:16) but the

@@ -1,0 +1,270 @@
+// vct_oracle_raster.cpp -- CPU restatement of the two raster input stages and of the
+// material texture fetches around them.  TEST INFRASTRUCTURE ONLY (see vct_oracle.h): these are the checkers of
+// csrc/vct_raster.hip; nothing in the product links them.
+//
+// Reference code restated: R/Voxel_Cone_Tracing.h:192-211 + S/Shadow.vs/.fs (depth pass), :161-189 +
+// S/VoxelConeTracing.vs:23-37 (vertex stage), S/VoxelConeTracing.fs:110-128 (CalcBumpNormal), :132-163 (PCF),
+// :167-172 (matColor, alpha test), :209-210 (specColor), R/main.cpp:55-58 (depth LESS, cull back), and the
+// OpenGL 4.3 rasterisation rules those draws invoke.
+#include "vct_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+struct V3 { float x, y, z; };
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline V3 normalize(V3 a) {
+    const float l = sqrtf(dot(a, a));
+    return l > 0.0f ? a * (1.0f / l) : V3{0, 0, 0};
+}
+inline void xform(const float* m, V3 p, float out[4]) {
+    for (int r = 0; r < 4; ++r) out[r] = m[r] * p.x + m[4 + r] * p.y + m[8 + r] * p.z + m[12 + r];
+}
+
+constexpr int kMaxVar = 14;
+struct RVert { float c[4]; float var[kMaxVar]; };
+
+inline RVert lerp_vert(const RVert& a, const RVert& b, float t, int nvar) {
+    RVert r;
+    for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] + (b.c[i] - a.c[i]) * t;
+    for (int i = 0; i < nvar; ++i) r.var[i] = a.var[i] + (b.var[i] - a.var[i]) * t;
+    return r;
+}
+
+// One clip-space triangle.  frag(x, y, z, var) is called for every fragment that passes the depth test and
+// returns false to discard it (trace.fs:171): a discarded fragment leaves the depth buffer untouched.
+template <class Frag>
+void raster_triangle(const RVert in[3], int nvar, bool cull_back, int W, int H, float* zbuf, Frag frag) {
+    RVert poly[4];
+    int np = 0;
+    for (int i = 0; i < 3; ++i) {             // clip against z >= -w
+        const RVert& a = in[i];
+        const RVert& b = in[(i + 1) % 3];
+        const float da = a.c[2] + a.c[3], db = b.c[2] + b.c[3];
+        if (da >= 0.0f) poly[np++] = a;
+        if ((da >= 0.0f) != (db >= 0.0f)) poly[np++] = lerp_vert(a, b, da / (da - db), nvar);
+    }
+    if (np < 3) return;
+    for (int t = 1; t + 1 < np; ++t) {
+        const RVert* v[3] = {&poly[0], &poly[t], &poly[t + 1]};
+        double sx[3], sy[3];
+        float sz[3], iw[3];
+        bool bad = false;
+        for (int k = 0; k < 3; ++k) {
+            if (!(v[k]->c[3] > 1e-20f)) { bad = true; break; }
+            iw[k] = 1.0f / v[k]->c[3];
+            sx[k] = floor((double)((v[k]->c[0] * iw[k] * 0.5f + 0.5f) * (float)W) * 256.0 + 0.5) / 256.0;
+            sy[k] = floor((double)((v[k]->c[1] * iw[k] * 0.5f + 0.5f) * (float)H) * 256.0 + 0.5) / 256.0;
+            sz[k] = v[k]->c[2] * iw[k] * 0.5f + 0.5f;
+        }
+        if (bad) continue;
+        double area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sx[2] - sx[0]) * (sy[1] - sy[0]);
+        if (area == 0.0 || area != area) continue;
+        if (area < 0.0 && cull_back) continue;
+        const double sgn = area > 0.0 ? 1.0 : -1.0;
+        area *= sgn;
+        const int x0 = std::max(0, (int)floor(std::min({sx[0], sx[1], sx[2]})));
+        const int x1 = std::min(W - 1, (int)floor(std::max({sx[0], sx[1], sx[2]})));
+        const int y0 = std::max(0, (int)floor(std::min({sy[0], sy[1], sy[2]})));
+        const int y1 = std::min(H - 1, (int)floor(std::max({sy[0], sy[1], sy[2]})));
+        for (int py = y0; py <= y1; ++py)
+            for (int px = x0; px <= x1; ++px) {
+                const double cx = (double)px + 0.5, cy = (double)py + 0.5;
+                double e[3];
+                bool inside = true;
+                for (int k = 0; k < 3; ++k) {
+                    const int a = (k + 1) % 3, b = (k + 2) % 3;
+                    const double dx = (sx[b] - sx[a]) * sgn, dy = (sy[b] - sy[a]) * sgn;
+                    e[k] = dx * (cy - sy[a]) - dy * (cx - sx[a]);
+                    const bool top_left = (dy > 0.0) || (dy == 0.0 && dx < 0.0);
+                    if (e[k] < 0.0 || (e[k] == 0.0 && !top_left)) { inside = false; break; }
+                }
+                if (!inside) continue;
+                const float b0 = (float)(e[0] / area), b1 = (float)(e[1] / area), b2 = 1.0f - b0 - b1;
+                const float z = b0 * sz[0] + b1 * sz[1] + b2 * sz[2];
+                if (!(z >= 0.0f && z <= 1.0f)) continue;               // far-plane clip
+                float& zb = zbuf[(size_t)py * W + px];
+                if (!(z < zb)) continue;                                 // GL_LESS
+                const float q0 = b0 * iw[0], q1 = b1 * iw[1], q2 = b2 * iw[2];
+                const float qs = 1.0f / (q0 + q1 + q2);
+                float var[kMaxVar];
+                for (int i = 0; i < nvar; ++i)
+                    var[i] = (q0 * v[0]->var[i] + q1 * v[1]->var[i] + q2 * v[2]->var[i]) * qs;
+                if (frag(px, py, z, var)) zb = z;
+            }
+    }
+}
+
+float shadow_fetch(const float* depth, int S, float u, float v) {   // bilinear, clamp-to-edge
+    const float x = u * (float)S - 0.5f, y = v * (float)S - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    auto cl = [S](float f) { return f < 0.0f ? 0 : (f > (float)(S - 1) ? S - 1 : (int)f); };
+    const int i0 = cl(fx), i1 = cl(fx + 1.0f), j0 = cl(fy), j1 = cl(fy + 1.0f);
+    const float d00 = depth[(size_t)j0 * S + i0], d10 = depth[(size_t)j0 * S + i1];
+    const float d01 = depth[(size_t)j1 * S + i0], d11 = depth[(size_t)j1 * S + i1];
+    return (1 - a) * (1 - b) * d00 + a * (1 - b) * d10 + (1 - a) * b * d01 + a * b * d11;
+}
+
+inline int tex_of(const vcto_mesh* m, int mat, int slot) {
+    if (!m->mat_tex || !m->textures) return -1;
+    const int t = m->mat_tex[3 * (size_t)mat + slot];
+    return t >= 0 && t < m->ntex ? t : -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vcto_tex_sample(const vcto_texture* t, float u, float v, float out[4]) {
+    const int W = t->width, H = t->height;
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    auto wrap = [](int i, int n) { const int r = i % n; return r < 0 ? r + n : r; };     // GL_REPEAT
+    const int i0 = wrap((int)fx, W), i1 = wrap((int)fx + 1, W), j0 = wrap((int)fy, H), j1 = wrap((int)fy + 1, H);
+    const uint8_t* p00 = t->rgba + 4 * ((size_t)j0 * W + i0);
+    const uint8_t* p10 = t->rgba + 4 * ((size_t)j0 * W + i1);
+    const uint8_t* p01 = t->rgba + 4 * ((size_t)j1 * W + i0);
+    const uint8_t* p11 = t->rgba + 4 * ((size_t)j1 * W + i1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    for (int c = 0; c < 4; ++c)
+        out[c] = w00 * ((float)p00[c] / 255.0f) + w10 * ((float)p10[c] / 255.0f) + w01 * ((float)p01[c] / 255.0f) +
+                 w11 * ((float)p11[c] / 255.0f);
+}
+
+void vcto_render_shadow_map(const vcto_mesh* s, const float light_vp[16], int32_t S, float* depth) {
+    const size_t n = (size_t)S * S;
+    for (size_t i = 0; i < n; ++i) depth[i] = 1.0f;                      // glClear depth
+    for (int t = 0; t < s->ntri; ++t) {
+        RVert v[3];
+        for (int k = 0; k < 3; ++k) {
+            const float* p = &s->pos[(size_t)t * 9 + 3 * k];
+            xform(light_vp, V3{p[0] * s->model_scale, p[1] * s->model_scale, p[2] * s->model_scale}, v[k].c);
+        }
+        raster_triangle(v, 0, true, S, S, depth, [](int, int, float, const float*) { return true; });
+    }
+    const float q = 16777215.0f;                                         // DEPTH_COMPONENT24
+    for (size_t i = 0; i < n; ++i) depth[i] = (float)(floor((double)depth[i] * q + 0.5) / q);
+}
+
+void vcto_render_gbuffer(const vcto_mesh* s, const float view_proj[16], int32_t W, int32_t H,
+                         const float* shadow_depth, int32_t shadow_size, const float light_vp[16],
+                         float* planes) {
+    const size_t npix = (size_t)W * H;
+    memset(planes, 0, npix * 23 * sizeof(float));
+    std::vector<float> zbuf(npix, 1.0f);
+    std::vector<int32_t> mat(npix, -1);
+    std::vector<float> uvbuf(npix * 2, 0.0f);
+    const float ms = s->model_scale;
+    for (int t = 0; t < s->ntri; ++t) {
+        RVert v[3];
+        for (int k = 0; k < 3; ++k) {
+            const size_t o9 = (size_t)t * 9 + 3 * k;
+            const V3 w = {s->pos[o9] * ms, s->pos[o9 + 1] * ms, s->pos[o9 + 2] * ms};   // trace.vs:27
+            xform(view_proj, w, v[k].c);                                                  // trace.vs:25
+            float* o = v[k].var;
+            o[0] = w.x; o[1] = w.y; o[2] = w.z;
+            for (int i = 0; i < 3; ++i) {
+                o[3 + i] = s->nrm[o9 + i] * ms;    // trace.vs:31 (w = 0)
+                o[6 + i] = s->tan[o9 + i] * ms;    // trace.vs:32
+                o[9 + i] = s->bit[o9 + i] * ms;    // trace.vs:33
+            }
+            o[12] = s->uv ? s->uv[(size_t)t * 6 + 2 * k] : 0.0f;                           // trace.vs:36
+            o[13] = s->uv ? s->uv[(size_t)t * 6 + 2 * k + 1] : 0.0f;
+        }
+        const int32_t m = s->material[t];
+        const int td = tex_of(s, m, 0);
+        raster_triangle(v, 14, true, W, H, zbuf.data(), [&](int x, int y, float, const float* var) {
+            float alpha = s->albedo[4 * (size_t)m + 3];
+            if (td >= 0) {
+                float c[4];
+                vcto_tex_sample(&s->textures[td], var[12], var[13], c);                     // trace.fs:167
+                alpha = c[3];
+            }
+            if (alpha < 0.5f) return false;                                                  // trace.fs:171 discard
+            const size_t i = (size_t)y * W + x;
+            for (int k = 0; k < 12; ++k) planes[(size_t)k * npix + i] = var[k];
+            uvbuf[2 * i] = var[12]; uvbuf[2 * i + 1] = var[13];
+            mat[i] = m;
+            return true;
+        });
+    }
+    // per-pixel material + bump normal + shadow term (the non-cone part of trace.fs)
+    for (size_t i = 0; i < npix; ++i) {
+        if (mat[i] < 0) continue;
+        auto G = [&](int k) -> float& { return planes[(size_t)k * npix + i]; };
+        const V3 P = {G(0), G(1), G(2)}, N = {G(3), G(4), G(5)}, T = {G(6), G(7), G(8)}, B = {G(9), G(10), G(11)};
+        const int m = mat[i];
+        const float u = uvbuf[2 * i], v = uvbuf[2 * i + 1];
+        const int td = tex_of(s, m, 0), tsp = tex_of(s, m, 1), th = tex_of(s, m, 2);
+        const V3 c2 = cross(T, B);
+        const float det = dot(T, cross(B, N));
+        if (th < 0) {
+            // CalcBumpNormal with a flat height map: normalize(TBN * (0,0,1)), TBN = inverse(transpose(M))
+            const V3 bn = normalize(c2 * (1.0f / det));                               // trace.fs:127,175
+            G(12) = bn.x; G(13) = bn.y; G(14) = bn.z;
+        } else {
+            const vcto_texture* ht = &s->textures[th];
+            const float ox = 1.0f / (float)ht->width, oy = 1.0f / (float)ht->height;   // trace.fs:112
+            float c0[4], c1[4], c3[4];
+            vcto_tex_sample(ht, u, v, c0);                                              // :114
+            vcto_tex_sample(ht, u + ox, v, c1);                                         // :115
+            vcto_tex_sample(ht, u, v + oy, c3);                                         // :116
+            const float dx = c1[0] - c0[0], dy = c3[0] - c0[0];
+            const V3 t1 = normalize(V3{1.0f, 0.0f, dx}), t2 = normalize(V3{0.0f, 1.0f, dy});   // :120-121
+            const V3 bump = normalize(cross(t1, t2));                                   // :125
+            // TBN = inverse(transpose(mat3(T,B,N))): columns (BxN, NxT, TxB) / det    trace.fs:175
+            const float inv = 1.0f / det;
+            const V3 k0 = cross(B, N) * inv, k1 = cross(N, T) * inv, k2 = c2 * inv;
+            const V3 r = {k0.x * bump.x + k1.x * bump.y + k2.x * bump.z, k0.y * bump.x + k1.y * bump.y + k2.y * bump.z,
+                          k0.z * bump.x + k1.z * bump.y + k2.z * bump.z};
+            const V3 bn = normalize(r);                                                 // :127
+            G(12) = bn.x; G(13) = bn.y; G(14) = bn.z;
+        }
+        if (td >= 0) {
+            float c[4];
+            vcto_tex_sample(&s->textures[td], u, v, c);                                 // trace.fs:167
+            for (int k = 0; k < 4; ++k) G(15 + k) = c[k];
+        } else {
+            for (int k = 0; k < 4; ++k) G(15 + k) = s->albedo[4 * (size_t)m + k];
+        }
+        float sp[3] = {s->specular[3 * (size_t)m], s->specular[3 * (size_t)m + 1], s->specular[3 * (size_t)m + 2]};
+        if (tsp >= 0) {
+            float c[4];
+            vcto_tex_sample(&s->textures[tsp], u, v, c);                                // trace.fs:209
+            sp[0] = c[0]; sp[1] = c[1]; sp[2] = c[2];
+        }
+        const bool has_gb = sqrtf(sp[1] * sp[1] + sp[2] * sp[2]) > 0.0f;
+        G(19) = sp[0];
+        G(20) = has_gb ? sp[1] : sp[0];                                                 // trace.fs:210
+        G(21) = has_gb ? sp[2] : sp[0];
+        float shadow = 25.0f * 0.111f;
+        if (shadow_depth) {
+            float d[4];
+            xform(light_vp, P, d);                                                     // trace.vs:28
+            const float cx = d[0] * 0.5f + 0.5f, cy = d[1] * 0.5f + 0.5f, cz = d[2] * 0.5f + 0.5f;   // :29
+            float cnt = 0.0f;
+            for (int x = -2; x <= 2; ++x)
+                for (int y = -2; y <= 2; ++y) {
+                    const float ox = 1.0f / (float)shadow_size * (float)x;            // trace.fs:147
+                    const float oy = 1.0f / (float)shadow_size * (float)y;
+                    if (cz / d[3] - 0.002f <= shadow_fetch(shadow_depth, shadow_size, cx + ox, cy + oy))
+                        cnt += 1.0f;                                                   // trace.fs:151-152
+                }
+            shadow = cnt * 0.111f;                                                     // trace.fs:158
+        }
+        G(22) = shadow;
+    }
+}
+
+}  // extern "C"

@@ -20,6 +20,7 @@ import os
 import numpy as np
 import pytest
 
+import raster_oracle
 import synth
 import vctpkg
 
@@ -71,14 +72,14 @@ class Pipeline:
 
     def shadow_map(self):
         """DrawDepthTexture on the GPU == the CPU rasteriser, bit for bit (f2 at full size)."""
-        self.depth, self.light_vp_row = self.scene.shadow_map(LIGHT, self.S)
+        self.depth, self.light_vp_row = raster_oracle.shadow_map(self.sc, self.scene, LIGHT, self.S)
         self.ctx.render_shadow_map(self.sc.light_view_proj(LIGHT))
         got = self.ctx.download_shadow_map()
         assert np.array_equal(got.view(np.uint32), self.depth.view(np.uint32))
 
     def gbuffer(self):
         """Raster part of Render() on the GPU == the CPU rasteriser, bit for bit (f1 at full size)."""
-        want = self.scene.gbuffer(self.cam, self.w, self.h, self.depth, self.light_vp_row)
+        want = raster_oracle.gbuffer(self.sc, self.scene, self.cam, self.w, self.h, self.depth, self.light_vp_row)
         self.ctx.render_gbuffer(self.sc.camera_view_proj(self.cam, self.w, self.h))
         self.planes = self.ctx.download_gbuffer()
         bad = np.nonzero((self.planes.view(np.uint32) != want.view(np.uint32)).any(0))[0]
@@ -87,8 +88,7 @@ class Pipeline:
         return self.planes
 
     def oracle_scene(self):
-        return self.oracle.make_scene(self.scene.pos, self.scene.material, self.scene.albedo,
-                                      shadow_depth=self.depth, light_vp=self.light_vp_row)
+        return raster_oracle.oracle_scene(self.scene, self.depth, self.light_vp_row)
 
     def check_frame(self, frame, steps, chain, sel=None, tag=""):
         """GPU frame + per-cone step counts against the oracle on pixels `sel` (None = all)."""

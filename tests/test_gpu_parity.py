@@ -281,9 +281,10 @@ def test_facade_demo_matches_binding(vct):
     fields = dict(kv.split("=") for kv in out.stdout.strip().split("\n")[-1].split())
     scene = sc.Scene(sc.CORNELL)
     light = (0.0, 1.0, 0.25)
-    depth, light_vp = scene.shadow_map(light, S)
+    import raster_oracle
+    depth, light_vp = raster_oracle.shadow_map(sc, scene, light, S)
     cam = sc.default_camera(position=(0.0, 0.0, 58.0))
-    planes = scene.gbuffer(cam, w, h, depth, light_vp)
+    planes = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, light_vp)
     with vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=S)) as ctx:
         ctx.set_camera_position((0.0, 0.0, 58.0))
         ctx.set_light_direction(light)

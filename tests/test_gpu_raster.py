@@ -1,9 +1,10 @@
 """GPU raster input stages (shadow map, G-buffer) against the CPU rasterisers of
-host/vct_host.cpp on the same scenes: bit-exact depth maps and G-buffers, and the same frame when
+oracle/vct_oracle_raster.cpp on the same scenes: bit-exact depth maps and G-buffers, and the same frame when
 the whole pipeline (shadow -> voxelize -> inject -> mips -> G-buffer -> trace) stays on the GPU."""
 import numpy as np
 import pytest
 
+import raster_oracle
 import vctpkg
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +30,7 @@ def setup_scene(vct, kind, detail, V, w, h, S):
 def test_shadow_map_raster_bit_exact(vct, kind, detail, S):
     sc, scene, ctx = setup_scene(vct, kind, detail, 32, 16, 16, S)
     light = (0.0, 1.0, 0.25)
-    want, _ = scene.shadow_map(light, S)
+    want, _ = raster_oracle.shadow_map(sc, scene, light, S)
     ctx.render_shadow_map(sc.light_view_proj(light))
     got = ctx.download_shadow_map()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
@@ -46,9 +47,9 @@ def test_gbuffer_raster_bit_exact(vct, kind, detail, cam_kw, w, h):
     S = 256
     sc, scene, ctx = setup_scene(vct, kind, detail, 32, w, h, S)
     light = (0.0, 1.0, 0.25)
-    depth, light_vp_row = scene.shadow_map(light, S)
+    depth, light_vp_row = raster_oracle.shadow_map(sc, scene, light, S)
     cam = sc.default_camera(**cam_kw)
-    want = scene.gbuffer(cam, w, h, depth, light_vp_row)
+    want = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, light_vp_row)
     ctx.render_shadow_map(sc.light_view_proj(light))
     ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
     got = ctx.download_gbuffer()
@@ -77,13 +78,13 @@ def test_resident_pipeline_equals_host_staged_pipeline(vct):
     chain_resident = ctx.download_chain()
     # host-staged path on a second context
     with vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=S)) as c2:
-        depth, light_vp_row = scene.shadow_map(light, S)
+        depth, light_vp_row = raster_oracle.shadow_map(sc, scene, light, S)
         c2.set_camera_position(tuple(cam.position))
         c2.set_light_direction(light)
         c2.upload_triangles(scene.pos, scene.material, scene.albedo)
         c2.upload_shadow_map(depth, light_vp_row)
         c2.voxelize(); c2.inject_light(); c2.build_mips()
         assert np.array_equal(c2.download_chain(), chain_resident)
-        staged = c2.trace(scene.gbuffer(cam, w, h, depth, light_vp_row))
+        staged = c2.trace(raster_oracle.gbuffer(sc, scene, cam, w, h, depth, light_vp_row))
     assert np.array_equal(resident, staged)
     ctx.close()

@@ -1,4 +1,4 @@
-// vct_host.cpp -- procedural scenes, shadow-map raster and G-buffer raster (see vct_host.h).
+// vct_host.cpp -- scenes (procedural + OBJ/MTL reader with textures), camera and light matrices (see vct_host.h).
 #include "vct_host.h"
 
 #include <math.h>
@@ -79,23 +79,31 @@ inline void xform(const float* m, V3 p, float out[4]) {
     for (int r = 0; r < 4; ++r) out[r] = m[r] * p.x + m[4 + r] * p.y + m[8 + r] * p.z + m[12 + r];
 }
 
-struct Material { float albedo[4]; float spec[3]; };
+struct Material { float albedo[4]; float spec[3]; int tex[3] = {-1, -1, -1}; };   // tex: diffuse, specular, height
+struct Texture { int w = 0, h = 0; std::vector<uint8_t> rgba; };
 
 }  // namespace
 
 struct vcth_scene {
     std::vector<float> pos, nrm, tan, bit;   // per triangle-vertex, 3 floats each
+    std::vector<float> uv;                   // per triangle-vertex, 2 floats
     std::vector<int32_t> mat;                // per triangle
     std::vector<Material> materials;
+    std::vector<Texture> textures;
 };
 
 namespace {
 
+struct UV { float u, v; };
+constexpr float kTexTile = 8.0f;     // world units per texture repeat of the procedural scenes
+
 struct Builder {
     vcth_scene* s;
-    void tri(V3 a, V3 b, V3 c, V3 na, V3 nb, V3 nc, int m) {
+    void tri(V3 a, V3 b, V3 c, V3 na, V3 nb, V3 nc, int m, UV ta = {0, 0}, UV tb = {0, 0}, UV tc = {0, 0}) {
         const V3 p[3] = {a, b, c}, n[3] = {na, nb, nc};
+        const UV tx[3] = {ta, tb, tc};
         for (int k = 0; k < 3; ++k) {
+            s->uv.insert(s->uv.end(), {tx[k].u, tx[k].v});
             const V3 nn = normalize(n[k]);
             const V3 hint = fabsf(nn.y) < 0.9f ? V3{0, 1, 0} : V3{1, 0, 0};
             const V3 t = normalize(cross(hint, nn));
@@ -123,11 +131,13 @@ struct Builder {
             const V3 b = dv + n0 * ((disp(u, v + e) - disp(u, v - e)) / (2 * e));
             return normalize(cross(a, b));
         };
+        const float lu = sqrtf(dot(du, du)) / kTexTile, lv = sqrtf(dot(dv, dv)) / kTexTile;
+        auto T = [&](int i, int j) { return UV{lu * (float)i / nu, lv * (float)j / nv}; };
         for (int j = 0; j < nv; ++j)
             for (int i = 0; i < nu; ++i) {
                 const V3 a = P(i, j), b = P(i + 1, j), c = P(i + 1, j + 1), d = P(i, j + 1);
-                tri(a, b, c, Nn(i, j), Nn(i + 1, j), Nn(i + 1, j + 1), m);
-                tri(a, c, d, Nn(i, j), Nn(i + 1, j + 1), Nn(i, j + 1), m);
+                tri(a, b, c, Nn(i, j), Nn(i + 1, j), Nn(i + 1, j + 1), m, T(i, j), T(i + 1, j), T(i + 1, j + 1));
+                tri(a, c, d, Nn(i, j), Nn(i + 1, j + 1), Nn(i, j + 1), m, T(i, j), T(i + 1, j + 1), T(i, j + 1));
             }
     }
     void quad(V3 o, V3 du, V3 dv, int nu, int nv, int m) {
@@ -154,8 +164,10 @@ struct Builder {
                 const V3 n0 = {cosf(a0), 0, sinf(a0)}, n1 = {cosf(a1), 0, sinf(a1)};
                 const V3 p00 = base + n0 * radius + V3{0, y0, 0}, p10 = base + n1 * radius + V3{0, y0, 0};
                 const V3 p01 = base + n0 * radius + V3{0, y1, 0}, p11 = base + n1 * radius + V3{0, y1, 0};
-                tri(p00, p01, p11, n0, n0, n1, m);     // CCW seen from outside
-                tri(p00, p11, p10, n0, n1, n1, m);
+                const float u0 = a0 * radius / kTexTile, u1 = a1 * radius / kTexTile;
+                const float v0 = y0 / kTexTile, v1 = y1 / kTexTile;
+                tri(p00, p01, p11, n0, n0, n1, m, {u0, v0}, {u0, v1}, {u1, v1});     // CCW seen from outside
+                tri(p00, p11, p10, n0, n1, n1, m, {u0, v0}, {u1, v1}, {u1, v0});
             }
     }
     void sphere(V3 c, float r, int seg, int rings, int m) {
@@ -167,8 +179,9 @@ struct Builder {
         for (int j = 0; j < rings; ++j)
             for (int i = 0; i < seg; ++i) {
                 const V3 a = P(i, j), b = P(i + 1, j), cc = P(i + 1, j + 1), d = P(i, j + 1);
-                if (j > 0) tri(c + a * r, c + b * r, c + cc * r, a, b, cc, m);
-                if (j < rings - 1) tri(c + a * r, c + cc * r, c + d * r, a, cc, d, m);
+                auto T = [&](int ii, int jj) { return UV{4.0f * ii / seg, 2.0f * jj / rings}; };
+                if (j > 0) tri(c + a * r, c + b * r, c + cc * r, a, b, cc, m, T(i, j), T(i + 1, j), T(i + 1, j + 1));
+                if (j < rings - 1) tri(c + a * r, c + cc * r, c + d * r, a, cc, d, m, T(i, j), T(i + 1, j + 1), T(i, j + 1));
             }
     }
 };
@@ -206,7 +219,99 @@ void build_cornell(vcth_scene* s) {
     finish(s);
 }
 
-void build_atrium(vcth_scene* s, float detail, uint32_t seed) {
+// ---- procedural textures (the reference loads image files with stb_image, R/Model.h:141-226; there are no
+// assets and no network here, so the textured scene generates its maps: same data path from there on) ----
+inline uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+inline float hash01(int x, int y, uint32_t seed) {
+    return (float)(hash32((uint32_t)x * 374761393u + (uint32_t)y * 668265263u + seed * 2246822519u) >> 8) / 16777216.0f;
+}
+// tileable value noise in [0,1]: `cells` lattice cells across the texture
+float value_noise(float u, float v, int cells, uint32_t seed) {
+    const float x = u * cells, y = v * cells;
+    const int i = (int)floorf(x), j = (int)floorf(y);
+    float a = x - i, b = y - j;
+    a = a * a * (3 - 2 * a); b = b * b * (3 - 2 * b);
+    auto L = [&](int ii, int jj) { return hash01(((ii % cells) + cells) % cells, ((jj % cells) + cells) % cells, seed); };
+    return (L(i, j) * (1 - a) + L(i + 1, j) * a) * (1 - b) + (L(i, j + 1) * (1 - a) + L(i + 1, j + 1) * a) * b;
+}
+template <class F>
+int add_texture(vcth_scene* s, int w, int h, F texel) {     // texel(u, v, x, y, out rgba 0..1)
+    Texture t;
+    t.w = w; t.h = h;
+    t.rgba.resize((size_t)w * h * 4);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float c[4] = {0, 0, 0, 1};
+            texel(((float)x + 0.5f) / w, ((float)y + 0.5f) / h, x, y, c);
+            for (int k = 0; k < 4; ++k) {
+                const float f = c[k] < 0.0f ? 0.0f : (c[k] > 1.0f ? 1.0f : c[k]);
+                t.rgba[((size_t)y * w + x) * 4 + k] = (uint8_t)(f * 255.0f + 0.5f);
+            }
+        }
+    s->textures.push_back(t);
+    return (int)s->textures.size() - 1;
+}
+
+// material textures of the textured atrium (kind 2): checker floor with a red-only specular map (the .rrra
+// rule of trace.fs:210), brick walls, stone with a noisy height map, bronze with a coloured specular map,
+// cloth with alpha cut-outs (the alpha test of trace.fs:169-172)
+void texture_atrium(vcth_scene* s, int stone, int floorm, int brick, const int curtains[3], int bronze, uint32_t seed) {
+    const int checker = add_texture(s, 256, 256, [&](float u, float v, int x, int y, float* c) {
+        const bool k = ((x / 32) + (y / 32)) & 1;
+        const float n = 0.08f * (value_noise(u, v, 32, seed + 1) - 0.5f);
+        const float base = k ? 0.62f : 0.30f;
+        c[0] = base + n; c[1] = base * 0.95f + n; c[2] = base * 0.85f + n;
+    });
+    const int floor_spec = add_texture(s, 64, 64, [&](float u, float v, int, int, float* c) {
+        c[0] = 0.25f + 0.3f * value_noise(u, v, 8, seed + 2); c[1] = 0.0f; c[2] = 0.0f;     // r only -> .rrra
+    });
+    const int bricks = add_texture(s, 256, 128, [&](float u, float v, int x, int y, float* c) {
+        const int row = y / 16, xo = x + ((row & 1) ? 16 : 0);
+        const bool mortar = (y % 16) < 2 || (xo % 32) < 2;
+        const float n = 0.12f * (value_noise(u, v, 64, seed + 3) - 0.5f);
+        const float tone = 0.85f + 0.3f * (hash01(xo / 32, row, seed + 4) - 0.5f);
+        if (mortar) { c[0] = 0.55f + n; c[1] = 0.53f + n; c[2] = 0.50f + n; }
+        else { c[0] = 0.55f * tone + n; c[1] = 0.30f * tone + n; c[2] = 0.22f * tone + n; }
+    });
+    const int brick_h = add_texture(s, 256, 128, [&](float u, float v, int x, int y, float* c) {
+        const int row = y / 16, xo = x + ((row & 1) ? 16 : 0);
+        const bool mortar = (y % 16) < 2 || (xo % 32) < 2;
+        const float hgt = mortar ? 0.15f : 0.7f + 0.2f * value_noise(u, v, 64, seed + 5);
+        c[0] = c[1] = c[2] = hgt;
+    });
+    const int stone_d = add_texture(s, 256, 256, [&](float u, float v, int, int, float* c) {
+        const float n = 0.55f * value_noise(u, v, 16, seed + 6) + 0.45f * value_noise(u, v, 64, seed + 7);
+        c[0] = 0.50f + 0.25f * n; c[1] = 0.47f + 0.23f * n; c[2] = 0.40f + 0.20f * n;
+    });
+    const int stone_h = add_texture(s, 256, 256, [&](float u, float v, int, int, float* c) {
+        const float n = 0.6f * value_noise(u, v, 16, seed + 8) + 0.4f * value_noise(u, v, 96, seed + 9);
+        c[0] = c[1] = c[2] = n;
+    });
+    const int bronze_s = add_texture(s, 64, 64, [&](float u, float v, int, int, float* c) {
+        const float n = 0.7f + 0.3f * value_noise(u, v, 8, seed + 10);
+        c[0] = 0.8f * n; c[1] = 0.6f * n; c[2] = 0.3f * n;
+    });
+    int cloth[3];
+    const float tint[3][3] = {{0.75f, 0.08f, 0.06f}, {0.10f, 0.55f, 0.14f}, {0.10f, 0.18f, 0.70f}};
+    for (int k = 0; k < 3; ++k)
+        cloth[k] = add_texture(s, 128, 128, [&](float u, float v, int x, int y, float* c) {
+            const float n = 0.85f + 0.3f * (value_noise(u, v, 32, seed + 11 + k) - 0.5f);
+            const int dx = (x % 32) - 16, dy = (y % 32) - 16;
+            c[0] = tint[k][0] * n; c[1] = tint[k][1] * n; c[2] = tint[k][2] * n;
+            c[3] = dx * dx + dy * dy < 36 ? 0.0f : 1.0f;                 // lace holes: alpha test
+        });
+    auto set = [&](int m, int d, int sp, int h) { s->materials[(size_t)m].tex[0] = d; s->materials[(size_t)m].tex[1] = sp; s->materials[(size_t)m].tex[2] = h; };
+    set(floorm, checker, floor_spec, stone_h);
+    set(brick, bricks, -1, brick_h);
+    set(stone, stone_d, -1, stone_h);
+    set(bronze, -1, bronze_s, -1);
+    for (int k = 0; k < 3; ++k) set(curtains[k], cloth[k], -1, -1);
+}
+
+void build_atrium(vcth_scene* s, float detail, uint32_t seed, bool textured) {
     Builder b{s};
     uint32_t rng = seed * 2654435761u + 12345u;
     auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return (float)(rng >> 8) / 16777216.0f; };
@@ -275,98 +380,63 @@ void build_atrium(vcth_scene* s, float detail, uint32_t seed) {
         b.box({x, Y0, z}, {x + 3.0f + 3.0f * rnd(), Y0 + hgt, z + 3.0f + 2.0f * rnd()}, cell,
               (i & 1) ? brick : stone);
     }
+    if (textured) texture_atrium(s, stone, floorm, brick, curtains, bronze, seed);
     finish(s);
 }
 
-// ---- rasteriser ------------------------------------------------------------------------
-
-constexpr int kMaxVar = 12;
-struct RVert { float c[4]; float var[kMaxVar]; };
-
-inline RVert lerp_vert(const RVert& a, const RVert& b, float t, int nvar) {
-    RVert r;
-    for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] + (b.c[i] - a.c[i]) * t;
-    for (int i = 0; i < nvar; ++i) r.var[i] = a.var[i] + (b.var[i] - a.var[i]) * t;
-    return r;
-}
-
-// Rasterises one clip-space triangle (GL rules: near-plane clip, pixel-centre sampling, top-left
-// fill rule, optional back-face cull with CCW front faces, depth test LESS).  frag(x, y, z, var)
-// is called for every fragment that passes the depth test.
-template <class Frag>
-void raster_triangle(const RVert in[3], int nvar, bool cull_back, int W, int H, float* zbuf, Frag frag) {
-    RVert poly[4];
-    int np = 0;
-    for (int i = 0; i < 3; ++i) {             // clip against z >= -w
-        const RVert& a = in[i];
-        const RVert& b = in[(i + 1) % 3];
-        const float da = a.c[2] + a.c[3], db = b.c[2] + b.c[3];
-        if (da >= 0.0f) poly[np++] = a;
-        if ((da >= 0.0f) != (db >= 0.0f)) poly[np++] = lerp_vert(a, b, da / (da - db), nvar);
-    }
-    if (np < 3) return;
-    for (int t = 1; t + 1 < np; ++t) {
-        const RVert* v[3] = {&poly[0], &poly[t], &poly[t + 1]};
-        // window coordinates snapped to 1/256 pixel (GL sub-pixel precision) and edge functions in
-        // double: with snapped inputs every product is exact, so shared edges are watertight.
-        double sx[3], sy[3];
-        float sz[3], iw[3];
-        bool bad = false;
-        for (int k = 0; k < 3; ++k) {
-            if (!(v[k]->c[3] > 1e-20f)) { bad = true; break; }
-            iw[k] = 1.0f / v[k]->c[3];
-            sx[k] = floor((double)((v[k]->c[0] * iw[k] * 0.5f + 0.5f) * (float)W) * 256.0 + 0.5) / 256.0;
-            sy[k] = floor((double)((v[k]->c[1] * iw[k] * 0.5f + 0.5f) * (float)H) * 256.0 + 0.5) / 256.0;
-            sz[k] = v[k]->c[2] * iw[k] * 0.5f + 0.5f;
+// Image files of an MTL's map_Kd / map_Ks / map_bump (the reference decodes them with stb_image,
+// R/Model.h:141-226): binary PPM (P6, maxval 255) and uncompressed true-colour TGA (type 2, 24 / 32 bpp) --
+// formats that need no entropy decoder.  Rows are stored bottom-up (row 0 at v = 0), which is what the
+// reference's aiProcess_FlipUVs + top-down stb rows amount to.
+bool load_image(const std::string& path, Texture& t) {
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) return false;
+    std::vector<uint8_t> buf;
+    uint8_t tmp[65536];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof(tmp), fp)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(fp);
+    if (buf.size() >= 2 && buf[0] == 'P' && buf[1] == '6') {
+        size_t pos = 2;
+        int vals[3], got = 0;
+        while (got < 3 && pos < buf.size()) {
+            while (pos < buf.size() && (buf[pos] == ' ' || buf[pos] == '\n' || buf[pos] == '\r' || buf[pos] == '\t')) ++pos;
+            if (pos < buf.size() && buf[pos] == '#') { while (pos < buf.size() && buf[pos] != '\n') ++pos; continue; }
+            int v = 0, digits = 0;
+            while (pos < buf.size() && buf[pos] >= '0' && buf[pos] <= '9') { v = v * 10 + (buf[pos] - '0'); ++pos; ++digits; }
+            if (!digits) return false;
+            vals[got++] = v;
         }
-        if (bad) continue;
-        double area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sx[2] - sx[0]) * (sy[1] - sy[0]);
-        if (area == 0.0 || area != area) continue;
-        if (area < 0.0 && cull_back) continue;
-        const double sgn = area > 0.0 ? 1.0 : -1.0;
-        area *= sgn;
-        const int x0 = std::max(0, (int)floor(std::min({sx[0], sx[1], sx[2]})));
-        const int x1 = std::min(W - 1, (int)floor(std::max({sx[0], sx[1], sx[2]})));
-        const int y0 = std::max(0, (int)floor(std::min({sy[0], sy[1], sy[2]})));
-        const int y1 = std::min(H - 1, (int)floor(std::max({sy[0], sy[1], sy[2]})));
-        for (int py = y0; py <= y1; ++py)
-            for (int px = x0; px <= x1; ++px) {
-                const double cx = (double)px + 0.5, cy = (double)py + 0.5;
-                double e[3];
-                bool inside = true;
-                for (int k = 0; k < 3; ++k) {
-                    const int a = (k + 1) % 3, b = (k + 2) % 3;
-                    const double dx = (sx[b] - sx[a]) * sgn, dy = (sy[b] - sy[a]) * sgn;
-                    e[k] = dx * (cy - sy[a]) - dy * (cx - sx[a]);
-                    const bool top_left = (dy > 0.0) || (dy == 0.0 && dx < 0.0);
-                    if (e[k] < 0.0 || (e[k] == 0.0 && !top_left)) { inside = false; break; }
-                }
-                if (!inside) continue;
-                const float b0 = (float)(e[0] / area), b1 = (float)(e[1] / area), b2 = 1.0f - b0 - b1;
-                const float z = b0 * sz[0] + b1 * sz[1] + b2 * sz[2];
-                if (!(z >= 0.0f && z <= 1.0f)) continue;               // far-plane clip
-                float& zb = zbuf[(size_t)py * W + px];
-                if (!(z < zb)) continue;                                 // GL_LESS
-                zb = z;
-                const float q0 = b0 * iw[0], q1 = b1 * iw[1], q2 = b2 * iw[2];
-                const float qs = 1.0f / (q0 + q1 + q2);
-                float var[kMaxVar];
-                for (int i = 0; i < nvar; ++i)
-                    var[i] = (q0 * v[0]->var[i] + q1 * v[1]->var[i] + q2 * v[2]->var[i]) * qs;
-                frag(px, py, z, var);
+        ++pos;      // the single whitespace after maxval
+        const int w = vals[0], h = vals[1];
+        if (got < 3 || vals[2] != 255 || w <= 0 || h <= 0 || pos + (size_t)w * h * 3 > buf.size()) return false;
+        t.w = w; t.h = h;
+        t.rgba.resize((size_t)w * h * 4);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const uint8_t* src = &buf[pos + ((size_t)(h - 1 - y) * w + x) * 3];
+                uint8_t* dst = &t.rgba[((size_t)y * w + x) * 4];
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = 255;
             }
+        return true;
     }
-}
-
-float shadow_fetch(const float* depth, int S, float u, float v) {   // bilinear, clamp-to-edge
-    const float x = u * (float)S - 0.5f, y = v * (float)S - 0.5f;
-    const float fx = floorf(x), fy = floorf(y);
-    const float a = x - fx, b = y - fy;
-    auto cl = [S](float f) { return f < 0.0f ? 0 : (f > (float)(S - 1) ? S - 1 : (int)f); };
-    const int i0 = cl(fx), i1 = cl(fx + 1.0f), j0 = cl(fy), j1 = cl(fy + 1.0f);
-    const float d00 = depth[(size_t)j0 * S + i0], d10 = depth[(size_t)j0 * S + i1];
-    const float d01 = depth[(size_t)j1 * S + i0], d11 = depth[(size_t)j1 * S + i1];
-    return (1 - a) * (1 - b) * d00 + a * (1 - b) * d10 + (1 - a) * b * d01 + a * b * d11;
+    if (buf.size() >= 18 && buf[2] == 2 && (buf[16] == 24 || buf[16] == 32)) {      // TGA
+        const int w = buf[12] | (buf[13] << 8), h = buf[14] | (buf[15] << 8), bpp = buf[16] / 8;
+        const size_t off = 18 + buf[0];
+        const bool top_down = (buf[17] & 0x20) != 0;
+        if (w <= 0 || h <= 0 || off + (size_t)w * h * bpp > buf.size()) return false;
+        t.w = w; t.h = h;
+        t.rgba.resize((size_t)w * h * 4);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const int sy = top_down ? h - 1 - y : y;
+                const uint8_t* src = &buf[off + ((size_t)sy * w + x) * bpp];
+                uint8_t* dst = &t.rgba[((size_t)y * w + x) * 4];
+                dst[0] = src[2]; dst[1] = src[1]; dst[2] = src[0]; dst[3] = bpp == 4 ? src[3] : 255;   // BGR(A)
+            }
+        return true;
+    }
+    return false;
 }
 
 }  // namespace
@@ -385,7 +455,8 @@ void vcth_default_camera(vcth_camera* cam) {
 vcth_scene* vcth_scene_create(int kind, float detail, uint32_t seed) {
     vcth_scene* s = new vcth_scene();
     if (kind == 0) build_cornell(s);
-    else if (kind == 1) build_atrium(s, detail, seed);
+    else if (kind == 1) build_atrium(s, detail, seed, false);
+    else if (kind == 2) build_atrium(s, detail, seed, true);
     else { delete s; return nullptr; }
     return s;
 }
@@ -406,6 +477,8 @@ vcth_scene* vcth_scene_load_obj(const char* path, char* error) {
     std::vector<Corner> corners;                 // 3 per triangle
     std::vector<int32_t> tri_mat;
     std::vector<Material> mats;
+    std::vector<Texture> texs;
+    std::map<std::string, int> tex_index;        // de-duplicated by file name, like R/Model.h:198-208
     std::map<std::string, int> mat_index;
     auto material = [&](const std::string& name) {
         auto it = mat_index.find(name);
@@ -428,6 +501,32 @@ vcth_scene* vcth_scene_load_obj(const char* path, char* error) {
             } else if (cur >= 0 && sscanf(line, " Ks %f %f %f", &a, &b, &c) == 3) {
                 mats[(size_t)cur].spec[0] = a; mats[(size_t)cur].spec[1] = b; mats[(size_t)cur].spec[2] = c;
             } else if (cur >= 0 && sscanf(line, " d %f", &a) == 1) mats[(size_t)cur].albedo[3] = a;
+            else if (cur >= 0) {
+                // map_Kd -> DiffuseTexture, map_Ks -> SpecularTexture, map_bump / bump -> HeightTexture
+                // (R/Model.h:126-136; options such as "-bm 1.0" are skipped: the file name is the last token)
+                int slot = -1;
+                char key[64];
+                if (sscanf(line, " %63s", key) == 1) {
+                    if (!strcmp(key, "map_Kd")) slot = 0;
+                    else if (!strcmp(key, "map_Ks")) slot = 1;
+                    else if (!strcmp(key, "map_bump") || !strcmp(key, "map_Bump") || !strcmp(key, "bump")) slot = 2;
+                }
+                if (slot >= 0) {
+                    std::string rest(line);
+                    while (!rest.empty() && (rest.back() == '\n' || rest.back() == '\r' || rest.back() == ' ')) rest.pop_back();
+                    const size_t sp = rest.find_last_of(" \t");
+                    const std::string fname = sp == std::string::npos ? rest : rest.substr(sp + 1);
+                    auto it = tex_index.find(fname);
+                    int ti = it != tex_index.end() ? it->second : -2;
+                    if (ti == -2) {
+                        Texture t;
+                        ti = load_image(dir + fname, t) ? (int)texs.size() : -1;     // unreadable / unsupported: flat colour
+                        if (ti >= 0) texs.push_back(t);
+                        tex_index[fname] = ti;
+                    }
+                    mats[(size_t)cur].tex[slot] = ti;
+                }
+            }
         }
         fclose(mf);
     };
@@ -482,6 +581,7 @@ vcth_scene* vcth_scene_load_obj(const char* path, char* error) {
     }
     vcth_scene* s = new vcth_scene();
     s->materials = mats;
+    s->textures = texs;
     s->mat = tri_mat;
     for (size_t t = 0; t < tri_mat.size(); ++t) {
         const Corner* c = &corners[3 * t];
@@ -510,6 +610,8 @@ vcth_scene* vcth_scene_load_obj(const char* path, char* error) {
             s->nrm.insert(s->nrm.end(), {n.x, n.y, n.z});
             s->tan.insert(s->tan.end(), {tg.x, tg.y, tg.z});
             s->bit.insert(s->bit.end(), {bt.x, bt.y, bt.z});
+            if (c[k].t >= 0) s->uv.insert(s->uv.end(), {vt[2 * (size_t)c[k].t], vt[2 * (size_t)c[k].t + 1]});
+            else s->uv.insert(s->uv.end(), {0.0f, 0.0f});
         }
     }
     return s;
@@ -558,86 +660,26 @@ void vcth_light_view_proj(const float L[3], float out_vp[16]) {
     memcpy(out_vp, vp.m, 64);
 }
 
-void vcth_render_shadow_map(const vcth_scene* s, float model_scale, const float light_vp[16],
-                            int32_t S, float* depth) {
-    const size_t n = (size_t)S * S;
-    for (size_t i = 0; i < n; ++i) depth[i] = 1.0f;                      // glClear depth
-    const size_t ntri = s->mat.size();
-    for (size_t t = 0; t < ntri; ++t) {
-        RVert v[3];
-        for (int k = 0; k < 3; ++k) {
-            const float* p = &s->pos[t * 9 + 3 * k];
-            xform(light_vp, V3{p[0] * model_scale, p[1] * model_scale, p[2] * model_scale}, v[k].c);
-        }
-        raster_triangle(v, 0, true, S, S, depth, [](int, int, float, const float*) {});
-    }
-    const float q = 16777215.0f;                                         // DEPTH_COMPONENT24
-    for (size_t i = 0; i < n; ++i) depth[i] = (float)(floor((double)depth[i] * q + 0.5) / q);
+void vcth_scene_get_uvs(const vcth_scene* s, float* uv) {
+    if (uv) memcpy(uv, s->uv.data(), s->uv.size() * sizeof(float));
 }
 
-void vcth_render_gbuffer(const vcth_scene* s, float model_scale, const vcth_camera* cam, int32_t W,
-                         int32_t H, const float* shadow_depth, int32_t shadow_size,
-                         const float light_vp[16], float* planes) {
-    const size_t npix = (size_t)W * H;
-    memset(planes, 0, npix * 23 * sizeof(float));
-    std::vector<float> zbuf(npix, 1.0f);
-    std::vector<int32_t> mat(npix, -1);
-    const M4 vp = camera_vp(cam, W, H);
-    const size_t ntri = s->mat.size();
-    for (size_t t = 0; t < ntri; ++t) {
-        RVert v[3];
-        for (int k = 0; k < 3; ++k) {
-            const float* p = &s->pos[t * 9 + 3 * k];
-            const V3 w = {p[0] * model_scale, p[1] * model_scale, p[2] * model_scale};   // trace.vs:27
-            xform(vp.m, w, v[k].c);                                                      // trace.vs:25
-            float* o = v[k].var;
-            o[0] = w.x; o[1] = w.y; o[2] = w.z;
-            for (int i = 0; i < 3; ++i) {
-                o[3 + i] = s->nrm[t * 9 + 3 * k + i] * model_scale;    // trace.vs:31 (w = 0)
-                o[6 + i] = s->tan[t * 9 + 3 * k + i] * model_scale;    // trace.vs:32
-                o[9 + i] = s->bit[t * 9 + 3 * k + i] * model_scale;    // trace.vs:33
-            }
-        }
-        const int32_t m = s->mat[t];
-        raster_triangle(v, 12, true, W, H, zbuf.data(), [&](int x, int y, float, const float* var) {
-            const size_t i = (size_t)y * W + x;
-            for (int k = 0; k < 12; ++k) planes[(size_t)k * npix + i] = var[k];
-            mat[i] = m;
-        });
-    }
-    // per-pixel material + bump normal + shadow term (the non-cone part of trace.fs)
-    for (size_t i = 0; i < npix; ++i) {
-        if (mat[i] < 0) continue;
-        auto G = [&](int k) -> float& { return planes[(size_t)k * npix + i]; };
-        const V3 P = {G(0), G(1), G(2)}, N = {G(3), G(4), G(5)}, T = {G(6), G(7), G(8)}, B = {G(9), G(10), G(11)};
-        // CalcBumpNormal with a flat height map: normalize(TBN * (0,0,1)), TBN = inverse(transpose(M))
-        const V3 c2 = cross(T, B);
-        const float det = dot(T, cross(B, N));
-        const V3 bn = normalize(c2 * (1.0f / det));                                   // trace.fs:127,175
-        G(12) = bn.x; G(13) = bn.y; G(14) = bn.z;
-        const Material& mm = s->materials[(size_t)mat[i]];
-        for (int k = 0; k < 4; ++k) G(15 + k) = mm.albedo[k];                          // trace.fs:167
-        const bool has_gb = sqrtf(mm.spec[1] * mm.spec[1] + mm.spec[2] * mm.spec[2]) > 0.0f;
-        G(19) = mm.spec[0];
-        G(20) = has_gb ? mm.spec[1] : mm.spec[0];                                      // trace.fs:210
-        G(21) = has_gb ? mm.spec[2] : mm.spec[0];
-        float shadow = 25.0f * 0.111f;
-        if (shadow_depth) {
-            float d[4];
-            xform(light_vp, P, d);                                                     // trace.vs:28
-            const float cx = d[0] * 0.5f + 0.5f, cy = d[1] * 0.5f + 0.5f, cz = d[2] * 0.5f + 0.5f;   // :29
-            float cnt = 0.0f;
-            for (int x = -2; x <= 2; ++x)
-                for (int y = -2; y <= 2; ++y) {
-                    const float ox = 1.0f / (float)shadow_size * (float)x;            // trace.fs:147
-                    const float oy = 1.0f / (float)shadow_size * (float)y;
-                    if (cz / d[3] - 0.002f <= shadow_fetch(shadow_depth, shadow_size, cx + ox, cy + oy))
-                        cnt += 1.0f;                                                   // trace.fs:151-152
-                }
-            shadow = cnt * 0.111f;                                                     // trace.fs:158
-        }
-        G(22) = shadow;
-    }
+int32_t vcth_scene_num_textures(const vcth_scene* s) { return s ? (int32_t)s->textures.size() : 0; }
+
+void vcth_scene_texture_info(const vcth_scene* s, int32_t i, int32_t* w, int32_t* h) {
+    const bool ok = s && i >= 0 && i < (int32_t)s->textures.size();
+    if (w) *w = ok ? s->textures[(size_t)i].w : 0;
+    if (h) *h = ok ? s->textures[(size_t)i].h : 0;
+}
+
+void vcth_scene_get_texture(const vcth_scene* s, int32_t i, uint8_t* rgba) {
+    if (!s || !rgba || i < 0 || i >= (int32_t)s->textures.size()) return;
+    memcpy(rgba, s->textures[(size_t)i].rgba.data(), s->textures[(size_t)i].rgba.size());
+}
+
+void vcth_scene_get_material_textures(const vcth_scene* s, int32_t* mat_tex) {
+    for (size_t i = 0; i < s->materials.size(); ++i)
+        for (int k = 0; k < 3; ++k) mat_tex[3 * i + k] = s->materials[i].tex[k];
 }
 
 }  // extern "C"

@@ -1,6 +1,5 @@
-"""ctypes binding of libvct_host.so: procedural scenes + the CPU input stages (shadow-map raster,
-G-buffer raster) that feed vct_voxelize / vct_trace.  See host/vct_host.h for what each stands in
-for in the reference."""
+"""ctypes binding of libvct_host.so: scenes (procedural, or a Wavefront OBJ + MTL with texture maps),
+camera and light matrices.  See host/vct_host.h for what each stands in for in the reference."""
 import ctypes as C
 import os
 
@@ -12,7 +11,7 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `make host`")
 _lib = C.CDLL(LIB_PATH)
 
-CORNELL, ATRIUM = 0, 1
+CORNELL, ATRIUM, ATRIUM_TEXTURED = 0, 1, 2
 
 
 class Camera(C.Structure):
@@ -31,9 +30,11 @@ _lib.vcth_scene_get.argtypes = [C.c_void_p] * 5
 _lib.vcth_light_view_proj.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vcth_scene_get_frames.argtypes = [C.c_void_p] * 4
 _lib.vcth_camera_view_proj.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
-_lib.vcth_render_shadow_map.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]
-_lib.vcth_render_gbuffer.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
-                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+_lib.vcth_scene_get_uvs.argtypes = [C.c_void_p, C.c_void_p]
+_lib.vcth_scene_num_textures.argtypes = [C.c_void_p]
+_lib.vcth_scene_texture_info.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+_lib.vcth_scene_get_texture.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+_lib.vcth_scene_get_material_textures.argtypes = [C.c_void_p, C.c_void_p]
 
 
 def default_camera(position=None, yaw=None, pitch=None, zoom=None):
@@ -85,6 +86,17 @@ class Scene:
         self.specular = np.zeros((self.nmat, 3), np.float32)
         _lib.vcth_scene_get(self._h, self.pos.ctypes.data, self.material.ctypes.data,
                             self.albedo.ctypes.data, self.specular.ctypes.data)
+        self.uv = np.zeros((self.ntri, 6), np.float32)
+        _lib.vcth_scene_get_uvs(self._h, self.uv.ctypes.data)
+        self.mat_tex = np.full((self.nmat, 3), -1, np.int32)       # diffuse / specular / height texture or -1
+        _lib.vcth_scene_get_material_textures(self._h, self.mat_tex.ctypes.data)
+        self.textures = []                                         # uint8 [h, w, 4], row 0 at v = 0
+        for i in range(_lib.vcth_scene_num_textures(self._h)):
+            w, h = C.c_int32(), C.c_int32()
+            _lib.vcth_scene_texture_info(self._h, i, C.byref(w), C.byref(h))
+            t = np.zeros((h.value, w.value, 4), np.uint8)
+            _lib.vcth_scene_get_texture(self._h, i, t.ctypes.data)
+            self.textures.append(t)
 
     def frames(self):
         """Per-vertex (normal, tangent, bitangent), each float32 [ntri, 9]."""
@@ -96,25 +108,3 @@ class Scene:
         if getattr(self, "_h", None) and _lib is not None:
             _lib.vcth_scene_destroy(self._h)
             self._h = None
-
-    def shadow_map(self, light_dir, size, model_scale=0.05):
-        """Returns (depth [size,size] fp32, light_vp row-major 4x4)."""
-        L = np.ascontiguousarray(light_dir, np.float32)
-        vp = np.zeros(16, np.float32)
-        _lib.vcth_light_view_proj(L.ctypes.data, vp.ctypes.data)
-        depth = np.zeros((size, size), np.float32)
-        _lib.vcth_render_shadow_map(self._h, model_scale, vp.ctypes.data, size, depth.ctypes.data)
-        return depth, vp.reshape(4, 4).T.copy()
-
-    def gbuffer(self, cam, w, h, shadow=None, light_vp=None, model_scale=0.05):
-        planes = np.zeros((23, w * h), np.float32)
-        if shadow is not None:
-            sd = np.ascontiguousarray(shadow, np.float32)
-            vp = np.ascontiguousarray(np.asarray(light_vp, np.float32).T)   # column-major
-            _lib.vcth_render_gbuffer(self._h, model_scale, C.byref(cam), w, h, sd.ctypes.data,
-                                     sd.shape[0], vp.ctypes.data, planes.ctypes.data)
-        else:
-            vp = np.eye(4, dtype=np.float32)
-            _lib.vcth_render_gbuffer(self._h, model_scale, C.byref(cam), w, h, None, 0,
-                                     vp.ctypes.data, planes.ctypes.data)
-        return planes
