@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--voxel-dim", type=int, default=256)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell", "noise"])
+    ap.add_argument("--scene", default="atrium", choices=["atrium", "atrium-textured", "cornell", "noise"],
+                    help="atrium-textured: the same atrium with procedural diffuse / specular / height maps "
+                         "(bump-mapped normals decohere the specular cones)")
     ap.add_argument("--obj", default=None, metavar="PATH",
                     help="Wavefront .obj (+ .mtl) to use instead of a procedural scene, e.g. the real Sponza; model "
                          "units like the reference's (world = 0.05 * model, VCT.h:183)")
@@ -79,10 +81,12 @@ def build_inputs(args, vct, sc):
         scene = sc.Scene(args.obj)
         cam = sc.default_camera()                                # VCT.h:8: (0,4,0), yaw -90
         label = f"{os.path.basename(args.obj)} ({scene.ntri} tris)"
-    elif args.scene == "atrium":
-        scene = sc.Scene(sc.ATRIUM, args.scene_detail, 1234)
+    elif args.scene in ("atrium", "atrium-textured"):
+        tex = args.scene == "atrium-textured"
+        scene = sc.Scene(sc.ATRIUM_TEXTURED if tex else sc.ATRIUM, args.scene_detail, 1234)
         cam = sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
-        label = f"procedural atrium (Sponza-class, {scene.ntri} tris, seed 1234)"
+        label = (f"procedural atrium (Sponza-class, {scene.ntri} tris, seed 1234" +
+                 (f", {len(scene.textures)} procedural texture maps)" if tex else ")"))
     else:
         scene = sc.Scene(sc.CORNELL)
         cam = sc.default_camera(position=(0.0, 0.0, 58.0), yaw=-90.0)
@@ -150,8 +154,7 @@ def main():
     with torch.cuda.stream(ext_stream):
         if inp["scene"] is not None:
             s = inp["scene"]
-            ctx.upload_triangles(s.pos, s.material, s.albedo)
-            ctx.upload_mesh_attributes(*s.frames(), s.specular)
+            ctx.upload_scene(s)         # triangles, frames, and (textured scenes) texture coordinates + maps
             for _ in range(2):          # second pass is the timed one (first warms caches/allocs)
                 ei = [ev() for _ in range(3)]
                 ei[0].record(); ctx.render_shadow_map(inp["light_vp"])        # DrawDepthTexture
@@ -322,7 +325,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if not args.obj else "user-supplied mesh (flat per-material colours)",
+            "data": "synthetic" if not args.obj else "user-supplied mesh",
             "config": {"workload": f"{inp['label']}, {V}^3 RGBA8 brick chain, {w}x{h}, 6 diffuse + 1 "
                                    f"specular cone/px, trace of a resident (GPU-rasterised) G-buffer",
                        "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7, "bounces": args.bounces,

@@ -132,6 +132,18 @@ int vct_upload_shadow_map(vct_ctx* ctx, const float* depth, int32_t size, const 
  * tangent, bitangent [ntri][3][3] model space, specular [nmat][3].  Call after vct_upload_triangles. */
 int vct_upload_mesh_attributes(vct_ctx* ctx, const float* normal, const float* tangent,
                                const float* bitangent, const float* specular);
+/* Texture coordinates of the uploaded triangles (attribute 2, R/Mesh.h:72-73): uv [ntri][3][2]. */
+int vct_upload_mesh_uvs(vct_ctx* ctx, const float* uv);
+/* Material textures (R/Model.h:126-136,141-226; bound per draw at R/Mesh.h:91-108): ntex RGBA8 images
+ * (rgba8[i]: height[i] * width[i] * 4 bytes, row 0 at v = 0) and, per material, the index of its
+ * DiffuseTexture / SpecularTexture / HeightTexture or -1 (mat_tex [nmat][3]; -1 keeps the flat colour of
+ * vct_upload_triangles / vct_upload_mesh_attributes, resp. a flat height map).  texture(sampler, uv) is
+ * restated as level 0, bilinear, GL_REPEAT (the reference samples mip-mapped).  Used by
+ * vct_voxelize (albedo fetch, vox.fs:56) and vct_render_gbuffer (matColor + alpha test trace.fs:167-172,
+ * CalcBumpNormal :110-128, specColor :209-210) once vct_upload_mesh_uvs has been called too.  ntex = 0
+ * detaches them.  Call after vct_upload_triangles. */
+int vct_upload_textures(vct_ctx* ctx, const uint8_t* const* rgba8, const int32_t* width, const int32_t* height,
+                        int32_t ntex, const int32_t* mat_tex);
 /* DrawDepthTexture (VCT.h:192-211, S/Shadow.vs/.fs): rasterises the uploaded triangles from the light
  * (column-major DepthViewProjectionMatrix, VCT.h:84-86) into the context's shadow map of
  * config.shadow_map_size^2 24-bit depths -- the map vct_voxelize and vct_render_gbuffer then read. */

@@ -33,8 +33,7 @@ def main():
     ctx.set_light_direction(inp["light"])
     if inp["scene"] is not None:
         s = inp["scene"]
-        ctx.upload_triangles(s.pos, s.material, s.albedo)
-        ctx.upload_mesh_attributes(*s.frames(), s.specular)
+        ctx.upload_scene(s)
         ctx.render_shadow_map(inp["light_vp"])
         ctx.render_gbuffer(inp["view_proj"])
         ctx.voxelize(); ctx.inject_light(); ctx.build_mips()

@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "vct_last_trace_stats", "vct_download_frame", "vct_render_gbuffer_rows",
     "vct_slab_partition", "vct_comm_get_unique_id", "vct_comm_init", "vct_comm_destroy", "vct_comm_slab",
     "vct_frame_step", "vct_comm_sync", "vct_comm_frame", "vct_comm_download_frame",
+    "vct_upload_mesh_uvs", "vct_upload_textures",
 ]
 
 
@@ -114,6 +115,8 @@ _lib.vct_comm_download_frame.argtypes = [C.c_void_p, C.c_void_p]
 for _n in ("vct_comm_destroy", "vct_frame_step", "vct_comm_sync"):
     getattr(_lib, _n).argtypes = [C.c_void_p]
 COMM_ID_BYTES = 128
+_lib.vct_upload_mesh_uvs.argtypes = [C.c_void_p, C.c_void_p]
+_lib.vct_upload_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
 
 
 def lib():
@@ -237,6 +240,29 @@ class Context:
         arrs = [np.ascontiguousarray(a, np.float32) for a in (normal, tangent, bitangent, specular)]
         self._ck(_lib.vct_upload_mesh_attributes(self._h, *(_ptr(a) for a in arrs)),
                  "vct_upload_mesh_attributes")
+
+    def upload_mesh_uvs(self, uv):
+        uv = np.ascontiguousarray(uv, np.float32)
+        self._ck(_lib.vct_upload_mesh_uvs(self._h, _ptr(uv)), "vct_upload_mesh_uvs")
+
+    def upload_textures(self, textures, mat_tex):
+        """textures: list of uint8 [h, w, 4] (row 0 at v = 0); mat_tex: int32 [nmat, 3] diffuse / specular /
+        height texture index or -1.  An empty list detaches the textures."""
+        texs = [np.ascontiguousarray(t, np.uint8) for t in textures]
+        n = len(texs)
+        ptrs = (C.c_void_p * max(n, 1))(*[t.ctypes.data for t in texs])
+        w = np.array([t.shape[1] for t in texs], np.int32)
+        h = np.array([t.shape[0] for t in texs], np.int32)
+        mt = np.ascontiguousarray(mat_tex, np.int32)
+        self._ck(_lib.vct_upload_textures(self._h, ptrs, _ptr(w), _ptr(h), n, _ptr(mt)), "vct_upload_textures")
+
+    def upload_scene(self, scene):
+        """Everything of a voxel_cone_tracing_amd.scene.Scene: triangles, frames, texture coordinates, maps."""
+        self.upload_triangles(scene.pos, scene.material, scene.albedo)
+        self.upload_mesh_attributes(*scene.frames(), scene.specular)
+        if scene.textures:
+            self.upload_mesh_uvs(scene.uv)
+            self.upload_textures(scene.textures, scene.mat_tex)
 
     def render_shadow_map(self, light_vp_colmajor):
         m = np.ascontiguousarray(light_vp_colmajor, np.float32).reshape(16)

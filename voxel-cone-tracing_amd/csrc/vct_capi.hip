@@ -230,6 +230,16 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     return VCT_OK;
 }
 
+// textures are used once both the maps and the texture coordinates are there
+VctTextures textures_of(const vct_ctx* c) {
+    VctTextures t;
+    memset(&t, 0, sizeof(t));
+    if (c->tex_texels && c->tri_uv && c->mat_tex) {
+        t.texels = c->tex_texels; t.desc = c->tex_desc; t.mat_tex = c->mat_tex; t.uv = c->tri_uv; t.ntex = c->ntex;
+    }
+    return t;
+}
+
 VctVoxParams vox_params(const vct_ctx* c) {
     VctVoxParams p;
     memset(&p, 0, sizeof(p));
@@ -250,6 +260,7 @@ VctVoxParams vox_params(const vct_ctx* c) {
     p.n_big = c->n_big;
     p.brick_flags = c->brick_flags;
     p.acc_attr = c->acc_attr;
+    p.tex = textures_of(c);
     return p;
 }
 
@@ -369,7 +380,7 @@ void vct_destroy(vct_ctx* c) {
                     c->dbg_cones, c->step_counter, c->stats, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
-                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->vis, c->raster_big,
+                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_big,
                     c->raster_big_count, c->raster_items};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -431,8 +442,9 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     if (c->worklist) { (void)hipFree(c->worklist); c->worklist = nullptr; }
     if (c->raster_big) { (void)hipFree(c->raster_big); c->raster_big = nullptr; }   // sized by ntri
     if (c->ref_big) { (void)hipFree(c->ref_big); c->ref_big = nullptr; }
-    float** frames[3] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit};                   // belong to the old mesh
+    float** frames[4] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit, &c->tri_uv};       // belong to the old mesh
     for (float** f : frames) if (*f) { (void)hipFree(*f); *f = nullptr; }
+    if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }           // indexed by the old materials
     c->n_entries = 0;
     c->n_big = 0;
     HIP_TRY(c, hipMalloc(&c->tri_pos, (size_t)ntri * 9 * sizeof(float)));
@@ -514,6 +526,7 @@ static int raster_args(vct_ctx* c, size_t pixels, VctRasterArgs& a) {
     a.wave_list = c->raster_big + (size_t)c->ntri * 2;
     a.wave_count = reinterpret_cast<uint32_t*>(c->raster_big_count + 2);
     a.item_capacity = c->raster_item_capacity;
+    a.tex = textures_of(c);
     return VCT_OK;
 }
 
@@ -537,6 +550,62 @@ int vct_upload_mesh_attributes(vct_ctx* c, const float* normal, const float* tan
     HIP_TRY(c, hipMemcpyAsync(c->mat_specular, specular, (size_t)c->nmat * 3 * sizeof(float),
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCT_OK;
+}
+
+int vct_upload_mesh_uvs(vct_ctx* c, const float* uv) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!uv) return fail(c, VCT_ERR_INVALID, "vct_upload_mesh_uvs: null input");
+    if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_upload_mesh_uvs: call vct_upload_triangles first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->tri_uv) { (void)hipFree(c->tri_uv); c->tri_uv = nullptr; }
+    const size_t bytes = (size_t)c->ntri * 6 * sizeof(float);
+    HIP_TRY(c, hipMalloc(&c->tri_uv, bytes));
+    HIP_TRY(c, hipMemcpyAsync(c->tri_uv, uv, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCT_OK;
+}
+
+int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* width, const int32_t* height,
+                        int32_t ntex, const int32_t* mat_tex) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_upload_textures: call vct_upload_triangles first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->tex_texels) { (void)hipFree(c->tex_texels); c->tex_texels = nullptr; }
+    if (c->tex_desc) { (void)hipFree(c->tex_desc); c->tex_desc = nullptr; }
+    if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }
+    c->ntex = 0;
+    if (ntex == 0) return VCT_OK;                     // detach: flat colours again
+    if (ntex < 0 || !rgba8 || !width || !height || !mat_tex)
+        return fail(c, VCT_ERR_INVALID, "vct_upload_textures: null or negative input");
+    std::vector<VctTexDesc> desc((size_t)ntex);
+    size_t total = 0;
+    for (int32_t i = 0; i < ntex; ++i) {
+        if (!rgba8[i] || width[i] <= 0 || height[i] <= 0 || width[i] > 16384 || height[i] > 16384)
+            return fail(c, VCT_ERR_INVALID, "vct_upload_textures: bad texture size");
+        desc[(size_t)i].off = (uint32_t)total;
+        desc[(size_t)i].w = width[i];
+        desc[(size_t)i].h = height[i];
+        const size_t n = (size_t)width[i] * height[i];
+        uint32_t flags = 0;
+        for (size_t k = 0; k < n; ++k)
+            if (rgba8[i][4 * k + 3] != 255) { flags = 1u; break; }
+        desc[(size_t)i].flags = flags;
+        total += n;
+        if (total > 0xffffffffull) return fail(c, VCT_ERR_INVALID, "vct_upload_textures: more than 2^32 texels");
+    }
+    for (int32_t m = 0; m < c->nmat * 3; ++m)
+        if (mat_tex[m] >= ntex) return fail(c, VCT_ERR_INVALID, "vct_upload_textures: texture index out of range");
+    HIP_TRY(c, hipMalloc(&c->tex_texels, total * 4));
+    HIP_TRY(c, hipMalloc(&c->tex_desc, (size_t)ntex * sizeof(VctTexDesc)));
+    HIP_TRY(c, hipMalloc(&c->mat_tex, (size_t)c->nmat * 3 * sizeof(int32_t)));
+    for (int32_t i = 0; i < ntex; ++i)
+        HIP_TRY(c, hipMemcpyAsync(c->tex_texels + desc[(size_t)i].off, rgba8[i], (size_t)width[i] * height[i] * 4,
+                                  hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->tex_desc, desc.data(), (size_t)ntex * sizeof(VctTexDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->mat_tex, mat_tex, (size_t)c->nmat * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ntex = ntex;
     return VCT_OK;
 }
 

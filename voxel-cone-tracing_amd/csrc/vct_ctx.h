@@ -60,6 +60,12 @@ struct vct_ctx {
     float* tri_tan = nullptr;
     float* tri_bit = nullptr;
     float* mat_specular = nullptr;
+    // material textures (vct_upload_textures) + texture coordinates (vct_upload_mesh_uvs)
+    float* tri_uv = nullptr;
+    uint32_t* tex_texels = nullptr;
+    VctTexDesc* tex_desc = nullptr;
+    int32_t* mat_tex = nullptr;
+    int32_t ntex = 0;
     unsigned long long* vis = nullptr;
     size_t vis_words = 0;
     int32_t* raster_big = nullptr;

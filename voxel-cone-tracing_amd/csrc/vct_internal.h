@@ -23,6 +23,49 @@ __device__ __forceinline__ uint32_t vct_float_to_unorm8(float f) {
 }
 #endif
 
+// ---- material textures (R/Model.h:126-136 loads them, R/Mesh.h:91-108 binds them) ---------------------------
+// All textures of a scene live in one packed RGBA8 buffer; texture(sampler2D, uv) is restated as LEVEL 0,
+// BILINEAR, GL_REPEAT with the operation order of oracle/vct_oracle_raster.cpp vcto_tex_sample.
+struct VctTexDesc {
+    uint32_t off;        // first texel in the packed buffer
+    int32_t w, h;
+    uint32_t flags;      // bit 0: some texel has alpha != 255 (fragments need the alpha test of trace.fs:169-172)
+};
+struct VctTextures {
+    const uint32_t* texels;    // null: the scene has no textures
+    const VctTexDesc* desc;
+    const int32_t* mat_tex;    // [nmat][3] diffuse / specular / height texture index or -1
+    const float* uv;           // [ntri][3][2]
+    int32_t ntex;
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ int vct_tex_of(const VctTextures& t, int material, int slot) {
+    if (!t.texels) return -1;
+    const int i = t.mat_tex[3 * (size_t)material + slot];
+    return i >= 0 && i < t.ntex ? i : -1;
+}
+__device__ __forceinline__ float4 vct_tex_sample(const VctTextures& t, int ti, float u, float v) {
+    const VctTexDesc d = t.desc[ti];
+    const int W = d.w, H = d.h;
+    const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    auto wrap = [](int i, int n) { const int r = i % n; return r < 0 ? r + n : r; };     // GL_REPEAT
+    const int i0 = wrap((int)fx, W), i1 = wrap((int)fx + 1, W), j0 = wrap((int)fy, H), j1 = wrap((int)fy + 1, H);
+    const uint32_t* base = t.texels + d.off;
+    const uint32_t p00 = base[(size_t)j0 * W + i0], p10 = base[(size_t)j0 * W + i1];
+    const uint32_t p01 = base[(size_t)j1 * W + i0], p11 = base[(size_t)j1 * W + i1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float4 o;
+#define VCT_TEXCH(ch, sh)                                                                                  \
+    o.ch = w00 * vct_unorm8_to_float((p00 >> sh) & 0xffu) + w10 * vct_unorm8_to_float((p10 >> sh) & 0xffu) + \
+           w01 * vct_unorm8_to_float((p01 >> sh) & 0xffu) + w11 * vct_unorm8_to_float((p11 >> sh) & 0xffu);
+    VCT_TEXCH(x, 0) VCT_TEXCH(y, 8) VCT_TEXCH(z, 16) VCT_TEXCH(w, 24)
+#undef VCT_TEXCH
+    return o;
+}
+#endif
+
 #define VCT_TILE 8
 #define VCT_TILE_PIX 64
 #define VCT_GB_NPLANES 23
@@ -111,6 +154,7 @@ struct VctVoxParams {
     unsigned long long* acc_attr;   // [V^3][3]: (albR | albG<<32), (albB | nX<<32), (nY | nZ<<32) or null
     float proj[48];            // ProjX, ProjY, ProjZ (VCT.h:128-134), column-major; reference mode only
     int32_t mode;
+    VctTextures tex;           // diffuse textures + texture coordinates (vox.fs:56); texels == null: flat colours
 };
 
 // inputs of the raster stages (vct_raster.hip); all device pointers
@@ -132,6 +176,7 @@ struct VctRasterArgs {
     uint2* items;                // tile work items of the raster pass
     uint32_t* item_count;
     uint32_t item_capacity;
+    VctTextures tex;             // material textures + texture coordinates (G-buffer pass)
 };
 
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,

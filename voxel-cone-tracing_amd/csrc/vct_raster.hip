@@ -17,6 +17,8 @@
 // go to the earliest triangle, which is what "depth test LESS in submission order" produces.  The
 // shading pass then re-derives the winning fragment from its triangle; nothing per-fragment is
 // stored besides the 8-byte visibility word.
+#include <string.h>
+
 #include "vct_internal.h"
 
 namespace {
@@ -69,6 +71,11 @@ struct SubTri {
     float sz[3], iw[3];
     int x0, x1, y0, y1;
     bool ok;
+    // alpha test (trace.fs:169-172; a discarded fragment writes neither colour nor depth): 0 = opaque, 1 = every
+    // fragment discarded (flat alpha < 0.5), 2 = per fragment from the diffuse texture `tex` at the
+    // perspective-correct (u, v)
+    int alpha_mode, tex;
+    float tu[3], tv[3];
 };
 
 // [ys0, ys1): scissor in pixel rows (a multi-GPU rank rasterises only its slab; the whole frame is [0, H))
@@ -94,6 +101,8 @@ __device__ __forceinline__ void setup_subtri(const RVert* v0, const RVert* v1, c
     s.y0 = max(ys0, (int)floor(fmin(fmin(s.sy[0], s.sy[1]), s.sy[2])));
     s.y1 = min(ys1 - 1, (int)floor(fmax(fmax(s.sy[0], s.sy[1]), s.sy[2])));
     s.ok = s.x1 >= s.x0 && s.y1 >= s.y0;
+    s.alpha_mode = 0;
+    s.tex = -1;
 }
 
 // pixel-centre coverage + barycentrics; returns false when the pixel is not covered
@@ -133,6 +142,10 @@ struct RasterParams {
     uint2* items;                // tile work items: (tri * 2 + sub, tile_y << 16 | tile_x)
     uint32_t* item_count;
     uint32_t item_capacity;
+    // alpha test of the main draw (null material: depth-only pass, S/Shadow.fs has no alpha test)
+    const int32_t* material;
+    const float* albedo;
+    VctTextures tex;
 };
 
 __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVert in[3]) {
@@ -149,10 +162,45 @@ __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVer
 #define VCT_RASTER_WAVE 4096     // <= this many: one wave, lanes stride the bounding box
 #define VCT_RTILE 16             // larger: cut into 16x16-pixel work items by a workgroup
 
+// Decides how fragments of triangle t are alpha-tested and, for the per-fragment case, loads the texture
+// coordinates of the sub-triangle's three vertices (poly == null: the unclipped triangle; otherwise vertices
+// 0, f, f+1 of the near-clipped polygon, interpolated like every other varying).
+__device__ __forceinline__ void setup_alpha(const RasterParams& p, int t, const ClipPoly* poly, int f, SubTri& s) {
+    if (!p.material) return;
+    const int m = p.material[t];
+    const int td = vct_tex_of(p.tex, m, 0);
+    if (td < 0) { s.alpha_mode = p.albedo[4 * (size_t)m + 3] < 0.5f ? 1 : 0; return; }
+    if (!(p.tex.desc[td].flags & 1u)) return;             // every texel opaque: alpha = 1 wherever it is sampled
+    s.alpha_mode = 2;
+    s.tex = td;
+    const float* uv = p.tex.uv + (size_t)t * 6;
+    if (!poly) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s.tu[k] = uv[2 * k]; s.tv[k] = uv[2 * k + 1]; }
+        return;
+    }
+    const int pv[3] = {0, f, f + 1};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pi = pv[k], a = poly->src_a[pi], b = poly->src_b[pi];
+        const float ua = uv[2 * a], va = uv[2 * a + 1];
+        s.tu[k] = b < 0 ? ua : ua + (uv[2 * b] - ua) * poly->t[pi];
+        s.tv[k] = b < 0 ? va : va + (uv[2 * b + 1] - va) * poly->t[pi];
+    }
+}
+
 __device__ __forceinline__ void plot(const RasterParams& p, const SubTri& s, int px, int py,
                                      unsigned long long id) {
     float b0, b1, b2, z;
+    if (s.alpha_mode == 1) return;
     if (!cover(s, px, py, b0, b1, b2, z)) return;
+    if (s.alpha_mode == 2) {
+        const float q0 = b0 * s.iw[0], q1 = b1 * s.iw[1], q2 = b2 * s.iw[2];
+        const float qs = __fdiv_rn(1.0f, q0 + q1 + q2);
+        const float u = (q0 * s.tu[0] + q1 * s.tu[1] + q2 * s.tu[2]) * qs;
+        const float v = (q0 * s.tv[0] + q1 * s.tv[1] + q2 * s.tv[2]) * qs;
+        if (vct_tex_sample(p.tex, s.tex, u, v).w < 0.5f) return;                 // trace.fs:171 discard
+    }
     atomicMin(&p.vis[(size_t)py * p.W + px], ((unsigned long long)__float_as_uint(z) << 32) | id);
 }
 
@@ -199,6 +247,8 @@ k_raster_vis(const RasterParams p) {
         if (whole) setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, p.ys0, p.ys1, s);
         else setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, p.ys0, p.ys1, s);
         if (!s.ok) continue;
+        setup_alpha(p, t, whole ? nullptr : &poly, f, s);
+        if (s.alpha_mode == 1) continue;
         const unsigned long long id = (unsigned long long)(uint32_t)(t * 2 + (f - 1));
         const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
         if (box <= VCT_RASTER_SMALL) {
@@ -217,11 +267,13 @@ __device__ __forceinline__ bool rebuild_subtri(const RasterParams& p, int id, Su
     load_clip_tri(p, t, in);
     if (unclipped(in)) {
         setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, p.ys0, p.ys1, s);
+        if (s.ok) setup_alpha(p, t, nullptr, f, s);
         return s.ok;
     }
     ClipPoly poly;
     clip_near(in, poly);
     setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, p.ys0, p.ys1, s);
+    if (s.ok) setup_alpha(p, t, &poly, f, s);
     return s.ok;
 }
 
@@ -368,23 +420,79 @@ k_gbuffer_shade(const ShadeParams p) {
             }
             g[i] = (q0 * var[0] + q1 * var[1] + q2 * var[2]) * qs;
         }
-        // CalcBumpNormal with a flat height map: normalize(TBN * (0,0,1)), TBN = inverse(transpose(M))
+        const int m = p.material[t];
+        const int td = vct_tex_of(p.r.tex, m, 0), tsp = vct_tex_of(p.r.tex, m, 1), th = vct_tex_of(p.r.tex, m, 2);
+        float tcu = 0.0f, tcv = 0.0f;                                             // tex (trace.vs:36)
+        if (td >= 0 || tsp >= 0 || th >= 0) {
+            const float* uv = p.r.tex.uv + (size_t)t * 6;
+            float vu[3], vv[3];
+            if (whole) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { vu[k] = uv[2 * k]; vv[k] = uv[2 * k + 1]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int pi = pv[k], a = poly.src_a[pi], b = poly.src_b[pi];
+                    const float ua = uv[2 * a], va = uv[2 * a + 1];
+                    vu[k] = b < 0 ? ua : ua + (uv[2 * b] - ua) * poly.t[pi];
+                    vv[k] = b < 0 ? va : va + (uv[2 * b + 1] - va) * poly.t[pi];
+                }
+            }
+            tcu = (q0 * vu[0] + q1 * vu[1] + q2 * vu[2]) * qs;
+            tcv = (q0 * vv[0] + q1 * vv[1] + q2 * vv[2]) * qs;
+        }
+        // TBN = inverse(transpose(mat3(T,B,N))): columns (BxN, NxT, TxB) / det                    trace.fs:175
         const float Tx = g[6], Ty = g[7], Tz = g[8], Bx = g[9], By = g[10], Bz = g[11];
         const float Nx = g[3], Ny = g[4], Nz = g[5];
         const float c2x = Ty * Bz - Tz * By, c2y = Tz * Bx - Tx * Bz, c2z = Tx * By - Ty * Bx;   // T x B
         const float bnx = By * Nz - Bz * Ny, bny = Bz * Nx - Bx * Nz, bnz = Bx * Ny - By * Nx;   // B x N
         const float det = Tx * bnx + Ty * bny + Tz * bnz;
         const float inv = __fdiv_rn(1.0f, det);
-        const float ux = c2x * inv, uy = c2y * inv, uz = c2z * inv;
+        float ux, uy, uz;
+        if (th < 0) {
+            // CalcBumpNormal with a flat height map: normalize(TBN * (0,0,1))
+            ux = c2x * inv; uy = c2y * inv; uz = c2z * inv;
+        } else {
+            // CalcBumpNormal (trace.fs:110-128): three HeightTexture taps one texel apart
+            const VctTexDesc hd = p.r.tex.desc[th];
+            const float ox = __fdiv_rn(1.0f, (float)hd.w), oy = __fdiv_rn(1.0f, (float)hd.h);      // :112
+            const float cur = vct_tex_sample(p.r.tex, th, tcu, tcv).x;                               // :114
+            const float dx = vct_tex_sample(p.r.tex, th, tcu + ox, tcv).x - cur;                     // :115
+            const float dy = vct_tex_sample(p.r.tex, th, tcu, tcv + oy).x - cur;                     // :116
+            // t1 = normalize(1,0,dx), t2 = normalize(0,1,dy)   (host normalize(): a * (1/l))
+            const float l1 = __builtin_sqrtf(1.0f * 1.0f + 0.0f * 0.0f + dx * dx), i1 = __fdiv_rn(1.0f, l1);
+            const float l2 = __builtin_sqrtf(0.0f * 0.0f + 1.0f * 1.0f + dy * dy), i2 = __fdiv_rn(1.0f, l2);
+            const float t1x = 1.0f * i1, t1y = 0.0f * i1, t1z = dx * i1;
+            const float t2x = 0.0f * i2, t2y = 1.0f * i2, t2z = dy * i2;
+            float bx = t1y * t2z - t1z * t2y, by = t1z * t2x - t1x * t2z, bz = t1x * t2y - t1y * t2x;   // cross(t1, t2)
+            const float lb = __builtin_sqrtf(bx * bx + by * by + bz * bz);
+            const float ib = lb > 0.0f ? __fdiv_rn(1.0f, lb) : 0.0f;
+            bx = lb > 0.0f ? bx * ib : 0.0f; by = lb > 0.0f ? by * ib : 0.0f; bz = lb > 0.0f ? bz * ib : 0.0f;
+            const float c1x = Ny * Tz - Nz * Ty, c1y = Nz * Tx - Nx * Tz, c1z = Nx * Ty - Ny * Tx;     // N x T
+            const float k0x = bnx * inv, k0y = bny * inv, k0z = bnz * inv;
+            const float k1x = c1x * inv, k1y = c1y * inv, k1z = c1z * inv;
+            const float k2x = c2x * inv, k2y = c2y * inv, k2z = c2z * inv;
+            ux = k0x * bx + k1x * by + k2x * bz;
+            uy = k0y * bx + k1y * by + k2y * bz;
+            uz = k0z * bx + k1z * by + k2z * bz;
+        }
         const float len = __builtin_sqrtf(ux * ux + uy * uy + uz * uz);
         const float il = len > 0.0f ? __fdiv_rn(1.0f, len) : 0.0f;      // host normalize(): a * (1/l)
         g[12] = len > 0.0f ? ux * il : 0.0f;
         g[13] = len > 0.0f ? uy * il : 0.0f;
         g[14] = len > 0.0f ? uz * il : 0.0f;
-        const int m = p.material[t];
         const float* alb = p.albedo + 4 * (size_t)m;
-        const float* sp = p.specular + 3 * (size_t)m;
-        g[15] = alb[0]; g[16] = alb[1]; g[17] = alb[2]; g[18] = alb[3];           // trace.fs:167
+        if (td >= 0) {
+            const float4 c = vct_tex_sample(p.r.tex, td, tcu, tcv);               // trace.fs:167
+            g[15] = c.x; g[16] = c.y; g[17] = c.z; g[18] = c.w;
+        } else {
+            g[15] = alb[0]; g[16] = alb[1]; g[17] = alb[2]; g[18] = alb[3];
+        }
+        float sp[3] = {p.specular[3 * (size_t)m], p.specular[3 * (size_t)m + 1], p.specular[3 * (size_t)m + 2]};
+        if (tsp >= 0) {
+            const float4 c = vct_tex_sample(p.r.tex, tsp, tcu, tcv);              // trace.fs:209
+            sp[0] = c.x; sp[1] = c.y; sp[2] = c.z;
+        }
         const bool has_gb = __builtin_sqrtf(sp[1] * sp[1] + sp[2] * sp[2]) > 0.0f;
         g[19] = sp[0];
         g[20] = has_gb ? sp[1] : sp[0];                                           // trace.fs:210
@@ -486,6 +594,9 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
     r.items = a.items;
     r.item_count = a.item_count;
     r.item_capacity = a.item_capacity;
+    r.material = nullptr;
+    r.albedo = nullptr;
+    memset(&r.tex, 0, sizeof(r.tex));
     return r;
 }
 
@@ -527,6 +638,9 @@ hipError_t vct_launch_gbuffer_raster(const VctRasterArgs& a, const float view_pr
                                      const float light_vp[16], float* tiled, hipStream_t s) {
     ShadeParams p;
     p.r = make_raster(a, view_proj, W, H, row0 * VCT_TILE, row1 * VCT_TILE);
+    p.r.material = a.material;        // main draw: alpha test before the depth write (trace.fs:169-172)
+    p.r.albedo = a.albedo;
+    p.r.tex = a.tex;
     hipError_t e = run_visibility(p.r, s);
     if (e != hipSuccess) return e;
     p.nrm = a.nrm; p.tan = a.tan; p.bit = a.bit;

@@ -145,9 +145,34 @@ struct TriSetup {
     int ua, ub;
     float area;
     float alb[3];
+    float uv[3][2];     // TexCoord per vertex (vox.vs:17)
+    int tex;            // diffuse texture of the triangle's material or -1 (flat colour)
     uint32_t attr[6];   // per-fragment voxel attributes: unorm8 albedo rgb, biased quantised face normal xyz
     bool valid;
 };
+
+// vox.fs:56: the fragment's albedo -- texture(DiffuseTexture, uv) with uv interpolated by the fragment's
+// barycentrics, or the flat material colour when the material has no diffuse texture
+template <class Setup>
+__device__ __forceinline__ void frag_albedo(const VctVoxParams& p, const Setup& r, float b0, float b1, float b2,
+                                            float alb[3]) {
+    alb[0] = r.alb[0]; alb[1] = r.alb[1]; alb[2] = r.alb[2];
+    if (r.tex >= 0) {
+        const float u = b0 * r.uv[0][0] + b1 * r.uv[1][0] + b2 * r.uv[2][0];
+        const float v = b0 * r.uv[0][1] + b1 * r.uv[1][1] + b2 * r.uv[2][1];
+        const float4 c = vct_tex_sample(p.tex, r.tex, u, v);
+        alb[0] = c.x; alb[1] = c.y; alb[2] = c.z;
+    }
+}
+template <class Setup>
+__device__ __forceinline__ void load_tex_setup(const VctVoxParams& p, int t, Setup& r) {
+    r.tex = vct_tex_of(p.tex, p.material[t], 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.uv[k][0] = r.tex >= 0 ? p.tex.uv[(size_t)t * 6 + 2 * k] : 0.0f;
+        r.uv[k][1] = r.tex >= 0 ? p.tex.uv[(size_t)t * 6 + 2 * k + 1] : 0.0f;
+    }
+}
 
 __device__ __forceinline__ void setup_tri(const VctVoxParams& p, int t, TriSetup& r) {
     F3 w[3];
@@ -208,6 +233,7 @@ __device__ __forceinline__ void setup_tri(const VctVoxParams& p, int t, TriSetup
     r.area = (ax1 - ax0) * (ay2 - ay0) - (ax2 - ax0) * (ay1 - ay0);
     const float* alb = p.albedo + 4 * (size_t)p.material[t];
     r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
+    load_tex_setup(p, t, r);
     if (p.acc_attr) {
         // front-face unit normal n = normalize(cross(v1-v0, v2-v0)), quantised floor(n*127+.5)+128
         const F3 fn = cross3(sub3(w[1], w[0]), sub3(w[2], w[0]));
@@ -257,8 +283,10 @@ __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& 
                        b0 * r.dc[0].z + b1 * r.dc[1].z + b2 * r.dc[2].z};
         sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_size, dc, 0.002f), 25.0f);   // vox.fs:46
     }
-    const unsigned long long cr = to_unorm8(r.alb[0] * sh), cg = to_unorm8(r.alb[1] * sh),
-                             cb = to_unorm8(r.alb[2] * sh);                          // vox.fs:88
+    float alb[3];
+    frag_albedo(p, r, b0, b1, b2, alb);                                              // vox.fs:56
+    const unsigned long long cr = to_unorm8(alb[0] * sh), cg = to_unorm8(alb[1] * sh),
+                             cb = to_unorm8(alb[2] * sh);                            // vox.fs:88
     const uint32_t vox = vct_morton3((uint32_t)i, (uint32_t)j, (uint32_t)k);
     unsigned long long* a = p.acc + 2 * (size_t)vox;
     atomicAdd(a, cr | (cg << 32));
@@ -266,8 +294,10 @@ __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& 
     p.brick_flags[vox >> 9] = 1u;      // benign race: every writer stores the same value
     if (p.acc_attr) {
         unsigned long long* q = p.acc_attr + 3 * (size_t)vox;
-        atomicAdd(q, (unsigned long long)r.attr[0] | ((unsigned long long)r.attr[1] << 32));
-        atomicAdd(q + 1, (unsigned long long)r.attr[2] | ((unsigned long long)r.attr[3] << 32));
+        const uint32_t a0 = r.tex >= 0 ? to_unorm8(alb[0]) : r.attr[0], a1 = r.tex >= 0 ? to_unorm8(alb[1]) : r.attr[1],
+                       a2 = r.tex >= 0 ? to_unorm8(alb[2]) : r.attr[2];              // the fragment's albedo
+        atomicAdd(q, (unsigned long long)a0 | ((unsigned long long)a1 << 32));
+        atomicAdd(q + 1, (unsigned long long)a2 | ((unsigned long long)r.attr[3] << 32));
         atomicAdd(q + 2, (unsigned long long)r.attr[4] | ((unsigned long long)r.attr[5] << 32));
     }
 }
@@ -371,6 +401,8 @@ struct RefSetup {
     float area, sgn;
     int x0, x1, y0, y1, axis;
     float alb[3];
+    float uv[3][2];
+    int tex;
     bool ok;
 };
 
@@ -408,6 +440,7 @@ __device__ __forceinline__ void ref_setup(const VctVoxParams& p, int t, RefSetup
     r.y1 = min((int)floorf(fmaxf(fmaxf(r.wy[0], r.wy[1]), r.wy[2])), p.V - 1);
     const float* alb = p.albedo + 4 * (size_t)p.material[t];
     r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
+    load_tex_setup(p, t, r);
 }
 
 __device__ __forceinline__ void ref_fragment(const VctVoxParams& p, const RefSetup& r, int t, int px, int py) {
@@ -437,8 +470,10 @@ __device__ __forceinline__ void ref_fragment(const VctVoxParams& p, const RefSet
                        l0 * r.dc[0].z + l1 * r.dc[1].z + l2 * r.dc[2].z};
         sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_size, dc, 0.002f), 25.0f);    // vox.fs:46
     }
-    const unsigned long long rgb = to_unorm8(r.alb[0] * sh) | (to_unorm8(r.alb[1] * sh) << 8) |
-                                   (to_unorm8(r.alb[2] * sh) << 16);                 // vox.fs:88
+    float alb[3];
+    frag_albedo(p, r, l0, l1, l2, alb);                                               // vox.fs:56
+    const unsigned long long rgb = to_unorm8(alb[0] * sh) | (to_unorm8(alb[1] * sh) << 8) |
+                                   (to_unorm8(alb[2] * sh) << 16);                   // vox.fs:88
     const uint32_t vox = vct_morton3((uint32_t)vx, (uint32_t)vy, (uint32_t)vz);
     atomicMax(p.acc + 2 * (size_t)vox, ((unsigned long long)(uint32_t)(t + 1) << 32) | rgb);
     p.brick_flags[vox >> 9] = 1u;

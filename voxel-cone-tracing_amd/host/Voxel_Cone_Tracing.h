@@ -20,7 +20,8 @@
 //   * `VoxelDimensions` / `VoxelGridWorldSize` are plain members (the reference declares them const,
 //     which pins it to 128^3): set them before init_voxel_cone_tracing().
 //   * `model_path` replaces the reference's hard-coded absolute Windows path (VCT.h:77; the reference
-//     ships no assets): "procedural:atrium", "procedural:cornell", or the path of a Wavefront .obj.
+//     ships no assets): "procedural:atrium", "procedural:atrium-textured", "procedural:cornell", or the path of
+//     a Wavefront .obj (+ .mtl with map_Kd / map_Ks / map_bump as PPM or TGA).
 //   * Errors keep the reference's print-and-continue behaviour (VCT.h:101-105) and are also
 //     readable through `last_status` / vct_last_error(ctx).
 #ifndef VOXEL_CONE_TRACING_FACADE_H_
@@ -152,6 +153,7 @@ struct Model {
         char err[256] = "";
         if (p == "procedural:cornell") scene = vcth_scene_create(0, 1.0f, 1234u);
         else if (p == "procedural:atrium") scene = vcth_scene_create(1, 1.0f, 1234u);
+        else if (p == "procedural:atrium-textured") scene = vcth_scene_create(2, 1.0f, 1234u);
         else scene = vcth_scene_load_obj(p.c_str(), err);             // R/Model.h:39-61
         if (!scene) printf("ERROR::MODEL: cannot load '%s' (%s; or use procedural:atrium | procedural:cornell)\n",
                            p.c_str(), err);
@@ -236,6 +238,24 @@ struct Voxel_Cone_Tracing {
         vcth_scene_get_frames(model.scene, nrm.data(), tan.data(), bit.data());
         if (!check(vct_upload_mesh_attributes(ctx, nrm.data(), tan.data(), bit.data(), specular.data()),
                    "vct_upload_mesh_attributes")) return;
+        const int32_t ntex = vcth_scene_num_textures(model.scene);        // R/Model.h:126-136: material textures
+        if (ntex > 0) {
+            std::vector<float> uv((size_t)ntri * 6);
+            vcth_scene_get_uvs(model.scene, uv.data());
+            std::vector<std::vector<uint8_t>> texels((size_t)ntex);
+            std::vector<const uint8_t*> ptr((size_t)ntex);
+            std::vector<int32_t> tw((size_t)ntex), th((size_t)ntex), mat_tex((size_t)nmat * 3);
+            for (int32_t i = 0; i < ntex; ++i) {
+                vcth_scene_texture_info(model.scene, i, &tw[(size_t)i], &th[(size_t)i]);
+                texels[(size_t)i].resize((size_t)tw[(size_t)i] * th[(size_t)i] * 4);
+                vcth_scene_get_texture(model.scene, i, texels[(size_t)i].data());
+                ptr[(size_t)i] = texels[(size_t)i].data();
+            }
+            vcth_scene_get_material_textures(model.scene, mat_tex.data());
+            if (!check(vct_upload_mesh_uvs(ctx, uv.data()), "vct_upload_mesh_uvs")) return;
+            if (!check(vct_upload_textures(ctx, ptr.data(), tw.data(), th.data(), ntex, mat_tex.data()),
+                       "vct_upload_textures")) return;
+        }
         DrawDepthTexture();     // VCT.h:138
         DrawVoxelTexture();     // VCT.h:139
     }
