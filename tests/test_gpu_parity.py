@@ -500,6 +500,28 @@ def test_device_resident_tiled_gbuffer_is_traced_in_place(vct, oracle):
         assert not np.array_equal(blank, want)
 
 
+def test_accumulators_are_allocated_per_touched_brick(vct):
+    """A 1024^3 context with voxel attributes: the voxelizer's accumulators (16 + 24 B per voxel) and the
+    resolved attribute volumes (8 B per voxel) are pooled per brick the mesh can touch, so the context costs
+    the 4.57 GiB chain plus megabytes -- not the 52 GiB of dense V^3 buffers."""
+    import torch
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(sc.ATRIUM, 0.5, 1234)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    with vct.Context(vct.default_config(voxel_dim=1024, width=64, height=64, shadow_map_size=512,
+                                        voxel_attributes=1)) as ctx:
+        ctx.upload_triangles(scene.pos, scene.material, scene.albedo)
+        ctx.upload_mesh_attributes(*scene.frames(), scene.specular)
+        ctx.render_shadow_map(sc.light_view_proj((0.0, 1.0, 0.25)))
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        ctx.voxelize(vct.VOX_REFERENCE); ctx.inject_light(); ctx.build_mips()
+        ctx.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        used_gib = (free0 - free1) / 2 ** 30
+        assert 4.5 < used_gib < 8.0, used_gib
+
+
 def test_contexts_release_all_hbm(vct):
     """vct_destroy frees every buffer a context acquired along the way (accumulators, attribute and
     directional chains, work lists, raster buffers, bounce chain, ...)."""

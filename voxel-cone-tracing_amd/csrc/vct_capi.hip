@@ -254,6 +254,7 @@ VctVoxParams vox_params(const vct_ctx* c) {
     p.shadow_size = c->shadow_size;
     memcpy(p.light_vp, c->light_vp, 64);
     p.acc = c->acc;
+    p.brick_slot = c->brick_slot;
     p.worklist = c->worklist;
     p.n_entries = c->n_entries;
     p.big_list = c->big_list;
@@ -262,6 +263,97 @@ VctVoxParams vox_params(const vct_ctx* c) {
     p.acc_attr = c->acc_attr;
     p.tex = textures_of(c);
     return p;
+}
+
+void glm_voxel_projections(const vct_ctx* c, float proj[48]) {
+    // VCT.h:128-134: ortho(-G/2, G/2, -G/2, G/2, G/2, 3G/2) * lookAt(+-G on the axis) per dominant axis
+    const float G = c->cfg.grid_world_size, h = G * 0.5f;
+    float o[16], v[16];
+    glm_ortho(-h, h, -h, h, h, G * 1.5f, o);
+    const float eye[3][3] = {{G, 0, 0}, {0, G, 0}, {0, 0, G}};
+    const float up[3][3] = {{0, 1, 0}, {0, 0, -1}, {0, 1, 0}};
+    for (int a = 0; a < 3; ++a) {
+        glm_lookat_origin(eye[a], up[a], v);
+        mat_mul(o, v, proj + 16 * a);
+    }
+}
+
+// Per-mesh accumulator pools.  The bricks a fragment of this mesh can land in depend only on geometry, V and G
+// (not on the light, the shadow map or the textures), so they are found ONCE per upload by running both
+// voxelizers in mark-only mode -- the very code that later produces the fragments -- and every marked brick
+// gets a slot of 512 accumulators (+ attribute accumulators and resolved attributes when
+// config.voxel_attributes).  Everything is allocated into locals and committed only when every allocation
+// succeeded, so a failed hipMalloc leaves the context without pools (vct_voxelize then reports it) instead
+// of half-initialised.
+int build_accumulator_pools(vct_ctx* c) {
+    const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
+    const uint32_t nbricks = (uint32_t)(nvox / 512);
+    // drop the pools of the previous mesh; level 0 / brick_prev keep describing what the chain shows
+    void** old[] = {(void**)&c->acc, (void**)&c->acc_attr, (void**)&c->attr_albedo, (void**)&c->attr_normal,
+                    (void**)&c->brick_slot};
+    for (void** q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    c->nslots = 0;
+    c->acc_pending = false;
+    uint32_t *mark = nullptr, *slot = nullptr, *count = nullptr;
+    unsigned long long *acc = nullptr, *acc_attr = nullptr;
+    uint32_t *attr_albedo = nullptr, *attr_normal = nullptr;
+    auto cleanup = [&]() {
+        void* tmp[] = {mark, slot, count, acc, acc_attr, attr_albedo, attr_normal};
+        for (void* q : tmp) if (q) (void)hipFree(q);
+    };
+#define POOL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            cleanup();                                                                                  \
+            return fail(c, e_ == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE,                  \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+        }                                                                                               \
+    } while (0)
+    POOL_TRY(hipMalloc(&mark, (size_t)nbricks * sizeof(uint32_t)));
+    POOL_TRY(hipMalloc(&slot, (size_t)nbricks * sizeof(uint32_t)));
+    POOL_TRY(hipMalloc(&count, sizeof(uint32_t)));
+    POOL_TRY(hipMemsetAsync(mark, 0, (size_t)nbricks * sizeof(uint32_t), c->stream));
+    if (!c->ref_big) POOL_TRY(hipMalloc(&c->ref_big, ((size_t)c->ntri + 1) * sizeof(int32_t)));
+    VctVoxParams p = vox_params(c);
+    p.mark_only = 1;
+    p.brick_mark = mark;
+    p.shadow = nullptr;
+    p.acc_attr = nullptr;
+    POOL_TRY(vct_launch_voxelize(p, c->stream));                                     // conservative mode
+    glm_voxel_projections(c, p.proj);
+    POOL_TRY(vct_launch_voxelize_reference(p, c->ref_big + 1, c->ref_big, c->stream));   // reference mode
+    POOL_TRY(vct_launch_assign_slots(mark, slot, count, nbricks, c->stream));
+    uint32_t nslots = 0;
+    POOL_TRY(hipMemcpyAsync(&nslots, count, sizeof(nslots), hipMemcpyDeviceToHost, c->stream));
+    POOL_TRY(hipStreamSynchronize(c->stream));
+    const size_t pool_vox = (size_t)(nslots ? nslots : 1u) * 512;
+    POOL_TRY(hipMalloc(&acc, pool_vox * 16));
+    POOL_TRY(hipMemsetAsync(acc, 0, pool_vox * 16, c->stream));          // zeroed once: every resolve re-zeroes what it consumed
+    if (c->cfg.voxel_attributes) {
+        POOL_TRY(hipMalloc(&acc_attr, pool_vox * 24));
+        POOL_TRY(hipMalloc(&attr_albedo, pool_vox * 4));
+        POOL_TRY(hipMalloc(&attr_normal, pool_vox * 4));
+        POOL_TRY(hipMemsetAsync(acc_attr, 0, pool_vox * 24, c->stream));
+        POOL_TRY(hipMemsetAsync(attr_albedo, 0, pool_vox * 4, c->stream));
+        POOL_TRY(hipMemsetAsync(attr_normal, 0, pool_vox * 4, c->stream));
+    }
+    const size_t flag_bytes = (size_t)nbricks * sizeof(uint32_t);
+    uint32_t** flags[] = {&c->brick_flags, &c->brick_prev, &c->mip_seen};
+    for (uint32_t** f : flags)
+        if (!*f) {
+            POOL_TRY(hipMalloc(f, flag_bytes));
+            POOL_TRY(hipMemsetAsync(*f, 0, flag_bytes, c->stream));
+        }
+    POOL_TRY(hipMemsetAsync(c->brick_flags, 0, flag_bytes, c->stream));
+    POOL_TRY(hipStreamSynchronize(c->stream));
+#undef POOL_TRY
+    (void)hipFree(mark);
+    (void)hipFree(count);
+    c->acc = acc; c->acc_attr = acc_attr; c->attr_albedo = attr_albedo; c->attr_normal = attr_normal;
+    c->brick_slot = slot;
+    c->nslots = nslots;
+    return VCT_OK;
 }
 
 }  // namespace
@@ -378,7 +470,7 @@ void vct_destroy(vct_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->stats, c->steps_dev, c->tri_pos,
-                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->big_list, c->worklist, c->plan,
+                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->big_list, c->worklist, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_big,
                     c->raster_big_count, c->raster_items};
@@ -473,7 +565,7 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_entries = counts[0];
     c->n_big = (int32_t)counts[1];
-    return VCT_OK;
+    return build_accumulator_pools(c);
 }
 
 int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const float light_vp[16]) {
@@ -676,44 +768,20 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         return fail(c, VCT_ERR_INVALID, "vct_voxelize: unknown mode");
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_voxelize: no triangles uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
-    const size_t nbricks = nvox / 512;
-    if (!c->acc) {      // zeroed once: every resolve re-zeroes what it consumed
-        HIP_TRY(c, hipMalloc(&c->acc, nvox * 16));
-        HIP_TRY(c, hipMalloc(&c->brick_flags, nbricks * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->brick_prev, nbricks * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
+    if (!c->acc || !c->brick_slot)
+        return fail(c, VCT_ERR_NOMEM, "vct_voxelize: the accumulator pools of this mesh could not be allocated "
+                                      "(vct_upload_triangles reported it)");
+    if (c->acc_pending) {   // a pass that was never resolved: discard it
+        const size_t pool_vox = (size_t)(c->nslots ? c->nslots : 1u) * 512;
+        const size_t nbricks = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512;
+        HIP_TRY(c, hipMemsetAsync(c->acc, 0, pool_vox * 16, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->brick_flags, 0, nbricks * sizeof(uint32_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->brick_prev, 0, nbricks * sizeof(uint32_t), c->stream));
-        HIP_TRY(c, hipMalloc(&c->mip_seen, nbricks * sizeof(uint32_t)));
-        HIP_TRY(c, hipMemsetAsync(c->mip_seen, 0, nbricks * sizeof(uint32_t), c->stream));
-        if (c->cfg.voxel_attributes) {
-            HIP_TRY(c, hipMalloc(&c->acc_attr, nvox * 24));
-            HIP_TRY(c, hipMalloc(&c->attr_albedo, nvox * 4));
-            HIP_TRY(c, hipMalloc(&c->attr_normal, nvox * 4));
-            HIP_TRY(c, hipMemsetAsync(c->acc_attr, 0, nvox * 24, c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->attr_albedo, 0, nvox * 4, c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->attr_normal, 0, nvox * 4, c->stream));
-        }
-    } else if (c->acc_pending) {   // a pass that was never resolved: discard it
-        HIP_TRY(c, hipMemsetAsync(c->acc, 0, nvox * 16, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->brick_flags, 0, nbricks * sizeof(uint32_t), c->stream));
-        if (c->acc_attr) HIP_TRY(c, hipMemsetAsync(c->acc_attr, 0, nvox * 24, c->stream));
+        if (c->acc_attr) HIP_TRY(c, hipMemsetAsync(c->acc_attr, 0, pool_vox * 24, c->stream));
     }
     VctVoxParams p = vox_params(c);
     p.mode = mode;
     if (mode == VCT_VOX_REFERENCE) {
-        // VCT.h:128-134: ortho(-G/2, G/2, -G/2, G/2, G/2, 3G/2) * lookAt(+-G on the axis) per dominant axis
-        const float G = c->cfg.grid_world_size, h = G * 0.5f;
-        float o[16], v[16];
-        glm_ortho(-h, h, -h, h, h, G * 1.5f, o);
-        const float eye[3][3] = {{G, 0, 0}, {0, G, 0}, {0, 0, G}};
-        const float up[3][3] = {{0, 1, 0}, {0, 0, -1}, {0, 1, 0}};
-        for (int a = 0; a < 3; ++a) {
-            glm_lookat_origin(eye[a], up[a], v);
-            mat_mul(o, v, p.proj + 16 * a);
-        }
-        if (!c->ref_big) HIP_TRY(c, hipMalloc(&c->ref_big, ((size_t)c->ntri + 1) * sizeof(int32_t)));
+        glm_voxel_projections(c, p.proj);
         HIP_TRY(c, vct_launch_voxelize_reference(p, c->ref_big + 1, c->ref_big, c->stream));
     } else {
         HIP_TRY(c, vct_launch_voxelize(p, c->stream));
@@ -727,7 +795,7 @@ int vct_inject_light(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     if (!c->acc_pending) return fail(c, VCT_ERR_INVALID, "vct_inject_light: call vct_voxelize first");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, vct_launch_resolve(c->acc, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
+    HIP_TRY(c, vct_launch_resolve(c->acc, c->brick_slot, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
                                   c->level0_dirty, c->acc_attr, c->attr_albedo, c->attr_normal,
                                   c->acc_mode == VCT_VOX_REFERENCE, c->stream));
     c->acc_pending = false;
@@ -791,6 +859,7 @@ int vct_bounce(vct_ctx* c) {
     fill_march_params(c, p, c->chain);
     p.attr_albedo = c->attr_albedo;
     p.attr_normal = c->attr_normal;
+    p.brick_slot = c->brick_slot;
     p.brick_prev = c->brick_prev;
     p.bounce_seen = c->mip_seen_b;
     p.bounce_out = c->chain_b;
@@ -825,11 +894,16 @@ int vct_download_voxel_attributes(vct_ctx* c, uint8_t* albedo, uint8_t* normal) 
     const size_t n = (size_t)V * V * V;
     const uint32_t* src[2] = {c->attr_albedo, c->attr_normal};
     uint8_t* dst[2] = {albedo, normal};
+    uint32_t* dense = nullptr;          // pooled [slot][512] -> dense Morton volume -> linear staging
+    HIP_TRY(c, hipMalloc(&dense, n * 4));
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(c, vct_launch_morton_to_linear(src[k], c->staging, V, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(dst[k], c->staging, n * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipError_t e = vct_launch_unpool(src[k], c->brick_slot, dense, (uint32_t)(n / 512), c->stream);
+        if (e == hipSuccess) e = vct_launch_morton_to_linear(dense, c->staging, V, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst[k], c->staging, n * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(dense); HIP_TRY(c, e); }
     }
+    (void)hipFree(dense);
     return VCT_OK;
 }
 

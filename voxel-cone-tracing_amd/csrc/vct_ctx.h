@@ -73,7 +73,9 @@ struct vct_ctx {
     uint2* raster_items = nullptr;
     uint32_t raster_item_capacity = 0;
     float light_vp[16];
-    unsigned long long* acc = nullptr;
+    unsigned long long* acc = nullptr;         // accumulator pool [nslots][512][2] (one slot per brick the mesh can touch)
+    uint32_t* brick_slot = nullptr;            // [V^3/512] brick -> slot or VCT_NO_SLOT
+    uint32_t nslots = 0;
     // voxelization plan (geometry only; built by vct_upload_triangles) and sparse-resolve state
     uint2* worklist = nullptr;
     uint32_t n_entries = 0;

@@ -66,6 +66,7 @@ __device__ __forceinline__ float4 vct_tex_sample(const VctTextures& t, int ti, f
 }
 #endif
 
+#define VCT_NO_SLOT 0xffffffffu
 #define VCT_TILE 8
 #define VCT_TILE_PIX 64
 #define VCT_GB_NPLANES 23
@@ -117,9 +118,11 @@ struct VctTraceParams {
     float* dbg_cones;                   // [npix][7][4] or null
     unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] partial sums of executed steps
     unsigned long long* stats;          // [8] wave-level march counters (builds with -DVCT_STATS=1 only)
-    // second bounce (k_bounce): per-voxel attributes (Morton order), touched-brick flags, output level 0
+    // second bounce (k_bounce): per-voxel attributes (pooled like the accumulators: [slot][512]), touched-brick
+    // flags, output level 0
     const uint32_t* attr_albedo;
     const uint32_t* attr_normal;
+    const uint32_t* brick_slot;
     const uint32_t* brick_prev;
     const uint32_t* bounce_seen;        // bricks the bounce chain showed when its mips were last built
     uint32_t* bounce_out;
@@ -145,13 +148,19 @@ struct VctVoxParams {
     const float* shadow;       // [S*S] or null
     int32_t shadow_size;
     float light_vp[16];
-    unsigned long long* acc;   // [V^3][2]: (sumR | sumG<<32), (sumB | count<<32), Morton order
+    // Accumulators live in a POOL of 8^3-voxel slots, one slot per brick that any fragment of the uploaded mesh
+    // can touch (found once per mesh by a mark-only run of the voxelizer itself); brick_slot maps brick ->
+    // slot (VCT_NO_SLOT: no fragment ever lands there).  A 1024^3 grid costs the surface, not 16 GiB.
+    unsigned long long* acc;   // [nslots][512][2]: (sumR | sumG<<32), (sumB | count<<32), Morton order inside the brick
+    const uint32_t* brick_slot;   // [V^3 / 512]
+    uint32_t* brick_mark;      // mark_only: bricks a fragment lands in
+    int32_t mark_only;
     const uint2* worklist;     // (triangle, candidate voxel of its bbox), built at upload (k_vox_plan)
     uint32_t n_entries;
     const int32_t* big_list;   // triangles with more than VCT_VOX_BIG candidates
     int32_t n_big;
     uint32_t* brick_flags;     // [V^3 / 512] raised by fragments, consumed by the sparse resolve
-    unsigned long long* acc_attr;   // [V^3][3]: (albR | albG<<32), (albB | nX<<32), (nY | nZ<<32) or null
+    unsigned long long* acc_attr;   // [nslots][512][3]: (albR | albG<<32), (albB | nX<<32), (nY | nZ<<32) or null
     float proj[48];            // ProjX, ProjY, ProjZ (VCT.h:128-134), column-major; reference mode only
     int32_t mode;
     VctTextures tex;           // diffuse textures + texture coordinates (vox.fs:56); texels == null: flat colours
@@ -199,9 +208,13 @@ hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int
 hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* worklist,
                                int32_t* big_list, bool write, hipStream_t s);
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s);
-hipError_t vct_launch_resolve(unsigned long long* acc, uint32_t* level0, uint32_t* flags,
+hipError_t vct_launch_resolve(unsigned long long* acc, const uint32_t* brick_slot, uint32_t* level0, uint32_t* flags,
                               uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
                               uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, hipStream_t s);
+// mark[b] != 0 -> slot[b] = next free slot (order irrelevant), else VCT_NO_SLOT; *count = slots handed out
+hipError_t vct_launch_assign_slots(const uint32_t* mark, uint32_t* slot, uint32_t* count, uint32_t nbricks, hipStream_t s);
+// pooled per-voxel attribute -> dense Morton volume (downloads)
+hipError_t vct_launch_unpool(const uint32_t* pooled, const uint32_t* brick_slot, uint32_t* dense, uint32_t nbricks, hipStream_t s);
 hipError_t vct_launch_voxelize_reference(const VctVoxParams& p, int32_t* big_list, int32_t* big_count,
                                          hipStream_t s);
 hipError_t vct_launch_bounce(const VctTraceParams& p, hipStream_t s);

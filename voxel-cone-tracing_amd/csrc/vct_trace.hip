@@ -811,7 +811,8 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
                                               March march) {
     const uint32_t* __restrict__ level0 = p.chain;          // level 0 starts the chain
     const float fV = (float)p.V;
-    const uint32_t src = level0[vox], nq = p.attr_normal[vox], aq = p.attr_albedo[vox];
+    const size_t pv = (size_t)p.brick_slot[vox >> 9] * 512 + (vox & 511u);      // attributes are pooled per touched brick
+    const uint32_t src = level0[vox], nq = p.attr_normal[pv], aq = p.attr_albedo[pv];
     const uint32_t mi = (uint32_t)vox;
     const int i = (int)vct_compact3(mi), j = (int)vct_compact3(mi >> 1), k = (int)vct_compact3(mi >> 2);
     const F3 P = f3((div_rn((float)i + 0.5f, fV) - 0.5f) * p.G, (div_rn((float)j + 0.5f, fV) - 0.5f) * p.G,
@@ -872,7 +873,8 @@ __device__ __forceinline__ int compact_brick(const VctTraceParams& p, uint32_t b
         const size_t vox = (size_t)b * 512 + v;
         const uint32_t src0 = p.chain[vox];
         p.bounce_out[vox] = src0;
-        const bool occ = (src0 >> 24) != 0u && (p.attr_normal[vox] & 0xffffffu) != 0x808080u;
+        const bool occ = (src0 >> 24) != 0u &&
+                         (p.attr_normal[(size_t)p.brick_slot[b] * 512 + v] & 0xffffffu) != 0x808080u;
         const unsigned long long m = ballot64(occ);
         if (occ) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)v;
         n += __popcll(m);

@@ -264,6 +264,8 @@ __device__ __forceinline__ bool overlap(const TriSetup& c, int i, int j, int k) 
 __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& r, int i, int j,
                                          int k) {
     if (!overlap(r, i, j, k)) return;
+    const uint32_t vox = vct_morton3((uint32_t)i, (uint32_t)j, (uint32_t)k);
+    if (p.mark_only) { p.brick_mark[vox >> 9] = 1u; return; }      // which bricks can this mesh touch at all
     const F3 ctr = {(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
     const float cx = comp(ctr, r.ua), cy = comp(ctr, r.ub);
     const float ax0 = comp(r.g[0], r.ua), ay0 = comp(r.g[0], r.ub);
@@ -287,13 +289,13 @@ __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& 
     frag_albedo(p, r, b0, b1, b2, alb);                                              // vox.fs:56
     const unsigned long long cr = to_unorm8(alb[0] * sh), cg = to_unorm8(alb[1] * sh),
                              cb = to_unorm8(alb[2] * sh);                            // vox.fs:88
-    const uint32_t vox = vct_morton3((uint32_t)i, (uint32_t)j, (uint32_t)k);
-    unsigned long long* a = p.acc + 2 * (size_t)vox;
+    const size_t pv = (size_t)p.brick_slot[vox >> 9] * 512 + (vox & 511u);      // pooled voxel
+    unsigned long long* a = p.acc + 2 * pv;
     atomicAdd(a, cr | (cg << 32));
     atomicAdd(a + 1, cb | (1ull << 32));
     p.brick_flags[vox >> 9] = 1u;      // benign race: every writer stores the same value
     if (p.acc_attr) {
-        unsigned long long* q = p.acc_attr + 3 * (size_t)vox;
+        unsigned long long* q = p.acc_attr + 3 * pv;
         const uint32_t a0 = r.tex >= 0 ? to_unorm8(alb[0]) : r.attr[0], a1 = r.tex >= 0 ? to_unorm8(alb[1]) : r.attr[1],
                        a2 = r.tex >= 0 ? to_unorm8(alb[2]) : r.attr[2];              // the fragment's albedo
         atomicAdd(q, (unsigned long long)a0 | ((unsigned long long)a1 << 32));
@@ -463,6 +465,8 @@ __device__ __forceinline__ void ref_fragment(const VctVoxParams& p, const RefSet
     else if (r.axis == 2) { vz = V - 1 - iy; vy = V - 1 - iz; vx = ix; }              // :76-81
     else { vx = ix; vy = iy; vz = V - 1 - iz; }                                       // :82-86
     if (vx < 0 || vy < 0 || vz < 0 || vx >= V || vy >= V || vz >= V) return;          // [GL] store dropped
+    const uint32_t vox = vct_morton3((uint32_t)vx, (uint32_t)vy, (uint32_t)vz);
+    if (p.mark_only) { p.brick_mark[vox >> 9] = 1u; return; }
     float sh = 1.0f;
     if (p.shadow) {
         const F3 dc = {l0 * r.dc[0].x + l1 * r.dc[1].x + l2 * r.dc[2].x,
@@ -474,8 +478,8 @@ __device__ __forceinline__ void ref_fragment(const VctVoxParams& p, const RefSet
     frag_albedo(p, r, l0, l1, l2, alb);                                               // vox.fs:56
     const unsigned long long rgb = to_unorm8(alb[0] * sh) | (to_unorm8(alb[1] * sh) << 8) |
                                    (to_unorm8(alb[2] * sh) << 16);                   // vox.fs:88
-    const uint32_t vox = vct_morton3((uint32_t)vx, (uint32_t)vy, (uint32_t)vz);
-    atomicMax(p.acc + 2 * (size_t)vox, ((unsigned long long)(uint32_t)(t + 1) << 32) | rgb);
+    atomicMax(p.acc + 2 * ((size_t)p.brick_slot[vox >> 9] * 512 + (vox & 511u)),
+              ((unsigned long long)(uint32_t)(t + 1) << 32) | rgb);
     p.brick_flags[vox >> 9] = 1u;
 }
 
@@ -523,7 +527,8 @@ __device__ __forceinline__ uint32_t resolve_voxel(ulonglong2 a) {
 // One wave per 8^3 brick (512 voxels, one contiguous 8 KiB run of accumulators); bricks that were
 // touched neither in this pass nor in the previous one are skipped unless `dense`.
 __global__ void __launch_bounds__(256)
-k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ level0,
+k_resolve_sparse(unsigned long long* __restrict__ acc, const uint32_t* __restrict__ brick_slot,
+                 uint32_t* __restrict__ level0,
                  uint32_t* __restrict__ flags, uint32_t* __restrict__ prev, uint32_t nbricks,
                  uint32_t brick_voxels, int dense, unsigned long long* __restrict__ acc_attr,
                  uint32_t* __restrict__ attr_albedo, uint32_t* __restrict__ attr_normal, int reference) {
@@ -532,8 +537,14 @@ k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ le
     for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nbricks; b += waves) {
         const uint32_t now = flags[b], before = prev[b];
         if (!dense && !(now | before)) continue;
-        ulonglong2* a2 = reinterpret_cast<ulonglong2*>(acc) + (size_t)b * brick_voxels;
         uint32_t* l0 = level0 + (size_t)b * brick_voxels;
+        const uint32_t slot = brick_slot[b];
+        if (slot == VCT_NO_SLOT) {        // no fragment of this mesh can land here: level 0 is empty
+            for (uint32_t v = lane; v < brick_voxels; v += 64) l0[v] = 0u;
+            if (lane == 0) { prev[b] = 0u; flags[b] = 0u; }
+            continue;
+        }
+        ulonglong2* a2 = reinterpret_cast<ulonglong2*>(acc) + (size_t)slot * brick_voxels;
         for (uint32_t v = lane; v < brick_voxels; v += 64) {
             const ulonglong2 a = a2[v];
             if (reference) {        // (triangle + 1) << 32 | rgb of the last triangle that stored here
@@ -544,7 +555,7 @@ k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ le
             l0[v] = resolve_voxel(a);
             if (a.y) a2[v] = make_ulonglong2(0ull, 0ull);
             if (acc_attr) {
-                const size_t vox = (size_t)b * brick_voxels + v;
+                const size_t vox = (size_t)slot * brick_voxels + v;       // attributes are pooled like the accumulators
                 unsigned long long* q = acc_attr + 3 * vox;
                 const uint32_t c = (uint32_t)(a.y >> 32);
                 uint32_t alb = 0u, nrm = 0u;
@@ -565,7 +576,41 @@ k_resolve_sparse(unsigned long long* __restrict__ acc, uint32_t* __restrict__ le
     }
 }
 
+__global__ void __launch_bounds__(256)
+k_assign_slots(const uint32_t* __restrict__ mark, uint32_t* __restrict__ slot, uint32_t* __restrict__ count,
+               uint32_t nbricks) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nbricks; b += gridDim.x * blockDim.x)
+        slot[b] = mark[b] ? atomicAdd(count, 1u) : VCT_NO_SLOT;
+}
+
+__global__ void __launch_bounds__(256)
+k_unpool(const uint32_t* __restrict__ pooled, const uint32_t* __restrict__ brick_slot, uint32_t* __restrict__ dense,
+         uint32_t nbricks) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nbricks; b += waves) {
+        const uint32_t slot = brick_slot[b];
+        for (uint32_t v = lane; v < 512u; v += 64)
+            dense[(size_t)b * 512 + v] = slot == VCT_NO_SLOT ? 0u : pooled[(size_t)slot * 512 + v];
+    }
+}
+
 }  // namespace
+
+hipError_t vct_launch_assign_slots(const uint32_t* mark, uint32_t* slot, uint32_t* count, uint32_t nbricks, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_assign_slots, dim3((nbricks + 255) / 256 < 4096 ? (nbricks + 255) / 256 : 4096), dim3(256), 0, s,
+                       mark, slot, count, nbricks);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_unpool(const uint32_t* pooled, const uint32_t* brick_slot, uint32_t* dense, uint32_t nbricks, hipStream_t s) {
+    size_t blocks = ((size_t)nbricks + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_unpool, dim3((unsigned)blocks), dim3(256), 0, s, pooled, brick_slot, dense, nbricks);
+    return hipGetLastError();
+}
 
 hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* worklist,
                                int32_t* big_list, bool write, hipStream_t s) {
@@ -605,14 +650,14 @@ hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
     return hipSuccess;
 }
 
-hipError_t vct_launch_resolve(unsigned long long* acc, uint32_t* level0, uint32_t* flags,
+hipError_t vct_launch_resolve(unsigned long long* acc, const uint32_t* brick_slot, uint32_t* level0, uint32_t* flags,
                               uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
                               uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, hipStream_t s) {
     const uint32_t brick_voxels = V >= 8 ? 512u : (uint32_t)(V * V * V);
     const uint32_t nbricks = (uint32_t)(((size_t)V * V * V) / brick_voxels);
     size_t blocks = ((size_t)nbricks + 3) / 4;      // 4 waves per workgroup, one brick per wave
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)blocks), dim3(256), 0, s, acc, level0, flags,
+    hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)blocks), dim3(256), 0, s, acc, brick_slot, level0, flags,
                        prev, nbricks, brick_voxels, dense ? 1 : 0, reference ? nullptr : acc_attr, attr_albedo,
                        attr_normal, reference ? 1 : 0);
     return hipGetLastError();
