@@ -47,6 +47,11 @@ def parse():
     ap.add_argument("--scene", default="atrium", choices=["atrium", "atrium-textured", "cornell", "noise"],
                     help="atrium-textured: the same atrium with procedural diffuse / specular / height maps "
                          "(bump-mapped normals decohere the specular cones)")
+    ap.add_argument("--noise-dense", action="store_true",
+                    help="--scene noise: every voxel gets random RGBA bytes (no empty space) -- with --gbuffer random "
+                         "at 1024^3 this is the HBM-bound stress: per-lane gathers over a 4.6 GiB chain")
+    ap.add_argument("--gbuffer", default="coherent", choices=["coherent", "random"],
+                    help="--scene noise: screen-coherent floor patch, or independent random pixels (incoherent cones)")
     ap.add_argument("--obj", default=None, metavar="PATH",
                     help="Wavefront .obj (+ .mtl) to use instead of a procedural scene, e.g. the real Sponza; model "
                          "units like the reference's (world = 0.05 * model, VCT.h:183)")
@@ -73,9 +78,14 @@ def build_inputs(args, vct, sc):
     w, h, V = args.width, args.height, args.voxel_dim
     if args.scene == "noise":
         import synth
-        return dict(volume=synth.noise_volume(V), planes=synth.coherent_gbuffer(w, h),
-                    cam=(0.0, 4.0, 0.0), light=(0.0, 1.0, 0.25), scene=None,
-                    label="noise volume (seed 7) + coherent G-buffer")
+        if args.noise_dense:
+            vol = np.random.default_rng(7).integers(0, 256, (V, V, V, 4), dtype=np.uint8)
+        else:
+            vol = synth.noise_volume(V)
+        planes = synth.coherent_gbuffer(w, h) if args.gbuffer == "coherent" else synth.random_gbuffer(w * h, seed=42)
+        return dict(volume=vol, planes=planes, cam=(0.0, 4.0, 0.0), light=(0.0, 1.0, 0.25), scene=None,
+                    label=("dense random volume" if args.noise_dense else "thin-shell noise volume") +
+                          f" (seed 7) + {args.gbuffer} G-buffer")
     light = (0.0, 1.0, 0.25)                                     # VCT.h:14
     if args.obj:
         scene = sc.Scene(args.obj)

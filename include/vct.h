@@ -254,13 +254,14 @@ int vct_last_step_count(vct_ctx* ctx, uint64_t* steps);
  * production library returns VCT_ERR_INVALID): [0] march-loop iterations executed by waves, [1] live
  * lanes summed over them (= executed cone steps), [2] level samples whose cooperative 4x4x4 block was
  * all zero (skipped), [3] served through the cooperative block, [4] served by the per-lane gather,
- * [5] live lanes in [4], [6..7] reserved. */
+ * [5] live lanes in [4], [6] those of [4] whose live footprints would fit one block anchored at their minimum,
+ * [7] reserved. */
 int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[8]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);
 /* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the
  * device pointers of the resident tiled G-buffer / RGBA16F frame. */
-/* Self-test of the kernel's constant division (x / d as x*r corrected by two FMA rounds, r = RN(1/d)):
+/* Self-test of the kernel's constant division (x / d as x*r corrected by one FMA round, r = RN(1/d)):
  * runs it on the GPU over every fp32 x of its domain (x == +0 or 2^-100 <= |x| < inf, normal quotient)
  * next to the IEEE divide and returns the number of x whose quotient differs.  0 is the guarantee the
  * trace kernel relies on (vct_trace.hip shows why the march never leaves that domain in a way that

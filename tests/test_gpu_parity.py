@@ -248,21 +248,26 @@ def test_stale_mips_are_refused_and_upload_then_sparse_builds_stay_correct(vct, 
 
 
 def test_const_divide_exhaustive(vct):
-    """The trace kernel's x/d (two FMA correction rounds) equals the IEEE divide for EVERY finite
-    fp32 x, for the divisors the default configs use: half_G = 75 and the per-step occlusion
-    denominators 1 + 0.03*diameter (trace.fs:61,101)."""
+    """The trace kernel's x/d (x*r + ONE FMA correction round) equals the IEEE divide for EVERY finite fp32 x,
+    for every divisor the BASELINE grids and apertures use: half_G = 75 and the per-step occlusion denominators
+    1 + 0.03*diameter (trace.fs:61,101).  One round is not exact for arbitrary divisors -- the library verifies
+    the divisors of each step table on the device before using them and otherwise runs the IEEE-divide kernel;
+    `vct_selftest_const_divide` is that check."""
     with make_ctx(vct, 16, 8, 8) as ctx:
-        divisors = [75.0, 37.5, 3.0, 1.0 + 0.03 * (150.0 / 256), 1.0175781, 2.7341, 0.3333333, 1e-3, 977.0]
-        for V in (64, 256, 1024):
+        divisors = [75.0]
+        for V in (64, 256, 512, 1024):
             vs = np.float32(150.0) / np.float32(V)
-            for t in (0.577, 0.07):
+            for t in (0.577, 0.07, 0.105, 0.2):
                 dist = vs
                 while dist < 75.0:
                     dia = max(vs, np.float32(2.0) * np.float32(t) * dist)
                     divisors.append(float(np.float32(1.0) + np.float32(0.03) * dia))
                     dist = np.float32(dist + dia)
-        for d in sorted(set(divisors))[::3] + [75.0]:
+        for d in sorted(set(divisors)):
             assert ctx.selftest_const_divide(d) == 0, d
+        # arbitrary divisors may or may not pass; the call reports, it does not fail
+        others = [ctx.selftest_const_divide(d) for d in (37.5, 3.0, 1.0175781, 2.7341, 0.3333333, 1e-3, 977.0)]
+        assert all(n >= 0 for n in others)
 
 
 def test_facade_demo_matches_binding(vct):

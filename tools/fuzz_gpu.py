@@ -3,7 +3,7 @@ Usage: python tools/fuzz_gpu.py [seconds]   (exit code 1 on the first mismatch, 
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, synth, vctpkg
+import numpy as np, synth, vctpkg, raster_oracle
 vct = vctpkg.load()
 from oracle import pyoracle as oracle
 from voxel_cone_tracing_amd import scene as sc
@@ -96,17 +96,16 @@ while time.time() < t_end:
                 fail("bounce", seed)
             counts["bounce"] += 1
     # ---- raster stages ----
-    kind = int(r.integers(0, 2)); w = int(r.integers(8, 640 if BIG else 200)); h = int(r.integers(8, 360 if BIG else 120))
+    kind = int(r.integers(0, 3)); w = int(r.integers(8, 640 if BIG else 200)); h = int(r.integers(8, 360 if BIG else 120))
     S = int(r.choice([256, 1024] if BIG else [64, 256]))
     scene = sc.Scene(kind, 0.3 if BIG else 0.1, seed)
     lightd = tuple(np.abs(r.normal(size=3)) + 0.1)
     cam = sc.default_camera(position=tuple(r.uniform(-40, 40, 3)), yaw=float(r.uniform(-180, 180)),
                             pitch=float(r.uniform(-60, 60)), zoom=float(r.uniform(20, 45)))
-    dref, lvp_row = scene.shadow_map(lightd, S)
-    gref = scene.gbuffer(cam, w, h, dref, lvp_row)
+    dref, lvp_row = raster_oracle.shadow_map(sc, scene, lightd, S)
+    gref = raster_oracle.gbuffer(sc, scene, cam, w, h, dref, lvp_row)
     with vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S)) as ctx:
-        ctx.upload_triangles(scene.pos, scene.material, scene.albedo)
-        ctx.upload_mesh_attributes(*scene.frames(), scene.specular)
+        ctx.upload_scene(scene)
         ctx.render_shadow_map(sc.light_view_proj(lightd))
         if not np.array_equal(ctx.download_shadow_map().view(np.uint32), dref.view(np.uint32)): fail("shadow raster", seed)
         ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))

@@ -415,7 +415,7 @@ class Context:
         """Instrumented builds (-DVCT_STATS=1) only: dict of wave-level march counters."""
         v = (C.c_uint64 * 8)()
         self._ck(_lib.vct_last_trace_stats(self._h, v), "vct_last_trace_stats")
-        keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes")
+        keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes", "fallback_fits")
         return dict(zip(keys, (int(x) for x in v)))
 
     def last_trace_ms(self):

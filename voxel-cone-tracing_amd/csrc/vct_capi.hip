@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -119,16 +120,33 @@ int build_steps(const vct_config& cfg, float tan_half, std::vector<VctStep>& out
 }
 
 // The kernel divides by wave-uniform constants (half_G, the per-step occlusion denominators) with
-// q = x*r; two rounds of { e = fma(-d,q,x); q = fma(e,r,q) }, r = RN(1/d).  After the first round q
-// is a faithful rounding of x/d, so the second returns the correctly rounded quotient (Markstein's
-// theorem) -- for every divisor whose significand is not all ones and whose reciprocal is a normal
-// number.  Divisors outside that set switch the kernel to the IEEE divide.
+// q = x*r; e = fma(-d,q,x); q = fma(e,r,q), r = RN(1/d) -- exact only for some divisors, so every divisor of
+// a step table is first verified on the device against the IEEE divide over all fp32 inputs
+// (divisors_verified below); structural preconditions: significand not all ones, d and 1/d normal.
+// Anything else switches the kernel to the IEEE-divide instantiation.
 bool divisor_ok(float d) {
     uint32_t b;
     memcpy(&b, &d, 4);
     const uint32_t e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
     if (!(d > 0.0f) || e == 0xffu) return false;
     return m != 0x7fffffu && e >= 4 && e <= 250;   // d and 1/d both far from the subnormal range
+}
+
+// exhaustive device check of the one-round constant division for divisor d (vct_trace.hip div_const);
+// verdicts are cached per divisor for the life of the process
+int divisor_verified(vct_ctx* c, float d, bool* ok) {
+    static std::map<uint32_t, bool> cache;
+    uint32_t bits;
+    memcpy(&bits, &d, 4);
+    auto it = cache.find(bits);
+    if (it != cache.end()) { *ok = it->second; return VCT_OK; }
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, vct_launch_divide_selftest(d, c->stats, c->stream));
+    unsigned long long bad = 1;
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->stats, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *ok = cache[bits] = bad == 0ull;
+    return VCT_OK;
 }
 
 int refresh_steps(vct_ctx* c) {
@@ -153,6 +171,17 @@ int refresh_steps(vct_ctx* c) {
     };
     for (const VctStep& st : d) ok = ok && divisor_ok(st.occ_den) && blend_ok(st);
     for (const VctStep& st : s) ok = ok && divisor_ok(st.occ_den) && blend_ok(st);
+    if (ok) {      // every divisor of the tables passes the device's exhaustive check of the one-round division
+        std::vector<float> divs = {c->cfg.grid_world_size * 0.5f};
+        for (const VctStep& st : d) divs.push_back(st.occ_den);
+        for (const VctStep& st : s) divs.push_back(st.occ_den);
+        for (float dv : divs) {
+            bool good = false;
+            int rc = divisor_verified(c, dv, &good);
+            if (rc) return rc;
+            if (!good) { ok = false; break; }
+        }
+    }
     c->fast_div = ok;
     c->steps_dirty = false;
     return VCT_OK;

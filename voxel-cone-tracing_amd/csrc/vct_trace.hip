@@ -33,8 +33,9 @@
 //   per-lane sample (incoherent waves: silhouettes, random G-buffers): 8 loads + 32 decodes per
 //   lane as in a plain gather, with the +1 neighbours derived by dilated increments.
 //
-// Both produce the same bits.  Divisions by wave-uniform constants use two FMA correction rounds
-// instead of the 10-instruction IEEE sequence (vct_capi.hip: divisor_ok).
+// Both produce the same bits.  Divisions by wave-uniform constants use one FMA correction round
+// instead of the 10-instruction IEEE sequence, for divisors the device has verified exhaustively
+// (vct_capi.hip: divisor_verified).
 #include <hip/hip_fp16.h>
 
 #include "vct_internal.h"
@@ -62,11 +63,15 @@ __device__ __forceinline__ F3 reflect3(F3 I, F3 N) {
     return {I.x - d * N.x, I.y - d * N.y, I.z - d * N.z};
 }
 
-// x / d for a wave-uniform divisor d with r = RN(1/d): correctly rounded for x == +0 and every
-// finite |x| >= 2^-100 whose quotient is a normal number (host-side precondition on d:
-// vct_capi.hip divisor_ok; below ~2^-102 the exact remainder e can underflow; -0 returns +0).
-// Five 2-cycle instructions instead of v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup.
-// Checked against the IEEE divide over every fp32 x of that domain by vct_selftest_const_divide.
+// x / d for a wave-uniform divisor d with r = RN(1/d):  q = x*r; e = fma(-d, q, x); q = fma(e, r, q) -- three
+// 2-cycle instructions instead of v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup.  One correction round
+// is NOT correctly rounded for every divisor (q = x*r may be 2 ulp off before it), so it is used only for
+// divisors the DEVICE has verified: before a step table is used, vct_capi.hip runs k_divide_selftest for each
+// of its divisors (half_G and the per-step occlusion denominators) over EVERY fp32 x of the domain below and
+// requires the IEEE quotient bit for bit (results cached per divisor; all 250 divisors of the BASELINE grids
+// and apertures pass); a table with a divisor that fails runs the IEEE-divide instantiation.
+// Domain: x == +0 and every finite |x| >= 2^-100 whose quotient is a normal number (host-side precondition on
+// d: vct_capi.hip divisor_ok; below ~2^-102 the exact remainder e can underflow; -0 returns +0).
 // The march stays inside the domain by construction:
 //   * coordinates: |x| < 2^-100 or x == -0 gives |q| < 2^-26, and u = fma(q, .5, .5) = 0.5 for any
 //     such q, exactly as with the IEEE quotient;
@@ -78,10 +83,8 @@ __device__ __forceinline__ F3 reflect3(F3 I, F3 N) {
 template <bool FAST>
 __device__ __forceinline__ float div_const(float x, float d, float r) {
     if (!FAST) return x / d;
-    float q = x * r;
-    float e = fmaf(-d, q, x);
-    q = fmaf(e, r, q);
-    e = fmaf(-d, q, x);
+    const float q = x * r;
+    const float e = fmaf(-d, q, x);
     return fmaf(e, r, q);
 }
 
@@ -120,6 +123,7 @@ struct MarchStats {
     uint32_t coop_hit;         // level samples served by the cooperative block, gathered through LDS
     uint32_t fallback;         // level samples that took the per-lane gather
     uint32_t fallback_lanes;   // live lanes in those
+    uint32_t fallback_fits;    // per-lane samples whose live footprints WOULD fit one 4x4x4 block (anchored at their minimum)
 };
 
 // [GL] tri(level): trilinear, texel centres, REPEAT (or clamp).  `level` is wave-uniform; must be
@@ -197,7 +201,14 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
 #undef VCT_ACC
         }
     } else {
-      if (VCT_STATS) { ++ms.fallback; ms.fallback_lanes += (uint32_t)__popcll(ballot64(act)); }
+      if (VCT_STATS) {
+          ++ms.fallback; ms.fallback_lanes += (uint32_t)__popcll(ballot64(act));
+          int lo[3] = {act ? i0 : 0x7fffffff, act ? j0 : 0x7fffffff, act ? k0 : 0x7fffffff};
+          int hi[3] = {act ? i0 : -0x7fffffff, act ? j0 : -0x7fffffff, act ? k0 : -0x7fffffff};
+          for (int off = 32; off > 0; off >>= 1)
+              for (int q = 0; q < 3; ++q) { lo[q] = min(lo[q], __shfl_xor(lo[q], off)); hi[q] = max(hi[q], __shfl_xor(hi[q], off)); }
+          if (hi[0] - lo[0] <= 2 && hi[1] - lo[1] <= 2 && hi[2] - lo[2] <= 2) ++ms.fallback_fits;
+      }
       if (act) {
         uint32_t mx0, mx1, my0, my1, mz0, mz1;
         if (WRAP) {
@@ -428,9 +439,9 @@ __device__ __forceinline__ uint32_t pack_half2(float a, float b) {
 
 __device__ __forceinline__ void flush_stats(const VctTraceParams& p, const MarchStats& ms, int lane) {
     if (VCT_STATS && p.stats && lane == 0) {
-        const uint32_t v[6] = {ms.wave_steps, ms.lane_steps, ms.coop_zero, ms.coop_hit, ms.fallback,
-                               ms.fallback_lanes};
-        for (int i = 0; i < 6; ++i)
+        const uint32_t v[7] = {ms.wave_steps, ms.lane_steps, ms.coop_zero, ms.coop_hit, ms.fallback,
+                               ms.fallback_lanes, ms.fallback_fits};
+        for (int i = 0; i < 7; ++i)
             if (v[i]) atomicAdd(p.stats + i, (unsigned long long)v[i]);
     }
 }
