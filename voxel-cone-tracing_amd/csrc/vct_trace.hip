@@ -822,7 +822,10 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
                                               March march) {
     const uint32_t* __restrict__ level0 = p.chain;          // level 0 starts the chain
     const float fV = (float)p.V;
-    const size_t pv = (size_t)p.brick_slot[vox >> 9] * 512 + (vox & 511u);      // attributes are pooled per touched brick
+    // attributes are pooled per touched brick; lanes without a voxel (alive == false) may point at a brick that
+    // has no slot: they read slot 0 and their result is discarded
+    const uint32_t slot = p.brick_slot[vox >> 9];
+    const size_t pv = (size_t)(slot == VCT_NO_SLOT ? 0u : slot) * 512 + (vox & 511u);
     const uint32_t src = level0[vox], nq = p.attr_normal[pv], aq = p.attr_albedo[pv];
     const uint32_t mi = (uint32_t)vox;
     const int i = (int)vct_compact3(mi), j = (int)vct_compact3(mi >> 1), k = (int)vct_compact3(mi >> 2);
