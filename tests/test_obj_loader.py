@@ -109,3 +109,48 @@ def test_obj_scene_through_the_resident_pipeline(cube, oracle):
         ref = oracle.trace(oracle.default_params(V, camera_pos=(0.0, 10.0, 200.0), light_dir=light), chain, planes, nthreads=4)
         assert np.array_equal(ctx.last_step_count(), ref["total_steps"])
         assert (frame.reshape(-1, 4) == ref["rgba16f"]).mean() > 0.999
+
+
+def test_scene_cache_round_trip(tmp_path):
+    """the on-disk cache holds everything a scene holds (triangles, frames, texture coordinates,
+    materials, decoded maps); corrupt or foreign files are refused."""
+    import vctpkg
+    vctpkg.load()
+    from voxel_cone_tracing_amd import scene as sc
+    s = sc.Scene(sc.ATRIUM_TEXTURED, 0.05, 7)
+    path = str(tmp_path / "atrium.vctscene")
+    s.save(path)
+    t = sc.Scene(path)
+    assert t.ntri == s.ntri and t.nmat == s.nmat and len(t.textures) == len(s.textures) > 0
+    for a, b in ((s.pos, t.pos), (s.uv, t.uv), (s.material, t.material), (s.albedo, t.albedo),
+                 (s.specular, t.specular), (s.mat_tex, t.mat_tex)):
+        assert np.array_equal(a, b)
+    assert all(np.array_equal(a, b) for a, b in zip(s.frames(), t.frames()))
+    assert all(np.array_equal(a, b) for a, b in zip(s.textures, t.textures))
+    raw = open(path, "rb").read()
+    open(path, "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(ValueError):
+        sc.Scene(path)
+    open(path, "wb").write(b"NOTACACHE" + raw[9:])
+    with pytest.raises(ValueError):
+        sc.Scene(path)
+
+
+@pytest.mark.gpu
+def test_presenter_writes_the_tonemapped_frame(tmp_path):
+    """vct_demo --ppm (the headless stand-in for swap-buffers, R/main.cpp:92) writes the frame of
+    its last Render() as a P6 image, bottom row last, tonemapped from the RGBA16F halves."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo = os.path.join(root, "voxel-cone-tracing_amd", "vct_demo")
+    out = str(tmp_path / "frame.ppm")
+    r = subprocess.run([demo, "--scene", "procedural:cornell", "--voxels", "32", "--size", "96x64", "--shadow", "256",
+                        "--frames", "1", "--ppm", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    assert raw.startswith(b"P6\n96 64\n255\n") and len(raw) == len(b"P6\n96 64\n255\n") + 96 * 64 * 3
+    img = np.frombuffer(raw[-96 * 64 * 3:], np.uint8).reshape(64, 96, 3)
+    assert 10 < img.mean() < 245 and img.std() > 5            # a lit scene, not a constant image
+    left, right = img[20:44, 4:24].mean((0, 1)), img[20:44, 72:92].mean((0, 1))
+    assert left[0] > left[1] and right[1] > right[0]          # red wall on the left, green wall on the right

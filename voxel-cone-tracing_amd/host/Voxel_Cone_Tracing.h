@@ -154,6 +154,7 @@ struct Model {
         if (p == "procedural:cornell") scene = vcth_scene_create(0, 1.0f, 1234u);
         else if (p == "procedural:atrium") scene = vcth_scene_create(1, 1.0f, 1234u);
         else if (p == "procedural:atrium-textured") scene = vcth_scene_create(2, 1.0f, 1234u);
+        else if (p.size() > 9 && p.compare(p.size() - 9, 9, ".vctscene") == 0) scene = vcth_scene_load_cache(p.c_str(), err);
         else scene = vcth_scene_load_obj(p.c_str(), err);             // R/Model.h:39-61
         if (!scene) printf("ERROR::MODEL: cannot load '%s' (%s; or use procedural:atrium | procedural:cornell)\n",
                            p.c_str(), err);

@@ -617,6 +617,87 @@ vcth_scene* vcth_scene_load_obj(const char* path, char* error) {
     return s;
 }
 
+// ---- on-disk scene cache: everything a loaded / generated scene holds, little-endian,
+// one file.  Parsing a large OBJ + decoding its maps is the slow part of start-up; the cache is one read.
+extern "C++" {
+namespace {
+const char kCacheMagic[8] = {'V', 'C', 'T', 'S', 'C', 'N', '0', '2'};
+template <class T> bool put(FILE* f, const std::vector<T>& v) {
+    const uint64_t n = v.size();
+    return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <class T> bool get(FILE* f, std::vector<T>& v, uint64_t max_n) {
+    uint64_t n = 0;
+    if (fread(&n, 8, 1, f) != 1 || n > max_n) return false;
+    v.resize(n);
+    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+}  // namespace
+}  // extern "C++"
+
+int vcth_scene_save(const vcth_scene* s, const char* path) {
+    if (!s || !path) return -1;
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    bool ok = fwrite(kCacheMagic, 8, 1, f) == 1 && put(f, s->pos) && put(f, s->nrm) && put(f, s->tan) && put(f, s->bit) &&
+              put(f, s->uv) && put(f, s->mat);
+    std::vector<float> mf;
+    std::vector<int32_t> mt;
+    for (const Material& m : s->materials) {
+        mf.insert(mf.end(), m.albedo, m.albedo + 4);
+        mf.insert(mf.end(), m.spec, m.spec + 3);
+        mt.insert(mt.end(), m.tex, m.tex + 3);
+    }
+    ok = ok && put(f, mf) && put(f, mt);
+    const uint64_t ntex = s->textures.size();
+    ok = ok && fwrite(&ntex, 8, 1, f) == 1;
+    for (const Texture& t : s->textures) {
+        const int32_t wh[2] = {t.w, t.h};
+        ok = ok && fwrite(wh, 4, 2, f) == 2 && put(f, t.rgba);
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : -1;
+}
+
+vcth_scene* vcth_scene_load_cache(const char* path, char* error) {
+    auto failmsg = [&](const char* m) -> vcth_scene* { if (error) snprintf(error, 256, "%s", m); return nullptr; };
+    FILE* f = path ? fopen(path, "rb") : nullptr;
+    if (!f) return failmsg("cannot open the cache file");
+    char magic[8];
+    vcth_scene* s = new vcth_scene();
+    std::vector<float> mf;
+    std::vector<int32_t> mt;
+    const uint64_t big = 1ull << 33;
+    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, kCacheMagic, 8) == 0 && get(f, s->pos, big) && get(f, s->nrm, big) &&
+              get(f, s->tan, big) && get(f, s->bit, big) && get(f, s->uv, big) && get(f, s->mat, big) && get(f, mf, big) &&
+              get(f, mt, big);
+    uint64_t ntex = 0;
+    ok = ok && fread(&ntex, 8, 1, f) == 1 && ntex < (1u << 20);
+    for (uint64_t i = 0; ok && i < ntex; ++i) {
+        Texture t;
+        int32_t wh[2];
+        ok = fread(wh, 4, 2, f) == 2 && get(f, t.rgba, big) && wh[0] > 0 && wh[1] > 0 &&
+             t.rgba.size() == (size_t)wh[0] * wh[1] * 4;
+        t.w = wh[0]; t.h = wh[1];
+        if (ok) s->textures.push_back(t);
+    }
+    fclose(f);
+    const size_t ntri = s->mat.size(), nmat = mt.size() / 3;
+    ok = ok && s->pos.size() == ntri * 9 && s->nrm.size() == ntri * 9 && s->tan.size() == ntri * 9 &&
+         s->bit.size() == ntri * 9 && s->uv.size() == ntri * 6 && mf.size() == nmat * 7 && ntri > 0 && nmat > 0;
+    for (size_t t = 0; ok && t < ntri; ++t) ok = s->mat[t] >= 0 && (size_t)s->mat[t] < nmat;
+    for (size_t i = 0; ok && i < mt.size(); ++i) ok = mt[i] >= -1 && mt[i] < (int32_t)s->textures.size();
+    if (!ok) { delete s; return failmsg("not a scene cache of this version, or truncated / inconsistent"); }
+    for (size_t m = 0; m < nmat; ++m) {
+        Material mm;
+        memcpy(mm.albedo, &mf[m * 7], 16);
+        memcpy(mm.spec, &mf[m * 7 + 4], 12);
+        memcpy(mm.tex, &mt[m * 3], 12);
+        s->materials.push_back(mm);
+    }
+    return s;
+}
+
 void vcth_scene_destroy(vcth_scene* s) { delete s; }
 int32_t vcth_scene_num_triangles(const vcth_scene* s) { return s ? (int32_t)s->mat.size() : 0; }
 int32_t vcth_scene_num_materials(const vcth_scene* s) { return s ? (int32_t)s->materials.size() : 0; }

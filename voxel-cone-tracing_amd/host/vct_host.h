@@ -45,6 +45,12 @@ vcth_scene* vcth_scene_create(int kind, float detail, uint32_t seed);
  * are taken as MODEL space (the orchestrator scales by 0.05, VCT.h:183).  Returns NULL on failure;
  * `error` (optional, >= 256 bytes) receives the reason. */
 vcth_scene* vcth_scene_load_obj(const char* path, char* error);
+/* On-disk cache of a scene (triangles, frames, texture coordinates, materials, decoded texture maps): what
+ * R/Model.h:39-61 + :141-226 rebuild from the .obj and its images on every start.  vcth_scene_save returns 0 on
+ * success; vcth_scene_load_cache returns NULL (reason in `error`, optional, >= 256 bytes) for a missing,
+ * truncated, inconsistent or differently versioned file. */
+int vcth_scene_save(const vcth_scene* s, const char* path);
+vcth_scene* vcth_scene_load_cache(const char* path, char* error);
 void vcth_scene_destroy(vcth_scene* s);
 int32_t vcth_scene_num_triangles(const vcth_scene* s);
 int32_t vcth_scene_num_materials(const vcth_scene* s);

@@ -30,6 +30,9 @@ _lib.vcth_scene_get.argtypes = [C.c_void_p] * 5
 _lib.vcth_light_view_proj.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vcth_scene_get_frames.argtypes = [C.c_void_p] * 4
 _lib.vcth_camera_view_proj.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+_lib.vcth_scene_save.argtypes = [C.c_void_p, C.c_char_p]
+_lib.vcth_scene_load_cache.restype = C.c_void_p
+_lib.vcth_scene_load_cache.argtypes = [C.c_char_p, C.c_char_p]
 _lib.vcth_scene_get_uvs.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vcth_scene_num_textures.argtypes = [C.c_void_p]
 _lib.vcth_scene_texture_info.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -71,7 +74,10 @@ class Scene:
         """kind: CORNELL / ATRIUM (procedural) or the path of a Wavefront .obj file."""
         if isinstance(kind, (str, bytes, os.PathLike)):
             err = C.create_string_buffer(256)
-            self._h = _lib.vcth_scene_load_obj(os.fsencode(kind), err)
+            if os.fsdecode(kind).endswith(".vctscene"):           # on-disk cache written by Scene.save()
+                self._h = _lib.vcth_scene_load_cache(os.fsencode(kind), err)
+            else:
+                self._h = _lib.vcth_scene_load_obj(os.fsencode(kind), err)
             if not self._h:
                 raise ValueError(f"cannot load {kind}: {err.value.decode()}")
         else:
@@ -97,6 +103,11 @@ class Scene:
             t = np.zeros((h.value, w.value, 4), np.uint8)
             _lib.vcth_scene_get_texture(self._h, i, t.ctypes.data)
             self.textures.append(t)
+
+    def save(self, path):
+        """Write the on-disk cache of this scene (load it back with Scene(path); use the suffix .vctscene)."""
+        if _lib.vcth_scene_save(self._h, os.fsencode(path)) != 0:
+            raise OSError(f"cannot write {path}")
 
     def frames(self):
         """Per-vertex (normal, tangent, bitangent), each float32 [ntri, 9]."""
