@@ -255,8 +255,9 @@ int vct_last_step_count(vct_ctx* ctx, uint64_t* steps);
  * lanes summed over them (= executed cone steps), [2] level samples whose cooperative 4x4x4 block was
  * all zero (skipped), [3] served through the cooperative block, [4] served by the per-lane gather,
  * [5] live lanes in [4], [6] those of [4] whose live footprints would fit one block anchored at their minimum,
- * [7] reserved. */
-int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[8]);
+ * [7] blocks a greedy multi-anchor cover of [4] needs in total, [8..10] those of [4] it covers with <= 2 / 3 / 4
+ * blocks, [11..15] reserved. */
+int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[16]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);
 /* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the

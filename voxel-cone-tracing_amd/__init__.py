@@ -413,9 +413,10 @@ class Context:
 
     def last_trace_stats(self):
         """Instrumented builds (-DVCT_STATS=1) only: dict of wave-level march counters."""
-        v = (C.c_uint64 * 8)()
+        v = (C.c_uint64 * 16)()
         self._ck(_lib.vct_last_trace_stats(self._h, v), "vct_last_trace_stats")
-        keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes", "fallback_fits")
+        keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes", "fallback_fits",
+                "greedy_blocks", "greedy_le2", "greedy_le3", "greedy_le4")
         return dict(zip(keys, (int(x) for x in v)))
 
     def last_trace_ms(self):

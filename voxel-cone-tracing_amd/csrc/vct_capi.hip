@@ -248,7 +248,7 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long),
                               c->stream));
 #if defined(VCT_STATS) && VCT_STATS
-    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
 #endif
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
@@ -474,8 +474,8 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     CREATE_TRY(hipMalloc(&c->frame, npix * 8));
     CREATE_TRY(hipMemsetAsync(c->frame, 0, npix * 8, c->stream));
     CREATE_TRY(hipMalloc(&c->step_counter, VCT_STEP_COUNTERS * sizeof(unsigned long long)));
-    CREATE_TRY(hipMalloc(&c->stats, 8 * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemsetAsync(c->stats, 0, 8 * sizeof(unsigned long long), c->stream));
+    CREATE_TRY(hipMalloc(&c->stats, 16 * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
     CREATE_TRY(hipMalloc(&c->steps_dev, 2 * VCT_MAX_STEPS * sizeof(VctStep)));
     if (cfg->debug_outputs) {
         CREATE_TRY(hipMalloc(&c->dbg_steps, npix * 7));
@@ -621,8 +621,8 @@ static int raster_args(vct_ctx* c, size_t pixels, VctRasterArgs& a) {
         HIP_TRY(c, hipMalloc(&c->vis, pixels * sizeof(unsigned long long)));
         c->vis_words = pixels;
     }
-    if (!c->raster_big) HIP_TRY(c, hipMalloc(&c->raster_big, (size_t)c->ntri * 4 * sizeof(int32_t)));
-    if (!c->raster_big_count) HIP_TRY(c, hipMalloc(&c->raster_big_count, 3 * sizeof(int32_t)));
+    if (!c->raster_big) HIP_TRY(c, hipMalloc(&c->raster_big, (size_t)c->ntri * 6 * sizeof(int32_t)));
+    if (!c->raster_big_count) HIP_TRY(c, hipMalloc(&c->raster_big_count, 4 * sizeof(int32_t)));
     // tile work items: 16x16-pixel pieces of large triangles; pixels/16 entries is ~16x the typical
     // demand (sum of visible bounding boxes ~ a few frames' worth of pixels); overflow is handled
     const size_t want_items = pixels / 16 + 4096;
@@ -646,6 +646,8 @@ static int raster_args(vct_ctx* c, size_t pixels, VctRasterArgs& a) {
     a.item_count = reinterpret_cast<uint32_t*>(c->raster_big_count + 1);
     a.wave_list = c->raster_big + (size_t)c->ntri * 2;
     a.wave_count = reinterpret_cast<uint32_t*>(c->raster_big_count + 2);
+    a.group_list = c->raster_big + (size_t)c->ntri * 4;
+    a.group_count = reinterpret_cast<uint32_t*>(c->raster_big_count + 3);
     a.item_capacity = c->raster_item_capacity;
     a.tex = textures_of(c);
     return VCT_OK;
@@ -1161,12 +1163,12 @@ int vct_last_step_count(vct_ctx* c, uint64_t* steps) {
     return VCT_OK;
 }
 
-int vct_last_trace_stats(vct_ctx* c, uint64_t out[8]) {
+int vct_last_trace_stats(vct_ctx* c, uint64_t out[16]) {
     if (!c || !out) return VCT_ERR_INVALID;
 #if defined(VCT_STATS) && VCT_STATS
     if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out, c->stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out, c->stats, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return VCT_OK;
 #else
     return fail(c, VCT_ERR_INVALID, "vct_last_trace_stats: this library was built without -DVCT_STATS=1 "

@@ -69,7 +69,7 @@ struct vct_ctx {
     unsigned long long* vis = nullptr;
     size_t vis_words = 0;
     int32_t* raster_big = nullptr;
-    int32_t* raster_big_count = nullptr;      // [0] huge sub-triangles, [1] tile work items, [2] wave list
+    int32_t* raster_big_count = nullptr;      // [0] huge sub-triangles, [1] tile work items, [2] wave list, [3] group list
     uint2* raster_items = nullptr;
     uint32_t raster_item_capacity = 0;
     float light_vp[16];

@@ -180,8 +180,10 @@ struct VctRasterArgs {
     unsigned long long* vis;     // visibility words, max(W*H, S*S)
     int32_t* wave_list;          // [2*ntri] medium sub-triangles
     uint32_t* wave_count;
+    int32_t* group_list;         // [2*ntri] small-medium sub-triangles (one 16-lane group each)
+    uint32_t* group_count;
     int32_t* big_list;           // [2*ntri] huge sub-triangles
-    int32_t* big_count;          // followed in memory by item_count and wave_count (one memset)
+    int32_t* big_count;          // followed in memory by item_count, wave_count and group_count (one memset)
     uint2* items;                // tile work items of the raster pass
     uint32_t* item_count;
     uint32_t item_capacity;

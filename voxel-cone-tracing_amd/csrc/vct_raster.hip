@@ -137,6 +137,9 @@ struct RasterParams {
     unsigned long long* vis;     // [H][W] (depth bits << 32) | (tri * 2 + sub); ~0 = empty
     int32_t* wave_list;          // (tri * 2 + sub) of medium sub-triangles (one wave each)
     uint32_t* wave_count;
+    int32_t* group_list;         // (tri * 2 + sub) of small-medium sub-triangles (one 16-lane group each)
+    uint32_t* group_count;
+    uint32_t* vis32;             // depth-only pass: 32-bit visibility words (depth bits), else null
     int32_t* big_list;           // (tri * 2 + sub) of huge sub-triangles (tiles emitted by a workgroup)
     int32_t* big_count;
     uint2* items;                // tile work items: (tri * 2 + sub, tile_y << 16 | tile_x)
@@ -159,6 +162,7 @@ __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVer
 // Work granularity by bounding-box size (the bench scene: half of the visible triangles cover <= 64
 // pixels, 91-100 % <= 256, the largest ~2k; a Cornell wall covers the whole frame):
 #define VCT_RASTER_SMALL 16      // <= this many pixels: rasterised inline by the triangle's own thread
+#define VCT_RASTER_GROUP 256     // <= this many: a 16-lane group (4 sub-triangles per wave), lanes stride the box
 #define VCT_RASTER_WAVE 4096     // <= this many: one wave, lanes stride the bounding box
 #define VCT_RTILE 16             // larger: cut into 16x16-pixel work items by a workgroup
 
@@ -200,6 +204,10 @@ __device__ __forceinline__ void plot(const RasterParams& p, const SubTri& s, int
         const float u = (q0 * s.tu[0] + q1 * s.tu[1] + q2 * s.tu[2]) * qs;
         const float v = (q0 * s.tv[0] + q1 * s.tv[1] + q2 * s.tv[2]) * qs;
         if (vct_tex_sample(p.tex, s.tex, u, v).w < 0.5f) return;                 // trace.fs:171 discard
+    }
+    if (p.vis32) {        // depth-only pass (shadow map): the nearest depth is all that is kept
+        atomicMin(&p.vis32[(size_t)py * p.W + px], __float_as_uint(z));
+        return;
     }
     atomicMin(&p.vis[(size_t)py * p.W + px], ((unsigned long long)__float_as_uint(z) << 32) | id);
 }
@@ -256,7 +264,8 @@ k_raster_vis(const RasterParams p) {
                 for (int px = s.x0; px <= s.x1; ++px) plot(p, s, px, py, id);
             continue;
         }
-        if (box <= VCT_RASTER_WAVE) p.wave_list[atomicAdd(p.wave_count, 1u)] = (int32_t)id;
+        if (box <= VCT_RASTER_GROUP) p.group_list[atomicAdd(p.group_count, 1u)] = (int32_t)id;
+        else if (box <= VCT_RASTER_WAVE) p.wave_list[atomicAdd(p.wave_count, 1u)] = (int32_t)id;
         else p.big_list[atomicAdd(p.big_count, 1)] = (int32_t)id;
     }
 }
@@ -294,6 +303,24 @@ k_raster_waves(const RasterParams p) {
     }
 }
 
+// one 16-lane group per small-medium sub-triangle (half of the visible sub-triangles of the bench scene cover
+// <= 64 pixels: a whole wave per triangle would leave most lanes idle after the first iteration)
+__global__ void __launch_bounds__(256)
+k_raster_groups(const RasterParams p) {
+    const uint32_t n = *p.group_count;
+    const int l16 = threadIdx.x & 15;
+    const uint32_t ngroups = (gridDim.x * blockDim.x) >> 4;
+    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; g < n; g += ngroups) {
+        const int id = p.group_list[g];
+        SubTri s;
+        if (!rebuild_subtri(p, id, s)) continue;
+        const int bw = s.x1 - s.x0 + 1;
+        const int box = bw * (s.y1 - s.y0 + 1);
+        for (int i = l16; i < box; i += 16)
+            plot(p, s, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+    }
+}
+
 // one workgroup per huge sub-triangle: its threads emit the tile work items in parallel
 __global__ void __launch_bounds__(256)
 k_raster_emit_big(const RasterParams p) {
@@ -326,12 +353,12 @@ k_raster_tiles(const RasterParams p) {
     }
 }
 
-// visibility words -> DEPTH_COMPONENT24 depths in [0,1] (cleared to 1)
+// 32-bit visibility words of the depth-only pass (depth bits, ~0 = empty) -> DEPTH_COMPONENT24
 __global__ void __launch_bounds__(256)
-k_vis_to_depth24(const unsigned long long* __restrict__ vis, float* __restrict__ depth, size_t n) {
+k_vis32_to_depth24(const uint32_t* __restrict__ vis, float* __restrict__ depth, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const unsigned long long v = vis[i];
-        const float z = v == ~0ull ? 1.0f : __uint_as_float((uint32_t)(v >> 32));
+        const uint32_t v = vis[i];
+        const float z = v == ~0u ? 1.0f : __uint_as_float(v);
         depth[i] = (float)(floor((double)z * 16777215.0 + 0.5) / 16777215.0);
     }
 }
@@ -589,6 +616,9 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
     r.vis = a.vis;
     r.wave_list = a.wave_list;
     r.wave_count = a.wave_count;
+    r.group_list = a.group_list;
+    r.group_count = a.group_count;
+    r.vis32 = nullptr;
     r.big_list = a.big_list;
     r.big_count = a.big_count;
     r.items = a.items;
@@ -602,13 +632,18 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
 
 hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
     if (r.ys1 <= r.ys0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(r.vis + (size_t)r.ys0 * r.W, 0xff,
-                                  (size_t)r.W * (r.ys1 - r.ys0) * sizeof(unsigned long long), s);
+    hipError_t e = r.vis32 ? hipMemsetAsync(r.vis32 + (size_t)r.ys0 * r.W, 0xff,
+                                            (size_t)r.W * (r.ys1 - r.ys0) * sizeof(uint32_t), s)
+                           : hipMemsetAsync(r.vis + (size_t)r.ys0 * r.W, 0xff,
+                                            (size_t)r.W * (r.ys1 - r.ys0) * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(r.big_count, 0, 3 * sizeof(int32_t), s);     // big, item and wave counters
+    e = hipMemsetAsync(r.big_count, 0, 4 * sizeof(int32_t), s);     // big, item, wave and group counters
     if (e != hipSuccess) return e;
     if (r.ntri <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_raster_vis, dim3((r.ntri + 255) / 256), dim3(256), 0, s, r);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_raster_groups, dim3(256 * 16), dim3(256), 0, s, r);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_raster_waves, dim3(256 * 16), dim3(256), 0, s, r);
@@ -625,11 +660,12 @@ hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
 
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
                                     hipStream_t s) {
-    const RasterParams r = make_raster(a, light_vp, S, S, 0, S);
+    RasterParams r = make_raster(a, light_vp, S, S, 0, S);
+    r.vis32 = reinterpret_cast<uint32_t*>(a.vis);      // depth only: half the clear and half the read-back traffic
     hipError_t e = run_visibility(r, s);
     if (e != hipSuccess) return e;
     const size_t n = (size_t)S * S;
-    hipLaunchKernelGGL(k_vis_to_depth24, dim3(256 * 8), dim3(256), 0, s, a.vis, depth, n);
+    hipLaunchKernelGGL(k_vis32_to_depth24, dim3(256 * 8), dim3(256), 0, s, r.vis32, depth, n);
     return hipGetLastError();
 }
 

@@ -124,6 +124,7 @@ struct MarchStats {
     uint32_t fallback;         // level samples that took the per-lane gather
     uint32_t fallback_lanes;   // live lanes in those
     uint32_t fallback_fits;    // per-lane samples whose live footprints WOULD fit one 4x4x4 block (anchored at their minimum)
+    uint32_t greedy_blocks, greedy_le2, greedy_le3, greedy_le4;   // blocks a greedy multi-anchor cover of them would need
 };
 
 // [GL] tri(level): trilinear, texel centres, REPEAT (or clamp).  `level` is wave-uniform; must be
@@ -208,6 +209,21 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
           for (int off = 32; off > 0; off >>= 1)
               for (int q = 0; q < 3; ++q) { lo[q] = min(lo[q], __shfl_xor(lo[q], off)); hi[q] = max(hi[q], __shfl_xor(hi[q], off)); }
           if (hi[0] - lo[0] <= 2 && hi[1] - lo[1] <= 2 && hi[2] - lo[2] <= 2) ++ms.fallback_fits;
+          // greedy cover: blocks anchored at the first lane not yet covered
+          unsigned long long pending = ballot64(act);
+          int nb = 0;
+          while (pending != 0ull && nb < 16) {
+              const int src = (int)__ffsll((long long)pending) - 1;
+              const int bx = __builtin_amdgcn_readlane(i0, src) - 1, by = __builtin_amdgcn_readlane(j0, src) - 1,
+                        bz = __builtin_amdgcn_readlane(k0, src) - 1;
+              const bool in = (uint32_t)(i0 - bx) <= 2u && (uint32_t)(j0 - by) <= 2u && (uint32_t)(k0 - bz) <= 2u;
+              pending &= ~ballot64(act && in);
+              ++nb;
+          }
+          ms.greedy_blocks += (uint32_t)nb;
+          if (nb <= 2) ++ms.greedy_le2;
+          if (nb <= 3) ++ms.greedy_le3;
+          if (nb <= 4) ++ms.greedy_le4;
       }
       if (act) {
         uint32_t mx0, mx1, my0, my1, mz0, mz1;
@@ -439,9 +455,10 @@ __device__ __forceinline__ uint32_t pack_half2(float a, float b) {
 
 __device__ __forceinline__ void flush_stats(const VctTraceParams& p, const MarchStats& ms, int lane) {
     if (VCT_STATS && p.stats && lane == 0) {
-        const uint32_t v[7] = {ms.wave_steps, ms.lane_steps, ms.coop_zero, ms.coop_hit, ms.fallback,
-                               ms.fallback_lanes, ms.fallback_fits};
-        for (int i = 0; i < 7; ++i)
+        const uint32_t v[11] = {ms.wave_steps, ms.lane_steps, ms.coop_zero, ms.coop_hit, ms.fallback,
+                                ms.fallback_lanes, ms.fallback_fits, ms.greedy_blocks, ms.greedy_le2, ms.greedy_le3,
+                                ms.greedy_le4};
+        for (int i = 0; i < 11; ++i)
             if (v[i]) atomicAdd(p.stats + i, (unsigned long long)v[i]);
     }
 }
