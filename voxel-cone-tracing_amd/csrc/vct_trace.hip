@@ -132,8 +132,10 @@ struct MarchStats {
 // fetch the block and return garbage-free zeros / unused values.
 template <bool WRAP, bool COOP>
 __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, const VctLevelRef lv,
-                                           float ux, float uy, float uz, bool act,
+                                           float ux, float uy, float uz, bool act, unsigned long long am,
                                            float4* __restrict__ blk, const LaneBlock& lb, MarchStats& ms) {
+    // `am` is ballot64(act), passed in so that compound predicates are ANDed as lane masks on the
+    // scalar unit (a ballot of `x && y` costs a v_cndmask + v_cmp_ne pair to materialise the bool).
     const int m = lv.m;
     const float fN = lv.fN;
     // ux * fN is exact (power of two), so the fused form is the oracle's (ux*fN) - 0.5f bit for bit
@@ -149,14 +151,13 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
     int ax = 0, ay = 0, az = 0, dx = 0, dy = 0, dz = 0;
     if (COOP) {
         // anchor = footprint of the tile's centre pixel (lane 27) if it is live, else the first live lane
-        const unsigned long long am = ballot64(act);
         const int src = ((am >> 27) & 1ull) ? 27 : (int)__ffsll((long long)am) - 1;
         ax = __builtin_amdgcn_readlane(i0, src) - 1;
         ay = __builtin_amdgcn_readlane(j0, src) - 1;
         az = __builtin_amdgcn_readlane(k0, src) - 1;
         dx = i0 - ax; dy = j0 - ay; dz = k0 - az;
         const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
-        coop = ballot64(act && far > 2u) == 0ull;
+        coop = (ballot64(far > 2u) & am) == 0ull;
     }
     if (COOP && coop) {
         uint32_t idx;
@@ -203,21 +204,21 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         }
     } else {
       if (VCT_STATS) {
-          ++ms.fallback; ms.fallback_lanes += (uint32_t)__popcll(ballot64(act));
+          ++ms.fallback; ms.fallback_lanes += (uint32_t)__popcll(am);
           int lo[3] = {act ? i0 : 0x7fffffff, act ? j0 : 0x7fffffff, act ? k0 : 0x7fffffff};
           int hi[3] = {act ? i0 : -0x7fffffff, act ? j0 : -0x7fffffff, act ? k0 : -0x7fffffff};
           for (int off = 32; off > 0; off >>= 1)
               for (int q = 0; q < 3; ++q) { lo[q] = min(lo[q], __shfl_xor(lo[q], off)); hi[q] = max(hi[q], __shfl_xor(hi[q], off)); }
           if (hi[0] - lo[0] <= 2 && hi[1] - lo[1] <= 2 && hi[2] - lo[2] <= 2) ++ms.fallback_fits;
           // greedy cover: blocks anchored at the first lane not yet covered
-          unsigned long long pending = ballot64(act);
+          unsigned long long pending = am;
           int nb = 0;
           while (pending != 0ull && nb < 16) {
               const int src = (int)__ffsll((long long)pending) - 1;
               const int bx = __builtin_amdgcn_readlane(i0, src) - 1, by = __builtin_amdgcn_readlane(j0, src) - 1,
                         bz = __builtin_amdgcn_readlane(k0, src) - 1;
               const bool in = (uint32_t)(i0 - bx) <= 2u && (uint32_t)(j0 - by) <= 2u && (uint32_t)(k0 - bz) <= 2u;
-              pending &= ~ballot64(act && in);
+              pending &= ~ballot64(in);
               ++nb;
           }
           ms.greedy_blocks += (uint32_t)nb;
@@ -278,12 +279,12 @@ struct AnisoCone {
 
 template <bool WRAP, bool COOP>
 __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLevelRef lv, float ux,
-                                           float uy, float uz, bool act, float4* __restrict__ blk,
-                                           const LaneBlock& lb, const AnisoCone& ac, MarchStats& ms) {
+                                           float uy, float uz, bool act, unsigned long long m,
+                                           float4* __restrict__ blk, const LaneBlock& lb, const AnisoCone& ac,
+                                           MarchStats& ms) {
     // chain pointer of direction d such that (pointer + lv.off) is the level's first texel
     auto chain_of = [&](int d) { return p.aniso + (size_t)d * p.aniso_stride - p.level_off[1]; };
-    const unsigned long long m = ballot64(act);
-    const unsigned long long mx = ballot64(act && ac.nx), my = ballot64(act && ac.ny), mz = ballot64(act && ac.nz);
+    const unsigned long long mx = ballot64(ac.nx) & m, my = ballot64(ac.ny) & m, mz = ballot64(ac.nz) & m;
     F4 tx, ty, tz;
     bool done = false;
     if (COOP && WRAP) {
@@ -305,7 +306,7 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
         const int az = __builtin_amdgcn_readlane(k0, src) - 1;
         const int dx = i0 - ax, dy = j0 - ay, dz = k0 - az;
         const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
-        if (ballot64(act && far > 2u) == 0ull) {
+        if ((ballot64(far > 2u) & m) == 0ull) {
             done = true;
             const uint32_t MX = lv.mask_x, MY = MX << 1, MZ = MX << 2;
             const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)mm);
@@ -361,10 +362,10 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
     if (!done) {
         // per axis: lanes that disagree on the sign are served in two masked passes
         auto axis_sample = [&](int axis, bool neg, unsigned long long mn) -> F4 {
-            if (mn == 0ull) return sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act, blk, lb, ms);
-            if (mn == m) return sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act, blk, lb, ms);
-            const F4 a = sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act && !neg, blk, lb, ms);
-            const F4 b = sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act && neg, blk, lb, ms);
+            if (mn == 0ull) return sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act, m, blk, lb, ms);
+            if (mn == m) return sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act, m, blk, lb, ms);
+            const F4 a = sample_level<WRAP, COOP>(chain_of(2 * axis), lv, ux, uy, uz, act && !neg, m & ~mn, blk, lb, ms);
+            const F4 b = sample_level<WRAP, COOP>(chain_of(2 * axis + 1), lv, ux, uy, uz, act && neg, mn, blk, lb, ms);
             return neg ? b : a;
         };
         tx = axis_sample(0, ac.nx, mx);
@@ -408,9 +409,10 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
         ac.nx = !(dir.x >= 0.0f); ac.ny = !(dir.y >= 0.0f); ac.nz = !(dir.z >= 0.0f);
     }
     VctStep nxt = load_step(tab, 0);
+    const unsigned long long alive_mask = ballot64(alive);
     for (int k = 0; k < n; ++k) {
         const bool act = alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
-        const unsigned long long live = ballot64(act);
+        const unsigned long long live = ballot64(alpha < p.max_alpha) & alive_mask;
         if (live == 0ull) break;
         if (VCT_STATS) { ++ms.wave_steps; ms.lane_steps += (uint32_t)__popcll(live); }
         const VctStep st = nxt;
@@ -423,11 +425,11 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
         const float ux = fmaf(div_const<FASTDIV>(px, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
         const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
         const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, blk, lb, ac, ms)
-                                         : sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, blk, lb, ms);
+        F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, live, blk, lb, ac, ms)
+                                         : sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms);
         if (st.two_levels) {
-            const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, blk + 64, lb, ac, ms)
-                                : sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, blk + 64, lb, ms);
+            const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, live, blk + 64, lb, ac, ms)
+                                : sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms);
             const float g = 1.0f - st.frac;
             vc.x = fmaf(st.frac, t2.x, g * vc.x);
             vc.y = fmaf(st.frac, t2.y, g * vc.y);
