@@ -161,6 +161,7 @@ def main():
 
     # ---- once-per-scene GPU stages (timed with events on the context's stream) ----
     gi = {}
+    gi_fused = None
     with torch.cuda.stream(ext_stream):
         if inp["scene"] is not None:
             s = inp["scene"]
@@ -187,6 +188,18 @@ def main():
             if args.bounces == 2:
                 gi["bounce_and_mips"] = e[3].elapsed_time(e[4])
                 gi["bounce_cone_steps"] = float(ctx.last_step_count())
+            if args.bounces != 2 and world == 1:
+                # the same six stages as ONE call (vct_gi_pass: G-buffer raster on a second stream beside the
+                # voxel stages) -- wall time of the whole pass, events around the call, mean of 5 after 2 warm-ups
+                for _ in range(2):
+                    ctx.gi_pass(inp["light_vp"], inp["view_proj"])
+                ef = [ev(), ev()]
+                ef[0].record()
+                for _ in range(5):
+                    ctx.gi_pass(inp["light_vp"], inp["view_proj"])
+                ef[1].record()
+                ctx.synchronize()
+                gi_fused = ef[0].elapsed_time(ef[1]) / 5.0
             inp["planes"] = ctx.download_gbuffer()     # host copy only for the CPU baseline / checks
         else:
             ctx.upload_volume(inp["volume"])
@@ -354,6 +367,8 @@ def main():
             # voxelize, inject, mips, (bounce,) trace
             "gi_pass_total_ms": round(sum(v for k, v in gi.items() if v is not None and k != "bounce_cone_steps")
                                       + kernel_ms_avg, 4),
+            # the same pass issued as one vct_gi_pass call (raster and voxel stages overlapped on two streams)
+            "gi_pass_one_call_ms": None if gi_fused is None else round(gi_fused, 4),
             "roofline": roofline_block(prof, k_ms, steps_slab, alg_bytes, alg_gbs),
         }
         if world == 1 and not args.no_sweep:

@@ -209,6 +209,14 @@ int vct_trace_resident(vct_ctx* ctx);
 /* Same for the tile-row slab [tile_row0, tile_row1) of the resident G-buffer; later
  * vct_trace_resident calls repeat this slab. */
 int vct_trace_resident_rows(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
+/* One whole GI pass for a light AND a camera that moved -- init_voxel_cone_tracing's DrawDepthTexture +
+ * DrawVoxelTexture (VCT.h:138-139) followed by Render (VCT.h:146-190) -- issued as one call:
+ *   shadow map -> { voxelize(mode) -> inject -> mips }  ||  { G-buffer raster }  -> trace.
+ * The voxel stages and the G-buffer raster only READ the shadow map and write disjoint buffers, so the raster
+ * runs on a second HIP stream beside them (neither fills the GPU on its own); the trace waits for both.  The
+ * frame is bit-identical to vct_render_shadow_map, vct_voxelize, vct_inject_light, vct_build_mips,
+ * vct_render_gbuffer, vct_trace_resident called in that order.  Asynchronous (vct_synchronize). */
+int vct_gi_pass(vct_ctx* ctx, const float light_vp[16], const float view_proj[16], int32_t voxelize_mode);
 /* Redirect the trace kernel's RGBA16F output to caller-owned HBM (full-frame addressing: pixel (x,y)
  * at ((y*width + x) * 4) halves from `rgba16f_dev`); NULL restores the context-owned frame.  A slab
  * rank passes its gather buffer minus the slab's first row so the kernel writes the gather buffer

@@ -88,3 +88,56 @@ def test_resident_pipeline_equals_host_staged_pipeline(vct):
         staged = c2.trace(raster_oracle.gbuffer(sc, scene, cam, w, h, depth, light_vp_row))
     assert np.array_equal(resident, staged)
     ctx.close()
+
+
+def test_gi_pass_equals_the_six_calls(vct):
+    """vct_gi_pass (G-buffer raster on a second stream beside the voxel stages) produces, bit for bit, the frame
+    and the chain of the six stage calls in sequence -- also when it is repeated with a moved light and camera
+    (the visibility words and list counters are re-armed by the kernels themselves, never by a clear)."""
+    V, w, h, S = 64, 160, 90, 512
+    sc, scene, ctx = setup_scene(vct, 1, 0.15, V, w, h, S)
+    _, _, ref = setup_scene(vct, 1, 0.15, V, w, h, S)
+    poses = [((0.0, 1.0, 0.25), dict(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)),
+             ((0.3, 1.0, -0.2), dict(position=(-40.0, -5.0, 6.0), yaw=20.0, pitch=2.0)),
+             ((0.0, 1.0, 0.25), dict(position=(0.0, 0.0, 20.0), yaw=-60.0, pitch=-20.0))]
+    for light, cam_kw in poses:
+        cam = sc.default_camera(**cam_kw)
+        lvp, vp = sc.light_view_proj(light), sc.camera_view_proj(cam, w, h)
+        for c in (ctx, ref):
+            c.set_camera_position(tuple(cam.position))
+            c.set_light_direction(light)
+        ctx.gi_pass(lvp, vp)
+        fused = ctx.download_frame()
+        ref.render_shadow_map(lvp)
+        ref.voxelize(); ref.inject_light(); ref.build_mips()
+        ref.render_gbuffer(vp)
+        ref.trace_resident()
+        want = ref.download_frame()
+        assert np.array_equal(fused, want)
+        assert np.array_equal(ctx.download_chain(), ref.download_chain())
+        assert np.array_equal(ctx.download_gbuffer(), ref.download_gbuffer())
+        assert np.array_equal(ctx.download_shadow_map(), ref.download_shadow_map())
+        assert ctx.last_step_count() == ref.last_step_count() > 0
+    ctx.close(); ref.close()
+
+
+def test_scissored_passes_leave_the_raster_scratch_armed(vct):
+    """Slab passes (multi-GPU scissor) interleaved with whole-frame passes and shadow passes: every pass finds
+    empty visibility words and zero counters although nothing is cleared between them."""
+    V, w, h, S = 32, 96, 64, 256
+    sc, scene, ctx = setup_scene(vct, 0, 1.0, V, w, h, S)
+    light = (0.0, 1.0, 0.25)
+    cam = sc.default_camera(position=(0.0, 0.0, 20.0), yaw=-60.0, pitch=-20.0)     # inside the box: huge + clipped triangles
+    depth, light_vp_row = raster_oracle.shadow_map(sc, scene, light, S)
+    want = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, light_vp_row).reshape(23, -1)
+    vp, lvp = sc.camera_view_proj(cam, w, h), sc.light_view_proj(light)
+    ctx.render_shadow_map(lvp)
+    rows = (h + 7) // 8
+    for r0, r1 in [(0, rows), (2, 5), (0, 3), (0, rows), (5, rows)]:
+        ctx.render_gbuffer_rows(vp, r0, r1)
+        got = ctx.download_gbuffer().reshape(23, h, w)[:, r0 * 8:min(r1 * 8, h)].reshape(23, -1)
+        ref = want.reshape(23, h, w)[:, r0 * 8:min(r1 * 8, h)].reshape(23, -1)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (r0, r1)
+        ctx.render_shadow_map(lvp)
+        assert np.array_equal(ctx.download_shadow_map().view(np.uint32), depth.view(np.uint32))
+    ctx.close()

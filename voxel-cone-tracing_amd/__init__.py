@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "vct_last_trace_stats", "vct_download_frame", "vct_render_gbuffer_rows",
     "vct_slab_partition", "vct_comm_get_unique_id", "vct_comm_init", "vct_comm_destroy", "vct_comm_slab",
     "vct_frame_step", "vct_comm_sync", "vct_comm_frame", "vct_comm_download_frame",
-    "vct_upload_mesh_uvs", "vct_upload_textures",
+    "vct_upload_mesh_uvs", "vct_upload_textures", "vct_gi_pass",
 ]
 
 
@@ -98,6 +98,8 @@ for _n in ("vct_render_shadow_map", "vct_download_shadow_map", "vct_render_gbuff
     getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_trace_current.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 _lib.vct_trace_resident_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+_lib.vct_gi_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+_lib.vct_gi_pass.restype = C.c_int
 for _n in ("vct_inject_light", "vct_build_mips", "vct_trace_resident", "vct_synchronize", "vct_bounce"):
     getattr(_lib, _n).argtypes = [C.c_void_p]
 _lib.vct_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
@@ -277,6 +279,12 @@ class Context:
     def render_gbuffer(self, view_proj_colmajor):
         m = np.ascontiguousarray(view_proj_colmajor, np.float32).reshape(16)
         self._ck(_lib.vct_render_gbuffer(self._h, _ptr(m)), "vct_render_gbuffer")
+
+    def gi_pass(self, light_vp_colmajor, view_proj_colmajor, mode=VOX_CONSERVATIVE_AVG):
+        """Shadow map -> {voxelize, inject, mips} beside {G-buffer raster} -> trace, one call (include/vct.h)."""
+        lv = np.ascontiguousarray(light_vp_colmajor, np.float32).reshape(16)
+        m = np.ascontiguousarray(view_proj_colmajor, np.float32).reshape(16)
+        self._ck(_lib.vct_gi_pass(self._h, _ptr(lv), _ptr(m), mode), "vct_gi_pass")
 
     def render_gbuffer_rows(self, view_proj_colmajor, row0, row1):
         m = np.ascontiguousarray(view_proj_colmajor, np.float32).reshape(16)

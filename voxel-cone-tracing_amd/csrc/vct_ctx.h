@@ -66,12 +66,22 @@ struct vct_ctx {
     VctTexDesc* tex_desc = nullptr;
     int32_t* mat_tex = nullptr;
     int32_t ntex = 0;
-    unsigned long long* vis = nullptr;
+    // raster scratch.  Between passes every visibility word is all-ones and the counter set of the next pass is
+    // zero: the kernels re-establish both themselves (vct_raster.hip run_visibility), so a pass launches no memset.
+    // `raster_dirty` (a launch failed, or nothing is initialised yet) makes the next pass clear everything once.
+    unsigned long long* vis = nullptr;        // 64-bit words of the main draw
     size_t vis_words = 0;
-    int32_t* raster_big = nullptr;
-    int32_t* raster_big_count = nullptr;      // [0] huge sub-triangles, [1] tile work items, [2] wave list, [3] group list
+    uint32_t* vis32 = nullptr;                // 32-bit depth-only words of the shadow pass
+    size_t vis32_words = 0;
+    int32_t* raster_lists = nullptr;          // [2*ntri] wave list, [2*ntri] group list
+    uint32_t* raster_counts = nullptr;        // two sets of [tile work items, wave list, group list, pad]
+    int raster_set = 0;                       // the set the next pass uses
+    bool raster_dirty = true;
     uint2* raster_items = nullptr;
     uint32_t raster_item_capacity = 0;
+    // second stream: vct_gi_pass runs the G-buffer raster beside the voxel stages
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float light_vp[16];
     unsigned long long* acc = nullptr;         // accumulator pool [nslots][512][2] (one slot per brick the mesh can touch)
     uint32_t* brick_slot = nullptr;            // [V^3/512] brick -> slot or VCT_NO_SLOT

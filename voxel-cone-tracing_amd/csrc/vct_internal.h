@@ -177,16 +177,18 @@ struct VctRasterArgs {
     const float* specular;       // [nmat][3]
     int32_t ntri;
     float model_scale;
-    unsigned long long* vis;     // visibility words, max(W*H, S*S)
+    // Visibility words: 64-bit (depth | id) of the main draw, W*H; 32-bit depth-only of the shadow pass, S*S.
+    // Invariant between passes: every word is all-ones ("empty") -- the consumer of a word resets it.
+    unsigned long long* vis;
+    uint32_t* vis32;
     int32_t* wave_list;          // [2*ntri] medium sub-triangles
     uint32_t* wave_count;
     int32_t* group_list;         // [2*ntri] small-medium sub-triangles (one 16-lane group each)
     uint32_t* group_count;
-    int32_t* big_list;           // [2*ntri] huge sub-triangles
-    int32_t* big_count;          // followed in memory by item_count, wave_count and group_count (one memset)
-    uint2* items;                // tile work items of the raster pass
+    uint2* items;                // tile work items of huge sub-triangles
     uint32_t* item_count;
     uint32_t item_capacity;
+    uint32_t* next_counts;       // [3] the other counter set (item, wave, group): zeroed by this pass for the next
     VctTextures tex;             // material textures + texture coordinates (G-buffer pass)
 };
 

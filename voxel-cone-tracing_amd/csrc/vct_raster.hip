@@ -30,33 +30,70 @@ __device__ __forceinline__ void xform4(const float* m, float x, float y, float z
     for (int r = 0; r < 4; ++r) out[r] = m[r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r];
 }
 
-// Near-plane clip (z >= -w) of a clip-space triangle; `t01[i]` is the interpolation parameter of
-// the vertex inserted after input vertex i (or < 0 when poly vertex i is an input vertex).
+// Near-plane clip (z >= -w) of a clip-space triangle.  A polygon vertex is lerp(in[a], in[b], t) (b < 0: a copy
+// of in[a]); every varying is interpolated the same way.  Nothing here is indexed at run time: a run-time index
+// puts the polygon into scratch memory, and with more than ~120 B of scratch per lane the runtime allocates the
+// scratch arena of a kernel per dispatch (+1.2 ms per launch, measured) -- appends and reads go through selects.
+struct PolyVert { RVert v; int a, b; float t; };
 struct ClipPoly {
-    RVert v[4];
-    int src_a[4], src_b[4];     // poly vertex = lerp(in[src_a], in[src_b], t); src_b < 0: copy of src_a
-    float t[4];
+    PolyVert p0, p1, p2, p3;        // named slots, not an array: the compiler turns "if (n == k) p[k] = x" back into p[n] = x
     int n;
 };
 
+__device__ __forceinline__ PolyVert pv_select(bool c, const PolyVert& x, const PolyVert& y) {
+    PolyVert r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v.c[k] = c ? x.v.c[k] : y.v.c[k];
+    r.a = c ? x.a : y.a; r.b = c ? x.b : y.b; r.t = c ? x.t : y.t;
+    return r;
+}
+
+__device__ __forceinline__ void poly_push(ClipPoly& q, const PolyVert& x) {
+    q.p0 = pv_select(q.n == 0, x, q.p0);
+    q.p1 = pv_select(q.n == 1, x, q.p1);
+    q.p2 = pv_select(q.n == 2, x, q.p2);
+    q.p3 = pv_select(q.n == 3, x, q.p3);
+    ++q.n;
+}
+
+// polygon vertex i (1..3) by value
+__device__ __forceinline__ PolyVert poly_vertex(const ClipPoly& q, int i) {
+    return pv_select(i == 1, q.p1, pv_select(i == 2, q.p2, q.p3));
+}
+
 __device__ __forceinline__ void clip_near(const RVert in[3], ClipPoly& p) {
     p.n = 0;
+    p.p0.v = in[0]; p.p0.a = 0; p.p0.b = -1; p.p0.t = 0.0f;
+    p.p1 = p.p0; p.p2 = p.p0; p.p3 = p.p0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const RVert& a = in[i];
         const RVert& b = in[(i + 1) % 3];
         const float da = a.c[2] + a.c[3], db = b.c[2] + b.c[3];
         if (da >= 0.0f) {
-            p.v[p.n] = a; p.src_a[p.n] = i; p.src_b[p.n] = -1; p.t[p.n] = 0.0f; ++p.n;
+            PolyVert x;
+            x.v = a; x.a = i; x.b = -1; x.t = 0.0f;
+            poly_push(p, x);
         }
         if ((da >= 0.0f) != (db >= 0.0f)) {
             const float t = __fdiv_rn(da, da - db);
-            RVert r;
+            PolyVert x;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r.c[k] = a.c[k] + (b.c[k] - a.c[k]) * t;
-            p.v[p.n] = r; p.src_a[p.n] = i; p.src_b[p.n] = (i + 1) % 3; p.t[p.n] = t; ++p.n;
+            for (int k = 0; k < 4; ++k) x.v.c[k] = a.c[k] + (b.c[k] - a.c[k]) * t;
+            x.a = i; x.b = (i + 1) % 3; x.t = t;
+            poly_push(p, x);
         }
     }
+}
+
+// the three polygon vertices of fan sub-triangle f (1 or 2): 0, f, f + 1
+struct FanTri { PolyVert v[3]; };
+__device__ __forceinline__ FanTri fan_tri(const ClipPoly& q, int f) {
+    FanTri r;
+    r.v[0] = q.p0;
+    r.v[1] = poly_vertex(q, f);
+    r.v[2] = poly_vertex(q, f + 1);
+    return r;
 }
 
 // true when no vertex is behind the near plane: the polygon is the triangle itself.  Almost every
@@ -140,11 +177,10 @@ struct RasterParams {
     int32_t* group_list;         // (tri * 2 + sub) of small-medium sub-triangles (one 16-lane group each)
     uint32_t* group_count;
     uint32_t* vis32;             // depth-only pass: 32-bit visibility words (depth bits), else null
-    int32_t* big_list;           // (tri * 2 + sub) of huge sub-triangles (tiles emitted by a workgroup)
-    int32_t* big_count;
-    uint2* items;                // tile work items: (tri * 2 + sub, tile_y << 16 | tile_x)
+    uint2* items;                // tile work items of huge sub-triangles: (tri * 2 + sub, tile_y << 16 | tile_x)
     uint32_t* item_count;
     uint32_t item_capacity;
+    uint32_t* next_counts;       // [3] the counters the NEXT pass will use: zeroed by this pass (no memset launch)
     // alpha test of the main draw (null material: depth-only pass, S/Shadow.fs has no alpha test)
     const int32_t* material;
     const float* albedo;
@@ -167,9 +203,9 @@ __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVer
 #define VCT_RTILE 16             // larger: cut into 16x16-pixel work items by a workgroup
 
 // Decides how fragments of triangle t are alpha-tested and, for the per-fragment case, loads the texture
-// coordinates of the sub-triangle's three vertices (poly == null: the unclipped triangle; otherwise vertices
-// 0, f, f+1 of the near-clipped polygon, interpolated like every other varying).
-__device__ __forceinline__ void setup_alpha(const RasterParams& p, int t, const ClipPoly* poly, int f, SubTri& s) {
+// coordinates of the sub-triangle's three vertices (fan == null: the unclipped triangle; otherwise the vertices
+// of the near-clipped polygon's fan sub-triangle, interpolated like every other varying).
+__device__ __forceinline__ void setup_alpha(const RasterParams& p, int t, const FanTri* fan, SubTri& s) {
     if (!p.material) return;
     const int m = p.material[t];
     const int td = vct_tex_of(p.tex, m, 0);
@@ -178,18 +214,17 @@ __device__ __forceinline__ void setup_alpha(const RasterParams& p, int t, const 
     s.alpha_mode = 2;
     s.tex = td;
     const float* uv = p.tex.uv + (size_t)t * 6;
-    if (!poly) {
+    if (!fan) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { s.tu[k] = uv[2 * k]; s.tv[k] = uv[2 * k + 1]; }
         return;
     }
-    const int pv[3] = {0, f, f + 1};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int pi = pv[k], a = poly->src_a[pi], b = poly->src_b[pi];
+        const int a = fan->v[k].a, b = fan->v[k].b;
         const float ua = uv[2 * a], va = uv[2 * a + 1];
-        s.tu[k] = b < 0 ? ua : ua + (uv[2 * b] - ua) * poly->t[pi];
-        s.tv[k] = b < 0 ? va : va + (uv[2 * b + 1] - va) * poly->t[pi];
+        s.tu[k] = b < 0 ? ua : ua + (uv[2 * b] - ua) * fan->v[k].t;
+        s.tv[k] = b < 0 ? va : va + (uv[2 * b + 1] - va) * fan->v[k].t;
     }
 }
 
@@ -221,52 +256,117 @@ __device__ __forceinline__ TileBox tile_box(const SubTri& s) {
     return t;
 }
 
-// Emit tile i of the box as a work item; if the item buffer is full, rasterise the tile right here.
-template <class Loop>
-__device__ __forceinline__ void emit_tile(const RasterParams& p, const SubTri& s, const TileBox& tb, int i,
-                                          unsigned long long id, Loop serial_pixels) {
-    const int tx = tb.tx0 + i % tb.tw, ty = tb.ty0 + i / tb.tw;
-    const uint32_t slot = atomicAdd(p.item_count, 1u);
-    if (slot < p.item_capacity) {
-        p.items[slot] = make_uint2((uint32_t)id, ((uint32_t)ty << 16) | (uint32_t)tx);
-        return;
-    }
-    const int x0 = max(s.x0, tx * VCT_RTILE), x1 = min(s.x1, tx * VCT_RTILE + VCT_RTILE - 1);
-    const int y0 = max(s.y0, ty * VCT_RTILE), y1 = min(s.y1, ty * VCT_RTILE + VCT_RTILE - 1);
-    serial_pixels(x0, x1, y0, y1);
-}
+// forward: the sub-triangle of a list entry, rebuilt from the mesh
+__device__ __forceinline__ bool rebuild_subtri(const RasterParams& p, int id, SubTri& s);
 
-// one thread per triangle: clip, cull, classify; tiny sub-triangles are rasterised inline
-__global__ void __launch_bounds__(256)
-k_raster_vis(const RasterParams p) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= p.ntri) return;
-    RVert in[3];
-    load_clip_tri(p, t, in);
-    const bool whole = unclipped(in);
-    ClipPoly poly;
-    poly.n = 3;
-    if (!whole) {
-        clip_near(in, poly);
-        if (poly.n < 3) return;
-    }
-    for (int f = 1; f + 1 < poly.n; ++f) {
-        SubTri s;
-        if (whole) setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, p.ys0, p.ys1, s);
-        else setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, p.ys0, p.ys1, s);
-        if (!s.ok) continue;
-        setup_alpha(p, t, whole ? nullptr : &poly, f, s);
-        if (s.alpha_mode == 1) continue;
-        const unsigned long long id = (unsigned long long)(uint32_t)(t * 2 + (f - 1));
-        const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
-        if (box <= VCT_RASTER_SMALL) {
-            for (int py = s.y0; py <= s.y1; ++py)
-                for (int px = s.x0; px <= s.x1; ++px) plot(p, s, px, py, id);
+// A huge sub-triangle met by one lane of k_raster_vis is cut into 16x16-pixel work items by the whole wave:
+// one atomic reserves the item range, the 64 lanes write the items (a full-screen Cornell wall at 1080p is
+// 8160 items = 128 stores per lane).  Items that do not fit the buffer are rasterised right here.
+__device__ __forceinline__ void emit_big_wave(const RasterParams& p, int id, int lane) {
+    SubTri s;
+    if (!rebuild_subtri(p, id, s)) return;              // wave-uniform
+    const TileBox tb = tile_box(s);
+    const int n = tb.tw * tb.th;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(p.item_count, (uint32_t)n);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    for (int i = lane; i < n; i += 64) {
+        const int tx = tb.tx0 + i % tb.tw, ty = tb.ty0 + i / tb.tw;
+        const uint32_t slot = base + (uint32_t)i;
+        if (slot < p.item_capacity) {
+            p.items[slot] = make_uint2((uint32_t)id, ((uint32_t)ty << 16) | (uint32_t)tx);
             continue;
         }
-        if (box <= VCT_RASTER_GROUP) p.group_list[atomicAdd(p.group_count, 1u)] = (int32_t)id;
-        else if (box <= VCT_RASTER_WAVE) p.wave_list[atomicAdd(p.wave_count, 1u)] = (int32_t)id;
-        else p.big_list[atomicAdd(p.big_count, 1)] = (int32_t)id;
+        const int x0 = max(s.x0, tx * VCT_RTILE), x1 = min(s.x1, tx * VCT_RTILE + VCT_RTILE - 1);
+        const int y0 = max(s.y0, ty * VCT_RTILE), y1 = min(s.y1, ty * VCT_RTILE + VCT_RTILE - 1);
+        for (int py = y0; py <= y1; ++py)
+            for (int px = x0; px <= x1; ++px) plot(p, s, px, py, (unsigned long long)(uint32_t)id);
+    }
+}
+
+// Wave-aggregated list append, called by all 64 lanes: the slot of this lane's entry (meaningful where `pred`).
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred, int lane) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+    if (m == 0ull) return 0u;
+    const int leader = (int)__ffsll((long long)m) - 1;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// one thread per triangle: clip, cull, classify; tiny sub-triangles are rasterised inline, huge ones are cut into
+// tile work items by the wave, the rest go to the group / wave lists of k_raster_mid
+__global__ void __launch_bounds__(256, 3)
+k_raster_vis(const RasterParams p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (t == 0) { p.next_counts[0] = 0u; p.next_counts[1] = 0u; p.next_counts[2] = 0u; }
+    const bool valid = t < p.ntri;          // no early return: the wave cooperates on huge triangles below
+    RVert in[3];
+    ClipPoly poly;
+    poly.n = 0;
+    bool whole = false;
+    if (valid) {
+        load_clip_tri(p, t, in);
+        whole = unclipped(in);
+        poly.n = 3;
+        if (!whole) clip_near(in, poly);
+    }
+    if (whole || !valid) {
+        poly.p0.v.c[0] = poly.p0.v.c[1] = poly.p0.v.c[2] = poly.p0.v.c[3] = 0.0f;
+        poly.p0.a = 0; poly.p0.b = -1; poly.p0.t = 0.0f;
+        poly.p1 = poly.p0; poly.p2 = poly.p0; poly.p3 = poly.p0;
+    }
+    unsigned long long big1 = 0ull, big2 = 0ull;
+#pragma unroll
+    for (int f = 1; f <= 2; ++f) {          // a near-clipped triangle is at most a quad: two sub-triangles
+        bool big = false, to_group = false, to_wave = false;
+        const int id = t * 2 + (f - 1);
+        if (valid && f + 1 < poly.n) {
+            SubTri s;
+            const FanTri fan = fan_tri(poly, f);
+            if (whole) setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, p.ys0, p.ys1, s);
+            else setup_subtri(&fan.v[0].v, &fan.v[1].v, &fan.v[2].v, p.W, p.H, p.ys0, p.ys1, s);
+            if (s.ok) setup_alpha(p, t, whole ? nullptr : &fan, s);
+            if (s.ok && s.alpha_mode != 1) {
+                const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
+                if (box <= VCT_RASTER_SMALL) {
+                    for (int py = s.y0; py <= s.y1; ++py)
+                        for (int px = s.x0; px <= s.x1; ++px) plot(p, s, px, py, (unsigned long long)(uint32_t)id);
+                } else if (box <= VCT_RASTER_GROUP) {
+                    to_group = true;
+                } else if (box <= VCT_RASTER_WAVE) {
+                    to_wave = true;
+                } else {
+                    big = true;
+                }
+            }
+        }
+        // list appends: ONE atomic per wave and list (a per-lane atomicAdd on the two counters serialises ~10^5
+        // same-address atomics in L2: 1.2 ms per pass, measured)
+        const uint32_t gslot = wave_append(p.group_count, to_group, lane);
+        if (to_group) p.group_list[gslot] = (int32_t)id;
+        const uint32_t wslot = wave_append(p.wave_count, to_wave, lane);
+        if (to_wave) p.wave_list[wslot] = (int32_t)id;
+        if (f == 1) big1 = __builtin_amdgcn_ballot_w64(big); else big2 = __builtin_amdgcn_ballot_w64(big);
+    }
+    // huge sub-triangles of this wave's 64 triangles, one after the other, all lanes helping (outside the loop
+    // above so that its triangle set-up is dead here: fewer live registers)
+    const int t0 = t - lane;
+    // (bits of the second mask are moved behind the first: one loop, one copy of the emit code)
+    unsigned long long pending = big1;
+    int k = 0;
+    while (true) {
+        if (pending == 0ull) {
+            if (k == 1) break;
+            k = 1;
+            pending = big2;
+            continue;
+        }
+        const int src = (int)__ffsll((long long)pending) - 1;
+        pending &= pending - 1ull;
+        emit_big_wave(p, (t0 + src) * 2 + k, lane);
     }
 }
 
@@ -276,73 +376,62 @@ __device__ __forceinline__ bool rebuild_subtri(const RasterParams& p, int id, Su
     load_clip_tri(p, t, in);
     if (unclipped(in)) {
         setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, p.ys0, p.ys1, s);
-        if (s.ok) setup_alpha(p, t, nullptr, f, s);
+        if (s.ok) setup_alpha(p, t, nullptr, s);
         return s.ok;
     }
     ClipPoly poly;
     clip_near(in, poly);
-    setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], p.W, p.H, p.ys0, p.ys1, s);
-    if (s.ok) setup_alpha(p, t, &poly, f, s);
+    const FanTri fan = fan_tri(poly, f);
+    setup_subtri(&fan.v[0].v, &fan.v[1].v, &fan.v[2].v, p.W, p.H, p.ys0, p.ys1, s);
+    if (s.ok) setup_alpha(p, t, &fan, s);
     return s.ok;
 }
 
-// one wave per medium sub-triangle: 64 bounding-box pixels per iteration
+// The three list consumers in ONE launch (they are independent of each other, and a dependent dispatch costs
+// ~5 us of drain + launch latency on this GPU even when its list is empty): blocks [0, gblocks) serve the group
+// list, [gblocks, gblocks + wblocks) the wave list, the rest the tile work items.
+//   group: one 16-lane group per small-medium sub-triangle (half of the visible sub-triangles of the bench scene
+//          cover <= 64 pixels: a whole wave per triangle would leave most lanes idle after the first iteration)
+//   wave:  one wave per medium sub-triangle, 64 bounding-box pixels per iteration
+//   tile:  one workgroup per 16x16-pixel work item of a huge sub-triangle, one pixel per thread
 __global__ void __launch_bounds__(256)
-k_raster_waves(const RasterParams p) {
-    const uint32_t n = *p.wave_count;
-    const int lane = threadIdx.x & 63;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
-        const int id = p.wave_list[w];
-        SubTri s;
-        if (!rebuild_subtri(p, id, s)) continue;
-        const int bw = s.x1 - s.x0 + 1;
-        const int box = bw * (s.y1 - s.y0 + 1);
-        for (int i = lane; i < box; i += 64)
-            plot(p, s, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
+    int b = blockIdx.x;
+    if (b < gblocks) {
+        const uint32_t n = *p.group_count;
+        const int l16 = threadIdx.x & 15;
+        const uint32_t ngroups = ((uint32_t)gblocks * blockDim.x) >> 4;
+        for (uint32_t g = ((uint32_t)b * blockDim.x + threadIdx.x) >> 4; g < n; g += ngroups) {
+            const int id = p.group_list[g];
+            SubTri s;
+            if (!rebuild_subtri(p, id, s)) continue;
+            const int bw = s.x1 - s.x0 + 1;
+            const int box = bw * (s.y1 - s.y0 + 1);
+            for (int i = l16; i < box; i += 16)
+                plot(p, s, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+        }
+        return;
     }
-}
-
-// one 16-lane group per small-medium sub-triangle (half of the visible sub-triangles of the bench scene cover
-// <= 64 pixels: a whole wave per triangle would leave most lanes idle after the first iteration)
-__global__ void __launch_bounds__(256)
-k_raster_groups(const RasterParams p) {
-    const uint32_t n = *p.group_count;
-    const int l16 = threadIdx.x & 15;
-    const uint32_t ngroups = (gridDim.x * blockDim.x) >> 4;
-    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4; g < n; g += ngroups) {
-        const int id = p.group_list[g];
-        SubTri s;
-        if (!rebuild_subtri(p, id, s)) continue;
-        const int bw = s.x1 - s.x0 + 1;
-        const int box = bw * (s.y1 - s.y0 + 1);
-        for (int i = l16; i < box; i += 16)
-            plot(p, s, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+    b -= gblocks;
+    if (b < wblocks) {
+        const uint32_t n = *p.wave_count;
+        const int lane = threadIdx.x & 63;
+        const uint32_t nwaves = ((uint32_t)wblocks * blockDim.x) >> 6;
+        for (uint32_t w = ((uint32_t)b * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+            const int id = p.wave_list[w];
+            SubTri s;
+            if (!rebuild_subtri(p, id, s)) continue;
+            const int bw = s.x1 - s.x0 + 1;
+            const int box = bw * (s.y1 - s.y0 + 1);
+            for (int i = lane; i < box; i += 64)
+                plot(p, s, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+        }
+        return;
     }
-}
-
-// one workgroup per huge sub-triangle: its threads emit the tile work items in parallel
-__global__ void __launch_bounds__(256)
-k_raster_emit_big(const RasterParams p) {
-    const int nbig = *p.big_count;
-    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
-        const int id = p.big_list[b];
-        SubTri s;
-        if (!rebuild_subtri(p, id, s)) continue;
-        const TileBox tb = tile_box(s);
-        for (int i = threadIdx.x; i < tb.tw * tb.th; i += blockDim.x)
-            emit_tile(p, s, tb, i, (unsigned long long)(uint32_t)id, [&](int x0, int x1, int y0, int y1) {
-                for (int py = y0; py <= y1; ++py)
-                    for (int px = x0; px <= x1; ++px) plot(p, s, px, py, (unsigned long long)(uint32_t)id);
-            });
-    }
-}
-
-// one workgroup per tile work item, one pixel per thread
-__global__ void __launch_bounds__(VCT_RTILE * VCT_RTILE)
-k_raster_tiles(const RasterParams p) {
+    b -= wblocks;
+    const int tblocks = (int)gridDim.x - gblocks - wblocks;
     const uint32_t n = min(*p.item_count, p.item_capacity);
-    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+    for (uint32_t it = (uint32_t)b; it < n; it += (uint32_t)tblocks) {
         const uint2 e = p.items[it];
         SubTri s;
         if (!rebuild_subtri(p, (int)e.x, s)) continue;
@@ -354,10 +443,12 @@ k_raster_tiles(const RasterParams p) {
 }
 
 // 32-bit visibility words of the depth-only pass (depth bits, ~0 = empty) -> DEPTH_COMPONENT24
+// -- and the word is set back to "empty", so the next pass needs no clear
 __global__ void __launch_bounds__(256)
-k_vis32_to_depth24(const uint32_t* __restrict__ vis, float* __restrict__ depth, size_t n) {
+k_vis32_to_depth24(uint32_t* __restrict__ vis, float* __restrict__ depth, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t v = vis[i];
+        vis[i] = ~0u;
         const float z = v == ~0u ? 1.0f : __uint_as_float(v);
         depth[i] = (float)(floor((double)z * 16777215.0 + 0.5) / 16777215.0);
     }
@@ -406,27 +497,33 @@ k_gbuffer_shade(const ShadeParams p) {
 #pragma unroll
     for (int k = 0; k < VCT_GB_NPLANES; ++k) g[k] = 0.0f;
     unsigned long long v = ~0ull;
-    if (px < W && py < H) v = p.r.vis[(size_t)py * W + px];
+    if (px < W && py < H) {
+        v = p.r.vis[(size_t)py * W + px];
+        p.r.vis[(size_t)py * W + px] = ~0ull;       // consumed: leave the word "empty" for the next pass (no clear launch)
+    }
     if (v != ~0ull) {
         const int id = (int)(uint32_t)v;
         const int t = id >> 1, f = (id & 1) + 1;
         RVert in[3];
         load_clip_tri(p.r, t, in);
         const bool whole = unclipped(in);
-        ClipPoly poly;
+        FanTri fan;
         SubTri s;
         if (whole) {
             setup_subtri(&in[0], &in[1], &in[2], W, H, 0, H, s);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { fan.v[k].v = in[k]; fan.v[k].a = k; fan.v[k].b = -1; fan.v[k].t = 0.0f; }
         } else {
+            ClipPoly poly;
             clip_near(in, poly);
-            setup_subtri(&poly.v[0], &poly.v[f], &poly.v[f + 1], W, H, 0, H, s);
+            fan = fan_tri(poly, f);
+            setup_subtri(&fan.v[0].v, &fan.v[1].v, &fan.v[2].v, W, H, 0, H, s);
         }
         float b0, b1, b2, z;
         cover(s, px, py, b0, b1, b2, z);
         // perspective-correct interpolation of the 12 varyings (trace.vs:27,31-33)
         const float q0 = b0 * s.iw[0], q1 = b1 * s.iw[1], q2 = b2 * s.iw[2];
         const float qs = __fdiv_rn(1.0f, q0 + q1 + q2);
-        const int pv[3] = {0, f, f + 1};
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
             float var[3];
@@ -440,9 +537,8 @@ k_gbuffer_shade(const ShadeParams p) {
             } else {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const int pi = pv[k];
-                    const float va = attr(poly.src_a[pi]);
-                    var[k] = poly.src_b[pi] < 0 ? va : va + (attr(poly.src_b[pi]) - va) * poly.t[pi];
+                    const float va = attr(fan.v[k].a);
+                    var[k] = fan.v[k].b < 0 ? va : va + (attr(fan.v[k].b) - va) * fan.v[k].t;
                 }
             }
             g[i] = (q0 * var[0] + q1 * var[1] + q2 * var[2]) * qs;
@@ -459,10 +555,10 @@ k_gbuffer_shade(const ShadeParams p) {
             } else {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const int pi = pv[k], a = poly.src_a[pi], b = poly.src_b[pi];
+                    const int a = fan.v[k].a, b = fan.v[k].b;
                     const float ua = uv[2 * a], va = uv[2 * a + 1];
-                    vu[k] = b < 0 ? ua : ua + (uv[2 * b] - ua) * poly.t[pi];
-                    vv[k] = b < 0 ? va : va + (uv[2 * b + 1] - va) * poly.t[pi];
+                    vu[k] = b < 0 ? ua : ua + (uv[2 * b] - ua) * fan.v[k].t;
+                    vv[k] = b < 0 ? va : va + (uv[2 * b + 1] - va) * fan.v[k].t;
                 }
             }
             tcu = (q0 * vu[0] + q1 * vu[1] + q2 * vu[2]) * qs;
@@ -619,40 +715,28 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
     r.group_list = a.group_list;
     r.group_count = a.group_count;
     r.vis32 = nullptr;
-    r.big_list = a.big_list;
-    r.big_count = a.big_count;
     r.items = a.items;
     r.item_count = a.item_count;
     r.item_capacity = a.item_capacity;
+    r.next_counts = a.next_counts;
     r.material = nullptr;
     r.albedo = nullptr;
     memset(&r.tex, 0, sizeof(r.tex));
     return r;
 }
 
+// Visibility of one pass.  The caller guarantees (vct_capi.hip raster_args) that the visibility words of the
+// scissor rows are all-ones and that this pass's three counters are zero: both are re-established by the pass
+// itself (the consumer of a word writes ~0 back, k_raster_vis zeroes the next pass's counters), so a pass is two
+// dependent launches and no memset.
 hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
-    if (r.ys1 <= r.ys0) return hipSuccess;
-    hipError_t e = r.vis32 ? hipMemsetAsync(r.vis32 + (size_t)r.ys0 * r.W, 0xff,
-                                            (size_t)r.W * (r.ys1 - r.ys0) * sizeof(uint32_t), s)
-                           : hipMemsetAsync(r.vis + (size_t)r.ys0 * r.W, 0xff,
-                                            (size_t)r.W * (r.ys1 - r.ys0) * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(r.big_count, 0, 4 * sizeof(int32_t), s);     // big, item, wave and group counters
-    if (e != hipSuccess) return e;
-    if (r.ntri <= 0) return hipSuccess;
+    if (r.ys1 <= r.ys0 || r.ntri <= 0)        // nothing to draw: keep the "next counters are zero" invariant
+        return hipMemsetAsync(r.next_counts, 0, 3 * sizeof(uint32_t), s);
     hipLaunchKernelGGL(k_raster_vis, dim3((r.ntri + 255) / 256), dim3(256), 0, s, r);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_raster_groups, dim3(256 * 16), dim3(256), 0, s, r);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_raster_waves, dim3(256 * 16), dim3(256), 0, s, r);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_raster_emit_big, dim3(256 * 4), dim3(256), 0, s, r);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_raster_tiles, dim3(256 * 32), dim3(VCT_RTILE * VCT_RTILE), 0, s, r);
+    const int gblocks = 4096, wblocks = 2048, tblocks = 2048;
+    hipLaunchKernelGGL(k_raster_mid, dim3(gblocks + wblocks + tblocks), dim3(256), 0, s, r, gblocks, wblocks);
     return hipGetLastError();
 }
 
@@ -661,7 +745,7 @@ hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
                                     hipStream_t s) {
     RasterParams r = make_raster(a, light_vp, S, S, 0, S);
-    r.vis32 = reinterpret_cast<uint32_t*>(a.vis);      // depth only: half the clear and half the read-back traffic
+    r.vis32 = a.vis32;                                  // depth only: half the traffic of the 64-bit words
     hipError_t e = run_visibility(r, s);
     if (e != hipSuccess) return e;
     const size_t n = (size_t)S * S;

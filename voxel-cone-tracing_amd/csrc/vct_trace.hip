@@ -108,7 +108,7 @@ __device__ __forceinline__ unsigned long long ballot64(bool pred) {
 
 struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
     int lane;
-    uint32_t sbx, sby, sbz;     // dilated (l&3), ((l>>2)&3)<<1, (l>>4)<<2
+    uint32_t sbx, sby, sbz;     // BYTE offsets: 4 * dilated (l&3), ((l>>2)&3)<<1, (l>>4)<<2
 };
 
 // Instrumented build (-DVCT_STATS=1, tools/trace_stats.py): wave-level counters of the march, kept in
@@ -143,8 +143,11 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
     const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
     const float a = u - fu, b = v - fv, c = w - fw;
     const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
-    const uint32_t* __restrict__ base = chain + lv.off;
-    const uint32_t MX = lv.mask_x, MY = MX << 1, MZ = MX << 2;
+    // Texels are addressed by 32-bit BYTE offsets from the level's first texel (4 * Morton index <= 2^32 - 4 at
+    // 1024^3): the dilated-integer arithmetic runs on pre-shifted masks, so no shift and no 64-bit address add
+    // is left per load (global_load_dword v, voffset, s[base]).
+    const char* __restrict__ base = (const char*)(chain + lv.off);
+    const uint32_t MX = lv.mask_x << 2, MY = MX << 1, MZ = MX << 2;
 
     F4 r = {0.0f, 0.0f, 0.0f, 0.0f};
     bool coop = false;
@@ -163,18 +166,18 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         uint32_t idx;
         if (WRAP) {
             // scalar unit: dilate the anchor; vector unit: one dilated add per axis
-            const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)m);
-            const uint32_t say = vct_spread3((uint32_t)ay & (uint32_t)m) << 1;
-            const uint32_t saz = vct_spread3((uint32_t)az & (uint32_t)m) << 2;
+            const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)m) << 2;
+            const uint32_t say = vct_spread3((uint32_t)ay & (uint32_t)m) << 3;
+            const uint32_t saz = vct_spread3((uint32_t)az & (uint32_t)m) << 4;
             idx = (((sax | ~MX) + lb.sbx) & MX) | (((say | ~MY) + lb.sby) & MY) |
                   (((saz | ~MZ) + lb.sbz) & MZ);
         } else {
             const int x = min(max(ax + (lb.lane & 3), 0), m);
             const int y = min(max(ay + ((lb.lane >> 2) & 3), 0), m);
             const int z = min(max(az + (lb.lane >> 4), 0), m);
-            idx = vct_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
+            idx = vct_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z) << 2;
         }
-        const uint32_t t = base[idx];
+        const uint32_t t = *(const uint32_t*)(base + idx);
         const bool any_texel = ballot64(t != 0u) != 0ull;
         if (VCT_STATS) { if (any_texel) ++ms.coop_hit; else ++ms.coop_zero; }
         if (any_texel) {     // all 64 texels zero: every footprint sums to exactly +0
@@ -229,25 +232,27 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
       if (act) {
         uint32_t mx0, mx1, my0, my1, mz0, mz1;
         if (WRAP) {
-            mx0 = vct_spread3((uint32_t)i0 & (uint32_t)m);
-            my0 = vct_spread3((uint32_t)j0 & (uint32_t)m) << 1;
-            mz0 = vct_spread3((uint32_t)k0 & (uint32_t)m) << 2;
-            mx1 = ((mx0 | ~MX) + 1u) & MX;      // dilated increment, wraps at N
-            my1 = ((my0 | ~MY) + 2u) & MY;
-            mz1 = ((mz0 | ~MZ) + 4u) & MZ;
+            mx0 = vct_spread3((uint32_t)i0 & (uint32_t)m) << 2;
+            my0 = vct_spread3((uint32_t)j0 & (uint32_t)m) << 3;
+            mz0 = vct_spread3((uint32_t)k0 & (uint32_t)m) << 4;
+            mx1 = ((mx0 | ~MX) + 4u) & MX;      // dilated increment, wraps at N
+            my1 = ((my0 | ~MY) + 8u) & MY;
+            mz1 = ((mz0 | ~MZ) + 16u) & MZ;
         } else {
             const int ci0 = min(max(i0, 0), m), ci1 = min(max(i0 + 1, 0), m);
             const int cj0 = min(max(j0, 0), m), cj1 = min(max(j0 + 1, 0), m);
             const int ck0 = min(max(k0, 0), m), ck1 = min(max(k0 + 1, 0), m);
-            mx0 = vct_spread3((uint32_t)ci0); mx1 = vct_spread3((uint32_t)ci1);
-            my0 = vct_spread3((uint32_t)cj0) << 1; my1 = vct_spread3((uint32_t)cj1) << 1;
-            mz0 = vct_spread3((uint32_t)ck0) << 2; mz1 = vct_spread3((uint32_t)ck1) << 2;
+            mx0 = vct_spread3((uint32_t)ci0) << 2; mx1 = vct_spread3((uint32_t)ci1) << 2;
+            my0 = vct_spread3((uint32_t)cj0) << 3; my1 = vct_spread3((uint32_t)cj1) << 3;
+            mz0 = vct_spread3((uint32_t)ck0) << 4; mz1 = vct_spread3((uint32_t)ck1) << 4;
         }
         uint32_t t[8];
-        t[0] = base[mx0 | my0 | mz0]; t[1] = base[mx1 | my0 | mz0];
-        t[2] = base[mx0 | my1 | mz0]; t[3] = base[mx1 | my1 | mz0];
-        t[4] = base[mx0 | my0 | mz1]; t[5] = base[mx1 | my0 | mz1];
-        t[6] = base[mx0 | my1 | mz1]; t[7] = base[mx1 | my1 | mz1];
+#define VCT_TEXEL(o) (*(const uint32_t*)(base + (o)))
+        t[0] = VCT_TEXEL(mx0 | my0 | mz0); t[1] = VCT_TEXEL(mx1 | my0 | mz0);
+        t[2] = VCT_TEXEL(mx0 | my1 | mz0); t[3] = VCT_TEXEL(mx1 | my1 | mz0);
+        t[4] = VCT_TEXEL(mx0 | my0 | mz1); t[5] = VCT_TEXEL(mx1 | my0 | mz1);
+        t[6] = VCT_TEXEL(mx0 | my1 | mz1); t[7] = VCT_TEXEL(mx1 | my1 | mz1);
+#undef VCT_TEXEL
         const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
         const float wg[8] = {(a0 * b0) * c0, (a * b0) * c0, (a0 * b) * c0, (a * b) * c0,
                              (a0 * b0) * c,  (a * b0) * c,  (a0 * b) * c,  (a * b) * c};
@@ -308,10 +313,10 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
         const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
         if ((ballot64(far > 2u) & m) == 0ull) {
             done = true;
-            const uint32_t MX = lv.mask_x, MY = MX << 1, MZ = MX << 2;
-            const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)mm);
-            const uint32_t say = vct_spread3((uint32_t)ay & (uint32_t)mm) << 1;
-            const uint32_t saz = vct_spread3((uint32_t)az & (uint32_t)mm) << 2;
+            const uint32_t MX = lv.mask_x << 2, MY = MX << 1, MZ = MX << 2;      // byte offsets, as in sample_level
+            const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)mm) << 2;
+            const uint32_t say = vct_spread3((uint32_t)ay & (uint32_t)mm) << 3;
+            const uint32_t saz = vct_spread3((uint32_t)az & (uint32_t)mm) << 4;
             const uint32_t idx = (((sax | ~MX) + lb.sbx) & MX) | (((say | ~MY) + lb.sby) & MY) |
                                  (((saz | ~MZ) + lb.sbz) & MZ);
             const unsigned long long mneg[3] = {mx, my, mz};
@@ -319,8 +324,8 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
             uint32_t tpos[3], tneg[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {          // all block loads first (up to 6 in flight)
-                tpos[k] = mneg[k] != m ? (chain_of(2 * k) + lv.off)[idx] : 0u;          // some lane is >= 0
-                tneg[k] = mneg[k] != 0ull ? (chain_of(2 * k + 1) + lv.off)[idx] : 0u;   // some lane is < 0
+                tpos[k] = mneg[k] != m ? *(const uint32_t*)((const char*)(chain_of(2 * k) + lv.off) + idx) : 0u;          // some lane is >= 0
+                tneg[k] = mneg[k] != 0ull ? *(const uint32_t*)((const char*)(chain_of(2 * k + 1) + lv.off) + idx) : 0u;   // some lane is < 0
             }
             const int slot = act ? (dz * 4 + dy) * 4 + dx : 0;
             const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
@@ -527,9 +532,9 @@ k_trace_tile(const VctTraceParams p) {
 
     LaneBlock lb;
     lb.lane = lane;
-    lb.sbx = vct_spread3((uint32_t)lane & 3u);
-    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;
-    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;
+    lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
+    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
     MarchStats ms = {};
 
     const int tile = p.tile_row0 * p.tiles_x + ti;
@@ -687,9 +692,9 @@ k_trace_tile_split(const VctTraceParams p) {
 
     LaneBlock lb;
     lb.lane = lane;
-    lb.sbx = vct_spread3((uint32_t)lane & 3u);
-    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;
-    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;
+    lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
+    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
     MarchStats ms = {};
 
     const int tile = p.tile_row0 * p.tiles_x + ti;
@@ -893,9 +898,9 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
     float4* blk = &lds_blk[wave][0][0];                                      \
     LaneBlock lb;                                                            \
     lb.lane = lane;                                                          \
-    lb.sbx = vct_spread3((uint32_t)lane & 3u);                               \
-    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;                   \
-    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;                          \
+    lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;                          \
+    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;                   \
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;                          \
     MarchStats ms = {};
 
 // compaction of one brick into `list` (LDS); returns the number of occupied voxels
