@@ -211,7 +211,8 @@ void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chai
     p.steps_specular = c->steps_dev + VCT_MAX_STEPS;
     p.n_diffuse = c->n_diffuse;
     p.n_specular = c->n_specular;
-    p.step_counter = c->step_counter;
+    p.step_counter = c->step_counter + (size_t)(c->step_set ^ 1) * VCT_STEP_COUNTERS;     // the zero set
+    p.step_counter_next = c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS;
 #if defined(VCT_STATS) && VCT_STATS
     p.stats = c->stats;
 #endif
@@ -245,14 +246,13 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.out = c->frame_target ? c->frame_target : c->frame;
     p.dbg_steps = c->cfg.debug_outputs ? c->dbg_steps : nullptr;
     p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
-    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long),
-                              c->stream));
 #if defined(VCT_STATS) && VCT_STATS
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
 #endif
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->step_set ^= 1;           // the kernel filled the zero set and zeroed the other one
     c->last_row0 = row0;
     c->last_row1 = row1;
     c->have_trace = true;
@@ -473,7 +473,8 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     }
     CREATE_TRY(hipMalloc(&c->frame, npix * 8));
     CREATE_TRY(hipMemsetAsync(c->frame, 0, npix * 8, c->stream));
-    CREATE_TRY(hipMalloc(&c->step_counter, VCT_STEP_COUNTERS * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&c->step_counter, 2 * VCT_STEP_COUNTERS * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(c->step_counter, 0, 2 * VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
     CREATE_TRY(hipMalloc(&c->stats, 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
     CREATE_TRY(hipMalloc(&c->steps_dev, 2 * VCT_MAX_STEPS * sizeof(VctStep)));
@@ -924,10 +925,12 @@ int vct_bounce(vct_ctx* c) {
     p.bounce_list = c->bounce_list + 1;
     p.bounce_list_cap = c->bounce_list_cap;
     p.brick_over = c->brick_over;
-    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
+    // the bounce kernels do not zero the other counter set: clear both, fill the one fill_march_params chose
+    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, 2 * VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_bounce(p, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->step_set ^= 1;
     HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
                                      b_sparse ? c->mip_seen_b : nullptr, c->stream));
     // the directional chains always describe the chain the trace reads (the bounce itself gathers
@@ -1207,7 +1210,7 @@ int vct_last_step_count(vct_ctx* c, uint64_t* steps) {
     if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned long long v[VCT_STEP_COUNTERS];
-    HIP_TRY(c, hipMemcpy(v, c->step_counter, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(v, c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS, sizeof(v), hipMemcpyDeviceToHost));
     unsigned long long sum = 0;
     for (int i = 0; i < VCT_STEP_COUNTERS; ++i) sum += v[i];
     *steps = sum;

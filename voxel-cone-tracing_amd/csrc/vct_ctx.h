@@ -35,7 +35,8 @@ struct vct_ctx {
     uint16_t* frame_target = nullptr; // caller-owned output (vct_set_frame_target) or null
     uint8_t* dbg_steps = nullptr;
     float* dbg_cones = nullptr;
-    unsigned long long* step_counter = nullptr;
+    unsigned long long* step_counter = nullptr;   // two sets of VCT_STEP_COUNTERS; invariant: the set NOT named by step_set is zero
+    int step_set = 0;                              // set written by the last launch
     unsigned long long* stats = nullptr;      // [8] march statistics of instrumented builds (VCT_STATS)
     VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
     int n_diffuse = 0, n_specular = 0;

@@ -116,7 +116,8 @@ struct VctTraceParams {
     uint16_t* out;                      // RGBA16F [h][w][4]
     uint8_t* dbg_steps;                 // [npix][7] or null
     float* dbg_cones;                   // [npix][7][4] or null
-    unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] partial sums of executed steps
+    unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] partial sums of executed steps (zero at launch)
+    unsigned long long* step_counter_next;   // the other set: zeroed by the trace kernels for the launch after this one
     unsigned long long* stats;          // [8] wave-level march counters (builds with -DVCT_STATS=1 only)
     // second bounce (k_bounce): per-voxel attributes (pooled like the accumulators: [slot][512]), touched-brick
     // flags, output level 0

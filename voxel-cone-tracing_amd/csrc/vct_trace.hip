@@ -527,6 +527,8 @@ k_trace_tile(const VctTraceParams p) {
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
     const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    if (blockIdx.x == 0)        // counters of the NEXT launch (two sets, used alternately: no memset dispatch per trace)
+        for (int i = (int)threadIdx.x; i < VCT_STEP_COUNTERS; i += (int)blockDim.x) p.step_counter_next[i] = 0ull;
     const int ti = vb * VCT_WAVES_PER_BLOCK + wave;
     if (ti >= ntiles) return;
 
@@ -688,6 +690,10 @@ k_trace_tile_split(const VctTraceParams p) {
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
     const int ti = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    // the executed-step counters of the NEXT launch are zeroed here (two sets, used alternately): no memset
+    // dispatch in front of every trace
+    if (blockIdx.x == 0)
+        for (int i = (int)threadIdx.x; i < VCT_STEP_COUNTERS; i += (int)blockDim.x) p.step_counter_next[i] = 0ull;
     if (ti >= ntiles) return;
 
     LaneBlock lb;
