@@ -484,7 +484,10 @@ __device__ __forceinline__ float shadow_fetch(const float* __restrict__ depth, i
 }
 
 // one thread per pixel, 64 threads = one 8x8 tile of the tiled G-buffer
-__global__ void __launch_bounds__(256)
+#ifndef VCT_SHADE_MIN_BLOCKS
+#define VCT_SHADE_MIN_BLOCKS 5       // 96 VGPRs, 5 waves per SIMD: 216 -> 208 us for the 1080p pass (6: spills)
+#endif
+__global__ void __launch_bounds__(256, VCT_SHADE_MIN_BLOCKS)
 k_gbuffer_shade(const ShadeParams p) {
     const int W = p.r.W, H = p.r.H;
     const int tile = p.tile0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
