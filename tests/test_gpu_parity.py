@@ -305,6 +305,15 @@ def test_facade_demo_matches_binding(vct):
         hsh = ((hsh ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert fields["fnv1a"] == f"{hsh:016x}"
     assert (planes[18] >= 0.5).mean() > 0.5          # the camera actually sees the box
+    # DynamicLight: every Render() is one vct_gi_pass; with an unchanged light it is the same frame
+    dyn = subprocess.run([exe, "--scene", "procedural:cornell", "--voxels", str(V), "--size", f"{w}x{h}",
+                          "--shadow", str(S), "--frames", "2", "--dynamic-light"], capture_output=True, text=True, timeout=300)
+    assert dyn.returncode == 0, dyn.stdout + dyn.stderr
+    two = subprocess.run([exe, "--scene", "procedural:cornell", "--voxels", str(V), "--size", f"{w}x{h}",
+                          "--shadow", str(S), "--frames", "2"], capture_output=True, text=True, timeout=300)
+    fd = dict(kv.split("=") for kv in dyn.stdout.strip().split("\n")[-1].split())
+    f2 = dict(kv.split("=") for kv in two.stdout.strip().split("\n")[-1].split())
+    assert fd["fnv1a"] == f2["fnv1a"] and fd["cone_steps"] == f2["cone_steps"]
 
 
 def test_frame_gather_single_rank_device_path(vct, oracle):

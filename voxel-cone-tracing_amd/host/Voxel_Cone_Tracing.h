@@ -187,6 +187,10 @@ struct Voxel_Cone_Tracing {
     // slab of tile rows and rank 0's Frame() receives the whole frame through ONE ncclGather.
     int Rank = 0, World = 1, Device = -1;
     unsigned char CommId[VCT_COMM_ID_BYTES] = {0};
+    // Extension: the reference never rebuilds the shadow map or the volume after init (a changed lightDirection only
+    // moves the direct term, VCT.h:168).  With DynamicLight every Render() is one whole GI pass for the current
+    // lightDirection (vct_gi_pass: shadow map, voxelize + inject + mips beside the G-buffer raster, trace).
+    bool DynamicLight = false;
     int Bounces = 1;    // 2 = re-inject the lit voxels once (the "2 bounces" of the reference's README.md:16,
                         // which its code does not implement: VCT.h:138-139 injects once); set before init
 
@@ -284,6 +288,13 @@ struct Voxel_Cone_Tracing {
             } else {
                 check(vct_comm_sync(ctx), "vct_comm_sync");
             }
+            return;
+        }
+        if (DynamicLight && Bounces < 2) {
+            vcth_light_view_proj(L, DepthViewProjectionMatrix.m);                          // VCT.h:84-86, per frame
+            if (!check(vct_gi_pass(ctx, DepthViewProjectionMatrix.m, vp, VCT_VOX_CONSERVATIVE_AVG), "vct_gi_pass")) return;
+            FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
+            check(vct_download_frame(ctx, FrameRGBA16F.data()), "vct_download_frame");
             return;
         }
         if (!check(vct_render_gbuffer(ctx, vp), "vct_render_gbuffer")) return;

@@ -5,7 +5,10 @@
 // optionally writes it as a tonemapped PPM.
 //
 //   vct_demo [--scene procedural:atrium|procedural:cornell] [--voxels 128] [--size 1280x720]
-//            [--shadow 4096] [--frames 3] [--bounces 1|2] [--ppm out.ppm] [--gpus N]
+//            [--shadow 4096] [--frames 3] [--bounces 1|2] [--ppm out.ppm] [--gpus N] [--dynamic-light]
+//
+// --dynamic-light: every Render() re-runs the whole GI pass (shadow map, voxelize, inject, mips, G-buffer, trace)
+// for the current lightDirection through vct_gi_pass instead of the reference's build-once volume.
 //
 // --gpus N: the frame is cut into N screen-tile slabs, one process per GPU (this program re-launches
 // itself N times BEFORE anything touches a GPU; rank r uses device r), each rank rasterises and traces its
@@ -73,6 +76,7 @@ int main(int argc, char** argv) {
     int gpus = 0, rank = -1;
     const char* scene = "procedural:atrium";
     const char* ppm = nullptr;
+    bool dynamic_light = false;
     const char* idfile = nullptr;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--gpus")) gpus = atoi(argv[i + 1]);
@@ -89,6 +93,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--bounces")) bounces = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--ppm")) ppm = argv[i + 1];
     }
+    for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], "--dynamic-light")) dynamic_light = true;
     GLFWwindow* window = nullptr;          // no window system on a compute node
 
     camera.MovementSpeed = 5.0f;           // R/main.cpp:64-65
@@ -105,6 +110,7 @@ int main(int argc, char** argv) {
     voxel_cone_tracing.ShadowMapSize = (unsigned)shadow;
     voxel_cone_tracing.model_path = scene;
     voxel_cone_tracing.Bounces = bounces;
+    voxel_cone_tracing.DynamicLight = dynamic_light;       // every Render() = one whole GI pass (vct_gi_pass)
     if (gpus > 0) {                                         // a rank of a multi-GPU run
         voxel_cone_tracing.Rank = rank;
         voxel_cone_tracing.World = gpus;
