@@ -429,6 +429,12 @@ def pmc_profile(args, world):
         return {"ok": False, "why": f"profiles/trace_traffic.json was recorded for kernel sources "
                                     f"{t.get('kernel_source_sha16')}, this build is {sha}: re-run tools/profile_gpu.sh"}
     t["ok"] = True
+    mp = os.path.join(ROOT, "profiles", "valu_model.json")      # tools/valu_model.py: issue-cycle model of the same sources
+    if os.path.exists(mp):
+        with open(mp) as fh:
+            m = json.load(fh)
+        if m.get("kernel_source_sha16") == sha:
+            t["model_issue_cycles_per_valu_instr"] = m.get("model_issue_cycles_per_valu_instr")
     return t
 
 
@@ -455,6 +461,13 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
         r["frac"] = round(rate / VALU_PEAK_GINSTR, 4)
         r["valu_wave_instructions_per_launch"] = int(valu)
         r["valu_wave_instructions_per_64_cone_steps"] = round(valu * 64 / max(cone_steps, 1), 1)
+        # `frac` counts every instruction as a 2-cycle issue; a third of this kernel's mix are 4-cycle ops.
+        # Pipe occupancy by the measured per-op issue costs (tools/valu_model.py -> profiles/valu_model.json):
+        # instruction count x mean issue cycles of the march loop's mix / (1024 SIMDs x GPU cycles of a
+        # launch, GRBM_GUI_ACTIVE of the PMC pass).
+        cyc, gpu_cyc = prof.get("model_issue_cycles_per_valu_instr"), prof.get("gpu_cycles_per_launch")
+        if cyc and gpu_cyc:
+            r["valu_pipe_busy_model"] = round(valu * cyc / 1024.0 / gpu_cyc, 3)
     hbm = prof.get("hbm_bytes_per_launch")
     if hbm:
         r["traffic"] = round(hbm / (kernel_ms * 1e-3) / 1e9, 1)
