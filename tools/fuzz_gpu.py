@@ -114,4 +114,17 @@ while time.time() < t_end:
             bad = np.nonzero((got.view(np.uint32) != gref.view(np.uint32)).any(0))[0]
             fail("gbuffer raster", seed, f"{len(bad)} px, first {bad[:5]} kind={kind} {w}x{h}")
         counts["raster"] += 1
+        # the same context again: nothing is cleared between passes (self-cleaning visibility words, alternating
+        # counters), a scissored slab pass in between, then another camera
+        rows = (h + 7) // 8
+        r0 = int(r.integers(0, rows)); r1 = int(r.integers(r0, rows + 1))
+        ctx.render_gbuffer_rows(sc.camera_view_proj(cam, w, h), r0, r1)
+        cam2 = sc.default_camera(position=tuple(r.uniform(-40, 40, 3)), yaw=float(r.uniform(-180, 180)),
+                                 pitch=float(r.uniform(-60, 60)), zoom=float(r.uniform(20, 45)))
+        gref2 = raster_oracle.gbuffer(sc, scene, cam2, w, h, dref, lvp_row)
+        ctx.render_shadow_map(sc.light_view_proj(lightd))
+        if not np.array_equal(ctx.download_shadow_map().view(np.uint32), dref.view(np.uint32)): fail("shadow raster (2nd pass)", seed)
+        ctx.render_gbuffer(sc.camera_view_proj(cam2, w, h))
+        if not np.array_equal(ctx.download_gbuffer().view(np.uint32), gref2.view(np.uint32)): fail("gbuffer raster (2nd pose)", seed)
+        counts["raster"] += 1
 print("fuzz ok:", counts, "seeds", seed - 1000)
