@@ -116,6 +116,9 @@ struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
 #ifndef VCT_STATS
 #define VCT_STATS 0
 #endif
+#ifndef VCT_HALF_GATHER
+#define VCT_HALF_GATHER 1     // gather + interpolate the lower z plane, then the upper one (half the texel registers live)
+#endif
 struct MarchStats {
     uint32_t wave_steps;       // march-loop iterations executed by the wave
     uint32_t lane_steps;       // sum over those iterations of the live lanes (== executed cone steps)
@@ -190,11 +193,29 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             wave_sync();
             const int slot = act ? (dz * 4 + dy) * 4 + dx : 0;
             const float4* q = blk + slot;
+            const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
+            const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
+#if VCT_HALF_GATHER
+            {   // lower z plane first, then the upper one: half the texel registers live at a time
+                const float4 t0 = q[0], t1 = q[1], t2 = q[4], t3 = q[5];
+                const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
+#define VCT_ACC(ch) r.ch = w0 * t0.ch; r.ch = fmaf(w1, t1.ch, r.ch); r.ch = fmaf(w2, t2.ch, r.ch); r.ch = fmaf(w3, t3.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float4 t4 = q[16], t5 = q[17], t6 = q[20], t7 = q[21];
+                wave_sync();
+                const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
+#define VCT_ACC(ch) r.ch = fmaf(w4, t4.ch, r.ch); r.ch = fmaf(w5, t5.ch, r.ch); r.ch = fmaf(w6, t6.ch, r.ch); r.ch = fmaf(w7, t7.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+#else
             const float4 t0 = q[0], t1 = q[1], t2 = q[4], t3 = q[5];
             const float4 t4 = q[16], t5 = q[17], t6 = q[20], t7 = q[21];
             wave_sync();
-            const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
-            const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
             const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
             const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
 #define VCT_ACC(ch)                                                                           \
@@ -204,6 +225,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
     r.ch = fmaf(w7, t7.ch, r.ch);
             VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
 #undef VCT_ACC
+#endif
         }
     } else {
       if (VCT_STATS) {
@@ -508,7 +530,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
 #define VCT_WAVES_PER_BLOCK 1
 #endif
 #ifndef VCT_TRACE_MIN_WAVES
-#define VCT_TRACE_MIN_WAVES 6     // waves per SIMD the register allocator must leave room for (<= 80 VGPRs)
+#define VCT_TRACE_MIN_WAVES 7     // waves per SIMD the register allocator must leave room for (<= 72 VGPRs).  A/B on the
+                                  // final round-2 kernel (ms at 256^3/1080p): 4: 0.776, 5: 0.775, 6: 0.7235, 7: 0.695, 8: 0.719
+                                  // (spills); with the half gather 7: 0.683 (69 VGPRs, no scratch), 8: 0.689 (rematerialises)
 #endif
 
 // One wave per tile, lane = pixel, the 7 cones in sequence; VCT_WAVES_PER_BLOCK horizontally
