@@ -532,7 +532,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
 #ifndef VCT_TRACE_MIN_WAVES
 #define VCT_TRACE_MIN_WAVES 7     // waves per SIMD the register allocator must leave room for (<= 72 VGPRs).  A/B on the
                                   // final round-2 kernel (ms at 256^3/1080p): 4: 0.776, 5: 0.775, 6: 0.7235, 7: 0.695, 8: 0.719
-                                  // (spills); with the half gather 7: 0.683 (69 VGPRs, no scratch), 8: 0.689 (rematerialises)
+                                  // (spills); with the two-plane gather 7: 0.683 (69 VGPRs, no scratch), 8: 0.689; gathering texel pairs: 7: 0.685, 8: 0.684
 #endif
 
 // One wave per tile, lane = pixel, the 7 cones in sequence; VCT_WAVES_PER_BLOCK horizontally
