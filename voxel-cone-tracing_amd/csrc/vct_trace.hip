@@ -697,11 +697,14 @@ k_trace_tile(const VctTraceParams p) {
 // order (the weighted sum is an fma chain over cones 0..5) and composites.  Same bits, waves one
 // third as long, no wave ever waits on another.
 #define VCT_SPLIT 3
+#ifndef VCT_ANISO_MIN_WAVES
+#define VCT_ANISO_MIN_WAVES 5     // A/B (ms, 256^3 1080p): 4: 1.61, 5: 1.47, 6: 1.88 (spills), 7: 1.60
+#endif
 
 // (the anisotropic instantiation carries three samples' worth of state: it gets 128 VGPRs instead of
 // spilling under the 80 of the default kernel)
 template <bool WRAP, bool FASTDIV, bool ANISO>
-__global__ void __launch_bounds__(64 * VCT_SPLIT, ANISO ? 4 : VCT_TRACE_MIN_WAVES)
+__global__ void __launch_bounds__(64 * VCT_SPLIT, ANISO ? VCT_ANISO_MIN_WAVES : VCT_TRACE_MIN_WAVES)
 k_trace_tile_split(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_SPLIT][ANISO ? 4 : 2][64];   // per wave: level-1 slab, level-2 slab (+ their "-axis" slabs)
     __shared__ float4 lds_cone[7][64];
@@ -981,7 +984,8 @@ k_bounce_list(const VctTraceParams p) {
 }
 
 #ifndef VCT_BOUNCE_MIN_WAVES
-#define VCT_BOUNCE_MIN_WAVES 4     // the per-voxel frame + attribute state spills under the trace kernel's 80 VGPRs (0.551 -> 0.539 ms at 512^3)
+#define VCT_BOUNCE_MIN_WAVES 5     // the per-voxel frame + attribute state spills under the trace kernel's budget; A/B at 512^3
+                                   // (bounce + mips, ms): 4: 0.495, 5: 0.489, 6: 0.500, 7: 0.504
 #endif
 template <bool WRAP, bool FASTDIV>
 __global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_BOUNCE_MIN_WAVES)
