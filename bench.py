@@ -167,7 +167,10 @@ def main():
         if inp["scene"] is not None:
             s = inp["scene"]
             ctx.upload_scene(s)         # triangles, frames, and (textured scenes) texture coordinates + maps
-            for _ in range(2):          # second pass is the timed one (first warms caches/allocs)
+            # 8 passes, every stage bracketed by events; reported = median of the last 5 (the first passes warm
+            # allocations and caches and bring the clocks up after the host-side scene set-up)
+            passes = []
+            for _ in range(8):
                 ei = [ev() for _ in range(3)]
                 ei[0].record(); ctx.render_shadow_map(inp["light_vp"])        # DrawDepthTexture
                 ei[1].record(); ctx.render_gbuffer(inp["view_proj"])          # raster part of Render
@@ -182,25 +185,27 @@ def main():
                     ctx.bounce()                 # bounce kernel + mips of the bounce-1 chain
                     e[4].record()
                 ctx.synchronize()
-            gi = {"voxelize": e[0].elapsed_time(e[1]), "inject_resolve": e[1].elapsed_time(e[2]),
-                  "build_mips": e[2].elapsed_time(e[3])}
-            gi["shadow_map_raster"] = ei[0].elapsed_time(ei[1])
-            gi["gbuffer_raster"] = ei[1].elapsed_time(ei[2])
+                one = {"voxelize": e[0].elapsed_time(e[1]), "inject_resolve": e[1].elapsed_time(e[2]),
+                       "build_mips": e[2].elapsed_time(e[3]), "shadow_map_raster": ei[0].elapsed_time(ei[1]),
+                       "gbuffer_raster": ei[1].elapsed_time(ei[2])}
+                if args.bounces == 2:
+                    one["bounce_and_mips"] = e[3].elapsed_time(e[4])
+                passes.append(one)
+            gi = {k: float(np.median([q[k] for q in passes[-5:]])) for k in passes[-1]}
             if args.bounces == 2:
-                gi["bounce_and_mips"] = e[3].elapsed_time(e[4])
                 gi["bounce_cone_steps"] = float(ctx.last_step_count())
             if args.bounces != 2 and world == 1:
                 # the same six stages as ONE call (vct_gi_pass: G-buffer raster on a second stream beside the
-                # voxel stages) -- wall time of the whole pass, events around the call, mean of 5 after 2 warm-ups
-                for _ in range(2):
+                # voxel stages) -- wall time of the whole pass, events around the calls, mean of 20 after 5 warm-ups
+                for _ in range(5):
                     ctx.gi_pass(inp["light_vp"], inp["view_proj"])
                 ef = [ev(), ev()]
                 ef[0].record()
-                for _ in range(5):
+                for _ in range(20):
                     ctx.gi_pass(inp["light_vp"], inp["view_proj"])
                 ef[1].record()
                 ctx.synchronize()
-                gi_fused = ef[0].elapsed_time(ef[1]) / 5.0
+                gi_fused = ef[0].elapsed_time(ef[1]) / 20.0
             inp["planes"] = ctx.download_gbuffer()     # host copy only for the CPU baseline / checks
         else:
             ctx.upload_volume(inp["volume"])
