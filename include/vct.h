@@ -211,9 +211,10 @@ int vct_trace_resident(vct_ctx* ctx);
 int vct_trace_resident_rows(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
 /* One whole GI pass for a light AND a camera that moved -- init_voxel_cone_tracing's DrawDepthTexture +
  * DrawVoxelTexture (VCT.h:138-139) followed by Render (VCT.h:146-190) -- issued as one call:
- *   shadow map -> { voxelize(mode) -> inject -> mips }  ||  { G-buffer raster }  -> trace.
- * The voxel stages and the G-buffer raster only READ the shadow map and write disjoint buffers, so the raster
- * runs on a second HIP stream beside them (neither fills the GPU on its own); the trace waits for both.  The
+ *   { shadow map -> voxelize(mode) -> inject -> mips }  ||  { G-buffer visibility -> (shadow map ready) -> shade }  -> trace.
+ * The main draw's visibility raster needs nothing of this pass and its shading kernel only READS the shadow map, so
+ * the G-buffer stage runs on a second HIP stream beside the shadow pass and the voxel stages (none of them fills the
+ * GPU on its own; the two raster passes have their own work lists); the trace waits for both.  The
  * frame is bit-identical to vct_render_shadow_map, vct_voxelize, vct_inject_light, vct_build_mips,
  * vct_render_gbuffer, vct_trace_resident called in that order.  Asynchronous (vct_synchronize). */
 int vct_gi_pass(vct_ctx* ctx, const float light_vp[16], const float view_proj[16], int32_t voxelize_mode);

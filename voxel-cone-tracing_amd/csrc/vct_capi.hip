@@ -502,13 +502,14 @@ void vct_destroy(vct_ctx* c) {
                     c->dbg_cones, c->step_counter, c->stats, c->steps_dev, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->big_list, c->worklist, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
-                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->vis32, c->raster_lists,
-                    c->raster_counts, c->raster_items};
+                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->vis32, c->raster_lists[0], c->raster_lists[1],
+                    c->raster_counts[0], c->raster_counts[1], c->raster_items[0], c->raster_items[1]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_shadow) (void)hipEventDestroy(c->ev_shadow);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -565,7 +566,8 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     if (c->mat_albedo) { (void)hipFree(c->mat_albedo); c->mat_albedo = nullptr; }
     if (c->big_list) { (void)hipFree(c->big_list); c->big_list = nullptr; }
     if (c->worklist) { (void)hipFree(c->worklist); c->worklist = nullptr; }
-    if (c->raster_lists) { (void)hipFree(c->raster_lists); c->raster_lists = nullptr; }   // sized by ntri
+    for (int k = 0; k < 2; ++k)
+        if (c->raster_lists[k]) { (void)hipFree(c->raster_lists[k]); c->raster_lists[k] = nullptr; }   // sized by ntri
     if (c->ref_big) { (void)hipFree(c->ref_big); c->ref_big = nullptr; }
     float** frames[4] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit, &c->tri_uv};       // belong to the old mesh
     for (float** f : frames) if (*f) { (void)hipFree(*f); *f = nullptr; }
@@ -621,6 +623,7 @@ int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const fl
 // Scratch of one raster pass on stream `s`: `pixels` 64-bit visibility words (main draw) or 32-bit ones (depth_only).
 static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s, VctRasterArgs& a) {
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "no triangles uploaded");
+    const int k = depth_only ? 0 : 1;
     if (depth_only ? c->vis32_words < pixels : c->vis_words < pixels) {
         if (depth_only) {
             if (c->vis32) { (void)hipFree(c->vis32); c->vis32 = nullptr; c->vis32_words = 0; }
@@ -631,23 +634,23 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
             HIP_TRY(c, hipMalloc(&c->vis, pixels * sizeof(unsigned long long)));
             c->vis_words = pixels;
         }
-        c->raster_dirty = true;
+        c->raster_dirty[k] = true;
     }
-    if (!c->raster_lists) HIP_TRY(c, hipMalloc(&c->raster_lists, (size_t)c->ntri * 4 * sizeof(int32_t)));
-    if (!c->raster_counts) { HIP_TRY(c, hipMalloc(&c->raster_counts, 8 * sizeof(uint32_t))); c->raster_dirty = true; }
+    if (!c->raster_lists[k]) HIP_TRY(c, hipMalloc(&c->raster_lists[k], (size_t)c->ntri * 4 * sizeof(int32_t)));
+    if (!c->raster_counts[k]) { HIP_TRY(c, hipMalloc(&c->raster_counts[k], 8 * sizeof(uint32_t))); c->raster_dirty[k] = true; }
     // tile work items: 16x16-pixel pieces of large triangles; pixels/16 entries is ~16x the typical
     // demand (sum of visible bounding boxes ~ a few frames' worth of pixels); overflow is handled
     const size_t want_items = pixels / 16 + 4096;
-    if (c->raster_item_capacity < want_items) {
-        if (c->raster_items) { (void)hipFree(c->raster_items); c->raster_items = nullptr; }
-        HIP_TRY(c, hipMalloc(&c->raster_items, want_items * sizeof(uint2)));
-        c->raster_item_capacity = (uint32_t)want_items;
+    if (c->raster_item_capacity[k] < want_items) {
+        if (c->raster_items[k]) { (void)hipFree(c->raster_items[k]); c->raster_items[k] = nullptr; }
+        HIP_TRY(c, hipMalloc(&c->raster_items[k], want_items * sizeof(uint2)));
+        c->raster_item_capacity[k] = (uint32_t)want_items;
     }
-    if (c->raster_dirty) {      // first pass, resized buffers, or a pass that failed half way: clear everything once
-        if (c->vis) HIP_TRY(c, hipMemsetAsync(c->vis, 0xff, c->vis_words * sizeof(unsigned long long), s));
-        if (c->vis32) HIP_TRY(c, hipMemsetAsync(c->vis32, 0xff, c->vis32_words * sizeof(uint32_t), s));
-        HIP_TRY(c, hipMemsetAsync(c->raster_counts, 0, 8 * sizeof(uint32_t), s));
-        c->raster_dirty = false;
+    if (c->raster_dirty[k]) {   // first pass, resized buffers, or a pass that failed half way: clear this kind's state once
+        if (depth_only) HIP_TRY(c, hipMemsetAsync(c->vis32, 0xff, c->vis32_words * sizeof(uint32_t), s));
+        else HIP_TRY(c, hipMemsetAsync(c->vis, 0xff, c->vis_words * sizeof(unsigned long long), s));
+        HIP_TRY(c, hipMemsetAsync(c->raster_counts[k], 0, 8 * sizeof(uint32_t), s));
+        c->raster_dirty[k] = false;
     }
     memset(&a, 0, sizeof(a));
     a.pos = c->tri_pos;
@@ -659,16 +662,16 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
     a.model_scale = c->cfg.model_scale;
     a.vis = c->vis;
     a.vis32 = c->vis32;
-    a.items = c->raster_items;
-    uint32_t* cur = c->raster_counts + 4 * c->raster_set;
+    a.items = c->raster_items[k];
+    uint32_t* cur = c->raster_counts[k] + 4 * c->raster_set[k];
     a.item_count = cur;
-    a.wave_list = c->raster_lists;
+    a.wave_list = c->raster_lists[k];
     a.wave_count = cur + 1;
-    a.group_list = c->raster_lists + (size_t)c->ntri * 2;
+    a.group_list = c->raster_lists[k] + (size_t)c->ntri * 2;
     a.group_count = cur + 2;
-    a.next_counts = c->raster_counts + 4 * (c->raster_set ^ 1);
-    c->raster_set ^= 1;
-    a.item_capacity = c->raster_item_capacity;
+    a.next_counts = c->raster_counts[k] + 4 * (c->raster_set[k] ^ 1);
+    c->raster_set[k] ^= 1;
+    a.item_capacity = c->raster_item_capacity[k];
     a.tex = textures_of(c);
     return VCT_OK;
 }
@@ -766,7 +769,7 @@ int vct_render_shadow_map(vct_ctx* c, const float light_vp[16]) {
     c->shadow_size = S;
     memcpy(c->light_vp, light_vp, 64);
     const hipError_t e = vct_launch_shadow_raster(a, light_vp, S, c->shadow, c->stream);
-    if (e != hipSuccess) { c->raster_dirty = true; HIP_TRY(c, e); }
+    if (e != hipSuccess) { c->raster_dirty[0] = true; HIP_TRY(c, e); }
     return VCT_OK;
 }
 
@@ -779,7 +782,10 @@ int vct_download_shadow_map(vct_ctx* c, float* depth) {
     return VCT_OK;
 }
 
-static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t row0, int32_t row1, hipStream_t s) {
+// `shadow_ready`: when not null the visibility raster is issued at once and only the shading kernel (which reads the
+// shadow map) waits for that event -- vct_gi_pass rasterises the main draw's visibility beside the shadow pass.
+static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t row0, int32_t row1, hipStream_t s,
+                                  hipEvent_t shadow_ready = nullptr) {
     if (!view_proj) return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer: null matrix");
     if (!c->tri_nrm) return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer: call vct_upload_mesh_attributes first");
     if (row0 < 0 || row1 > tiles_y(c) || row0 > row1)
@@ -788,9 +794,12 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     VctRasterArgs a;
     int rc = raster_args(c, (size_t)c->cfg.width * c->cfg.height, false, s, a);
     if (rc) return rc;
-    const hipError_t e = vct_launch_gbuffer_raster(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow,
-                                                   c->shadow_size, c->light_vp, c->gb_tiled, s);
-    if (e != hipSuccess) { c->raster_dirty = true; HIP_TRY(c, e); }
+    hipError_t e = vct_launch_gbuffer_visibility(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, s);
+    if (e == hipSuccess && shadow_ready) e = hipStreamWaitEvent(s, shadow_ready, 0);
+    if (e == hipSuccess)
+        e = vct_launch_gbuffer_shade(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow, c->shadow_size,
+                                     c->light_vp, c->gb_tiled, s);
+    if (e != hipSuccess) { c->raster_dirty[1] = true; HIP_TRY(c, e); }
     c->gb_current = c->gb_tiled;
     c->last_row0 = row0;
     c->last_row1 = row1;
@@ -1143,18 +1152,22 @@ int vct_trace_resident(vct_ctx* c) {
 int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16], int32_t mode) {
     if (!c) return VCT_ERR_INVALID;
     if (!light_vp || !view_proj) return fail(c, VCT_ERR_INVALID, "vct_gi_pass: null matrix");
+    if (c->cfg.shadow_map_size <= 0) return fail(c, VCT_ERR_INVALID, "vct_gi_pass: config.shadow_map_size <= 0");
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->aux_stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_shadow, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
-    int rc = vct_render_shadow_map(c, light_vp);
-    if (rc) return rc;
-    // fork: the G-buffer raster needs the shadow map (PCF term) and nothing of the voxel stages
-    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+    // fork at once: the main draw's VISIBILITY raster needs nothing of this pass (it has its own lists and words);
+    // only its shading kernel reads the shadow map (PCF term), so that alone waits for the shadow pass
+    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));                 // everything issued before this call is done
     HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-    rc = render_gbuffer_rows_on(c, view_proj, 0, tiles_y(c), c->aux_stream);
+    int rc = vct_render_shadow_map(c, light_vp);                       // allocates / sizes the shadow map first
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_shadow, c->stream));
+    rc = render_gbuffer_rows_on(c, view_proj, 0, tiles_y(c), c->aux_stream, c->ev_shadow);
     // join before anything else can fail: later work on the context's stream must see the G-buffer
     const hipError_t ej = hipEventRecord(c->ev_join, c->aux_stream);
     if (rc == VCT_OK) rc = vct_voxelize(c, mode);

@@ -74,15 +74,17 @@ struct vct_ctx {
     size_t vis_words = 0;
     uint32_t* vis32 = nullptr;                // 32-bit depth-only words of the shadow pass
     size_t vis32_words = 0;
-    int32_t* raster_lists = nullptr;          // [2*ntri] wave list, [2*ntri] group list
-    uint32_t* raster_counts = nullptr;        // two sets of [tile work items, wave list, group list, pad]
-    int raster_set = 0;                       // the set the next pass uses
-    bool raster_dirty = true;
-    uint2* raster_items = nullptr;
-    uint32_t raster_item_capacity = 0;
+    // lists / counters / tile items exist twice, [0] for the shadow pass and [1] for the main draw, so that the main
+    // draw's visibility raster can run on the second stream WHILE the shadow map is rasterised (vct_gi_pass)
+    int32_t* raster_lists[2] = {nullptr, nullptr};     // [2*ntri] wave list, [2*ntri] group list
+    uint32_t* raster_counts[2] = {nullptr, nullptr};   // two sets of [tile work items, wave list, group list, pad]
+    int raster_set[2] = {0, 0};                        // the counter set the next pass of that kind uses
+    bool raster_dirty[2] = {true, true};
+    uint2* raster_items[2] = {nullptr, nullptr};
+    uint32_t raster_item_capacity[2] = {0, 0};
     // second stream: vct_gi_pass runs the G-buffer raster beside the voxel stages
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_shadow = nullptr, ev_join = nullptr;
     float light_vp[16];
     unsigned long long* acc = nullptr;         // accumulator pool [nslots][512][2] (one slot per brick the mesh can touch)
     uint32_t* brick_slot = nullptr;            // [V^3/512] brick -> slot or VCT_NO_SLOT

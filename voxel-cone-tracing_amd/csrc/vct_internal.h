@@ -195,10 +195,13 @@ struct VctRasterArgs {
 
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
                                     hipStream_t s);
-// tile rows [row0, row1) only (whole frame: 0 .. ceil(H/8))
-hipError_t vct_launch_gbuffer_raster(const VctRasterArgs& a, const float view_proj[16], int W, int H,
-                                     int row0, int row1, const float* shadow, int shadow_size,
-                                     const float light_vp[16], float* tiled, hipStream_t s);
+// tile rows [row0, row1) only (whole frame: 0 .. ceil(H/8)); visibility (k_raster_vis + k_raster_mid) and shading
+// (k_gbuffer_shade, the only part that reads the shadow map) are separate calls so that a stream wait can sit between
+hipError_t vct_launch_gbuffer_visibility(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
+                                         hipStream_t s);
+hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
+                                    const float* shadow, int shadow_size, const float light_vp[16], float* tiled,
+                                    hipStream_t s);
 hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s);
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s);

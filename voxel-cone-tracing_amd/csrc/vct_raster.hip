@@ -756,16 +756,25 @@ hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp
     return hipGetLastError();
 }
 
-hipError_t vct_launch_gbuffer_raster(const VctRasterArgs& a, const float view_proj[16], int W, int H,
-                                     int row0, int row1, const float* shadow, int shadow_size,
-                                     const float light_vp[16], float* tiled, hipStream_t s) {
+static ShadeParams make_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1) {
     ShadeParams p;
     p.r = make_raster(a, view_proj, W, H, row0 * VCT_TILE, row1 * VCT_TILE);
     p.r.material = a.material;        // main draw: alpha test before the depth write (trace.fs:169-172)
     p.r.albedo = a.albedo;
     p.r.tex = a.tex;
-    hipError_t e = run_visibility(p.r, s);
-    if (e != hipSuccess) return e;
+    return p;
+}
+
+hipError_t vct_launch_gbuffer_visibility(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
+                                         hipStream_t s) {
+    const ShadeParams p = make_shade(a, view_proj, W, H, row0, row1);
+    return run_visibility(p.r, s);
+}
+
+hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
+                                    const float* shadow, int shadow_size, const float light_vp[16], float* tiled,
+                                    hipStream_t s) {
+    ShadeParams p = make_shade(a, view_proj, W, H, row0, row1);
     p.nrm = a.nrm; p.tan = a.tan; p.bit = a.bit;
     p.material = a.material; p.albedo = a.albedo; p.specular = a.specular;
     p.shadow = shadow; p.shadow_size = shadow_size;
