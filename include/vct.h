@@ -216,7 +216,8 @@ int vct_trace_resident_rows(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
  * the G-buffer stage runs on a second HIP stream beside the shadow pass and the voxel stages (none of them fills the
  * GPU on its own; the two raster passes have their own work lists); the trace waits for both.  The
  * frame is bit-identical to vct_render_shadow_map, vct_voxelize, vct_inject_light, vct_build_mips,
- * vct_render_gbuffer, vct_trace_resident called in that order.  Asynchronous (vct_synchronize). */
+ * vct_render_gbuffer, vct_trace_resident called in that order.  Asynchronous (vct_synchronize).  Single-GPU contexts
+ * only (VCT_ERR_INVALID after vct_comm_init: a rank issues the stages and vct_render_gbuffer_rows + vct_frame_step). */
 int vct_gi_pass(vct_ctx* ctx, const float light_vp[16], const float view_proj[16], int32_t voxelize_mode);
 /* Redirect the trace kernel's RGBA16F output to caller-owned HBM (full-frame addressing: pixel (x,y)
  * at ((y*width + x) * 4) halves from `rgba16f_dev`); NULL restores the context-owned frame.  A slab

@@ -1153,6 +1153,9 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
     if (!c) return VCT_ERR_INVALID;
     if (!light_vp || !view_proj) return fail(c, VCT_ERR_INVALID, "vct_gi_pass: null matrix");
     if (c->cfg.shadow_map_size <= 0) return fail(c, VCT_ERR_INVALID, "vct_gi_pass: config.shadow_map_size <= 0");
+    if (c->comm)        // a rank of a multi-GPU frame rasterises and traces its slab only and ends the frame with the gather
+        return fail(c, VCT_ERR_INVALID, "vct_gi_pass: this context is a rank of a multi-GPU frame; issue the stages and "
+                                        "vct_render_gbuffer_rows + vct_frame_step instead");
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->aux_stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
