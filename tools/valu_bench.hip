@@ -100,6 +100,43 @@ __global__ void __launch_bounds__(256) k_pk_mul(float* out, int iters) {
     if (s.x + s.y == 12345.678f) out[2] = s.x;
 }
 
+// scalar ALU: 8 independent SGPR chains per block (is the scalar unit a co-bottleneck of a kernel with half as
+// many SALU as VALU instructions?)
+#define SKERNEL(name, ASMSTR)                                                                  \
+    __global__ void __launch_bounds__(256) k_##name(float* out, int iters) {                   \
+        int a0 = iters, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4,                    \
+            a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;                                             \
+        const int b = iters | 3;                                                               \
+        for (int i = 0; i < iters; ++i) {                                                      \
+            REP16(asm volatile(ASMSTR : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3), "+s"(a4),      \
+                               "+s"(a5), "+s"(a6), "+s"(a7) : "s"(b) : "scc");)                \
+        }                                                                                      \
+        if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 123456789) out[2] = 1.0f;                 \
+    }
+#define SOP8(fmt) fmt("%0") fmt("%1") fmt("%2") fmt("%3") fmt("%4") fmt("%5") fmt("%6") fmt("%7")
+#define SADD(r) "s_add_i32 " r ", " r ", %8\n"
+#define SAND(r) "s_and_b32 " r ", " r ", %8\n"
+#define SMUL(r) "s_mul_i32 " r ", " r ", %8\n"
+#define SLSHL(r) "s_lshl_b32 " r ", " r ", 1\n"
+SKERNEL(s_add, SOP8(SADD))
+SKERNEL(s_and, SOP8(SAND))
+SKERNEL(s_mul, SOP8(SMUL))
+SKERNEL(s_lshl, SOP8(SLSHL))
+// two VALU + one SALU interleaved: does the scalar instruction cost VALU issue time?
+__global__ void __launch_bounds__(256) k_mix21(float* out, int iters) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    float b = out[0], c = out[1];
+    int s0 = iters, s1 = s0 + 1;
+    const int sb = iters | 3;
+    for (int i = 0; i < iters; ++i) {
+        REP16(asm volatile("v_fma_f32 %0, %0, %6, %7\nv_fma_f32 %1, %1, %6, %7\ns_add_i32 %4, %4, %8\n"
+                           "v_fma_f32 %2, %2, %6, %7\nv_fma_f32 %3, %3, %6, %7\ns_and_b32 %5, %5, %8\n"
+                           "v_fma_f32 %0, %0, %6, %7\nv_fma_f32 %1, %1, %6, %7\n"
+                           : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1) : "v"(b), "v"(c), "s"(sb) : "scc");)
+    }
+    if (a0 + a1 + a2 + a3 == 12345.678f || s0 + s1 == 123456789) out[2] = a0;
+}
+
 template <typename K>
 static void run(const char* name, K kern, float* d, int waves_per_simd) {
     const int iters = 2000;
@@ -125,9 +162,12 @@ int main() {
     float* d;
     hipMalloc(&d, 1024);
     hipMemset(d, 0, 1024);
-#define RUN(n) run(#n, k_##n, d, 1); run(#n, k_##n, d, 4);
+#define RUN(n) run(#n, k_##n, d, 1); run(#n, k_##n, d, 4); run(#n, k_##n, d, 8);
     RUN(fma) RUN(pk_fma) RUN(mul) RUN(pk_mul) RUN(add) RUN(cvt_ubyte) RUN(cvt_i32) RUN(floor) RUN(fract)
     RUN(rcp) RUN(and) RUN(lshl_or) RUN(and_or) RUN(add3) RUN(or3) RUN(bfe) RUN(perm) RUN(mad24)
     RUN(mul_lo) RUN(cvt_pkrtz) RUN(ldexp) RUN(div_fixup) RUN(med3) RUN(max) RUN(cndmask) RUN(dot4)
+    RUN(s_add) RUN(s_and) RUN(s_mul) RUN(s_lshl)
+    // mix21: 6 VALU + 2 SALU per block of 8: printed per instruction of the 8
+    RUN(mix21)
     return 0;
 }

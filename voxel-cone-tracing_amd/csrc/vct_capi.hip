@@ -207,6 +207,7 @@ void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chai
     p.fast_div = c->fast_div ? 1 : 0;
     p.max_alpha = c->cfg.max_alpha;
     p.wrap_repeat = c->cfg.wrap_repeat;
+    p.spread_lut = c->spread_lut;
     p.steps_diffuse = c->steps_dev;
     p.steps_specular = c->steps_dev + VCT_MAX_STEPS;
     p.n_diffuse = c->n_diffuse;
@@ -478,6 +479,12 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     CREATE_TRY(hipMalloc(&c->stats, 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
     CREATE_TRY(hipMalloc(&c->steps_dev, 2 * VCT_MAX_STEPS * sizeof(VctStep)));
+    {
+        std::vector<uint32_t> lut(1024);
+        for (uint32_t i = 0; i < 1024u; ++i) lut[i] = vct_spread3(i) << 2;
+        CREATE_TRY(hipMalloc(&c->spread_lut, lut.size() * sizeof(uint32_t)));
+        CREATE_TRY(hipMemcpy(c->spread_lut, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (cfg->debug_outputs) {
         CREATE_TRY(hipMalloc(&c->dbg_steps, npix * 7));
         CREATE_TRY(hipMalloc(&c->dbg_cones, npix * 28 * sizeof(float)));
@@ -499,7 +506,7 @@ void vct_destroy(vct_ctx* c) {
     vct_comm_release(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
-                    c->dbg_cones, c->step_counter, c->stats, c->steps_dev, c->tri_pos,
+                    c->dbg_cones, c->step_counter, c->stats, c->steps_dev, c->spread_lut, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->big_list, c->worklist, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->vis32, c->raster_lists[0], c->raster_lists[1],

@@ -39,6 +39,7 @@ struct vct_ctx {
     int step_set = 0;                              // set written by the last launch
     unsigned long long* stats = nullptr;      // [8] march statistics of instrumented builds (VCT_STATS)
     VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
+    uint32_t* spread_lut = nullptr;   // [1024] spread3(i) << 2 (vct_trace.hip: dilated anchor coordinates by scalar load)
     int n_diffuse = 0, n_specular = 0;
     bool steps_dirty = true;
     bool fast_div = false;            // set by refresh_steps: constant divisors admit the FMA division

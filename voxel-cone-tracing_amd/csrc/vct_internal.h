@@ -107,6 +107,7 @@ struct VctTraceParams {
     float light[3];
     float ambient, shininess, max_alpha;
     int32_t wrap_repeat;
+    const uint32_t* spread_lut;         // [1024] spread3(i) << 2: dilated byte offsets of an x coordinate (scalar loads)
     const VctStep* steps_diffuse;
     const VctStep* steps_specular;
     int32_t n_diffuse, n_specular;

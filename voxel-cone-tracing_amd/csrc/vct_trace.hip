@@ -106,7 +106,21 @@ __device__ __forceinline__ unsigned long long ballot64(bool pred) {
     return __builtin_amdgcn_ballot_w64(pred);
 }
 
+// Dilated anchor coordinates come from a table: computing spread3() of three scalars took 41 scalar-unit instructions
+// per level sample, and the scalar pipe issues one instruction per 4 cycles per SIMD (tools/valu_bench.hip: s_add /
+// s_and / s_mul 4.17 cycles at any occupancy) -- with half as many SALU as VALU instructions it was 68 % busy, and a
+// padding experiment showed the march paying 2.1 us per scalar instruction added to a step against 1.4 us per vector
+// one.  One s_load_dword per axis replaces 13 instructions.  Entry i = spread3(i) << 2 (byte offset of the x axis).
+typedef const __attribute__((address_space(4))) uint32_t* SpreadLut;
+// byte offset of x coordinate (a & m) in dilated form; m4 = m << 2.  All 32-bit, so the table entry is one
+// s_load_dword with an SGPR offset.
+__device__ __forceinline__ uint32_t spread_byte(SpreadLut lut, int a, uint32_t m4) {
+    const uint32_t off = ((uint32_t)a << 2) & m4;
+    return *(SpreadLut)((const __attribute__((address_space(4))) char*)lut + off);
+}
+
 struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
+    SpreadLut lut;              // (wave-uniform) the dilated-coordinate table
     int lane;
     uint32_t sbx, sby, sbz;     // BYTE offsets: 4 * dilated (l&3), ((l>>2)&3)<<1, (l>>4)<<2
 };
@@ -169,9 +183,10 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         uint32_t idx;
         if (WRAP) {
             // scalar unit: dilate the anchor; vector unit: one dilated add per axis
-            const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)m) << 2;
-            const uint32_t say = vct_spread3((uint32_t)ay & (uint32_t)m) << 3;
-            const uint32_t saz = vct_spread3((uint32_t)az & (uint32_t)m) << 4;
+            const uint32_t m4 = (uint32_t)m << 2;
+            const uint32_t sax = spread_byte(lb.lut, ax, m4);
+            const uint32_t say = spread_byte(lb.lut, ay, m4) << 1;
+            const uint32_t saz = spread_byte(lb.lut, az, m4) << 2;
             idx = (((sax | ~MX) + lb.sbx) & MX) | (((say | ~MY) + lb.sby) & MY) |
                   (((saz | ~MZ) + lb.sbz) & MZ);
         } else {
@@ -336,9 +351,11 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
         if ((ballot64(far > 2u) & m) == 0ull) {
             done = true;
             const uint32_t MX = lv.mask_x << 2, MY = MX << 1, MZ = MX << 2;      // byte offsets, as in sample_level
-            const uint32_t sax = vct_spread3((uint32_t)ax & (uint32_t)mm) << 2;
-            const uint32_t say = vct_spread3((uint32_t)ay & (uint32_t)mm) << 3;
-            const uint32_t saz = vct_spread3((uint32_t)az & (uint32_t)mm) << 4;
+            const uint32_t m4 = (uint32_t)mm << 2;
+            const SpreadLut lut = (SpreadLut)p.spread_lut;
+            const uint32_t sax = spread_byte(lut, ax, m4);
+            const uint32_t say = spread_byte(lut, ay, m4) << 1;
+            const uint32_t saz = spread_byte(lut, az, m4) << 2;
             const uint32_t idx = (((sax | ~MX) + lb.sbx) & MX) | (((say | ~MY) + lb.sby) & MY) |
                                  (((saz | ~MZ) + lb.sbz) & MZ);
             const unsigned long long mneg[3] = {mx, my, mz};
@@ -558,6 +575,7 @@ k_trace_tile(const VctTraceParams p) {
 
     LaneBlock lb;
     lb.lane = lane;
+    lb.lut = (SpreadLut)p.spread_lut;
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
     lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;
     lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
@@ -725,6 +743,7 @@ k_trace_tile_split(const VctTraceParams p) {
 
     LaneBlock lb;
     lb.lane = lane;
+    lb.lut = (SpreadLut)p.spread_lut;
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
     lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;
     lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
@@ -931,6 +950,7 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
     float4* blk = &lds_blk[wave][0][0];                                      \
     LaneBlock lb;                                                            \
     lb.lane = lane;                                                          \
+    lb.lut = (SpreadLut)p.spread_lut;                                        \
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;                          \
     lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;                   \
     lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;                          \
