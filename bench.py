@@ -448,6 +448,7 @@ def pmc_profile(args, world):
             m = json.load(fh)
         if m.get("kernel_source_sha16") == sha:
             t["model_issue_cycles_per_valu_instr"] = m.get("model_issue_cycles_per_valu_instr")
+            t["salu_issue_cycles_per_instr"] = m.get("salu_issue_cycles_per_instr")
     return t
 
 
@@ -481,6 +482,11 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
         cyc, gpu_cyc = prof.get("model_issue_cycles_per_valu_instr"), prof.get("gpu_cycles_per_launch")
         if cyc and gpu_cyc:
             r["valu_pipe_busy_model"] = round(valu * cyc / 1024.0 / gpu_cyc, 3)
+        # the scalar pipe issues one instruction per 4 cycles per SIMD (tools/valu_bench.hip); half as many scalar as
+        # vector instructions made it the hidden second bound of this kernel until the anchor spread became a table
+        scyc, salu = prof.get("salu_issue_cycles_per_instr"), wi.get("salu")
+        if scyc and salu and gpu_cyc:
+            r["salu_pipe_busy_model"] = round(salu * scyc / 1024.0 / gpu_cyc, 3)
     hbm = prof.get("hbm_bytes_per_launch")
     if hbm:
         r["traffic"] = round(hbm / (kernel_ms * 1e-3) / 1e9, 1)

@@ -11,7 +11,7 @@ k_trace_tile_split<true,true,false> (the diffuse loop has the same body), splits
   l2head    level-2 coordinates, anchor, coverage test
   tail      level blend + front-to-back composite
 and prices every VALU instruction with the issue cost MEASURED for its class on this GPU
-(tools/valu_bench.hip at 4 waves per SIMD, gpurun_out/valu_bench.txt; classes it does not cover are priced as
+(tools/valu_bench.hip at 8 waves per SIMD, gpurun_out/valu_bench.txt; classes it does not cover are priced as
 4-cycle ops).  The segments are weighted with the measured path frequencies (profiles/r02i_trace_stats.json:
 cooperative gather / empty block / per-lane = 75.5 / 10.9 / 13.7 % of the level samples).
 
@@ -30,8 +30,11 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-COST = {"fma": 2.75, "mul": 2.49, "add": 2.48, "logic2": 2.39, "cvt": 4.2, "floor": 4.24, "int3": 4.27, "max": 4.22,
-        "cndmask": 2.5, "readlane": 4.2, "cmp": 2.5, "mov": 2.4, "mul_lo": 4.26, "other": 4.2}
+# tools/valu_bench.hip at 8 waves per SIMD (the march runs at 7), x 0.96: the bench prints cycles for an assumed
+# 2.4 GHz and its scalar-ALU lines (one instruction per 4 cycles per SIMD by construction) read 4.17
+COST = {"fma": 2.42, "mul": 2.20, "add": 2.18, "logic2": 2.25, "cvt": 3.95, "floor": 3.95, "int3": 4.0, "max": 3.96,
+        "cndmask": 2.4, "readlane": 4.0, "cmp": 2.4, "mov": 2.3, "mul_lo": 4.0, "other": 4.0}
+SALU_CYCLES = 4.0       # s_add / s_and / s_mul / s_lshl: 4.17 "cycles @2.4 GHz" at 1, 4 and 8 waves per SIMD
 P_HIT, P_ZERO, P_FALLBACK = 0.7546, 0.1087, 0.1367
 
 
@@ -124,6 +127,10 @@ def main():
         res["valu_per_wave_step_pmc"] = round(measured, 1)
         res["pipe_busy_model"] = round(t["wave_instructions_per_launch"]["valu"] * res["model_issue_cycles_per_valu_instr"]
                                        / 1024.0 / t["gpu_cycles_per_launch"], 3)
+        # the scalar pipe: one instruction per 4 cycles per SIMD (measured), SALU + SMEM instructions of the launch
+        res["salu_issue_cycles_per_instr"] = SALU_CYCLES
+        res["salu_pipe_busy_model"] = round(t["wave_instructions_per_launch"]["salu"] * SALU_CYCLES
+                                            / 1024.0 / t["gpu_cycles_per_launch"], 3)
         ok = abs(measured - n_step) / measured < 0.08
     else:
         ok = False
