@@ -85,9 +85,13 @@ def main():
     sized = [(price(b), b) for b in blocks]
     big = sorted(((n, c), i) for i, ((n, c), b) in enumerate(sized) if n >= 60)
     # by construction: two per-lane blocks (~190 VALU) and two cooperative blocks (~70 VALU), one pair per level
-    fb = [x for x in big if x[0][0] > 150]
-    coop = [x for x in big if 60 <= x[0][0] <= 150]
-    assert len(fb) == 2 and len(coop) == 2, [x[0] for x in big]
+    fb = sorted((x for x in big if x[0][0] > 150), key=lambda x: x[1])
+    coop = sorted((x for x in big if 60 <= x[0][0] <= 150), key=lambda x: x[1])
+    # the march is unrolled by two (VCT_UNROLL2): two identical steps per loop body -- model the first
+    assert len(fb) in (2, 4) and len(coop) == len(fb), [x[0] for x in big]
+    unrolled = len(fb) == 4
+    fb, coop = fb[:2], coop[:2]
+    big = sorted(fb + coop)
     n_fb, c_fb = fb[0][0]
     n_coop, c_coop = coop[0][0]
     # the cooperative path starts in the block before (Morton offset, load, all-zero test): that prefix alone is the
@@ -102,7 +106,11 @@ def main():
     l2 = sorted(i for _, i in big)[2:]
     mid = [ln for (_, b) in sized[max(l1) + 1:min(l2)] for ln in b]
     n_mid_all, c_mid_all = price(mid)
-    tail = [ln for (_, b) in sized[max(l2) + 1:] for ln in b]
+    rest = sized[max(l2) + 1:]
+    if unrolled:        # the first step ends where the second one's head (position + coordinates, >= 30 VALU) begins
+        cut = next(i for i, ((n, _), _) in enumerate(rest) if n >= 30)
+        rest = rest[:cut]
+    tail = [ln for (_, b) in rest for ln in b]
     n_tail_all, c_tail_all = price(tail)
     # blocks between / after the samples also hold the zero-block paths (4 v_mov each): they are priced in full,
     # which overstates l2head / tail by a few instructions

@@ -442,6 +442,40 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
     return s;
 }
 
+// One march step with the table entry `st`; `live` = ballot of the lanes still marching.  A macro, not a lambda: the
+// plain loop of the anisotropic march must compile exactly as it did before the unrolled form existed (a lambda cost it 7 %).
+//   position: trace.fs:98 + :61-63  (q * 0.5f is exact, so fmaf(q, .5, .5) is the oracle's q*.5f + .5f; a coordinate below
+//             div_const's 2^-100 domain gives |q| < 2^-26 and u = 0.5 either way)
+//   sample:   textureLod = blend of the two levels (frac == 0: one level, decided in the table)
+//   composite: trace.fs:100 (colour), :101 (occlusion), :102 (alpha), front to back
+#define VCT_MARCH_STEP(st, act, live)                                                                        \
+        const float px = start.x + dir.x * st.dist; \
+        const float py = start.y + dir.y * st.dist; \
+        const float pz = start.z + dir.z * st.dist; \
+        const float ux = fmaf(div_const<FASTDIV>(px, p.half_G, p.half_G_rcp), 0.5f, 0.5f); \
+        const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f); \
+        const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f); \
+        F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, live, blk, lb, ac, ms) \
+                                         : sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms); \
+        if (st.two_levels) { \
+            const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, live, blk + 64, lb, ac, ms) \
+                                : sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms); \
+            const float g = 1.0f - st.frac; \
+            vc.x = fmaf(st.frac, t2.x, g * vc.x); \
+            vc.y = fmaf(st.frac, t2.y, g * vc.y); \
+            vc.z = fmaf(st.frac, t2.z, g * vc.z); \
+            vc.w = fmaf(st.frac, t2.w, g * vc.w); \
+        } \
+        if (act) { \
+            const float oma = 1.0f - alpha; \
+            cr = fmaf(oma, vc.x, cr); \
+            cg = fmaf(oma, vc.y, cg); \
+            cb = fmaf(oma, vc.z, cb); \
+            occ = occ + div_const<FASTDIV>(oma * vc.w, st.occ_den, st.occ_rcp); \
+            alpha = fmaf(oma, vc.w, alpha); \
+            ++steps; \
+        }
+
 template <bool WRAP, bool FASTDIV, bool COOP, bool ANISO = false>
 __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3 start, F3 dir,
                                          const VctStep* tab_global, int n,
@@ -456,41 +490,13 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
         ac.nx = !(dir.x >= 0.0f); ac.ny = !(dir.y >= 0.0f); ac.nz = !(dir.z >= 0.0f);
     }
     const unsigned long long alive_mask = ballot64(alive);
-    // one march step with the table entry `st`; `live` = ballot of the lanes still marching
-    auto march_step = [&](const VctStep& st, const bool act, const unsigned long long live) {
-        // trace.fs:98 + :61-63.  (q * 0.5f is exact, so fmaf(q, .5, .5) is the oracle's q*.5f + .5f;
-        // a coordinate below div_const's 2^-100 domain gives |q| < 2^-26 and u = 0.5 either way.)
-        const float px = start.x + dir.x * st.dist;
-        const float py = start.y + dir.y * st.dist;
-        const float pz = start.z + dir.z * st.dist;
-        const float ux = fmaf(div_const<FASTDIV>(px, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f);
-        F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, live, blk, lb, ac, ms)
-                                         : sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms);
-        if (st.two_levels) {
-            const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, live, blk + 64, lb, ac, ms)
-                                : sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms);
-            const float g = 1.0f - st.frac;
-            vc.x = fmaf(st.frac, t2.x, g * vc.x);
-            vc.y = fmaf(st.frac, t2.y, g * vc.y);
-            vc.z = fmaf(st.frac, t2.z, g * vc.z);
-            vc.w = fmaf(st.frac, t2.w, g * vc.w);
-        }
-        if (act) {
-            const float oma = 1.0f - alpha;
-            cr = fmaf(oma, vc.x, cr);                                                  // :100
-            cg = fmaf(oma, vc.y, cg);
-            cb = fmaf(oma, vc.z, cb);
-            occ = occ + div_const<FASTDIV>(oma * vc.w, st.occ_den, st.occ_rcp);        // :101
-            alpha = fmaf(oma, vc.w, alpha);                                            // :102
-            ++steps;
-        }
-    };
-#if VCT_UNROLL2
-    // Two steps per loop iteration, the table entries ping-pong between two register sets: the entry of step k + 1 is
+    if constexpr (VCT_UNROLL2 && !ANISO) {
+    // Two steps per loop iteration (not the anisotropic march: its body, twice, spills and ran 7x slower), the table entries ping-pong between two register sets: the entry of step k + 1 is
     // requested while step k is marched and is never copied (the rotating form below moves 12 SGPRs per step, and
     // the scalar pipe is the march's second bound).
+    // (the step body goes through a lambda here: measured 2 % faster than the macro expanded in place, while the
+    // plain loop below wants the macro expanded in place -- register allocation differs, the instructions do not)
+    auto march_step = [&](const VctStep& st, const bool act, const unsigned long long live) { VCT_MARCH_STEP(st, act, live) };
     VctStep ea = load_step(tab, 0), eb = ea;
     for (int k = 0; k < n;) {
         {
@@ -512,7 +518,7 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
             ++k;
         }
     }
-#else
+    } else {
     VctStep nxt = load_step(tab, 0);
     for (int k = 0; k < n; ++k) {
         const bool act = alive && (alpha < p.max_alpha);     // trace.fs:94 (dist < MAX: table)
@@ -521,9 +527,9 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
         if (VCT_STATS) { ++ms.wave_steps; ms.lane_steps += (uint32_t)__popcll(live); }
         const VctStep st = nxt;
         nxt = load_step(tab, k + 1 < n ? k + 1 : k);
-        march_step(st, act, live);
+        VCT_MARCH_STEP(st, act, live)
     }
-#endif
+    }
     steps_out = steps;
     return {cr, cg, cb, occ};
 }
