@@ -9,14 +9,15 @@
 //               shadow term with its 0.111 scale (:132-163).  Output: the tiled 23-plane G-buffer
 //               k_trace_tile reads, written in place -- a frame never leaves HBM.
 //
-// Rasterisation rules are those of the CPU rasteriser in host/vct_host.cpp (the checker of these
+// Rasterisation rules are those of the CPU rasteriser in oracle/vct_oracle_raster.cpp (the checker of these
 // stages): near-plane clip, window coordinates snapped to 1/256 pixel, edge functions in double
 // (exact with snapped inputs, so shared edges are watertight), pixel-centre sampling, top-left
 // rule, CCW front faces.  Visibility is order-independent here: one 64-bit atomicMin per covered
 // pixel on (depth bits << 32 | triangle id * 2 + sub-triangle) -- the nearest fragment wins and ties
 // go to the earliest triangle, which is what "depth test LESS in submission order" produces.  The
 // shading pass then re-derives the winning fragment from its triangle; nothing per-fragment is
-// stored besides the 8-byte visibility word.
+// stored besides the 8-byte visibility word (4 bytes of depth in the shadow pass).  A pass is two dependent launches
+// (k_raster_vis, k_raster_mid) and no clear: consumers reset the words they read, the counters alternate.
 #include <string.h>
 
 #include "vct_internal.h"
@@ -200,7 +201,7 @@ __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVer
 #define VCT_RASTER_SMALL 16      // <= this many pixels: rasterised inline by the triangle's own thread
 #define VCT_RASTER_GROUP 256     // <= this many: a 16-lane group (4 sub-triangles per wave), lanes stride the box
 #define VCT_RASTER_WAVE 4096     // <= this many: one wave, lanes stride the bounding box
-#define VCT_RTILE 16             // larger: cut into 16x16-pixel work items by a workgroup
+#define VCT_RTILE 16             // larger: cut into 16x16-pixel work items by the wave that met the triangle
 
 // Decides how fragments of triangle t are alpha-tested and, for the per-fragment case, loads the texture
 // coordinates of the sub-triangle's three vertices (fan == null: the unclipped triangle; otherwise the vertices
