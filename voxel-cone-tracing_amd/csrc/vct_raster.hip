@@ -486,7 +486,7 @@ __device__ __forceinline__ float shadow_fetch(const float* __restrict__ depth, i
 
 // one thread per pixel, 64 threads = one 8x8 tile of the tiled G-buffer
 #ifndef VCT_SHADE_MIN_BLOCKS
-#define VCT_SHADE_MIN_BLOCKS 5       // 96 VGPRs, 5 waves per SIMD: 216 -> 208 us for the 1080p pass (6: spills)
+#define VCT_SHADE_MIN_BLOCKS 7       // waves per SIMD; with the rolling PCF window 70 VGPRs, no scratch (G-buffer pass, us: 5: 204, 7: 201, 8: 212)
 #endif
 __global__ void __launch_bounds__(256, VCT_SHADE_MIN_BLOCKS)
 k_gbuffer_shade(const ShadeParams p) {
@@ -658,20 +658,25 @@ k_gbuffer_shade(const ShadeParams p) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) { col[k] = xi0[k]; row[k] = yj0[k]; }
                 col[5] = xi1[4]; row[5] = yj1[4];
-                float dd[6][6];
+                // two window rows live at a time (12 registers instead of 36: the kernel is latency-bound and every
+                // resident wave counts); the taps are counted, so their order is free
+                float r0[6], r1[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
+                for (int i = 0; i < 6; ++i) r0[i] = p.shadow[(size_t)row[0] * S + col[i]];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) dd[j][i] = p.shadow[(size_t)row[j] * S + col[i]];
+                for (int y = 0; y < 5; ++y) {
 #pragma unroll
-                for (int x = 0; x < 5; ++x)
+                    for (int i = 0; i < 6; ++i) r1[i] = p.shadow[(size_t)row[y + 1] * S + col[i]];
 #pragma unroll
-                    for (int y = 0; y < 5; ++y) {
+                    for (int x = 0; x < 5; ++x) {
                         const float a = xa[x], b = yb[y];
-                        const float tap = (1.0f - a) * (1.0f - b) * dd[y][x] + a * (1.0f - b) * dd[y][x + 1] +
-                                          (1.0f - a) * b * dd[y + 1][x] + a * b * dd[y + 1][x + 1];
+                        const float tap = (1.0f - a) * (1.0f - b) * r0[x] + a * (1.0f - b) * r0[x + 1] +
+                                          (1.0f - a) * b * r1[x] + a * b * r1[x + 1];
                         if (cur <= tap) cnt += 1.0f;
                     }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) r0[i] = r1[i];
+                }
             } else {
                 for (int x = -2; x <= 2; ++x)
                     for (int y = -2; y <= 2; ++y) {
