@@ -1164,12 +1164,10 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
         return fail(c, VCT_ERR_INVALID, "vct_gi_pass: this context is a rank of a multi-GPU frame; issue the stages and "
                                         "vct_render_gbuffer_rows + vct_frame_step instead");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->aux_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_shadow, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
+    if (!c->aux_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    if (!c->ev_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (!c->ev_shadow) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_shadow, hipEventDisableTiming));
+    if (!c->ev_join) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     // fork at once: the main draw's VISIBILITY raster needs nothing of this pass (it has its own lists and words);
     // only its shading kernel reads the shadow map (PCF term), so that alone waits for the shadow pass
     HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));                 // everything issued before this call is done
