@@ -24,6 +24,7 @@ def _params_kw(g):
 def test_fixture_set_is_complete():
     assert len(TRACE_CASES) == 3 and os.path.exists(os.path.join(GOLDEN, "aniso_v16_8x8.npz"))
     assert os.path.exists(os.path.join(GOLDEN, "voxelize_v32.npz"))
+    assert os.path.exists(os.path.join(GOLDEN, "raster_textured_48x32.npz"))
 
 
 @pytest.mark.parametrize("path", TRACE_CASES, ids=os.path.basename)
@@ -177,3 +178,40 @@ def test_config1_cornell_on_the_gpu_matches_the_scalar_path():
         img = vct.half_to_float(frame.reshape(-1, 4)).reshape(h, w, 4)
         small = img.reshape(16, 8, 16, 8, 4).mean((1, 3))
         assert synth.rel_l2(small, g["image16"]) <= REL_L2_TOL
+
+
+def _textured_inputs(g):
+    import vctpkg
+    vctpkg.load()
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(sc.ATRIUM_TEXTURED, float(g["detail"]), int(g["seed"]))
+    assert scene.ntri == int(g["ntri"])
+    return sc, scene, (0.0, 1.0, 0.25), sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
+
+
+def test_oracle_reproduces_golden_textured_raster(oracle):
+    """Shadow map + G-buffer of the procedurally textured atrium (alpha test, bump normal, specular map, PCF):
+    the CPU rasterisers against the committed planes, bit for bit."""
+    import raster_oracle
+    g = np.load(os.path.join(GOLDEN, "raster_textured_48x32.npz"))
+    sc, scene, light, cam = _textured_inputs(g)
+    depth, lvp_row = raster_oracle.shadow_map(sc, scene, light, int(g["S"]))
+    assert np.array_equal(depth.view(np.uint32), g["shadow"].view(np.uint32))
+    planes = raster_oracle.gbuffer(sc, scene, cam, int(g["w"]), int(g["h"]), depth, lvp_row)
+    assert np.array_equal(planes.view(np.uint32), g["planes"].view(np.uint32))
+    assert 0.9 < float(g["covered"]) <= 1.0
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_textured_raster():
+    import vctpkg
+    vct = vctpkg.load()
+    g = np.load(os.path.join(GOLDEN, "raster_textured_48x32.npz"))
+    sc, scene, light, cam = _textured_inputs(g)
+    w, h, S = int(g["w"]), int(g["h"]), int(g["S"])
+    with vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S)) as ctx:
+        ctx.upload_scene(scene)
+        ctx.render_shadow_map(sc.light_view_proj(light))
+        assert np.array_equal(ctx.download_shadow_map().view(np.uint32), g["shadow"].view(np.uint32))
+        ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
+        assert np.array_equal(ctx.download_gbuffer().view(np.uint32), g["planes"].view(np.uint32))
