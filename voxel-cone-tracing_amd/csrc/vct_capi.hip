@@ -239,6 +239,7 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.tiles_y = tiles_y(c);
     p.tile_row0 = row0;
     p.tile_row1 = row1;
+    p.spec_prio = (row1 - row0) * 2 <= tiles_y(c) ? 1 : 0;
     const int variant = c->cfg.trace_variant;
     p.gbuf = c->gb_current;
     p.aniso = c->cfg.anisotropic_mips ? c->aniso : nullptr;

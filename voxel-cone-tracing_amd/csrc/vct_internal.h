@@ -113,6 +113,7 @@ struct VctTraceParams {
     int32_t n_diffuse, n_specular;
     int32_t width, height, tiles_x, tiles_y;
     int32_t tile_row0, tile_row1;       // slab [row0,row1)
+    int32_t spec_prio;                  // 1: the specular waves raise their issue priority (slab launches, vct_trace.hip)
     const float* gbuf;                  // tiled [tile][23][64]
     uint16_t* out;                      // RGBA16F [h][w][4]
     uint8_t* dbg_steps;                 // [npix][7] or null

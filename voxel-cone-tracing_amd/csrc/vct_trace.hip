@@ -835,6 +835,11 @@ k_trace_tile_split(const VctTraceParams p) {
             if (p.dbg_steps && in_frame) p.dbg_steps[pixel_index(fresh_lane()) * 7 + i] = (uint8_t)st;
         }
     } else {
+        // the specular wave is the longest of a tile (29 march steps against 21) and the last ones of a launch are its
+        // tail: raised issue priority lets them run ahead of the diffuse waves, which have the slack.  Pays when the
+        // launch is a slab of a multi-GPU frame (8-way slabs of the 1080p frame: 0.1085 -> 0.1052 ms mean, 0.115 ->
+        // 0.111 ms max), costs 0.5 % on the whole frame: the host sets it for launches of at most half the frame.
+        if (p.spec_prio) __builtin_amdgcn_s_setprio(1);
         // specular cone along reflect(-E, N) with the bump normal                 trace.fs:217-218
         const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2)), Nw = f3(VCT_GB(3), VCT_GB(4), VCT_GB(5));
         const F3 N = f3(VCT_GB(12), VCT_GB(13), VCT_GB(14));
