@@ -17,6 +17,7 @@ the RGBA16F frame on rank 0 -- strong scaling of the same frame.
 Prints one JSON line (rank 0).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -143,7 +144,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
     if world > 1 or force_dist:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on STDOUT ("[Gloo] Rank r is connected to ..."): the contract is ONE line on
+        # stdout, so file descriptor 1 points at stderr while the process group forms
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     native = (world > 1 or force_dist) and backend == "nccl"
 
     w, h, V = args.width, args.height, args.voxel_dim
@@ -228,7 +241,15 @@ def main():
         if rank == 0:
             idt = torch.frombuffer(bytearray(vct.comm_unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(idt, src=0)
-        ctx.comm_init(bytes(idt.numpy().tobytes()), rank, world)
+        sys.stdout.flush()                   # RCCL prints a version banner on stdout when a communicator forms
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            ctx.comm_init(bytes(idt.numpy().tobytes()), rank, world)
+        finally:
+            ctypes.CDLL(None).fflush(None)   # the banner sits in the C library's stdout buffer
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         assert ctx.comm_slab() == (r0, r1)
         if inp["scene"] is not None and world > 1:
             ctx.render_gbuffer_rows(inp["view_proj"], r0, r1)   # each rank rasterises only its slab from now on
