@@ -134,3 +134,26 @@ def test_cpp_caller_multi_gpu_launcher(vct):
     def fnv(txt):
         return [t for t in txt.split() if t.startswith("fnv1a=")][-1]
     assert "gpus=1" in multi.stdout and fnv(one.stdout) == fnv(multi.stdout)
+
+
+def test_bench_native_step_prints_exactly_one_json_line():
+    """bench.py through the N-rank code path (native vct_frame_step with a 1-rank RCCL communicator, gloo control
+    plane): stdout carries the one JSON line of the contract and nothing else -- gloo and RCCL both announce
+    themselves on stdout when their groups form."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, VCT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--cpu-seconds", "0", "--no-sweep", "--voxel-dim", "64", "--width", "320", "--height", "200",
+                          "--shadow-size", "512", "--scene-detail", "0.2"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert "native vct_frame_step" in d["config"]["parallelism"] or d["config"]["parallelism"] == "single GPU"
