@@ -141,3 +141,26 @@ def test_scissored_passes_leave_the_raster_scratch_armed(vct):
         ctx.render_shadow_map(lvp)
         assert np.array_equal(ctx.download_shadow_map().view(np.uint32), depth.view(np.uint32))
     ctx.close()
+
+
+def test_nothing_visible_gives_an_empty_gbuffer_and_frame(vct):
+    """A camera that looks away from the scene: every triangle is culled or clipped away, the lists stay empty, the
+    G-buffer is the oracle's (all pixels discarded), no cone is marched and the frame is constant -- twice in a row."""
+    V, w, h, S = 32, 75, 41, 128
+    sc, scene, ctx = setup_scene(vct, 0, 1.0, V, w, h, S)
+    light = (0.0, 1.0, 0.25)
+    cam = sc.default_camera(position=(0.0, 0.0, 400.0), yaw=90.0, pitch=0.0)       # outside the box, looking along +z
+    depth, light_vp_row = raster_oracle.shadow_map(sc, scene, light, S)
+    want = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, light_vp_row)
+    assert (want[18] < 0.5).all()
+    ctx.set_camera_position(tuple(cam.position)); ctx.set_light_direction(light)
+    ctx.render_shadow_map(sc.light_view_proj(light))
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    for _ in range(2):
+        ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
+        assert np.array_equal(ctx.download_gbuffer().view(np.uint32), want.view(np.uint32))
+        frame = ctx.trace_current()
+        assert ctx.last_step_count() == 0                      # no cone is marched for a discarded pixel
+        assert np.array_equal(frame, ctx.trace(want))          # ... and the frame is the one of the host-staged G-buffer
+        assert len(np.unique(frame.reshape(-1, 4), axis=0)) == 1     # one constant pixel value everywhere
+    ctx.close()
