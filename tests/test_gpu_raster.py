@@ -164,3 +164,38 @@ def test_nothing_visible_gives_an_empty_gbuffer_and_frame(vct):
         assert np.array_equal(frame, ctx.trace(want))          # ... and the frame is the one of the host-staged G-buffer
         assert len(np.unique(frame.reshape(-1, 4), axis=0)) == 1     # one constant pixel value everywhere
     ctx.close()
+
+
+def test_tile_item_buffer_overflow_is_rasterised_in_place(vct, tmp_path):
+    """300 stacked screen-filling quads: their 16x16-pixel tile work items exceed the item buffer (pixels / 16 + 4096
+    entries), the rest is rasterised by the emitting wave itself.  Visibility must not care: G-buffer == oracle."""
+    from voxel_cone_tracing_amd import scene as sc
+    lines = ["mtllib none.mtl"]
+    n = 300
+    for k in range(n):                                   # model units (the scene scale is 0.05): z from -1000 to -400
+        z = -1000.0 + 2.0 * k
+        lines += [f"v -1400 -1400 {z}", f"v 1400 -1400 {z}", f"v 1400 1400 {z}", f"v -1400 1400 {z}"]
+    lines += ["vn 0 0 1"]
+    for k in range(n):
+        b = 4 * k
+        lines += [f"f {b + 1}//1 {b + 2}//1 {b + 3}//1 {b + 4}//1"]
+    path = tmp_path / "stack.obj"
+    path.write_text("\n".join(lines) + "\n")
+    scene = sc.Scene(str(path))
+    assert scene.ntri == 2 * n
+    w, h, S = 160, 96, 128
+    ctx = vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S))
+    ctx.upload_scene(scene)
+    light = (0.0, 1.0, 0.25)
+    cam = sc.default_camera(position=(0.0, 0.0, 40.0))             # looks down -z at the stack: every quad fills the frame
+    depth, light_vp_row = raster_oracle.shadow_map(sc, scene, light, S)
+    want = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, light_vp_row)
+    assert (want[18] >= 0.5).all()
+    assert 2 * n * (w // 16) * (h // 16) > w * h // 16 + 4096       # more tile items than the buffer holds
+    for _ in range(2):
+        ctx.render_shadow_map(sc.light_view_proj(light))
+        assert np.array_equal(ctx.download_shadow_map().view(np.uint32), depth.view(np.uint32))
+        ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
+        got = ctx.download_gbuffer()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ctx.close()
