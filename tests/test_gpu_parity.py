@@ -383,6 +383,34 @@ def test_second_bounce_matches_oracle(vct, oracle, with_shadow):
         check_frame(vct, oracle, ctx, chain0, planes, w, h)
 
 
+def test_second_bounce_dense_scene_overflows_the_voxel_list(vct, oracle):
+    """More than 1/8 of the grid occupied: the compacted list of occupied voxels (capacity V^3 / 8) overflows and the
+    bricks that did not fit are marched brick by brick (k_bounce_bricks).  Same level 0, chain and step count."""
+    V = 16
+    r = np.random.default_rng(77)
+    ntri = 1500
+    c = r.uniform(-1400, 1400, (ntri, 1, 3))
+    pos = (c + r.normal(scale=260.0, size=(ntri, 3, 3))).astype(np.float32)        # big triangles: a dense grid
+    mat = r.integers(0, 3, ntri).astype(np.int32)
+    alb = r.uniform(0.2, 0.9, (3, 4)).astype(np.float32)
+    p = oracle.default_params(V)
+    sc = oracle.make_scene(pos, mat, alb)
+    l0, want_alb, want_nrm = oracle.voxelize_conservative_attr(p, sc)
+    occupied = int((l0[..., 3] > 0).sum())
+    assert occupied > V ** 3 // 8, occupied                                        # the list cannot hold them all
+    chain0 = oracle.build_mips(l0)
+    want_l1, want_steps = oracle.bounce(p, chain0, want_alb, want_nrm, nthreads=8)
+    with make_ctx(vct, V, 8, 8, voxel_attributes=1) as ctx:
+        ctx.upload_triangles(pos, mat, alb)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), chain0)
+        for _ in range(2):
+            ctx.bounce()
+            assert ctx.last_step_count() == want_steps
+            assert np.array_equal(ctx.download_chain(), oracle.build_mips(want_l1))
+            ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+
+
 def test_bounce_needs_attributes(vct):
     pos, mat, alb = random_scene(50, seed=1)
     with make_ctx(vct, 16, 8, 8) as ctx:
