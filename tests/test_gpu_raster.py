@@ -26,7 +26,7 @@ def setup_scene(vct, kind, detail, V, w, h, S):
     return sc, scene, ctx
 
 
-@pytest.mark.parametrize("kind,detail,S", [(0, 1.0, 256), (1, 0.15, 512)])
+@pytest.mark.parametrize("kind,detail,S", [(0, 1.0, 256), (1, 0.15, 512), (1, 0.1, 100), (0, 1.0, 7)])      # odd sizes too
 def test_shadow_map_raster_bit_exact(vct, kind, detail, S):
     sc, scene, ctx = setup_scene(vct, kind, detail, 32, 16, 16, S)
     light = (0.0, 1.0, 0.25)
