@@ -411,6 +411,29 @@ def test_second_bounce_dense_scene_overflows_the_voxel_list(vct, oracle):
             ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (9, 3)])
+def test_smallest_grid_and_frames(vct, oracle, w, h):
+    """voxel_dim = 8 (the minimum: one brick, 4 levels, the coarse levels of every cone step are the one-texel level)
+    and frames smaller than a tile: mips, both voxelizer modes and the trace against the oracle."""
+    V = 8
+    l0 = synth.noise_volume(V, seed=5, occupancy=0.3)
+    chain = oracle.build_mips(l0)
+    pos, mat, alb = random_scene(40, seed=8)
+    p = oracle.default_params(V)
+    scn = oracle.make_scene(pos, mat, alb)
+    with make_ctx(vct, V, w, h) as ctx:
+        ctx.upload_volume(l0); ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), chain)
+        check_frame(vct, oracle, ctx, chain, synth.random_gbuffer(w * h, seed=w + h), w, h)
+        ctx.upload_triangles(pos, mat, alb)
+        ctx.voxelize(vct.VOX_REFERENCE); ctx.inject_light(); ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), oracle.build_mips(oracle.voxelize_reference(p, scn)))
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        cons = oracle.build_mips(oracle.voxelize_conservative(p, scn))
+        assert np.array_equal(ctx.download_chain(), cons)
+        check_frame(vct, oracle, ctx, cons, synth.coherent_gbuffer(w, h, seed=3), w, h)
+
+
 def test_bounce_needs_attributes(vct):
     pos, mat, alb = random_scene(50, seed=1)
     with make_ctx(vct, 16, 8, 8) as ctx:
