@@ -90,13 +90,15 @@ def test_resident_pipeline_equals_host_staged_pipeline(vct):
     ctx.close()
 
 
-def test_gi_pass_equals_the_six_calls(vct):
+@pytest.mark.parametrize("kind", [1, 2])          # flat and textured atrium
+def test_gi_pass_equals_the_six_calls(vct, kind):
     """vct_gi_pass (G-buffer raster on a second stream beside the voxel stages) produces, bit for bit, the frame
     and the chain of the six stage calls in sequence -- also when it is repeated with a moved light and camera
     (the visibility words and list counters are re-armed by the kernels themselves, never by a clear)."""
     V, w, h, S = 64, 160, 90, 512
-    sc, scene, ctx = setup_scene(vct, 1, 0.15, V, w, h, S)
-    _, _, ref = setup_scene(vct, 1, 0.15, V, w, h, S)
+    sc, scene, ctx = setup_scene(vct, kind, 0.15, V, w, h, S)
+    _, _, ref = setup_scene(vct, kind, 0.15, V, w, h, S)
+    ctx.upload_scene(scene); ref.upload_scene(scene)          # with texture coordinates + maps when the scene has them
     poses = [((0.0, 1.0, 0.25), dict(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)),
              ((0.3, 1.0, -0.2), dict(position=(-40.0, -5.0, 6.0), yaw=20.0, pitch=2.0)),
              ((0.0, 1.0, 0.25), dict(position=(0.0, 0.0, 20.0), yaw=-60.0, pitch=-20.0))]
