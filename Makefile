@@ -27,7 +27,7 @@ $(DEMO): $(PKG)/host/demo_main.cpp $(PKG)/host/Voxel_Cone_Tracing.h include/vct.
 	g++ -O2 -std=c++17 -Wall -Wextra -o $@ $(PKG)/host/demo_main.cpp -L$(PKG) -lvct_amd -lvct_host \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vct_internal.h $(CSRC)/vct_layout.h $(CSRC)/vct_ctx.h include/vct.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vct_internal.h $(CSRC)/vct_layout.h $(CSRC)/vct_ctx.h $(CSRC)/vct_divisors.h include/vct.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

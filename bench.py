@@ -10,9 +10,12 @@ HBM (what the reference does per frame: Render(), VCT.h:146-190; its voxelizatio
 init, VCT.h:138-139).  The once-per-scene GPU stages (voxelize, inject/resolve, mip build) are
 timed in the same run and reported in `gi_pass_ms`.
 
-N > 1 (launched by torch.distributed.run): the frame's 8-pixel tile rows are split into N slabs,
-each rank traces its slab against its own replica of the volume, and ONE gather (RCCL) assembles
-the RGBA16F frame on rank 0 -- strong scaling of the same frame.
+N > 1: the frame's 8-pixel tile rows are split into N slabs, each rank traces its slab against its own
+replica of the volume, and ONE gather (RCCL) assembles the RGBA16F frame on rank 0 -- strong scaling of the
+same frame.  Either launched by torch.distributed.run (RANK / WORLD_SIZE in the environment), or plainly as
+`python3 bench.py --gpus N`: the parent then starts the N rank processes itself -- before it has imported
+torch or loaded the HIP library, so nothing that touched a GPU is ever re-executed -- relays rank 0's JSON
+line, and kills every rank and exits non-zero if one fails or the run exceeds its deadline.
 
 Prints one JSON line (rank 0).
 """
@@ -20,6 +23,9 @@ import argparse
 import ctypes
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +40,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PREROLL_STEPS = 64
 VALU_PEAK_GINSTR = 1228.8      # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (same guide:
                                # "v_fma_f32 (wave64) 2 cyc"); conversions / 3-operand integer ops take 4
+USEFUL_FMA_PER_64_STEPS = 72   # 2 levels x 8 texels x 4 channels + 8 (level blend, composite): the algorithm's own FMAs
 BYTES_PER_STEP = 64            # 2 levels x 8 texels x 4 B
 BYTES_PER_PIXEL = 100          # 92 B G-buffer in + 8 B RGBA16F out
 
@@ -71,7 +78,68 @@ def parse():
                     help="skip the 3-aperture roughness sweep (profiling runs: keeps every trace launch identical)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the oracle baseline sample (0 disables)")
+    ap.add_argument("--slabs", default="balanced", choices=["balanced", "equal"],
+                    help="N > 1: balanced = slab boundaries of equal cone-step cost from the first frame's per-row step "
+                         "histogram (vct_slab_partition_weighted), equal = ceil(tile_rows / N) rows per rank")
+    ap.add_argument("--timeout", type=float, default=float(os.environ.get("VCT_BENCH_TIMEOUT_S", "900")),
+                    help="self-launched N > 1 run: seconds before the parent kills every rank and exits non-zero")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python3 bench.py --gpus N` without a launcher: start N fresh rank processes (own sessions), relay rank 0's
+    stdout, enforce a deadline.  Runs BEFORE torch or libvct_amd.so are imported: this process never touches a GPU."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VCT_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr,
+                                      text=True, start_new_session=True))
+
+    def kill_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)       # exactly the sessions started above
+                except (ProcessLookupError, PermissionError):
+                    pass
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    deadline = time.monotonic() + args.timeout
+    rc, why = 0, ""
+    try:
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc, why = (bad[0][1] if bad[0][1] > 0 else 1), f"rank {bad[0][0]} exited with {bad[0][1]}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                rc, why = 124, f"no result within {args.timeout:.0f} s (a rank hangs?)"
+                break
+            time.sleep(0.05)
+    finally:
+        kill_all()
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        rc, why = 1, f"rank 0 printed {len(lines)} JSON lines"
+    if rc:
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: {why}; all ranks killed\n")
+        sys.stderr.write(out[-2000:])
+        raise SystemExit(rc)
+    print(lines[0], flush=True)
 
 
 def build_inputs(args, vct, sc):
@@ -112,6 +180,8 @@ def build_inputs(args, vct, sc):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     import torch
     import torch.distributed as dist
     import vctpkg
@@ -123,9 +193,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N "
-                             "bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the voxel-cone-tracing path has no CPU fallback")
@@ -176,6 +243,7 @@ def main():
     # ---- once-per-scene GPU stages (timed with events on the context's stream) ----
     gi = {}
     gi_fused = None
+    stage_counts = None
     with torch.cuda.stream(ext_stream):
         if inp["scene"] is not None:
             s = inp["scene"]
@@ -219,6 +287,7 @@ def main():
                 ef[1].record()
                 ctx.synchronize()
                 gi_fused = ef[0].elapsed_time(ef[1]) / 20.0
+            stage_counts = ctx.stage_counts()
             inp["planes"] = ctx.download_gbuffer()     # host copy only for the CPU baseline / checks
         else:
             ctx.upload_volume(inp["volume"])
@@ -263,6 +332,28 @@ def main():
     else:                                   # G-buffer already resident (vct_render_gbuffer)
         ctx.trace_gbuffer_rows(r0, r1)
     steps_slab = ctx.last_step_count()
+    slab_rows = [vct.slab_partition(h, world, r)[:2] for r in range(world)]
+    if native and world > 1 and args.slabs == "balanced":
+        # load-aware slabs: equal rows are not equal work.  The trace counted its executed steps per
+        # tile row; the ranks' histograms are summed over the control plane, every rank cuts the same boundaries of
+        # equal step cost from them and installs them on its communicator (uneven slabs travel as one fused
+        # ncclSend / ncclRecv group, each straight to its rows of the root's frame).  Untimed set-up, like the
+        # first frame it is derived from; the gathered frame is checked against the single-GPU frame below.
+        hist = torch.from_numpy(ctx.last_row_steps().astype(np.int64))
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        starts = vct.slab_partition_weighted(hist.numpy().astype(np.uint64), world)
+        ctx.comm_set_slab_rows(starts)
+        slab_rows = [(int(starts[r]), int(starts[r + 1])) for r in range(world)]
+        r0, r1 = slab_rows[rank]
+        assert ctx.comm_slab() == (r0, r1)
+        y0, y1 = r0 * 8, min(r1 * 8, h)
+        slab_px = max(0, y1 - y0) * w
+        if inp["scene"] is not None:
+            ctx.render_gbuffer_rows(inp["view_proj"], r0, r1)
+            ctx.trace_gbuffer_rows(r0, r1)
+        else:
+            ctx.trace(inp["planes"], rows=(r0, r1))
+        steps_slab = ctx.last_step_count()
 
     comm_stream = torch.cuda.Stream(device=local_rank) if (use_dist and not native) else None
     traced = [torch.cuda.Event() for _ in range(len(fgs))]
@@ -388,9 +479,10 @@ def main():
                        "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7, "bounces": args.bounces,
                        "anisotropic_mips": bool(args.anisotropic),
                        "parallelism": "single GPU" if world == 1 else
-                       f"{world} screen-tile slabs + 1 RCCL gather (native vct_frame_step)" +
+                       f"{world} screen-tile slabs ({args.slabs if native else 'equal'}) + 1 RCCL gather (native vct_frame_step)" +
                        ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]"),
-                       "trace_variant": args.variant},
+                       "trace_variant": args.variant,
+                       "slab_tile_rows": [b - a for a, b in slab_rows]},
             "cone_steps_per_frame": total_steps,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
             "host_issue_us_per_step": round(t_issue / args.steps * 1e6, 2),
@@ -405,6 +497,8 @@ def main():
             "gi_pass_one_call_ms": None if gi_fused is None else round(gi_fused, 4),
             "roofline": roofline_block(prof, k_ms, steps_slab, alg_bytes, alg_gbs),
         }
+        if stage_counts is not None:
+            result["stage_roofline"] = stage_roofline(args, gi, stage_counts, k_ms, alg_bytes, w * h)
         if world == 1 and not args.no_sweep:
             # BASELINE.json config 5's "glossy cones at 3 roughness levels": the specular aperture is a
             # runtime parameter (trace.fs:218 uses 0.07 and mentions 0.105); same frame, same chain
@@ -485,6 +579,12 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
                              "frac_of_8TBps": round(alg_gbs / HBM_PEAK_GBS, 4),
                              "definition": "SURVEY.md 8d: cone steps * 64 B + px * 100 B per launch / HIP-event "
                                            "kernel time; NOT a bound of this kernel (can exceed 1)"}}
+    # implementation-independent floor: the algorithm's own arithmetic per 64 cone steps (one wave instruction
+    # serves 64 lanes) = 2 levels x 8 texels x 4 channels of trilinear FMAs + 8 for the level blend and the
+    # front-to-back composite; everything else the kernel issues (addresses, decode, weights, floor / cvt) is
+    # overhead of THIS implementation.  useful_frac = those instructions per second / the 2-cycle issue peak.
+    r["useful_fma_per_64_steps"] = USEFUL_FMA_PER_64_STEPS
+    r["useful_frac"] = round(cone_steps / 64.0 * USEFUL_FMA_PER_64_STEPS / (kernel_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4)
     if not prof.get("ok"):
         r["note"] = "VALU instruction count / HBM traffic not reported: " + prof["why"]
         return r
@@ -517,6 +617,58 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
                  f"passes of this command, kernel sources {prof.get('kernel_source_sha16')} = this build); "
                  f"kernel time measured live with HIP events on the context stream")
     return r
+
+
+def stage_roofline(args, gi, counts, trace_ms, trace_bytes, npix):
+    """Per stage of one GI pass: ALGORITHMIC bytes (what the stage must read and write once, cache-served
+    re-reads such as the per-pixel triangle fetch and the PCF taps not counted), measured time, and the fraction of the
+    8 TB/s HBM peak that corresponds to.  Every stage but the trace streams its data once, so HBM is their roofline;
+    where a stage sits far below it the `bound` field says what it waits on instead.  PMC
+    FETCH_SIZE / WRITE_SIZE per kernel: profiles/stage_traffic.json (tools/summarize_prof.py), replayed when present."""
+    S, V = args.shadow_size, args.voxel_dim
+    ntri, cand, bricks = counts["triangles"], counts["vox_candidates"], counts["touched_bricks"]
+    upper = sum((V >> l) ** 3 for l in range(3, V.bit_length()))          # levels >= 3: dense (tiny)
+    stage_bytes = {
+        # triangles in, one depth word per shadow-map texel out
+        "shadow_map_raster": (ntri * 36 + S * S * 4, "fp64 triangle set-up + L2 atomics (latency)"),
+        # triangles in, per pixel 8 B visibility word + 92 B G-buffer out
+        "gbuffer_raster": (ntri * 36 + npix * 100, "L2 atomics (visibility), then ALU + dependent fetches (shade)"),
+        # work-list entry 8 B + two 64-bit atomics per candidate voxel, triangles in
+        "voxelize": (ntri * 36 + cand * 24, "device-scope 64-bit atomics + shadow-tap latency"),
+        # per voxel of a touched brick: 16 B accumulators read + re-zeroed, 4 B texel written
+        "inject_resolve": (bricks * 512 * 36, "hbm"),
+        # per touched brick 2 KiB read, 1/8 + 1/64 + 1/512 of it written; dense above level 2
+        "build_mips": (int(bricks * 2048 * (1 + 0.142)) + upper * 36, "launch latency (3 dependent dispatches of microseconds)"),
+        "trace": (int(trace_bytes), "valu_issue (roofline block above; the SURVEY 8d byte figure is not a bound of it)"),
+    }
+    out = {}
+    for k, (b, bound) in stage_bytes.items():
+        ms = trace_ms if k == "trace" else gi.get(k)
+        if not ms:
+            continue
+        gbs = b / (ms * 1e-3) / 1e9
+        out[k] = {"algorithmic_bytes": int(b), "ms": round(ms, 4), "GBps": round(gbs, 1),
+                  "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "bound": bound}
+    path = os.path.join(ROOT, "profiles", "stage_traffic.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            t = json.load(fh)
+        if t.get("source_sha16") == all_sources_sha():
+            out["pmc_hbm_bytes_per_dispatch"] = t.get("kernels")
+            out["pmc_source"] = t.get("source")
+    return out
+
+
+def all_sources_sha():
+    """sha256 over every kernel source + the Makefile (gate of profiles/stage_traffic.json)."""
+    import glob
+    import hashlib
+    hs = hashlib.sha256()
+    csrc = os.path.join(ROOT, "voxel-cone-tracing_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + [os.path.join(ROOT, "Makefile")]:
+        with open(f, "rb") as fh:
+            hs.update(fh.read())
+    return hs.hexdigest()[:16]
 
 
 def usable_cpus():

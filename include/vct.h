@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 4
+#define VCT_ABI_VERSION 5
 
 typedef enum vct_status {
     VCT_OK = 0,
@@ -216,8 +216,10 @@ int vct_trace_resident_rows(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
  * the G-buffer stage runs on a second HIP stream beside the shadow pass and the voxel stages (none of them fills the
  * GPU on its own; the two raster passes have their own work lists); the trace waits for both.  The
  * frame is bit-identical to vct_render_shadow_map, vct_voxelize, vct_inject_light, vct_build_mips,
- * vct_render_gbuffer, vct_trace_resident called in that order.  Asynchronous (vct_synchronize).  Single-GPU contexts
- * only (VCT_ERR_INVALID after vct_comm_init: a rank issues the stages and vct_render_gbuffer_rows + vct_frame_step). */
+ * vct_render_gbuffer, vct_trace_resident called in that order.  Asynchronous (vct_synchronize).
+ * On a rank of a multi-GPU frame (after vct_comm_init) the same call runs the rank's share: the G-buffer stream is
+ * scissored to the rank's slab (vct_render_gbuffer_rows) and the pass ends with vct_frame_step -- slab trace + the
+ * frame's one gather -- instead of the full-frame trace; collective like vct_frame_step (vct_comm_sync to wait). */
 int vct_gi_pass(vct_ctx* ctx, const float light_vp[16], const float view_proj[16], int32_t voxelize_mode);
 /* Redirect the trace kernel's RGBA16F output to caller-owned HBM (full-frame addressing: pixel (x,y)
  * at ((y*width + x) * 4) halves from `rgba16f_dev`); NULL restores the context-owned frame.  A slab
@@ -242,6 +244,8 @@ int vct_slab_partition(int32_t height, int32_t world, int32_t rank, int32_t* til
 int vct_comm_get_unique_id(void* id128);
 /* ncclCommInitRank on the context's device; allocates the two gather buffers (the root's are whole
  * frames), a communication stream and events.  Collective: every rank must call it. */
+/* All or nothing: on any failure (allocation, ncclCommInitRank) nothing stays attached to the context and the call
+ * may be repeated. */
 int vct_comm_init(vct_ctx* ctx, const void* id128, int32_t rank, int32_t world);
 int vct_comm_destroy(vct_ctx* ctx);
 int vct_comm_slab(vct_ctx* ctx, int32_t* tile_row0, int32_t* tile_row1);
@@ -249,7 +253,22 @@ int vct_comm_slab(vct_ctx* ctx, int32_t* tile_row0, int32_t* tile_row1);
  * (k alternates), then ONE ncclGather on the communication stream; the gather of frame k overlaps the
  * trace of frame k+1.  Collective: every rank calls it once per frame. */
 int vct_frame_step(vct_ctx* ctx);
+/* Waits for this rank's trace and gather.  A peer that died or hangs would keep every other rank inside the
+ * collective forever: after the communicator's timeout (default 60 s; VCT_COMM_TIMEOUT_MS in the environment or
+ * vct_comm_set_timeout_ms) or on an asynchronous RCCL error the communicator is ABORTED (ncclCommAbort) and the call
+ * returns VCT_ERR_DEVICE; afterwards only vct_comm_destroy (then a new vct_comm_init) is accepted on it. */
 int vct_comm_sync(vct_ctx* ctx);
+int vct_comm_set_timeout_ms(vct_ctx* ctx, int32_t milliseconds);
+/* Load-aware slabs (SURVEY.md 8e offers unequal assignment as an option): equal ROWS are not equal WORK -- rows
+ * showing sky or near walls march fewer steps.  vct_last_row_steps returns the executed cone steps per 8-pixel tile
+ * row of the last screen trace (rows outside a slab trace are 0; nrows = ceil(height / 8)); after summing the
+ * ranks' histograms (any out-of-band reduction) vct_slab_partition_weighted cuts [0, tile_rows) into `world`
+ * contiguous slabs of near-equal cost (starts[world + 1]), and vct_comm_set_slab_rows installs those boundaries on a
+ * communicator (collective; NULL restores the equal partition).  Unequal slabs travel as one fused group of
+ * ncclSend / ncclRecv, each slab straight to its rows of the root's frame -- still one exchange step per frame. */
+int vct_last_row_steps(vct_ctx* ctx, uint64_t* rows, int32_t nrows);
+int vct_slab_partition_weighted(const uint64_t* row_cost, int32_t tile_rows, int32_t world, int32_t* starts);
+int vct_comm_set_slab_rows(vct_ctx* ctx, const int32_t* starts);
 /* Root only: the last gathered frame (device pointer valid until the next-but-one vct_frame_step) / a host copy. */
 int vct_comm_frame(vct_ctx* ctx, void** rgba16f_dev, size_t* bytes);
 int vct_comm_download_frame(vct_ctx* ctx, void* out_rgba16f_host);
@@ -268,6 +287,11 @@ int vct_last_step_count(vct_ctx* ctx, uint64_t* steps);
  * [7] blocks a greedy multi-anchor cover of [4] needs in total, [8..10] those of [4] it covers with <= 2 / 3 / 4
  * blocks, [11..15] reserved. */
 int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[16]);
+/* Work-item counts behind the per-stage byte figures of bench.py (`stage_roofline`): [0] triangles uploaded,
+ * [1] (triangle, candidate voxel) entries of the voxelizer's work list, [2] triangles of its workgroup-per-triangle
+ * pass, [3] accumulator slots = 8^3 bricks a fragment of the mesh can land in, [4] bricks level 0 shows after the last
+ * resolve, [5..7] reserved (0).  Synchronises the stream. */
+int vct_get_stage_counts(vct_ctx* ctx, uint64_t out[8]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);
 /* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the

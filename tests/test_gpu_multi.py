@@ -157,3 +157,121 @@ def test_bench_native_step_prints_exactly_one_json_line():
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert "native vct_frame_step" in d["config"]["parallelism"] or d["config"]["parallelism"] == "single GPU"
+
+
+def test_bench_self_launches_its_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 2 ...` exactly as the driver types it for N > 1 when no torch.distributed.run wraps it:
+    the parent starts the two ranks itself (fresh processes, before it touched a GPU), relays ONE JSON line and exits 0.
+    Over gloo here (two ranks share the one GPU; RCCL refuses that) -- the launcher is what is under test."""
+    env = dict(os.environ, VCT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--width", "320", "--height", "180", "--voxel-dim", "64", "--scene-detail", "0.15", "--shadow-size", "512",
+           "--cpu-seconds", "0", "--no-sweep"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gathered_frame_equals_single_gpu_frame"] is True and d["value"] > 0
+
+
+def test_self_launcher_kills_all_ranks_when_one_fails():
+    """A rank that fails (here: an impossible grid size) must not leave its peers waiting in a collective: the parent
+    kills every rank and exits non-zero without a JSON line."""
+    env = dict(os.environ, VCT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--voxel-dim", "100", "--width", "64", "--height", "64", "--cpu-seconds", "0", "--no-sweep",
+                          "--timeout", "300"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "all ranks killed" in out.stderr
+
+
+def test_frame_step_leaves_the_frame_target_alone(vct):
+    """vct_frame_step passes its gather buffer to the launch instead of re-pointing the context's frame target
+    (ADVICE round 2): full-frame calls after a step still use the context-owned frame or the caller's target."""
+    import torch
+    ctx, vp = small_pipeline(vct)
+    ctx.render_gbuffer(vp)
+    want = ctx.trace_current()
+    mine = torch.zeros((120, 200, 4), dtype=torch.float16, device="cuda")
+    ctx.set_frame_target(mine.data_ptr())
+    ctx.comm_init(vct.comm_unique_id(), 0, 1)
+    ctx.frame_step(); ctx.frame_step()
+    ctx.comm_sync()
+    assert ctx.frame_device()[0] == mine.data_ptr()          # the caller's target survived the steps
+    assert np.array_equal(ctx.comm_download_frame(), want)
+    assert float(mine.abs().sum()) == 0.0                    # and the steps did not write through it
+    got = ctx.trace_current()                                # a full-frame call on the rank context
+    torch.cuda.synchronize()
+    assert np.array_equal(got, want) and np.array_equal(mine.cpu().numpy().view(np.uint16), want)
+    ctx.comm_destroy()
+    assert ctx.frame_device()[0] == mine.data_ptr()
+    ctx.set_frame_target(None)
+    ctx.close()
+
+
+def test_gi_pass_on_a_rank_context_equals_the_single_gpu_pass(vct):
+    """vct_gi_pass after vct_comm_init: the rank's share of the moving-light frame as ONE call (slab-scissored G-buffer
+    stream, vct_frame_step at the join).  With a 1-rank communicator the gathered frame is the single-GPU pass's."""
+    from voxel_cone_tracing_amd import scene as sc
+    ctx, vp = small_pipeline(vct)
+    lights = [(0.0, 1.0, 0.25), (0.3, 1.0, -0.2)]
+    want = []
+    for L in lights:
+        ctx.set_light_direction(L)
+        ctx.gi_pass(sc.light_view_proj(L), vp)
+        ctx.synchronize()
+        want.append(ctx.download_frame())
+    ctx.comm_init(vct.comm_unique_id(), 0, 1)
+    for L, w in zip(lights, want):
+        ctx.set_light_direction(L)
+        ctx.gi_pass(sc.light_view_proj(L), vp)
+        ctx.comm_sync()
+        assert np.array_equal(ctx.comm_download_frame(), w)
+    ctx.comm_destroy()
+    ctx.close()
+
+
+def test_row_step_histogram_and_load_aware_slabs(vct):
+    """The step counters double as the per-tile-row cost histogram; boundaries cut from it give slabs whose union is
+    the single-GPU frame and whose step counts are closer to equal than equal-row slabs."""
+    ctx, vp = small_pipeline(vct, w=320, h=200, V=64)
+    ctx.render_gbuffer(vp)
+    frame = ctx.trace_current()
+    total = ctx.last_step_count()
+    rows = ctx.last_row_steps()
+    assert rows.shape == (25,) and int(rows.sum()) == total and total > 0
+    world = 4
+    starts = vct.slab_partition_weighted(rows, world)
+    parts = np.zeros_like(frame)
+    steps = []
+    for r in range(world):
+        r0, r1 = int(starts[r]), int(starts[r + 1])
+        ctx.trace_gbuffer_rows(r0, r1)
+        steps.append(ctx.last_step_count())
+        assert steps[-1] == int(rows[r0:r1].sum())
+        got = ctx.last_row_steps()
+        assert np.array_equal(got[r0:r1], rows[r0:r1]) and int(got.sum()) == steps[-1]
+        parts[r0 * 8:min(r1 * 8, 200)] = ctx.download_frame()[r0 * 8:min(r1 * 8, 200)]
+    assert np.array_equal(parts, frame)
+    equal = [int(rows[a:b].sum()) for a, b in ((0, 7), (7, 14), (14, 21), (21, 25))]
+    assert max(steps) <= max(equal)
+    # installing boundaries on a (1-rank) communicator: validated, and the frame is still the frame
+    ctx.comm_init(vct.comm_unique_id(), 0, 1)
+    with pytest.raises(vct.VctError):
+        ctx.comm_set_slab_rows([0, 24])                       # must end at the frame's 25 tile rows
+    ctx.comm_set_slab_rows([0, 25])
+    assert ctx.comm_slab() == (0, 25)
+    ctx.frame_step(); ctx.frame_step()
+    ctx.comm_sync()
+    assert np.array_equal(ctx.comm_download_frame(), frame)
+    ctx.comm_set_slab_rows(None)
+    ctx.frame_step()
+    assert np.array_equal(ctx.comm_download_frame(), frame)
+    ctx.comm_destroy()
+    ctx.close()

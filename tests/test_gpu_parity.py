@@ -645,3 +645,72 @@ def test_extreme_sizes(vct, oracle):
         ctx.bounce()
         l1, _ = oracle.bounce(p, c0, a, n)
         assert np.array_equal(ctx.download_chain(), oracle.build_mips(l1))
+
+
+def test_bounce_is_refused_after_a_new_mesh_until_it_is_voxelized(vct, oracle):
+    """vct_upload_triangles replaces the per-brick attribute pools but level 0 / the touched-brick
+    flags still describe the OLD mesh; a bounce in that state would index the new pools with the old bricks."""
+    V = 32
+    pos, mat, alb = random_scene(300, seed=33)
+    pos2, mat2, alb2 = random_scene(40, seed=91)
+    pos2 = (pos2 * 0.2 + 900.0).astype(np.float32)          # a small mesh in a corner: most old bricks get no slot
+    p = oracle.default_params(V)
+    with make_ctx(vct, V, 8, 8, voxel_attributes=1) as ctx:
+        ctx.upload_triangles(pos, mat, alb)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        ctx.bounce()
+        ctx.upload_triangles(pos2, mat2, alb2)
+        with pytest.raises(vct.VctError) as e:
+            ctx.bounce()
+        assert "voxel attributes" in str(e.value)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        sc = oracle.make_scene(pos2, mat2, alb2)
+        l0, want_alb, want_nrm = oracle.voxelize_conservative_attr(p, sc)
+        chain0 = oracle.build_mips(l0)
+        assert np.array_equal(ctx.download_chain(), chain0)
+        want_l1, want_steps = oracle.bounce(p, chain0, want_alb, want_nrm, nthreads=8)
+        ctx.bounce()
+        assert ctx.last_step_count() == want_steps
+        assert np.array_equal(ctx.download_chain(), oracle.build_mips(want_l1))
+
+
+def test_empty_row_range_counts_zero_steps(vct, oracle):
+    """a trace over an empty tile-row range (a rank whose slab is empty) launches nothing -- the step
+    count it reports is 0 and the next launch does not inherit stale counters."""
+    V, w, h = 16, 24, 16
+    chain = oracle.build_mips(synth.noise_volume(V, seed=3, occupancy=0.2))
+    planes = synth.random_gbuffer(w * h, seed=9)
+    with make_ctx(vct, V, w, h) as ctx:
+        ctx.upload_chain(chain)
+        ctx.trace(planes)
+        full = ctx.last_step_count()
+        assert full > 0
+        for _ in range(3):
+            ctx.trace_gbuffer_rows(1, 1)
+            assert ctx.last_step_count() == 0
+            assert int(ctx.last_row_steps().sum()) == 0
+        ctx.trace_gbuffer_rows(0, 2)
+        assert ctx.last_step_count() == full
+        ctx.trace_gbuffer_rows(2, 2)
+        ctx.trace_gbuffer_rows(0, 2)
+        assert ctx.last_step_count() == full
+
+
+def test_shipped_divisor_table_is_verified_entry_by_entry(vct):
+    """csrc/vct_divisors.h lets a fresh process skip the 2 ms device check per divisor; EVERY entry must pass that
+    check here, and the table must cover the BASELINE grids and apertures (tools/gen_divisor_table.py)."""
+    import os
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "voxel-cone-tracing_amd", "csrc", "vct_divisors.h")).read()
+    bits = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", txt)]
+    assert bits == sorted(bits) and len(bits) == len(set(bits)) >= 250
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_divisor_table
+    want = {int(np.float32(d).view(np.uint32)) for d in gen_divisor_table.divisors()}
+    assert want == set(bits), "regenerate the table: python3 tools/gen_divisor_table.py"
+    with make_ctx(vct, 16, 8, 8) as ctx:
+        for b in bits:
+            d = float(np.uint32(b).view(np.float32))
+            assert ctx.selftest_const_divide(d) == 0, hex(b)

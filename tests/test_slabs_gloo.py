@@ -89,3 +89,43 @@ def test_slab_gather_equals_single_process_frame(world, h):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_weighted_partition_balances_cost_not_rows():
+    """vct_slab_partition_weighted (pure host arithmetic in libvct_amd.so): contiguous slabs of near-equal COST."""
+    import vctpkg
+    vct = vctpkg.load()
+    rng = np.random.default_rng(3)
+    for rows, world in ((135, 8), (270, 8), (135, 2), (23, 4), (5, 8), (1, 3)):
+        cost = rng.integers(0, 10 ** 6, rows).astype(np.uint64)
+        cost[: rows // 3] //= 50                      # a cheap "sky" band at the top of the frame
+        starts = vct.slab_partition_weighted(cost, world)
+        assert starts[0] == 0 and starts[-1] == rows and np.all(np.diff(starts) >= 0)
+        per = np.array([cost[a:b].sum() + (b - a) for a, b in zip(starts[:-1], starts[1:])], np.float64)
+        target = (cost.sum() + rows) / world
+        biggest_row = float(cost.max() + 1)
+        assert per.max() <= target + biggest_row        # no slab exceeds its share by more than one row
+        if rows >= 8 * world:
+            equal = [cost[a:b].sum() for a, b in slabs_equal(rows, world)]
+            assert per.max() <= max(equal) + world      # never worse than the equal-rows cut
+    flat = vct.slab_partition_weighted(np.full(136, 7, np.uint64), 8)
+    assert list(np.diff(flat)) == [17] * 8            # uniform cost -> equal rows
+
+
+def slabs_equal(rows, world):
+    per = (rows + world - 1) // world
+    return [(min(r * per, rows), min((r + 1) * per, rows)) for r in range(world)]
+
+
+def test_bench_self_launcher_fails_loudly_when_a_rank_fails():
+    """`python3 bench.py --gpus 2` with no launcher and no GPU: the parent starts two rank processes (before touching
+    torch.cuda or the HIP library), every rank exits with "needs a GPU", and the parent kills the rest, prints no
+    JSON line and exits non-zero -- the failure path of the self-launcher the driver's SCALE run relies on."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the success path is covered by tests/test_gpu_multi.py")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--timeout", "240"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "all ranks killed" in out.stderr

@@ -25,7 +25,7 @@ GB_PLANES = 23
 GB_LINEAR, GB_TILED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 VOX_CONSERVATIVE_AVG, VOX_REFERENCE = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/vct.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -43,6 +43,8 @@ ABI_SYMBOLS = [
     "vct_slab_partition", "vct_comm_get_unique_id", "vct_comm_init", "vct_comm_destroy", "vct_comm_slab",
     "vct_frame_step", "vct_comm_sync", "vct_comm_frame", "vct_comm_download_frame",
     "vct_upload_mesh_uvs", "vct_upload_textures", "vct_gi_pass",
+    "vct_comm_set_timeout_ms", "vct_last_row_steps", "vct_slab_partition_weighted", "vct_comm_set_slab_rows",
+    "vct_get_stage_counts",
 ]
 
 
@@ -117,6 +119,11 @@ _lib.vct_comm_download_frame.argtypes = [C.c_void_p, C.c_void_p]
 for _n in ("vct_comm_destroy", "vct_frame_step", "vct_comm_sync"):
     getattr(_lib, _n).argtypes = [C.c_void_p]
 COMM_ID_BYTES = 128
+_lib.vct_get_stage_counts.argtypes = [C.c_void_p, C.c_void_p]
+_lib.vct_comm_set_timeout_ms.argtypes = [C.c_void_p, C.c_int32]
+_lib.vct_last_row_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+_lib.vct_slab_partition_weighted.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+_lib.vct_comm_set_slab_rows.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_upload_mesh_uvs.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_upload_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
 
@@ -139,6 +146,15 @@ def slab_partition(height, world, rank):
     if _lib.vct_slab_partition(height, world, rank, C.byref(r0), C.byref(r1), C.byref(per)) != 0:
         raise VctError("vct_slab_partition: bad arguments")
     return r0.value, r1.value, per.value
+
+
+def slab_partition_weighted(row_cost, world):
+    """Tile-row boundaries [world + 1] of `world` contiguous slabs of near-equal cost (row_cost: per tile row)."""
+    cost = np.ascontiguousarray(row_cost, np.uint64)
+    starts = np.zeros(world + 1, np.int32)
+    if _lib.vct_slab_partition_weighted(_ptr(cost), cost.shape[0], world, _ptr(starts)) != 0:
+        raise VctError("vct_slab_partition_weighted: bad arguments")
+    return starts
 
 
 def comm_unique_id():
@@ -303,6 +319,21 @@ class Context:
         self._ck(_lib.vct_comm_slab(self._h, C.byref(r0), C.byref(r1)), "vct_comm_slab")
         return r0.value, r1.value
 
+    def comm_set_timeout_ms(self, ms):
+        self._ck(_lib.vct_comm_set_timeout_ms(self._h, int(ms)), "vct_comm_set_timeout_ms")
+
+    def comm_set_slab_rows(self, starts):
+        """Collective: load-aware slab boundaries [world + 1] in tile rows (None: the equal partition)."""
+        a = None if starts is None else np.ascontiguousarray(starts, np.int32)
+        self._ck(_lib.vct_comm_set_slab_rows(self._h, _ptr(a)), "vct_comm_set_slab_rows")
+
+    def last_row_steps(self):
+        """Executed cone steps per 8-pixel tile row of the last screen trace (uint64 [ceil(height / 8)])."""
+        n = (self.cfg.height + 7) // 8
+        out = np.zeros(n, np.uint64)
+        self._ck(_lib.vct_last_row_steps(self._h, _ptr(out), n), "vct_last_row_steps")
+        return out
+
     def frame_step(self):
         self._ck(_lib.vct_frame_step(self._h), "vct_frame_step")
 
@@ -426,6 +457,12 @@ class Context:
         keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes", "fallback_fits",
                 "greedy_blocks", "greedy_le2", "greedy_le3", "greedy_le4")
         return dict(zip(keys, (int(x) for x in v)))
+
+    def stage_counts(self):
+        v = (C.c_uint64 * 8)()
+        self._ck(_lib.vct_get_stage_counts(self._h, v), "vct_get_stage_counts")
+        return dict(zip(("triangles", "vox_candidates", "vox_big_triangles", "accumulator_bricks", "touched_bricks"),
+                        (int(x) for x in v)))
 
     def last_trace_ms(self):
         v = C.c_float()

@@ -7,11 +7,16 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "vct_ctx.h"
+#include "vct_divisors.h"
+
+bool vct_comm_rows(const vct_ctx* c, int* row0, int* row1);      // vct_multi.hip: slab of the attached communicator
 
 namespace {
 
@@ -132,20 +137,33 @@ bool divisor_ok(float d) {
     return m != 0x7fffffu && e >= 4 && e <= 250;   // d and 1/d both far from the subnormal range
 }
 
-// exhaustive device check of the one-round constant division for divisor d (vct_trace.hip div_const);
-// verdicts are cached per divisor for the life of the process
+// Is the one-round constant division exact for divisor d (vct_trace.hip div_const)?  The divisors of the BASELINE
+// grids and apertures ship as a table (vct_divisors.h: verified on the device, and every entry re-verified by
+// tests/test_gpu_parity.py::test_const_divide_exhaustive), so a fresh process pays nothing for them; any other
+// divisor is checked exhaustively on the device the first time a step table uses it (k_divide_selftest, 2 ms per
+// divisor, synchronous -- an aperture animated per frame pays it once per new divisor) and the verdict is cached for
+// the life of the process.  The cache is shared by every context of the process (one host thread per context, so
+// two GPUs' threads may race here): guarded by a mutex.
 int divisor_verified(vct_ctx* c, float d, bool* ok) {
     static std::map<uint32_t, bool> cache;
+    static std::mutex cache_lock;
     uint32_t bits;
     memcpy(&bits, &d, 4);
-    auto it = cache.find(bits);
-    if (it != cache.end()) { *ok = it->second; return VCT_OK; }
+    const uint32_t* end = kVerifiedDivisors + sizeof(kVerifiedDivisors) / sizeof(kVerifiedDivisors[0]);
+    if (std::binary_search(kVerifiedDivisors, end, bits)) { *ok = true; return VCT_OK; }
+    {
+        std::lock_guard<std::mutex> g(cache_lock);
+        auto it = cache.find(bits);
+        if (it != cache.end()) { *ok = it->second; return VCT_OK; }
+    }
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 2 * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, vct_launch_divide_selftest(d, c->stats, c->stream));
     unsigned long long bad = 1;
     HIP_TRY(c, hipMemcpyAsync(&bad, c->stats, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *ok = cache[bits] = bad == 0ull;
+    *ok = bad == 0ull;
+    std::lock_guard<std::mutex> g(cache_lock);
+    cache[bits] = *ok;
     return VCT_OK;
 }
 
@@ -219,7 +237,10 @@ void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chai
 #endif
 }
 
-int launch_trace(vct_ctx* c, int row0, int row1) {
+// `out_base`: where the kernel writes (full-frame addressing); null = the caller's vct_set_frame_target or the
+// context-owned frame.  vct_frame_step passes its gather buffer here instead of re-pointing c->frame_target, which
+// on a non-root rank would leave a pointer BEFORE a one-slab allocation behind for every later full-frame call.
+int launch_trace(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr) {
     // the reference rebuilds the mips right after every voxelization (VCT.h:248); tracing a chain whose
     // coarse levels describe an older level 0 would return wrong GI without any sign of it
     if (!c->mips_valid)
@@ -245,19 +266,24 @@ int launch_trace(vct_ctx* c, int row0, int row1) {
     p.aniso = c->cfg.anisotropic_mips ? c->aniso : nullptr;
     p.aniso_alt_slab = 128;     // k_trace_tile_split<ANISO>: slabs [level 1][level 2][-axis of 1][-axis of 2]
     p.aniso_stride = (uint32_t)(c->chain_texels - (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim);
-    p.out = c->frame_target ? c->frame_target : c->frame;
+    p.out = out_base ? out_base : (c->frame_target ? c->frame_target : c->frame);
     p.dbg_steps = c->cfg.debug_outputs ? c->dbg_steps : nullptr;
     p.dbg_cones = c->cfg.debug_outputs ? c->dbg_cones : nullptr;
 #if defined(VCT_STATS) && VCT_STATS
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
 #endif
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
+    if ((row1 - row0) * p.tiles_x <= 0)     // empty slab (more ranks than tile rows): no kernel runs, so nobody zeroes the
+        HIP_TRY(c, hipMemsetAsync(c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS, 0,      // set being retired
+                                  VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
+    else
+        HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->step_set ^= 1;           // the kernel filled the zero set and zeroed the other one
+    c->step_set ^= 1;           // the kernel filled the zero set and zeroed the other one (an empty launch: both are zero)
     c->last_row0 = row0;
     c->last_row1 = row1;
     c->have_trace = true;
+    c->last_was_screen_trace = true;
     return VCT_OK;
 }
 
@@ -325,6 +351,7 @@ int build_accumulator_pools(vct_ctx* c) {
     for (void** q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
     c->nslots = 0;
     c->acc_pending = false;
+    c->attrs_valid = false;     // the pooled attributes are indexed by the NEW mesh's slots: nothing resolved into them yet
     uint32_t *mark = nullptr, *slot = nullptr, *count = nullptr;
     unsigned long long *acc = nullptr, *acc_attr = nullptr;
     uint32_t *attr_albedo = nullptr, *attr_normal = nullptr;
@@ -390,7 +417,7 @@ int build_accumulator_pools(vct_ctx* c) {
 }  // namespace
 
 int vct_fail(vct_ctx* c, int code, const std::string& msg) { return fail(c, code, msg); }
-int vct_launch_trace_rows(vct_ctx* c, int row0, int row1) { return launch_trace(c, row0, row1); }
+int vct_launch_trace_rows(vct_ctx* c, int row0, int row1, uint16_t* out_base) { return launch_trace(c, row0, row1, out_base); }
 int vct_tiles_x(const vct_ctx* c) { return tiles_x(c); }
 int vct_tiles_y(const vct_ctx* c) { return tiles_y(c); }
 void vct_comm_release(vct_ctx* c);      // vct_multi.hip
@@ -876,6 +903,7 @@ int vct_inject_light(vct_ctx* c) {
     c->level0_dirty = false;
     c->use_chain_b = false;
     c->mips_valid = false;
+    c->attrs_valid = c->attr_normal != nullptr && c->acc_mode == VCT_VOX_CONSERVATIVE_AVG;
     return VCT_OK;
 }
 
@@ -907,6 +935,9 @@ int vct_bounce(vct_ctx* c) {
         return fail(c, VCT_ERR_INVALID, "vct_bounce: needs config.voxel_attributes = 1 and a voxelize + inject pass");
     if (c->acc_pending || !c->mips_valid)
         return fail(c, VCT_ERR_INVALID, "vct_bounce: call vct_inject_light and vct_build_mips first");
+    if (!c->attrs_valid)      // a new mesh was uploaded since: level 0 / brick_prev describe the OLD mesh, the slots the new one
+        return fail(c, VCT_ERR_INVALID, "vct_bounce: the voxel attributes belong to a mesh uploaded after the last "
+                                        "vct_inject_light (voxelize + inject + mips again first)");
     if (c->level0_dirty || c->acc_mode != VCT_VOX_CONSERVATIVE_AVG)
         return fail(c, VCT_ERR_INVALID, "vct_bounce: level 0 must come from a VCT_VOX_CONSERVATIVE_AVG pass (voxel attributes)");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -955,6 +986,7 @@ int vct_bounce(vct_ctx* c) {
     if (c->aniso) HIP_TRY(c, vct_launch_build_mips_aniso(c->chain_b, c->aniso, c->cfg.voxel_dim, c->stream));
     c->use_chain_b = true;
     c->have_trace = true;      // step counter / event pair now describe the bounce launch
+    c->last_was_screen_trace = false;
     return VCT_OK;
 }
 
@@ -1161,9 +1193,10 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
     if (!c) return VCT_ERR_INVALID;
     if (!light_vp || !view_proj) return fail(c, VCT_ERR_INVALID, "vct_gi_pass: null matrix");
     if (c->cfg.shadow_map_size <= 0) return fail(c, VCT_ERR_INVALID, "vct_gi_pass: config.shadow_map_size <= 0");
-    if (c->comm)        // a rank of a multi-GPU frame rasterises and traces its slab only and ends the frame with the gather
-        return fail(c, VCT_ERR_INVALID, "vct_gi_pass: this context is a rank of a multi-GPU frame; issue the stages and "
-                                        "vct_render_gbuffer_rows + vct_frame_step instead");
+    // A rank of a multi-GPU frame (vct_comm_init) runs the same pass on its slab: the G-buffer stream is scissored to
+    // the rank's tile rows and the pass ends with vct_frame_step (slab trace + the frame's one gather) at the join.
+    int row0 = 0, row1 = tiles_y(c);
+    const bool rank_ctx = vct_comm_rows(c, &row0, &row1);
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->aux_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     if (!c->ev_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1176,7 +1209,7 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
     int rc = vct_render_shadow_map(c, light_vp);                       // allocates / sizes the shadow map first
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev_shadow, c->stream));
-    rc = render_gbuffer_rows_on(c, view_proj, 0, tiles_y(c), c->aux_stream, c->ev_shadow);
+    rc = render_gbuffer_rows_on(c, view_proj, row0, row1, c->aux_stream, c->ev_shadow);
     // join before anything else can fail: later work on the context's stream must see the G-buffer
     const hipError_t ej = hipEventRecord(c->ev_join, c->aux_stream);
     if (rc == VCT_OK) rc = vct_voxelize(c, mode);
@@ -1185,6 +1218,7 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
     if (ej == hipSuccess) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     else HIP_TRY(c, ej);
     if (rc) return rc;
+    if (rank_ctx) return vct_frame_step(c);
     return launch_trace(c, c->last_row0, c->last_row1);
 }
 
@@ -1231,11 +1265,51 @@ int vct_last_step_count(vct_ctx* c, uint64_t* steps) {
     if (!c || !steps) return VCT_ERR_INVALID;
     if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long v[VCT_STEP_COUNTERS];
-    HIP_TRY(c, hipMemcpy(v, c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS, sizeof(v), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> v(VCT_STEP_COUNTERS);
+    HIP_TRY(c, hipMemcpy(v.data(), c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS,
+                         VCT_STEP_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long sum = 0;
     for (int i = 0; i < VCT_STEP_COUNTERS; ++i) sum += v[i];
     *steps = sum;
+    return VCT_OK;
+}
+
+int vct_get_stage_counts(vct_ctx* c, uint64_t out[8]) {
+    if (!c || !out) return VCT_ERR_INVALID;
+    memset(out, 0, 8 * sizeof(uint64_t));
+    out[0] = (uint64_t)c->ntri;
+    out[1] = c->n_entries;
+    out[2] = (uint64_t)c->n_big;
+    out[3] = c->nslots;
+    if (c->brick_prev) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        const size_t nbricks = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512;
+        std::vector<uint32_t> flags(nbricks);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(flags.data(), c->brick_prev, nbricks * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t n = 0;
+        for (uint32_t f : flags) n += f != 0u;
+        out[4] = n;
+    }
+    return VCT_OK;
+}
+
+int vct_last_row_steps(vct_ctx* c, uint64_t* rows, int32_t nrows) {
+    if (!c || !rows) return VCT_ERR_INVALID;
+    if (!c->have_trace || !c->last_was_screen_trace)
+        return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: the last march was not a screen trace");
+    if (nrows != tiles_y(c)) return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: nrows must be the frame's tile rows, ceil(height / 8)");
+    if (nrows * VCT_STEP_ROW_BANKS > VCT_STEP_COUNTERS)
+        return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: frames taller than 4096 px share counters between tile rows");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> v(VCT_STEP_COUNTERS);
+    HIP_TRY(c, hipMemcpy(v.data(), c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS,
+                         VCT_STEP_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int r = 0; r < nrows; ++r) {
+        unsigned long long sum = 0;
+        for (int b = 0; b < VCT_STEP_ROW_BANKS; ++b) sum += v[(size_t)r * VCT_STEP_ROW_BANKS + b];
+        rows[r] = sum;
+    }
     return VCT_OK;
 }
 

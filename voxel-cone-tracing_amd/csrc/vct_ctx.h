@@ -23,6 +23,7 @@ struct vct_ctx {
     uint32_t* attr_albedo = nullptr;  // [V^3] resolved mean albedo, Morton order
     uint32_t* attr_normal = nullptr;  // [V^3] resolved mean normal (biased), Morton order
     bool mips_valid = true;           // levels >= 1 describe level 0 (a fresh chain is all zero)
+    bool attrs_valid = false;         // attr_albedo / attr_normal hold a resolve of the CURRENT mesh's pools (vct_bounce needs it)
     uint32_t* aniso = nullptr;        // [6][chain_texels - V^3] directional chains (cfg.anisotropic_mips)
     size_t chain_texels = 0;
     uint32_t* staging = nullptr;      // linear staging for up/downloads (size of level 0)
@@ -45,6 +46,7 @@ struct vct_ctx {
     bool fast_div = false;            // set by refresh_steps: constant divisors admit the FMA division
     int last_row0 = 0, last_row1 = 0;
     bool have_trace = false;
+    bool last_was_screen_trace = false;   // the step counters hold a screen trace (indexed by tile row), not a bounce
     bool have_gbuffer = false;        // a G-buffer is resident (uploaded by vct_trace or rendered)
 
     float cam[3] = {0.0f, 4.0f, 0.0f};        // VCT.h:8
@@ -114,7 +116,8 @@ struct vct_ctx {
 
 // shared helpers (vct_capi.hip)
 int vct_fail(vct_ctx* c, int code, const std::string& msg);
-int vct_launch_trace_rows(vct_ctx* c, int row0, int row1);      // memset counters + trace kernel, asynchronous
+// trace kernel on the context stream, asynchronous; out_base (full-frame addressing) overrides the frame target when not null
+int vct_launch_trace_rows(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr);
 int vct_tiles_x(const vct_ctx* c);
 int vct_tiles_y(const vct_ctx* c);
 

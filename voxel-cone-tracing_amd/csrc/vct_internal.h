@@ -71,7 +71,11 @@ __device__ __forceinline__ float4 vct_tex_sample(const VctTextures& t, int ti, f
 #define VCT_TILE_PIX 64
 #define VCT_GB_NPLANES 23
 #define VCT_MAX_STEPS 1024
-#define VCT_STEP_COUNTERS 256   // bank of executed-step counters (power of two)
+// Executed-step counters: the screen trace adds a wave's steps to counter [tile_row * VCT_STEP_ROW_BANKS + (tile_x & 3)],
+// so the bank is also the per-tile-row cost histogram of the frame (vct_last_row_steps: load-aware slabs) at no extra
+// atomic; 2048 counters = 512 tile rows (4096 px) without aliasing, taller frames wrap (the total stays right).
+#define VCT_STEP_COUNTERS 2048  // power of two
+#define VCT_STEP_ROW_BANKS 4
 
 // One entry per march step of a cone aperture.  The step sequence of trace.fs:90-104 (dist,
 // diameter, lod) does not depend on the pixel, only on (V, G, tanHalfAngle, MAX_DISTANCE): the

@@ -20,23 +20,32 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "vct_ctx.h"
 
 namespace {
 
-// the five RCCL entry points used, with the types of rccl.h restated (opaque comm, 128-byte id)
+// the RCCL entry points used, with the types of rccl.h restated (opaque comm, 128-byte id)
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef int ncclResult_t;
-enum { ncclSuccess = 0, ncclFloat16 = 6 };
+enum { ncclSuccess = 0, ncclInProgress = 7, ncclFloat16 = 6 };
 struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
     ncclResult_t (*Gather)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -54,7 +63,13 @@ Rccl* rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
+    r.CommGetAsyncError = (decltype(r.CommGetAsyncError))sym("ncclCommGetAsyncError");
     r.Gather = (decltype(r.Gather))sym("ncclGather");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     return &r;
 }
@@ -65,27 +80,43 @@ struct vct_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     int row0 = 0, row1 = 0;            // tile rows of this rank's slab
-    int rows_per_rank = 0;             // padded slab height in tile rows (equal on every rank)
-    size_t slab_halves = 0;            // halves per padded slab = the gather's sendcount
+    int rows_per_rank = 0;             // padded slab height in tile rows of the EQUAL partition (the gather's sendcount)
+    size_t slab_halves = 0;            // halves per padded equal slab
+    // load-aware partition (vct_comm_set_slab_rows): tile-row boundaries of every rank, [world + 1]; empty = the equal
+    // partition above.  Uneven slabs travel by grouped ncclSend / ncclRecv straight to their rows of the root's frame.
+    std::vector<int> starts;
+    size_t buf_halves = 0;             // allocation of each gather buffer
     hipStream_t comm_stream = nullptr;
-    uint16_t* buf[2] = {nullptr, nullptr};   // root: world padded slabs (the frame); others: one padded slab
+    uint16_t* buf[2] = {nullptr, nullptr};   // root: the frame (world padded slabs); others: this rank's slab
     hipEvent_t traced[2] = {nullptr, nullptr}, gathered[2] = {nullptr, nullptr};
     unsigned long long frames = 0;     // steps issued
     int last = -1;                     // buffer of the last issued step
+    int timeout_ms = 60000;            // vct_comm_sync gives up after this long and aborts the communicator
+    bool broken = false;               // the communicator was aborted (a peer died or hung): only vct_comm_destroy is left
 };
 
-#define NCCL_TRY(c, expr)                                                                        \
-    do {                                                                                         \
-        ncclResult_t r_ = (expr);                                                                \
-        if (r_ != ncclSuccess)                                                                   \
-            return vct_fail((c), VCT_ERR_DEVICE, std::string(#expr) + ": " + rccl()->GetErrorString(r_)); \
+// An RCCL call failed: the communicator may be half way through a collective the peers will never finish, so it
+// is aborted (ncclCommAbort frees its resources without waiting for them) and the context keeps only the error.
+static int comm_fail(vct_ctx* c, vct_comm* m, const std::string& what, ncclResult_t r) {
+    std::string msg = what + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(r) : "RCCL error");
+    if (m && m->comm && rccl()->CommAbort) { (void)rccl()->CommAbort(m->comm); m->comm = nullptr; msg += " (communicator aborted)"; }
+    if (m) m->broken = true;
+    return vct_fail(c, VCT_ERR_DEVICE, msg);
+}
+
+#define NCCL_TRY(c, m, expr)                                              \
+    do {                                                                  \
+        ncclResult_t r_ = (expr);                                         \
+        if (r_ != ncclSuccess) return comm_fail((c), (m), #expr, r_);     \
     } while (0)
 
-void vct_comm_release(vct_ctx* c) {
-    if (!c || !c->comm) return;
-    vct_comm* m = c->comm;
-    if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
-    if (m->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(m->comm);
+static void comm_free(vct_comm* m) {
+    if (!m) return;
+    if (m->comm_stream && !m->broken) (void)hipStreamSynchronize(m->comm_stream);
+    if (m->comm) {
+        if (m->broken && rccl()->CommAbort) (void)rccl()->CommAbort(m->comm);
+        else if (rccl()->CommDestroy) (void)rccl()->CommDestroy(m->comm);
+    }
     for (int k = 0; k < 2; ++k) {
         if (m->buf[k]) (void)hipFree(m->buf[k]);
         if (m->traced[k]) (void)hipEventDestroy(m->traced[k]);
@@ -93,8 +124,20 @@ void vct_comm_release(vct_ctx* c) {
     }
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     delete m;
+}
+
+void vct_comm_release(vct_ctx* c) {
+    if (!c || !c->comm) return;
+    comm_free(c->comm);
     c->comm = nullptr;
-    c->frame_target = nullptr;
+}
+
+// slab of the attached communicator (vct_capi.hip: vct_gi_pass on a rank context); false when there is none
+bool vct_comm_rows(const vct_ctx* c, int* row0, int* row1) {
+    if (!c || !c->comm) return false;
+    *row0 = c->comm->row0;
+    *row1 = c->comm->row1;
+    return true;
 }
 
 extern "C" {
@@ -111,6 +154,32 @@ int vct_slab_partition(int32_t height, int32_t world, int32_t rank, int32_t* row
     return VCT_OK;
 }
 
+// Equal-WORK boundaries from a per-tile-row cost histogram (e.g. the executed cone steps per tile row of the previous
+// frame, vct_last_row_steps): starts[r] = first tile row of rank r, starts[world] = tile_rows, chosen so that every
+// slab's cost is as close to total / world as whole rows allow.  Pure host arithmetic; every rank computes the same
+// boundaries from the same (all-reduced or root-broadcast) histogram.
+int vct_slab_partition_weighted(const uint64_t* row_cost, int32_t tile_rows, int32_t world, int32_t* starts) {
+    if (!row_cost || !starts || tile_rows <= 0 || world <= 0) return VCT_ERR_INVALID;
+    long double total = 0.0L;
+    for (int i = 0; i < tile_rows; ++i) total += (long double)row_cost[i] + 1.0L;     // +1: empty rows still cost a launch slot
+    starts[0] = 0;
+    long double acc = 0.0L;
+    int row = 0;
+    for (int r = 1; r < world; ++r) {
+        const long double want = total * (long double)r / (long double)world;
+        // advance while taking the next row leaves the prefix closer to the target than stopping here
+        while (row < tile_rows) {
+            const long double with = acc + (long double)row_cost[row] + 1.0L;
+            if (with <= want || (with - want) < (want - acc)) { acc = with; ++row; } else break;
+        }
+        // every remaining rank must still be able to get a (possibly empty) slab inside the frame
+        if (row < starts[r - 1]) row = starts[r - 1];
+        starts[r] = row;
+    }
+    starts[world] = tile_rows;
+    return VCT_OK;
+}
+
 int vct_comm_get_unique_id(void* id128) {
     if (!id128) return VCT_ERR_INVALID;
     Rccl* r = rccl();
@@ -121,6 +190,9 @@ int vct_comm_get_unique_id(void* id128) {
     return VCT_OK;
 }
 
+// All or nothing: the communicator is built into a local object and attached to the context only when every
+// allocation and ncclCommInitRank succeeded; on any failure everything is released and the context is as before
+// (a retry is possible, vct_frame_step keeps refusing).
 int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
     if (!c) return VCT_ERR_INVALID;
     if (!id128 || world <= 0 || rank < 0 || rank >= world) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: bad rank / world / id");
@@ -129,25 +201,35 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
     if (!r->err.empty()) return vct_fail(c, VCT_ERR_DEVICE, r->err);
     HIP_TRY(c, hipSetDevice(c->device));
     vct_comm* m = new vct_comm();
-    c->comm = m;
     m->rank = rank;
     m->world = world;
     vct_slab_partition(c->cfg.height, world, rank, &m->row0, &m->row1, &m->rows_per_rank);
     m->slab_halves = (size_t)m->rows_per_rank * VCT_TILE * c->cfg.width * 4;
-    const size_t slab_bytes = m->slab_halves * 2;
-    HIP_TRY(c, hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
-        const size_t bytes = rank == 0 ? slab_bytes * world : slab_bytes;
-        HIP_TRY(c, hipMalloc(&m->buf[k], bytes));
-        HIP_TRY(c, hipMemsetAsync(m->buf[k], 0, bytes, c->stream));
-        HIP_TRY(c, hipEventCreateWithFlags(&m->traced[k], hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&m->gathered[k], hipEventDisableTiming));
-        HIP_TRY(c, hipEventRecord(m->gathered[k], c->stream));      // "previous gather" of the first use
+    m->buf_halves = rank == 0 ? m->slab_halves * world : m->slab_halves;
+    if (const char* t = getenv("VCT_COMM_TIMEOUT_MS")) { const int v = atoi(t); if (v > 0) m->timeout_ms = v; }
+    hipError_t e = hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMalloc(&m->buf[k], m->buf_halves * 2);
+        if (e == hipSuccess) e = hipMemsetAsync(m->buf[k], 0, m->buf_halves * 2, c->stream);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->traced[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->gathered[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(m->gathered[k], c->stream);      // "previous gather" of the first use
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        comm_free(m);
+        return vct_fail(c, e == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE,
+                        std::string("vct_comm_init: ") + hipGetErrorString(e));
+    }
     ncclUniqueId id;
     memcpy(id.internal, id128, 128);
-    NCCL_TRY(c, r->CommInitRank(&m->comm, world, id, rank));
+    const ncclResult_t nr = r->CommInitRank(&m->comm, world, id, rank);
+    if (nr != ncclSuccess) {
+        m->comm = nullptr;          // nothing to destroy: ncclCommInitRank failed
+        comm_free(m);
+        return vct_fail(c, VCT_ERR_DEVICE, std::string("ncclCommInitRank: ") + r->GetErrorString(nr));
+    }
+    c->comm = m;
     return VCT_OK;
 }
 
@@ -165,39 +247,137 @@ int vct_comm_slab(vct_ctx* c, int32_t* row0, int32_t* row1) {
     return VCT_OK;
 }
 
+int vct_comm_set_timeout_ms(vct_ctx* c, int32_t ms) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!c->comm) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_set_timeout_ms: call vct_comm_init first");
+    if (ms <= 0) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_set_timeout_ms: timeout must be > 0");
+    c->comm->timeout_ms = ms;
+    return VCT_OK;
+}
+
+// Collective (every rank passes the same boundaries): slab r = tile rows [starts[r], starts[r+1]).  starts == NULL
+// returns to the equal partition.  Frames in flight are drained first; a rank whose new slab outgrows its gather
+// buffers gets larger ones.
+int vct_comm_set_slab_rows(vct_ctx* c, const int32_t* starts) {
+    if (!c) return VCT_ERR_INVALID;
+    vct_comm* m = c->comm;
+    if (!m || m->broken) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_set_slab_rows: no usable communicator (vct_comm_init)");
+    const int ty = vct_tiles_y(c);
+    if (starts) {
+        if (starts[0] != 0 || starts[m->world] != ty) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_set_slab_rows: boundaries must run from 0 to the frame's tile rows");
+        for (int r = 0; r < m->world; ++r)
+            if (starts[r + 1] < starts[r]) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_set_slab_rows: boundaries must not decrease");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = vct_comm_sync(c);
+    if (rc) return rc;
+    if (!starts) {
+        m->starts.clear();
+        vct_slab_partition(c->cfg.height, m->world, m->rank, &m->row0, &m->row1, nullptr);
+    } else {
+        m->starts.assign(starts, starts + m->world + 1);
+        m->row0 = starts[m->rank];
+        m->row1 = starts[m->rank + 1];
+    }
+    const size_t need = m->rank == 0 ? m->buf_halves : (size_t)(m->row1 - m->row0) * VCT_TILE * c->cfg.width * 4;
+    if (need > m->buf_halves) {
+        uint16_t* nb[2] = {nullptr, nullptr};
+        for (int k = 0; k < 2; ++k) {
+            const hipError_t e = hipMalloc(&nb[k], need * 2);
+            if (e != hipSuccess) {
+                if (nb[0]) (void)hipFree(nb[0]);
+                return vct_fail(c, VCT_ERR_NOMEM, std::string("vct_comm_set_slab_rows: ") + hipGetErrorString(e));
+            }
+        }
+        for (int k = 0; k < 2; ++k) { (void)hipFree(m->buf[k]); m->buf[k] = nb[k]; }
+        m->buf_halves = need;
+    }
+    m->last = -1;
+    return VCT_OK;
+}
+
 // One frame: trace this rank's slab into gather buffer k and start its gather.  Asynchronous.
 int vct_frame_step(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     vct_comm* m = c->comm;
     if (!m) return vct_fail(c, VCT_ERR_INVALID, "vct_frame_step: call vct_comm_init first");
+    if (m->broken || !m->comm) return vct_fail(c, VCT_ERR_DEVICE, "vct_frame_step: the communicator was aborted (vct_comm_destroy, then vct_comm_init again)");
     if (!c->have_gbuffer) return vct_fail(c, VCT_ERR_INVALID, "vct_frame_step: no G-buffer resident yet");
     HIP_TRY(c, hipSetDevice(c->device));
     const int k = (int)(m->frames & 1ull);
-    // this rank's padded slab inside buffer k; full-frame addressing = that address minus the slab's first row
-    uint16_t* slab = m->buf[k];      // root: slab 0 of its frame buffer (in-place gather); others: their slab buffer
+    // This rank's slab inside buffer k.  The kernel addresses the full frame, so it gets the slab's address minus the
+    // slab's first row as its output base -- passed to the launch, never stored in the context (on a non-root rank
+    // that address lies before the allocation).  Root: the frame buffer itself (slab 0 at offset 0, in-place gather).
+    uint16_t* slab = m->buf[k];
     const size_t first_row_halves = (size_t)m->row0 * VCT_TILE * c->cfg.width * 4;
     HIP_TRY(c, hipStreamWaitEvent(c->stream, m->gathered[k], 0));    // buffer k is free once its last gather is done
-    c->frame_target = slab - first_row_halves;
-    int rc = VCT_OK;
-    if (m->row1 > m->row0) rc = vct_launch_trace_rows(c, m->row0, m->row1);
+    const bool uneven = !m->starts.empty();
+    uint16_t* out_base = (m->rank == 0 && uneven) ? m->buf[k] : slab - first_row_halves;
+    const int rc = vct_launch_trace_rows(c, m->row0, m->row1, out_base);     // an empty slab launches nothing
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(m->traced[k], c->stream));
     HIP_TRY(c, hipStreamWaitEvent(m->comm_stream, m->traced[k], 0));
-    // ONE collective per frame.  Root: in place (its slab already sits at offset rank * sendcount = 0).
-    NCCL_TRY(c, rccl()->Gather(slab, m->rank == 0 ? m->buf[k] : nullptr, m->slab_halves, ncclFloat16, 0, m->comm,
-                               m->comm_stream));
+    Rccl* r = rccl();
+    if (!uneven) {
+        // ONE collective per frame.  Root: in place (its slab already sits at offset rank * sendcount = 0).
+        NCCL_TRY(c, m, r->Gather(slab, m->rank == 0 ? m->buf[k] : nullptr, m->slab_halves, ncclFloat16, 0, m->comm,
+                                 m->comm_stream));
+    } else {
+        // load-aware slabs differ in size: one fused group of point-to-point transfers, each slab straight to its
+        // rows of the root's frame (what ncclGather is made of inside RCCL, with per-rank counts)
+        const size_t row_halves = (size_t)VCT_TILE * c->cfg.width * 4;
+        NCCL_TRY(c, m, r->GroupStart());
+        ncclResult_t gr = ncclSuccess;
+        if (m->rank == 0) {
+            for (int peer = 1; peer < m->world && gr == ncclSuccess; ++peer) {
+                const size_t n = (size_t)(m->starts[peer + 1] - m->starts[peer]) * row_halves;
+                if (n) gr = r->Recv(m->buf[k] + (size_t)m->starts[peer] * row_halves, n, ncclFloat16, peer, m->comm, m->comm_stream);
+            }
+        } else {
+            const size_t n = (size_t)(m->row1 - m->row0) * row_halves;
+            if (n) gr = r->Send(slab, n, ncclFloat16, 0, m->comm, m->comm_stream);
+        }
+        const ncclResult_t ge = r->GroupEnd();
+        if (gr != ncclSuccess) return comm_fail(c, m, "ncclSend/ncclRecv", gr);
+        if (ge != ncclSuccess) return comm_fail(c, m, "ncclGroupEnd", ge);
+    }
     HIP_TRY(c, hipEventRecord(m->gathered[k], m->comm_stream));
     m->last = k;
     ++m->frames;
     return VCT_OK;
 }
 
+// Waits for the trace and the gather streams -- with a deadline: a rank that died or hangs leaves its peers inside
+// the collective forever, so after timeout_ms (vct_comm_set_timeout_ms / VCT_COMM_TIMEOUT_MS, default 60 s) or on an
+// asynchronous RCCL error the communicator is aborted and the call fails; the context itself stays usable for
+// single-GPU calls after vct_comm_destroy.
 int vct_comm_sync(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
-    if (!c->comm) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_sync: call vct_comm_init first");
+    vct_comm* m = c->comm;
+    if (!m) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_sync: call vct_comm_init first");
+    if (m->broken) return vct_fail(c, VCT_ERR_DEVICE, "vct_comm_sync: the communicator was aborted");
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->comm->comm_stream));
-    return VCT_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (true) {
+        const hipError_t q = hipStreamQuery(m->comm_stream);
+        if (q == hipSuccess) return VCT_OK;
+        if (q != hipErrorNotReady) HIP_TRY(c, q);
+        ncclResult_t async = ncclSuccess;
+        if (m->comm && rccl()->CommGetAsyncError && rccl()->CommGetAsyncError(m->comm, &async) == ncclSuccess &&
+            async != ncclSuccess && async != ncclInProgress)
+            return comm_fail(c, m, "vct_comm_sync: asynchronous RCCL error", async);
+        const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > m->timeout_ms) {
+            if (m->comm && rccl()->CommAbort) { (void)rccl()->CommAbort(m->comm); m->comm = nullptr; }
+            m->broken = true;
+            return vct_fail(c, VCT_ERR_DEVICE, "vct_comm_sync: the gather did not complete within " + std::to_string(m->timeout_ms) +
+                                               " ms (a peer rank died or hangs); communicator aborted");
+        }
+        if (++spins < 2000) std::this_thread::yield();                         // the common case: done within microseconds
+        else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
 }
 
 int vct_comm_frame(vct_ctx* c, void** dev, size_t* bytes) {
@@ -216,8 +396,8 @@ int vct_comm_download_frame(vct_ctx* c, void* out) {
     size_t bytes = 0;
     int rc = vct_comm_frame(c, &dev, &bytes);
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->comm->comm_stream));
+    rc = vct_comm_sync(c);
+    if (rc) return rc;
     HIP_TRY(c, hipMemcpy(out, dev, bytes, hipMemcpyDeviceToHost));
     return VCT_OK;
 }

@@ -742,7 +742,8 @@ k_trace_tile(const VctTraceParams p) {
     // would serialise ~32k same-address atomics per 1080p frame)
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
     if (lane == 0 && total)
-        atomicAdd(p.step_counter + (ti & (VCT_STEP_COUNTERS - 1)), (unsigned long long)total);
+        atomicAdd(p.step_counter + ((ty * VCT_STEP_ROW_BANKS + (tx & (VCT_STEP_ROW_BANKS - 1))) & (VCT_STEP_COUNTERS - 1)),
+                  (unsigned long long)total);
     flush_stats(p, ms, lane);
 }
 
@@ -859,7 +860,8 @@ k_trace_tile_split(const VctTraceParams p) {
     }
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
     if (lane == 0 && total)
-        atomicAdd(p.step_counter + ((ti * VCT_SPLIT + wave) & (VCT_STEP_COUNTERS - 1)), (unsigned long long)total);
+        atomicAdd(p.step_counter + ((ty * VCT_STEP_ROW_BANKS + (tx & (VCT_STEP_ROW_BANKS - 1))) & (VCT_STEP_COUNTERS - 1)),
+                  (unsigned long long)total);
     flush_stats(p, ms, lane);
 
     // arrival: LDS operations of a wave are performed in order, so the cone values are in LDS before
@@ -1009,8 +1011,11 @@ __device__ __forceinline__ int compact_brick(const VctTraceParams& p, uint32_t b
         const size_t vox = (size_t)b * 512 + v;
         const uint32_t src0 = p.chain[vox];
         p.bounce_out[vox] = src0;
-        const bool occ = (src0 >> 24) != 0u &&
-                         (p.attr_normal[(size_t)p.brick_slot[b] * 512 + v] & 0xffffffu) != 0x808080u;
+        // a brick without a slot holds nothing of the current mesh (the host refuses the bounce when the attributes
+        // are stale, vct_capi.hip attrs_valid; this keeps the index in bounds regardless)
+        const uint32_t slot = p.brick_slot[b];
+        const bool occ = (src0 >> 24) != 0u && slot != VCT_NO_SLOT &&
+                         (p.attr_normal[(size_t)(slot == VCT_NO_SLOT ? 0u : slot) * 512 + v] & 0xffffffu) != 0x808080u;
         const unsigned long long m = ballot64(occ);
         if (occ) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)v;
         n += __popcll(m);
