@@ -66,8 +66,6 @@ def test_native_frame_step_one_rank_communicator(vct):
     assert np.array_equal(ctx.comm_download_frame(), want)
     with pytest.raises(vct.VctError):
         ctx.comm_init(vct.comm_unique_id(), 0, 1)       # already initialised
-    with pytest.raises(vct.VctError):
-        ctx.gi_pass(vp, vp)                              # the one-call pass is for single-GPU contexts
     ctx.comm_destroy()
     assert np.array_equal(ctx.trace_current(), want)     # the context-owned frame target is back
     with pytest.raises(vct.VctError):

@@ -310,3 +310,14 @@ def test_tbn_general_frame(oracle):                    # trace.fs:175,198
         d /= np.linalg.norm(d)
         want, _ = oracle.cone(p, chain, g2[0:3, 0], g2[3:6, 0], d.astype(np.float32), 0.577)
         assert np.allclose(r2["cones"][0, i], want, atol=2e-4)
+
+
+def test_depth24_dequantisation_needs_no_double():
+    """[GL] DEPTH_COMPONENT24 (VCT.h:90): the oracle's shadow map holds float(double(q) / (2^24 - 1)); the HIP raster
+    writes float(q) / 16777215.0f (IEEE fp32 divide) straight into the map's words (csrc/vct_internal.h
+    vct_depth24_bits).  The two agree for every one of the 2^24 codes."""
+    q = np.arange(1 << 24, dtype=np.uint32)
+    want = (q.astype(np.float64) / 16777215.0).astype(np.float32)
+    got = q.astype(np.float32) / np.float32(16777215.0)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    assert got.max() == np.float32(1.0) and got.view(np.uint32).max() == 0x3F800000      # fits under the epoch bits

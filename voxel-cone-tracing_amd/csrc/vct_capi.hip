@@ -230,8 +230,8 @@ void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chai
     p.steps_specular = c->steps_dev + VCT_MAX_STEPS;
     p.n_diffuse = c->n_diffuse;
     p.n_specular = c->n_specular;
-    p.step_counter = c->step_counter + (size_t)(c->step_set ^ 1) * VCT_STEP_COUNTERS;     // the zero set
-    p.step_counter_next = c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS;
+    p.step_counter = c->step_counter;
+    p.wave_steps = c->wave_steps;
 #if defined(VCT_STATS) && VCT_STATS
     p.stats = c->stats;
 #endif
@@ -273,13 +273,8 @@ int launch_trace(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr) {
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
 #endif
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if ((row1 - row0) * p.tiles_x <= 0)     // empty slab (more ranks than tile rows): no kernel runs, so nobody zeroes the
-        HIP_TRY(c, hipMemsetAsync(c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS, 0,      // set being retired
-                                  VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
-    else
-        HIP_TRY(c, vct_launch_trace(p, variant, c->stream));
+    HIP_TRY(c, vct_launch_trace(p, variant, c->stream));       // an empty row range (a rank without rows) launches nothing
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->step_set ^= 1;           // the kernel filled the zero set and zeroed the other one (an empty launch: both are zero)
     c->last_row0 = row0;
     c->last_row1 = row1;
     c->have_trace = true;
@@ -308,6 +303,7 @@ VctVoxParams vox_params(const vct_ctx* c) {
     p.albedo = c->mat_albedo;
     p.ntri = c->ntri;
     p.shadow = c->shadow;
+    p.shadow_ebase = c->shadow_ebase;
     p.shadow_size = c->shadow_size;
     memcpy(p.light_vp, c->light_vp, 64);
     p.acc = c->acc;
@@ -502,8 +498,13 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     }
     CREATE_TRY(hipMalloc(&c->frame, npix * 8));
     CREATE_TRY(hipMemsetAsync(c->frame, 0, npix * 8, c->stream));
-    CREATE_TRY(hipMalloc(&c->step_counter, 2 * VCT_STEP_COUNTERS * sizeof(unsigned long long)));
-    CREATE_TRY(hipMemsetAsync(c->step_counter, 0, 2 * VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
+    CREATE_TRY(hipMalloc(&c->step_counter, VCT_STEP_COUNTERS * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
+    {
+        const size_t nw = (size_t)tiles_x(c) * tiles_y(c) * VCT_TRACE_WAVES;
+        CREATE_TRY(hipMalloc(&c->wave_steps, nw * sizeof(uint32_t)));
+        CREATE_TRY(hipMemsetAsync(c->wave_steps, 0, nw * sizeof(uint32_t), c->stream));
+    }
     CREATE_TRY(hipMalloc(&c->stats, 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
     CREATE_TRY(hipMalloc(&c->steps_dev, 2 * VCT_MAX_STEPS * sizeof(VctStep)));
@@ -534,10 +535,10 @@ void vct_destroy(vct_ctx* c) {
     vct_comm_release(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
-                    c->dbg_cones, c->step_counter, c->stats, c->steps_dev, c->spread_lut, c->tri_pos,
+                    c->dbg_cones, c->step_counter, c->wave_steps, c->stats, c->steps_dev, c->spread_lut, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->big_list, c->worklist, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
-                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->vis32, c->raster_lists[0], c->raster_lists[1],
+                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_lists[0], c->raster_lists[1],
                     c->raster_counts[0], c->raster_counts[1], c->raster_items[0], c->raster_items[1]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -644,11 +645,20 @@ int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const fl
     if (c->shadow) { (void)hipFree(c->shadow); c->shadow = nullptr; c->shadow_size = 0; }
     if (!depth) return VCT_OK;
     if (size <= 0 || !light_vp) return fail(c, VCT_ERR_INVALID, "vct_upload_shadow_map: bad size");
-    HIP_TRY(c, hipMalloc(&c->shadow, (size_t)size * size * sizeof(float)));
-    HIP_TRY(c, hipMemcpyAsync(c->shadow, depth, (size_t)size * size * sizeof(float),
-                              hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the map lives as shadow-map words (vct_internal.h): depths clamped to [0, 1] like a GL depth texture, epoch 0;
+    // a later vct_render_shadow_map starts a fresh epoch cycle over this buffer (shadow_passes = 0: memset first)
+    const size_t n = (size_t)size * size;
+    float* tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&c->shadow, n * sizeof(uint32_t)));
+    hipError_t e = hipMalloc(&tmp, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp, depth, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = vct_launch_shadow_encode(tmp, c->shadow, n, 0u, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) { (void)hipFree(c->shadow); c->shadow = nullptr; HIP_TRY(c, e); }
     c->shadow_size = size;
+    c->shadow_ebase = 0u;
+    c->shadow_passes = 0u;
     memcpy(c->light_vp, light_vp, 64);
     return VCT_OK;
 }
@@ -659,16 +669,10 @@ int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const fl
 static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s, VctRasterArgs& a) {
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "no triangles uploaded");
     const int k = depth_only ? 0 : 1;
-    if (depth_only ? c->vis32_words < pixels : c->vis_words < pixels) {
-        if (depth_only) {
-            if (c->vis32) { (void)hipFree(c->vis32); c->vis32 = nullptr; c->vis32_words = 0; }
-            HIP_TRY(c, hipMalloc(&c->vis32, pixels * sizeof(uint32_t)));
-            c->vis32_words = pixels;
-        } else {
-            if (c->vis) { (void)hipFree(c->vis); c->vis = nullptr; c->vis_words = 0; }
-            HIP_TRY(c, hipMalloc(&c->vis, pixels * sizeof(unsigned long long)));
-            c->vis_words = pixels;
-        }
+    if (!depth_only && c->vis_words < pixels) {
+        if (c->vis) { (void)hipFree(c->vis); c->vis = nullptr; c->vis_words = 0; }
+        HIP_TRY(c, hipMalloc(&c->vis, pixels * sizeof(unsigned long long)));
+        c->vis_words = pixels;
         c->raster_dirty[k] = true;
     }
     if (!c->raster_lists[k]) HIP_TRY(c, hipMalloc(&c->raster_lists[k], (size_t)c->ntri * 4 * sizeof(int32_t)));
@@ -682,7 +686,7 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
         c->raster_item_capacity[k] = (uint32_t)want_items;
     }
     if (c->raster_dirty[k]) {   // first pass, resized buffers, or a pass that failed half way: clear this kind's state once
-        if (depth_only) HIP_TRY(c, hipMemsetAsync(c->vis32, 0xff, c->vis32_words * sizeof(uint32_t), s));
+        if (depth_only) c->shadow_passes = 0u;      // the shadow words restart their epoch cycle with a memset (below)
         else HIP_TRY(c, hipMemsetAsync(c->vis, 0xff, c->vis_words * sizeof(unsigned long long), s));
         HIP_TRY(c, hipMemsetAsync(c->raster_counts[k], 0, 8 * sizeof(uint32_t), s));
         c->raster_dirty[k] = false;
@@ -696,7 +700,8 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
     a.ntri = c->ntri;
     a.model_scale = c->cfg.model_scale;
     a.vis = c->vis;
-    a.vis32 = c->vis32;
+    a.vis32 = nullptr;          // vct_render_shadow_map points it at the shadow-map words
+    a.vis32_ebase = 0u;
     a.items = c->raster_items[k];
     uint32_t* cur = c->raster_counts[k] + 4 * c->raster_set[k];
     a.item_count = cur;
@@ -796,24 +801,41 @@ int vct_render_shadow_map(vct_ctx* c, const float light_vp[16]) {
     const int S = c->cfg.shadow_map_size;
     if (S <= 0) return fail(c, VCT_ERR_INVALID, "vct_render_shadow_map: config.shadow_map_size <= 0");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->shadow && c->shadow_size != S) { (void)hipFree(c->shadow); c->shadow = nullptr; c->shadow_size = 0; }
+    if (!c->shadow) {
+        HIP_TRY(c, hipMalloc(&c->shadow, (size_t)S * S * sizeof(uint32_t)));
+        c->shadow_passes = 0u;
+    }
+    c->shadow_size = S;
     VctRasterArgs a;
     int rc = raster_args(c, (size_t)S * S, true, c->stream, a);
     if (rc) return rc;
-    if (c->shadow && c->shadow_size != S) { (void)hipFree(c->shadow); c->shadow = nullptr; }
-    if (!c->shadow) HIP_TRY(c, hipMalloc(&c->shadow, (size_t)S * S * sizeof(float)));
-    c->shadow_size = S;
+    // The pass's atomicMin words ARE the map (vct_internal.h "shadow map words"): epoch 3, 2, 1, 0, then one memset
+    // and 3 again -- a new pass overwrites older epochs by itself, readers see them as depth 1.0.
+    const uint32_t epoch = 3u - (c->shadow_passes & 3u);
+    if (epoch == 3u) HIP_TRY(c, hipMemsetAsync(c->shadow, 0xff, (size_t)S * S * sizeof(uint32_t), c->stream));
+    a.vis32 = c->shadow;
+    a.vis32_ebase = VCT_SHADOW_EPOCH(epoch);
     memcpy(c->light_vp, light_vp, 64);
-    const hipError_t e = vct_launch_shadow_raster(a, light_vp, S, c->shadow, c->stream);
+    const hipError_t e = vct_launch_shadow_raster(a, light_vp, S, c->stream);
     if (e != hipSuccess) { c->raster_dirty[0] = true; HIP_TRY(c, e); }
+    c->shadow_ebase = a.vis32_ebase;
+    ++c->shadow_passes;
     return VCT_OK;
 }
 
 int vct_download_shadow_map(vct_ctx* c, float* depth) {
     if (!c || !depth) return VCT_ERR_INVALID;
     if (!c->shadow) return fail(c, VCT_ERR_INVALID, "no shadow map");
-    HIP_TRY(c, hipMemcpyAsync(depth, c->shadow, (size_t)c->shadow_size * c->shadow_size * sizeof(float),
-                              hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->shadow_size * c->shadow_size;
+    float* tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&tmp, n * sizeof(float)));
+    hipError_t e = vct_launch_shadow_decode(c->shadow, tmp, n, c->shadow_ebase, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(depth, tmp, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(c, e);
     return VCT_OK;
 }
 
@@ -832,8 +854,8 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     hipError_t e = vct_launch_gbuffer_visibility(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, s);
     if (e == hipSuccess && shadow_ready) e = hipStreamWaitEvent(s, shadow_ready, 0);
     if (e == hipSuccess)
-        e = vct_launch_gbuffer_shade(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow, c->shadow_size,
-                                     c->light_vp, c->gb_tiled, s);
+        e = vct_launch_gbuffer_shade(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow, c->shadow_ebase,
+                                     c->shadow_size, c->light_vp, c->gb_tiled, s);
     if (e != hipSuccess) { c->raster_dirty[1] = true; HIP_TRY(c, e); }
     c->gb_current = c->gb_tiled;
     c->last_row0 = row0;
@@ -973,12 +995,10 @@ int vct_bounce(vct_ctx* c) {
     p.bounce_list = c->bounce_list + 1;
     p.bounce_list_cap = c->bounce_list_cap;
     p.brick_over = c->brick_over;
-    // the bounce kernels do not zero the other counter set: clear both, fill the one fill_march_params chose
-    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, 2 * VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_bounce(p, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->step_set ^= 1;
     HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
                                      b_sparse ? c->mip_seen_b : nullptr, c->stream));
     // the directional chains always describe the chain the trace reads (the bounce itself gathers
@@ -1261,15 +1281,41 @@ int vct_download_cones(vct_ctx* c, float* cones) {
     return VCT_OK;
 }
 
+// executed steps per tile row of the last screen trace: sums of the waves' slots over the launched rows
+static int row_steps(vct_ctx* c, std::vector<uint64_t>& rows) {
+    const int tx = tiles_x(c), ty = tiles_y(c);
+    rows.assign((size_t)ty, 0);
+    const int r0 = c->last_row0, r1 = c->last_row1;
+    if (r1 <= r0) return VCT_OK;
+    const size_t per_row = (size_t)tx * VCT_TRACE_WAVES;
+    std::vector<uint32_t> v(per_row * (size_t)(r1 - r0));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(v.data(), c->wave_steps + per_row * (size_t)r0, v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int r = r0; r < r1; ++r) {
+        uint64_t sum = 0;
+        const uint32_t* q = v.data() + per_row * (size_t)(r - r0);
+        for (size_t i = 0; i < per_row; ++i) sum += q[i];
+        rows[(size_t)r] = sum;
+    }
+    return VCT_OK;
+}
+
 int vct_last_step_count(vct_ctx* c, uint64_t* steps) {
     if (!c || !steps) return VCT_ERR_INVALID;
     if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::vector<unsigned long long> v(VCT_STEP_COUNTERS);
-    HIP_TRY(c, hipMemcpy(v.data(), c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS,
-                         VCT_STEP_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long sum = 0;
-    for (int i = 0; i < VCT_STEP_COUNTERS; ++i) sum += v[i];
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint64_t sum = 0;
+    if (c->last_was_screen_trace) {
+        std::vector<uint64_t> rows;
+        const int rc = row_steps(c, rows);
+        if (rc) return rc;
+        for (uint64_t r : rows) sum += r;
+    } else {        // a bounce: its kernels add into the atomic bank
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        unsigned long long v[VCT_STEP_COUNTERS];
+        HIP_TRY(c, hipMemcpy(v, c->step_counter, sizeof(v), hipMemcpyDeviceToHost));
+        for (int i = 0; i < VCT_STEP_COUNTERS; ++i) sum += v[i];
+    }
     *steps = sum;
     return VCT_OK;
 }
@@ -1299,17 +1345,11 @@ int vct_last_row_steps(vct_ctx* c, uint64_t* rows, int32_t nrows) {
     if (!c->have_trace || !c->last_was_screen_trace)
         return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: the last march was not a screen trace");
     if (nrows != tiles_y(c)) return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: nrows must be the frame's tile rows, ceil(height / 8)");
-    if (nrows * VCT_STEP_ROW_BANKS > VCT_STEP_COUNTERS)
-        return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: frames taller than 4096 px share counters between tile rows");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::vector<unsigned long long> v(VCT_STEP_COUNTERS);
-    HIP_TRY(c, hipMemcpy(v.data(), c->step_counter + (size_t)c->step_set * VCT_STEP_COUNTERS,
-                         VCT_STEP_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int r = 0; r < nrows; ++r) {
-        unsigned long long sum = 0;
-        for (int b = 0; b < VCT_STEP_ROW_BANKS; ++b) sum += v[(size_t)r * VCT_STEP_ROW_BANKS + b];
-        rows[r] = sum;
-    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint64_t> v;
+    const int rc = row_steps(c, v);
+    if (rc) return rc;
+    memcpy(rows, v.data(), (size_t)nrows * sizeof(uint64_t));
     return VCT_OK;
 }
 

@@ -36,8 +36,8 @@ struct vct_ctx {
     uint16_t* frame_target = nullptr; // caller-owned output (vct_set_frame_target) or null
     uint8_t* dbg_steps = nullptr;
     float* dbg_cones = nullptr;
-    unsigned long long* step_counter = nullptr;   // two sets of VCT_STEP_COUNTERS; invariant: the set NOT named by step_set is zero
-    int step_set = 0;                              // set written by the last launch
+    unsigned long long* step_counter = nullptr;   // [VCT_STEP_COUNTERS] atomic bank of the bounce kernels (memset before each bounce)
+    uint32_t* wave_steps = nullptr;               // [tiles * VCT_TRACE_WAVES] executed steps per wave of the screen trace
     unsigned long long* stats = nullptr;      // [8] march statistics of instrumented builds (VCT_STATS)
     VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
     uint32_t* spread_lut = nullptr;   // [1024] spread3(i) << 2 (vct_trace.hip: dilated anchor coordinates by scalar load)
@@ -57,8 +57,10 @@ struct vct_ctx {
     int32_t* tri_mat = nullptr;
     float* mat_albedo = nullptr;
     int32_t ntri = 0, nmat = 0;
-    float* shadow = nullptr;
+    uint32_t* shadow = nullptr;       // shadow-map words (vct_internal.h vct_shadow_depth), shadow_size^2
     int32_t shadow_size = 0;
+    uint32_t shadow_ebase = 0;        // epoch base of the words the map currently shows
+    uint32_t shadow_passes = 0;       // shadow passes rasterised into this buffer since its last memset
     // raster input stages
     float* tri_nrm = nullptr;
     float* tri_tan = nullptr;
@@ -75,8 +77,6 @@ struct vct_ctx {
     // `raster_dirty` (a launch failed, or nothing is initialised yet) makes the next pass clear everything once.
     unsigned long long* vis = nullptr;        // 64-bit words of the main draw
     size_t vis_words = 0;
-    uint32_t* vis32 = nullptr;                // 32-bit depth-only words of the shadow pass
-    size_t vis32_words = 0;
     // lists / counters / tile items exist twice, [0] for the shadow pass and [1] for the main draw, so that the main
     // draw's visibility raster can run on the second stream WHILE the shadow map is rasterised (vct_gi_pass)
     int32_t* raster_lists[2] = {nullptr, nullptr};     // [2*ntri] wave list, [2*ntri] group list

@@ -66,16 +66,42 @@ __device__ __forceinline__ float4 vct_tex_sample(const VctTextures& t, int ti, f
 }
 #endif
 
+// ---- shadow map words (R/Voxel_Cone_Tracing.h:79-105 keeps a DEPTH_COMPONENT24 texture) ----------------------------
+// The map is stored as the very words the shadow pass's atomicMin leaves behind: the fp32 bits of the depth, already
+// quantised to 24 bits ([GL] fixed-point depth: float(round(z * (2^24 - 1)) / (2^24 - 1)), in [0, 1] so <= 0x3f800000),
+// plus an EPOCH in the two top bits: pass n writes with epoch 3 - (n & 3).  Positive floats order like their bit
+// patterns and a lower epoch is a smaller word, so a new pass simply overwrites what older passes left (no clear, no
+// conversion pass: the buffer is memset once every fourth pass, when the epoch wraps); a reader subtracts the pass's
+// epoch base and clamps -- words of older passes and never-written ones (all ones) come out as depth 1.0, the
+// cleared depth buffer.  Two VALU per texel instead of a 192 MiB conversion pass per shadow map.
+#define VCT_SHADOW_ONE 0x3f800000u
+#define VCT_SHADOW_EPOCH(e) ((uint32_t)(e) << 30)
+#if defined(__HIPCC__)
+__device__ __forceinline__ float vct_shadow_depth(uint32_t word, uint32_t ebase) {
+    const uint32_t v = word - ebase;
+    return __uint_as_float(v < VCT_SHADOW_ONE ? v : VCT_SHADOW_ONE);
+}
+// [GL] DEPTH_COMPONENT24: z in [0, 1) -> float(q / (2^24 - 1)), q = floor(z * (2^24 - 1) + 0.5) in double exactly as
+// the oracle computes it (the product is exact in double, so the fma is the same single rounding as mul + add);
+// float(q) / 16777215.0f (IEEE) equals float(double(q) / 16777215.0) for every q (tests/test_oracle_kat.py).
+__device__ __forceinline__ uint32_t vct_depth24_bits(float z) {
+    const uint32_t q = (uint32_t)floor(fma((double)z, 16777215.0, 0.5));
+    return __float_as_uint(__fdiv_rn((float)q, 16777215.0f));
+}
+#endif
+
 #define VCT_NO_SLOT 0xffffffffu
 #define VCT_TILE 8
 #define VCT_TILE_PIX 64
 #define VCT_GB_NPLANES 23
 #define VCT_MAX_STEPS 1024
-// Executed-step counters: the screen trace adds a wave's steps to counter [tile_row * VCT_STEP_ROW_BANKS + (tile_x & 3)],
-// so the bank is also the per-tile-row cost histogram of the frame (vct_last_row_steps: load-aware slabs) at no extra
-// atomic; 2048 counters = 512 tile rows (4096 px) without aliasing, taller frames wrap (the total stays right).
-#define VCT_STEP_COUNTERS 2048  // power of two
-#define VCT_STEP_ROW_BANKS 4
+// Executed steps.  The screen trace STORES each wave's count into its own slot, wave_steps[tile * VCT_TRACE_WAVES + wave]
+// (tile = frame-wide tile index): no atomic, nothing to zero between launches, and the host gets the total (sum over the
+// launched rows) as well as the per-tile-row cost histogram (vct_last_row_steps: load-aware slabs) from the same words.
+// (Device-scope atomicAdd into a shared bank cost 2.5 % of the trace when neighbouring tiles shared addresses.)
+// The bounce kernels, whose waves loop over many voxels, keep a small bank of atomic counters.
+#define VCT_TRACE_WAVES 3
+#define VCT_STEP_COUNTERS 256   // bounce kernels only (power of two)
 
 // One entry per march step of a cone aperture.  The step sequence of trace.fs:90-104 (dist,
 // diameter, lod) does not depend on the pixel, only on (V, G, tanHalfAngle, MAX_DISTANCE): the
@@ -122,8 +148,8 @@ struct VctTraceParams {
     uint16_t* out;                      // RGBA16F [h][w][4]
     uint8_t* dbg_steps;                 // [npix][7] or null
     float* dbg_cones;                   // [npix][7][4] or null
-    unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] partial sums of executed steps (zero at launch)
-    unsigned long long* step_counter_next;   // the other set: zeroed by the trace kernels for the launch after this one
+    unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] bounce kernels: partial sums of executed steps (zero at launch)
+    uint32_t* wave_steps;               // [tiles * VCT_TRACE_WAVES] screen trace: executed steps of each wave (stored, not added)
     unsigned long long* stats;          // [8] wave-level march counters (builds with -DVCT_STATS=1 only)
     // second bounce (k_bounce): per-voxel attributes (pooled like the accumulators: [slot][512]), touched-brick
     // flags, output level 0
@@ -152,7 +178,8 @@ struct VctVoxParams {
     const int32_t* material;   // [ntri]
     const float* albedo;       // [nmat][4]
     int32_t ntri;
-    const float* shadow;       // [S*S] or null
+    const uint32_t* shadow;    // [S*S] shadow-map words (vct_shadow_depth) or null
+    uint32_t shadow_ebase;     // epoch base of the pass that produced them
     int32_t shadow_size;
     float light_vp[16];
     // Accumulators live in a POOL of 8^3-voxel slots, one slot per brick that any fragment of the uploaded mesh
@@ -187,7 +214,8 @@ struct VctRasterArgs {
     // Visibility words: 64-bit (depth | id) of the main draw, W*H; 32-bit depth-only of the shadow pass, S*S.
     // Invariant between passes: every word is all-ones ("empty") -- the consumer of a word resets it.
     unsigned long long* vis;
-    uint32_t* vis32;
+    uint32_t* vis32;             // = the shadow-map words of the context
+    uint32_t vis32_ebase;        // epoch base this shadow pass writes with
     int32_t* wave_list;          // [2*ntri] medium sub-triangles
     uint32_t* wave_count;
     int32_t* group_list;         // [2*ntri] small-medium sub-triangles (one 16-lane group each)
@@ -199,15 +227,17 @@ struct VctRasterArgs {
     VctTextures tex;             // material textures + texture coordinates (G-buffer pass)
 };
 
-hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
-                                    hipStream_t s);
+hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, hipStream_t s);
+// float depths in [0, 1] <-> shadow-map words (uploads of maps made elsewhere, downloads)
+hipError_t vct_launch_shadow_encode(const float* depth, uint32_t* words, size_t n, uint32_t ebase, hipStream_t s);
+hipError_t vct_launch_shadow_decode(const uint32_t* words, float* depth, size_t n, uint32_t ebase, hipStream_t s);
 // tile rows [row0, row1) only (whole frame: 0 .. ceil(H/8)); visibility (k_raster_vis + k_raster_mid) and shading
 // (k_gbuffer_shade, the only part that reads the shadow map) are separate calls so that a stream wait can sit between
 hipError_t vct_launch_gbuffer_visibility(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
                                          hipStream_t s);
 hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
-                                    const float* shadow, int shadow_size, const float light_vp[16], float* tiled,
-                                    hipStream_t s);
+                                    const uint32_t* shadow, uint32_t shadow_ebase, int shadow_size,
+                                    const float light_vp[16], float* tiled, hipStream_t s);
 hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s);
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s);

@@ -177,7 +177,8 @@ struct RasterParams {
     uint32_t* wave_count;
     int32_t* group_list;         // (tri * 2 + sub) of small-medium sub-triangles (one 16-lane group each)
     uint32_t* group_count;
-    uint32_t* vis32;             // depth-only pass: 32-bit visibility words (depth bits), else null
+    uint32_t* vis32;             // depth-only pass: the shadow-map words (depth24 bits + epoch base), else null
+    uint32_t vis32_ebase;
     uint2* items;                // tile work items of huge sub-triangles: (tri * 2 + sub, tile_y << 16 | tile_x)
     uint32_t* item_count;
     uint32_t item_capacity;
@@ -241,8 +242,9 @@ __device__ __forceinline__ void plot(const RasterParams& p, const SubTri& s, int
         const float v = (q0 * s.tv[0] + q1 * s.tv[1] + q2 * s.tv[2]) * qs;
         if (vct_tex_sample(p.tex, s.tex, u, v).w < 0.5f) return;                 // trace.fs:171 discard
     }
-    if (p.vis32) {        // depth-only pass (shadow map): the nearest depth is all that is kept
-        atomicMin(&p.vis32[(size_t)py * p.W + px], __float_as_uint(z));
+    if (p.vis32) {        // depth-only pass (shadow map): the nearest depth is all that is kept, as the 24-bit depth
+        // the map will show (quantisation is monotonic: the minimum of the quantised depths is the quantised minimum)
+        atomicMin(&p.vis32[(size_t)py * p.W + px], vct_depth24_bits(z) + p.vis32_ebase);
         return;
     }
     atomicMin(&p.vis[(size_t)py * p.W + px], ((unsigned long long)__float_as_uint(z) << 32) | id);
@@ -443,16 +445,19 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
     }
 }
 
-// 32-bit visibility words of the depth-only pass (depth bits, ~0 = empty) -> DEPTH_COMPONENT24
-// -- and the word is set back to "empty", so the next pass needs no clear
+// float depths in [0, 1] <-> shadow-map words of epoch base `ebase`
 __global__ void __launch_bounds__(256)
-k_vis32_to_depth24(uint32_t* __restrict__ vis, float* __restrict__ depth, size_t n) {
+k_shadow_encode(const float* __restrict__ depth, uint32_t* __restrict__ words, size_t n, uint32_t ebase) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t v = vis[i];
-        vis[i] = ~0u;
-        const float z = v == ~0u ? 1.0f : __uint_as_float(v);
-        depth[i] = (float)(floor((double)z * 16777215.0 + 0.5) / 16777215.0);
+        const float d = depth[i];
+        const float c = !(d > 0.0f) ? 0.0f : (d > 1.0f ? 1.0f : d);        // [GL] depth textures are clamped to [0, 1]
+        words[i] = __float_as_uint(c) + ebase;
     }
+}
+__global__ void __launch_bounds__(256)
+k_shadow_decode(const uint32_t* __restrict__ words, float* __restrict__ depth, size_t n, uint32_t ebase) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        depth[i] = vct_shadow_depth(words[i], ebase);
 }
 
 struct ShadeParams {
@@ -463,7 +468,8 @@ struct ShadeParams {
     const int32_t* material;     // [ntri]
     const float* albedo;         // [nmat][4]
     const float* specular;       // [nmat][3]
-    const float* shadow;         // [S*S] or null
+    const uint32_t* shadow;      // [S*S] shadow-map words or null
+    uint32_t shadow_ebase;
     int32_t shadow_size;
     float light_vp[16];
     float* tiled;                // [tile][23][64]
@@ -472,15 +478,15 @@ struct ShadeParams {
 };
 
 // [GL] bilinear clamp-to-edge fetch with the operation order of host/vct_host.cpp shadow_fetch
-__device__ __forceinline__ float shadow_fetch(const float* __restrict__ depth, int S, float u, float v) {
+__device__ __forceinline__ float shadow_fetch(const uint32_t* __restrict__ words, uint32_t eb, int S, float u, float v) {
     const float x = u * (float)S - 0.5f, y = v * (float)S - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const float a = x - fx, b = y - fy;
     const float top = (float)(S - 1);
     auto cl = [&](float f) -> int { return f < 0.0f ? 0 : (f > top ? S - 1 : (int)f); };
     const int i0 = cl(fx), i1 = cl(fx + 1.0f), j0 = cl(fy), j1 = cl(fy + 1.0f);
-    const float d00 = depth[(size_t)j0 * S + i0], d10 = depth[(size_t)j0 * S + i1];
-    const float d01 = depth[(size_t)j1 * S + i0], d11 = depth[(size_t)j1 * S + i1];
+    const float d00 = vct_shadow_depth(words[(size_t)j0 * S + i0], eb), d10 = vct_shadow_depth(words[(size_t)j0 * S + i1], eb);
+    const float d01 = vct_shadow_depth(words[(size_t)j1 * S + i0], eb), d11 = vct_shadow_depth(words[(size_t)j1 * S + i1], eb);
     return (1.0f - a) * (1.0f - b) * d00 + a * (1.0f - b) * d10 + (1.0f - a) * b * d01 + a * b * d11;
 }
 
@@ -662,11 +668,11 @@ k_gbuffer_shade(const ShadeParams p) {
                 // resident wave counts); the taps are counted, so their order is free
                 float r0[6], r1[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) r0[i] = p.shadow[(size_t)row[0] * S + col[i]];
+                for (int i = 0; i < 6; ++i) r0[i] = vct_shadow_depth(p.shadow[(size_t)row[0] * S + col[i]], p.shadow_ebase);
 #pragma unroll
                 for (int y = 0; y < 5; ++y) {
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) r1[i] = p.shadow[(size_t)row[y + 1] * S + col[i]];
+                    for (int i = 0; i < 6; ++i) r1[i] = vct_shadow_depth(p.shadow[(size_t)row[y + 1] * S + col[i]], p.shadow_ebase);
 #pragma unroll
                     for (int x = 0; x < 5; ++x) {
                         const float a = xa[x], b = yb[y];
@@ -681,7 +687,7 @@ k_gbuffer_shade(const ShadeParams p) {
                 for (int x = -2; x <= 2; ++x)
                     for (int y = -2; y <= 2; ++y) {
                         const float ox = step * (float)x, oy = step * (float)y;       // trace.fs:147
-                        if (cur <= shadow_fetch(p.shadow, p.shadow_size, cx + ox, cy + oy)) cnt += 1.0f;
+                        if (cur <= shadow_fetch(p.shadow, p.shadow_ebase, p.shadow_size, cx + ox, cy + oy)) cnt += 1.0f;
                     }
             }
             shadow = cnt * 0.111f;                                                // trace.fs:158
@@ -724,6 +730,7 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
     r.group_list = a.group_list;
     r.group_count = a.group_count;
     r.vis32 = nullptr;
+    r.vis32_ebase = 0u;
     r.items = a.items;
     r.item_count = a.item_count;
     r.item_capacity = a.item_capacity;
@@ -751,14 +758,20 @@ hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
 
 }  // namespace
 
-hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, float* depth,
-                                    hipStream_t s) {
+hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, hipStream_t s) {
     RasterParams r = make_raster(a, light_vp, S, S, 0, S);
-    r.vis32 = a.vis32;                                  // depth only: half the traffic of the 64-bit words
-    hipError_t e = run_visibility(r, s);
-    if (e != hipSuccess) return e;
-    const size_t n = (size_t)S * S;
-    hipLaunchKernelGGL(k_vis32_to_depth24, dim3(256 * 8), dim3(256), 0, s, r.vis32, depth, n);
+    r.vis32 = a.vis32;                                  // depth only, straight into the shadow-map words
+    r.vis32_ebase = a.vis32_ebase;
+    return run_visibility(r, s);
+}
+
+hipError_t vct_launch_shadow_encode(const float* depth, uint32_t* words, size_t n, uint32_t ebase, hipStream_t s) {
+    hipLaunchKernelGGL(k_shadow_encode, dim3(256 * 8), dim3(256), 0, s, depth, words, n, ebase);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_shadow_decode(const uint32_t* words, float* depth, size_t n, uint32_t ebase, hipStream_t s) {
+    hipLaunchKernelGGL(k_shadow_decode, dim3(256 * 8), dim3(256), 0, s, words, depth, n, ebase);
     return hipGetLastError();
 }
 
@@ -778,12 +791,12 @@ hipError_t vct_launch_gbuffer_visibility(const VctRasterArgs& a, const float vie
 }
 
 hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
-                                    const float* shadow, int shadow_size, const float light_vp[16], float* tiled,
-                                    hipStream_t s) {
+                                    const uint32_t* shadow, uint32_t shadow_ebase, int shadow_size,
+                                    const float light_vp[16], float* tiled, hipStream_t s) {
     ShadeParams p = make_shade(a, view_proj, W, H, row0, row1);
     p.nrm = a.nrm; p.tan = a.tan; p.bit = a.bit;
     p.material = a.material; p.albedo = a.albedo; p.specular = a.specular;
-    p.shadow = shadow; p.shadow_size = shadow_size;
+    p.shadow = shadow; p.shadow_ebase = shadow_ebase; p.shadow_size = shadow_size;
     for (int i = 0; i < 16; ++i) p.light_vp[i] = light_vp[i];
     p.tiled = tiled;
     p.tiles_x = (W + VCT_TILE - 1) / VCT_TILE;

@@ -608,8 +608,6 @@ k_trace_tile(const VctTraceParams p) {
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
     const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    if (blockIdx.x == 0)        // counters of the NEXT launch (two sets, used alternately: no memset dispatch per trace)
-        for (int i = (int)threadIdx.x; i < VCT_STEP_COUNTERS; i += (int)blockDim.x) p.step_counter_next[i] = 0ull;
     const int ti = vb * VCT_WAVES_PER_BLOCK + wave;
     if (ti >= ntiles) return;
 
@@ -738,12 +736,9 @@ k_trace_tile(const VctTraceParams p) {
         *reinterpret_cast<uint2*>(p.out + pixel_index(fresh_lane()) * 4) = pk;
     }
 #undef VCT_GB
-    // executed-step count: wave reduction, then one atomic into a counter bank (a single word
-    // would serialise ~32k same-address atomics per 1080p frame)
+    // executed-step count: wave reduction, stored into the tile's slot (wave 0 of VCT_TRACE_WAVES; the others are zero)
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-    if (lane == 0 && total)
-        atomicAdd(p.step_counter + ((ty * VCT_STEP_ROW_BANKS + (tx & (VCT_STEP_ROW_BANKS - 1))) & (VCT_STEP_COUNTERS - 1)),
-                  (unsigned long long)total);
+    if (lane < VCT_TRACE_WAVES) p.wave_steps[(size_t)tile * VCT_TRACE_WAVES + lane] = lane == 0 ? (uint32_t)total : 0u;
     flush_stats(p, ms, lane);
 }
 
@@ -776,10 +771,6 @@ k_trace_tile_split(const VctTraceParams p) {
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
     const int ti = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    // the executed-step counters of the NEXT launch are zeroed here (two sets, used alternately): no memset
-    // dispatch in front of every trace
-    if (blockIdx.x == 0)
-        for (int i = (int)threadIdx.x; i < VCT_STEP_COUNTERS; i += (int)blockDim.x) p.step_counter_next[i] = 0ull;
     if (ti >= ntiles) return;
 
     LaneBlock lb;
@@ -859,9 +850,7 @@ k_trace_tile_split(const VctTraceParams p) {
         if (p.dbg_steps && in_frame) p.dbg_steps[pixel_index(fresh_lane()) * 7 + 6] = (uint8_t)st6;
     }
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-    if (lane == 0 && total)
-        atomicAdd(p.step_counter + ((ty * VCT_STEP_ROW_BANKS + (tx & (VCT_STEP_ROW_BANKS - 1))) & (VCT_STEP_COUNTERS - 1)),
-                  (unsigned long long)total);
+    if (lane == 0) p.wave_steps[(size_t)tile * VCT_TRACE_WAVES + wave] = (uint32_t)total;     // a plain store: no atomic, no clear
     flush_stats(p, ms, lane);
 
     // arrival: LDS operations of a wave are performed in order, so the cone values are in LDS before

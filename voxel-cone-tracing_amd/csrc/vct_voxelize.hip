@@ -39,7 +39,7 @@ __device__ __forceinline__ F3 xform_point(const float* m, F3 p) {
 }
 
 // [GL] bilinear, clamp-to-edge depth fetch (VCT.h:93-96)
-__device__ __forceinline__ float shadow_tex(const float* __restrict__ depth, int S, float u, float v) {
+__device__ __forceinline__ float shadow_tex(const uint32_t* __restrict__ words, uint32_t eb, int S, float u, float v) {
     const float fS = (float)S;
     const float x = u * fS - 0.5f, y = v * fS - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
@@ -51,8 +51,8 @@ __device__ __forceinline__ float shadow_tex(const float* __restrict__ depth, int
         return (int)f;
     };
     const int i0 = cl(fx), i1 = cl(fx + 1.0f), j0 = cl(fy), j1 = cl(fy + 1.0f);
-    const float d00 = depth[(size_t)j0 * S + i0], d10 = depth[(size_t)j0 * S + i1];
-    const float d01 = depth[(size_t)j1 * S + i0], d11 = depth[(size_t)j1 * S + i1];
+    const float d00 = vct_shadow_depth(words[(size_t)j0 * S + i0], eb), d10 = vct_shadow_depth(words[(size_t)j0 * S + i1], eb);
+    const float d01 = vct_shadow_depth(words[(size_t)j1 * S + i0], eb), d11 = vct_shadow_depth(words[(size_t)j1 * S + i1], eb);
     const float a0 = 1.0f - a, b0 = 1.0f - b;
     float acc = (a0 * b0) * d00;
     acc = fmaf(a * b0, d10, acc);
@@ -83,7 +83,7 @@ __device__ __forceinline__ void tap_axis(float coord, float inv, float fS, float
 // 100) and each tap is evaluated from registers with its own exact weights; lanes whose indices
 // are irregular (fp rounding at a texel boundary, clamped borders) take the tap-by-tap path.  Same
 // bits either way.
-__device__ __forceinline__ int pcf25(const float* __restrict__ depth, int S, F3 c, float bias) {
+__device__ __forceinline__ int pcf25(const uint32_t* __restrict__ words, uint32_t eb, int S, F3 c, float bias) {
     const float inv = __fdiv_rn(1.0f, (float)S);
     const float fS = (float)S, top = (float)(S - 1);
     TapAxis X, Y;
@@ -103,7 +103,7 @@ __device__ __forceinline__ int pcf25(const float* __restrict__ depth, int S, F3 
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) d[j][i] = depth[(size_t)row[j] * S + col[i]];
+            for (int i = 0; i < 6; ++i) d[j][i] = vct_shadow_depth(words[(size_t)row[j] * S + col[i]], eb);
 #pragma unroll
         for (int x = 0; x < 5; ++x)
 #pragma unroll
@@ -120,7 +120,7 @@ __device__ __forceinline__ int pcf25(const float* __restrict__ depth, int S, F3 
         for (int x = -2; x <= 2; ++x)
             for (int y = -2; y <= 2; ++y) {
                 const float ox = inv * (float)x, oy = inv * (float)y;
-                const float closest = shadow_tex(depth, S, c.x + ox, c.y + oy);
+                const float closest = shadow_tex(words, eb, S, c.x + ox, c.y + oy);
                 if (cur <= closest) ++count;
             }
     }
@@ -283,7 +283,7 @@ __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& 
         const F3 dc = {b0 * r.dc[0].x + b1 * r.dc[1].x + b2 * r.dc[2].x,
                        b0 * r.dc[0].y + b1 * r.dc[1].y + b2 * r.dc[2].y,
                        b0 * r.dc[0].z + b1 * r.dc[1].z + b2 * r.dc[2].z};
-        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_size, dc, 0.002f), 25.0f);   // vox.fs:46
+        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f), 25.0f);   // vox.fs:46
     }
     float alb[3];
     frag_albedo(p, r, b0, b1, b2, alb);                                              // vox.fs:56
@@ -472,7 +472,7 @@ __device__ __forceinline__ void ref_fragment(const VctVoxParams& p, const RefSet
         const F3 dc = {l0 * r.dc[0].x + l1 * r.dc[1].x + l2 * r.dc[2].x,
                        l0 * r.dc[0].y + l1 * r.dc[1].y + l2 * r.dc[2].y,
                        l0 * r.dc[0].z + l1 * r.dc[1].z + l2 * r.dc[2].z};
-        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_size, dc, 0.002f), 25.0f);    // vox.fs:46
+        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f), 25.0f);    // vox.fs:46
     }
     float alb[3];
     frag_albedo(p, r, l0, l1, l2, alb);                                               // vox.fs:56
