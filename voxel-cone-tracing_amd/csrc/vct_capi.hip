@@ -5,6 +5,7 @@
 // stream.  No CPU fallback exists: every entry point that computes launches a kernel or fails.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -101,10 +102,10 @@ int build_steps(const vct_config& cfg, float tan_half, std::vector<VctStep>& out
             s.level2 = s.level + 1 > maxl ? maxl : s.level + 1;
             s.frac = lam - fl;
         }
-        s.pad = 0;
         // frac == 0: the blend is fma(0, tri(level2), 1*tri(level)) = tri(level) exactly (texels are
         // finite and >= +0), so the second level need not be sampled.
         if (s.two_levels && s.frac == 0.0f) s.two_levels = 0;
+        s.omf = 1.0f - s.frac;
         auto ref = [&](int level) {
             VctLevelRef r;
             const int lg = maxl - level;
@@ -480,7 +481,15 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
         }                                                                                    \
     } while (0)
     CREATE_TRY(hipSetDevice(dev));
-    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        // VCT_STREAM_PRIORITY = high | low: experiments with two contexts sharing a GPU (tools/overlap_probe.py)
+        int lo = 0, hi = 0;
+        const char* pr = getenv("VCT_STREAM_PRIORITY");
+        if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+            CREATE_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo));
+        else
+            CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     CREATE_TRY(hipEventCreate(&c->ev0));
     CREATE_TRY(hipEventCreate(&c->ev1));
     const int V = cfg->voxel_dim;

@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t vct_depth24_bits(float z) {
 // launched rows) as well as the per-tile-row cost histogram (vct_last_row_steps: load-aware slabs) from the same words.
 // (Device-scope atomicAdd into a shared bank cost 2.5 % of the trace when neighbouring tiles shared addresses.)
 // The bounce kernels, whose waves loop over many voxels, keep a small bank of atomic counters.
-#define VCT_TRACE_WAVES 3
+#define VCT_TRACE_WAVES 8       // slots per tile (>= the waves a tile is split over, vct_trace.hip VCT_SPLIT)
 #define VCT_STEP_COUNTERS 256   // bounce kernels only (power of two)
 
 // One entry per march step of a cone aperture.  The step sequence of trace.fs:90-104 (dist,
@@ -122,7 +122,7 @@ struct VctStep {       // 64 B: one s_load_dwordx16 per march step
     int32_t level;     // floor(lod)
     int32_t level2;    // min(level+1, maxLevel)
     int32_t two_levels;  // lod > 0 (minification) and frac != 0: blend level/level2; else `level` only
-    int32_t pad;
+    float omf;         // 1 - frac (the level blend's other factor: one VALU per step less than computing it per lane)
     VctLevelRef l1, l2;
 };
 

@@ -436,7 +436,7 @@ typedef const __attribute__((address_space(4))) VctStep* StepTable;
 __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
     VctStep s;
     s.dist = t[k].dist; s.occ_rcp = t[k].occ_rcp; s.occ_den = t[k].occ_den; s.frac = t[k].frac;
-    s.level = t[k].level; s.level2 = t[k].level2; s.two_levels = t[k].two_levels; s.pad = 0;
+    s.level = t[k].level; s.level2 = t[k].level2; s.two_levels = t[k].two_levels; s.omf = t[k].omf;
     s.l1.off = t[k].l1.off; s.l1.mask_x = t[k].l1.mask_x; s.l1.fN = t[k].l1.fN; s.l1.m = t[k].l1.m;
     s.l2.off = t[k].l2.off; s.l2.mask_x = t[k].l2.mask_x; s.l2.fN = t[k].l2.fN; s.l2.m = t[k].l2.m;
     return s;
@@ -460,7 +460,7 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
         if (st.two_levels) { \
             const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, live, blk + 64, lb, ac, ms) \
                                 : sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms); \
-            const float g = 1.0f - st.frac; \
+            const float g = st.omf;      /* 1 - frac, from the table */ \
             vc.x = fmaf(st.frac, t2.x, g * vc.x); \
             vc.y = fmaf(st.frac, t2.y, g * vc.y); \
             vc.z = fmaf(st.frac, t2.z, g * vc.z); \
@@ -750,7 +750,15 @@ k_trace_tile(const VctTraceParams p) {
 // leave their raw cone vec4s in LDS and exit; the last one to arrive gathers them in the oracle's
 // order (the weighted sum is an fma chain over cones 0..5) and composites.  Same bits, waves one
 // third as long, no wave ever waits on another.
-#define VCT_SPLIT 3
+#ifndef VCT_SPLIT
+#define VCT_SPLIT 3               // waves per tile: 3 = {cones 0-2, cones 3-5, specular}, 4 = {0-1, 2-3, 4-5, specular}, 7 = one cone each
+#endif
+// A/B at 256^3 / 1080p (round 3, ms): 3 waves 0.615; 4 waves 0.661 and 7 waves 0.808 although they balance the waves
+// better and fill the CU's 28 wave slots exactly -- every wave pays the G-buffer fetch + frame inversion again and
+// a shorter wave amortises that start-up stall over fewer march steps; 2 waves {0-3, 4-5 + specular} 0.639.
+#define VCT_CONES_PER_WAVE (6 / (VCT_SPLIT - 1))
+static_assert(VCT_SPLIT == 3 || VCT_SPLIT == 4 || VCT_SPLIT == 7, "VCT_SPLIT must be 3, 4 or 7");
+static_assert(VCT_SPLIT <= VCT_TRACE_WAVES, "wave_steps holds VCT_TRACE_WAVES slots per tile");
 #ifndef VCT_ANISO_MIN_WAVES
 #define VCT_ANISO_MIN_WAVES 5     // A/B (ms, 256^3 1080p): 4: 1.61, 5: 1.47, 6: 1.88 (spills), 7: 1.60
 #endif
@@ -796,7 +804,7 @@ k_trace_tile_split(const VctTraceParams p) {
     const bool in_frame = (x < p.width) && (y < p.height);
     const bool alive = in_frame && !(VCT_GB(18) < 0.5f);            // trace.fs:171 discard
     int total = 0;
-    if (wave < 2) {
+    if (wave < VCT_SPLIT - 1) {
         F3 start, k0, k1, k2;
         {
             const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2)), Nw = f3(VCT_GB(3), VCT_GB(4), VCT_GB(5));
@@ -810,7 +818,7 @@ k_trace_tile_split(const VctTraceParams p) {
             start = f3(P.x + Nw.x * p.vs, P.y + Nw.y * p.vs, P.z + Nw.z * p.vs);       // :92
         }
 #pragma unroll 1
-        for (int i = wave * 3; i < wave * 3 + 3; ++i) {                     // :196-199
+        for (int i = wave * VCT_CONES_PER_WAVE; i < wave * VCT_CONES_PER_WAVE + VCT_CONES_PER_WAVE; ++i) {      // :196-199
             const float ddx = kConeDirs[3 * i], ddy = kConeDirs[3 * i + 1], ddz = kConeDirs[3 * i + 2];
             F3 dir = f3(k0.x * ddx + k1.x * ddy + k2.x * ddz, k0.y * ddx + k1.y * ddy + k2.y * ddz,
                         k0.z * ddx + k1.z * ddy + k2.z * ddz);
@@ -851,6 +859,8 @@ k_trace_tile_split(const VctTraceParams p) {
     }
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
     if (lane == 0) p.wave_steps[(size_t)tile * VCT_TRACE_WAVES + wave] = (uint32_t)total;     // a plain store: no atomic, no clear
+    if (VCT_SPLIT < VCT_TRACE_WAVES && wave == 0 && lane >= VCT_SPLIT && lane < VCT_TRACE_WAVES)
+        p.wave_steps[(size_t)tile * VCT_TRACE_WAVES + lane] = 0u;                               // slots no wave of this build owns
     flush_stats(p, ms, lane);
 
     // arrival: LDS operations of a wave are performed in order, so the cone values are in LDS before
