@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 5
+#define VCT_ABI_VERSION 6
 
 typedef enum vct_status {
     VCT_OK = 0,
@@ -93,6 +93,9 @@ typedef struct vct_config {
                                   levels >= 1 from them by cone direction (north-star option; the
                                   reference has one isotropic chain -- VCT.h:248 -- so the default 0 is
                                   what matches the shader transliteration) */
+    int32_t texture_mipmaps;   /* 1 (default) = material textures get mip chains (glGenerateMipmap, Model.h:168) and are
+                                  sampled LINEAR_MIPMAP_LINEAR with the implicit derivatives of texture() (Model.h:172;
+                                  trace.fs:114-116,167,209, vox.fs:56); 0 = level 0, bilinear (rounds 1-2) */
 } vct_config;
 
 typedef struct vct_ctx vct_ctx;
@@ -138,7 +141,9 @@ int vct_upload_mesh_uvs(vct_ctx* ctx, const float* uv);
  * (rgba8[i]: height[i] * width[i] * 4 bytes, row 0 at v = 0) and, per material, the index of its
  * DiffuseTexture / SpecularTexture / HeightTexture or -1 (mat_tex [nmat][3]; -1 keeps the flat colour of
  * vct_upload_triangles / vct_upload_mesh_attributes, resp. a flat height map).  texture(sampler, uv) is
- * restated as level 0, bilinear, GL_REPEAT (the reference samples mip-mapped).  Used by
+ * restated as GL_REPEAT, mip-mapped (config.texture_mipmaps: box-filtered chain built on the GPU at upload,
+ * LINEAR_MIPMAP_LINEAR / LINEAR, lambda from the differences of uv inside the fragment's 2x2 quad; the rules an
+ * OpenGL implementation is free to choose are written down in oracle/vct_oracle.h) or level 0 bilinear.  Used by
  * vct_voxelize (albedo fetch, vox.fs:56) and vct_render_gbuffer (matColor + alpha test trace.fs:167-172,
  * CalcBumpNormal :110-128, specColor :209-210) once vct_upload_mesh_uvs has been called too.  ntex = 0
  * detaches them.  Call after vct_upload_triangles. */

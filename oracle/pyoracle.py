@@ -33,7 +33,8 @@ class Params(C.Structure):
 
 
 class Texture(C.Structure):
-    _fields_ = [("rgba", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+    _fields_ = [("rgba", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("mips", C.c_void_p), ("nlev", C.c_int32)]
 
 
 class Scene(C.Structure):
@@ -231,8 +232,32 @@ def pcf25(depth, coord, bias=0.002):
     return lib().vcto_pcf25(_ptr(depth), depth.shape[0], _ptr(c), float(bias))
 
 
-def _texture_table(textures, keep):
-    """textures: list of uint8 [h, w, 4] arrays -> (ctypes array of Texture, count)."""
+def tex_build_mips(texture):
+    """uint8 [h, w, 4] -> (chain uint8 [texels, 4] with level 0 first, number of levels): glGenerateMipmap restated."""
+    t = np.ascontiguousarray(texture, np.uint8)
+    h, w = t.shape[:2]
+    L = lib()
+    L.vcto_tex_level_offset.restype = C.c_size_t
+    nlev = L.vcto_tex_num_levels(w, h)
+    chain = np.zeros((L.vcto_tex_level_offset(w, h, nlev), 4), np.uint8)
+    L.vcto_tex_build_mips(_ptr(t), w, h, _ptr(chain))
+    return chain, nlev
+
+
+def tex_level(texture, k):
+    """Level k of a texture's mip chain as uint8 [hk, wk, 4]."""
+    t = np.ascontiguousarray(texture, np.uint8)
+    h, w = t.shape[:2]
+    chain, nlev = tex_build_mips(t)
+    L = lib()
+    off = L.vcto_tex_level_offset(w, h, k)
+    wk, hk = max(1, w >> k), max(1, h >> k)
+    return chain[off:off + wk * hk].reshape(hk, wk, 4)
+
+
+def _texture_table(textures, keep, mipmaps=False):
+    """textures: list of uint8 [h, w, 4] arrays -> (ctypes array of Texture, count).  mipmaps: attach the mip chain
+    (mip-mapped sampling with implicit derivatives, the reference's sampler state); else level-0 sampling."""
     if not textures:
         return None, 0
     arr = (Texture * len(textures))()
@@ -241,20 +266,39 @@ def _texture_table(textures, keep):
         assert t.ndim == 3 and t.shape[2] == 4
         keep.append(t)
         arr[i].rgba, arr[i].height, arr[i].width = _ptr(t), t.shape[0], t.shape[1]
+        arr[i].mips, arr[i].nlev = None, 1
+        if mipmaps:
+            chain, nlev = tex_build_mips(t)
+            keep.append(chain)
+            arr[i].mips, arr[i].nlev = _ptr(chain), nlev
     keep.append(arr)
     return arr, len(textures)
 
 
-def tex_sample(texture, u, v):
+def tex_sample(texture, u, v, duv=None):
+    """texture(sampler, (u, v)).  duv = (ds_dx, dt_dx, ds_dy, dt_dy): mip-mapped with those quad differences."""
     keep = []
-    arr, _ = _texture_table([texture], keep)
+    arr, _ = _texture_table([texture], keep, mipmaps=duv is not None)
     out = np.zeros(4, np.float32)
-    lib().vcto_tex_sample(C.byref(arr[0]), float(u), float(v), _ptr(out))
+    L = lib()
+    if duv is None:
+        L.vcto_tex_sample.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.vcto_tex_sample(C.byref(arr[0]), float(u), float(v), _ptr(out))
+    else:
+        L.vcto_tex_sample_lod.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_void_p]
+        L.vcto_tex_sample_lod(C.byref(arr[0]), float(u), float(v), *[float(x) for x in duv], _ptr(out))
     return out
 
 
+def log2_det(x):
+    L = lib()
+    L.vcto_log2_det.restype = C.c_float
+    L.vcto_log2_det.argtypes = [C.c_float]
+    return L.vcto_log2_det(float(x))
+
+
 def make_mesh(pos, material, albedo, specular=None, frames=None, uv=None, mat_tex=None, textures=None,
-              model_scale=0.05):
+              model_scale=0.05, mipmaps=False):
     """Input of the raster oracles (render_shadow_map / render_gbuffer).  frames = (normal, tangent, bitangent)."""
     m = Mesh()
     k = m._keep = []
@@ -273,7 +317,7 @@ def make_mesh(pos, material, albedo, specular=None, frames=None, uv=None, mat_te
         m.nrm, m.tan, m.bit = (arr(f, np.float32, (-1, 9)) for f in frames)
     m.uv = arr(uv, np.float32, (-1, 6)) if uv is not None else None
     m.mat_tex = arr(mat_tex, np.int32, (-1, 3)) if mat_tex is not None else None
-    tab, n = _texture_table(textures, k)
+    tab, n = _texture_table(textures, k, mipmaps)
     m.textures = C.cast(tab, C.c_void_p) if tab is not None else None
     m.ntex = n
     m.model_scale = model_scale
@@ -303,7 +347,7 @@ def render_gbuffer(mesh, view_proj_colmajor, w, h, shadow_depth=None, light_vp_c
 
 
 def make_scene(pos, material, albedo, model_scale=0.05, shadow_depth=None, light_vp=None, uv=None, mat_tex=None,
-               textures=None):
+               textures=None, mipmaps=False):
     """Keeps references to the numpy arrays alive on the returned struct."""
     s = Scene()
     s._keep = [np.ascontiguousarray(pos, np.float32).reshape(-1, 9),
@@ -329,7 +373,7 @@ def make_scene(pos, material, albedo, model_scale=0.05, shadow_depth=None, light
         b = np.ascontiguousarray(mat_tex, np.int32).reshape(-1, 3)
         s._keep += [a, b]
         s.uv, s.mat_tex = _ptr(a), _ptr(b)
-        tab, n = _texture_table(textures, s._keep)
+        tab, n = _texture_table(textures, s._keep, mipmaps)
         s.textures, s.ntex = C.cast(tab, C.c_void_p), n
     return s
 

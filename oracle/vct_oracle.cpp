@@ -606,14 +606,16 @@ TriSetup setup_tri(const vcto_scene* s, int t) {
 
 // vox.fs:56,88 value: unorm8(texture(DiffuseTexture, uv).rgb * PCF/25), a = 1 (flat material colour when the
 // material has no diffuse texture).  b0..b2: the fragment's barycentrics; alb_out (optional): the albedo used.
+// duv (mip-mapped textures): (ds_dx, dt_dx, ds_dy, dt_dy) of the voxelization raster, vct_oracle.h vcto_scene
 inline void frag_value(const vcto_scene* s, int t, const TriSetup& ts, float b0, float b1, float b2, V3 dc,
-                       uint8_t out[3], float* alb_out = nullptr) {
+                       uint8_t out[3], float* alb_out = nullptr, const float* duv = nullptr) {
     float texel[4];
     const float* alb = s->albedo + 4 * (size_t)s->material[t];
     if (ts.tex >= 0) {
         const float u = b0 * ts.uv[0][0] + b1 * ts.uv[1][0] + b2 * ts.uv[2][0];
         const float v = b0 * ts.uv[0][1] + b1 * ts.uv[1][1] + b2 * ts.uv[2][1];
-        vcto_tex_sample(&s->textures[ts.tex], u, v, texel);
+        if (duv) vcto_tex_sample_lod(&s->textures[ts.tex], u, v, duv[0], duv[1], duv[2], duv[3], texel);
+        else vcto_tex_sample(&s->textures[ts.tex], u, v, texel);
         alb = texel;
     }
     if (alb_out) { alb_out[0] = alb[0]; alb_out[1] = alb[1]; alb_out[2] = alb[2]; }
@@ -680,7 +682,28 @@ void vcto_voxelize_reference(const vcto_params* p, const vcto_scene* s, uint8_t*
                 if (vp[0] < 0 || vp[1] < 0 || vp[2] < 0 || vp[0] >= V || vp[1] >= V || vp[2] >= V)
                     continue;   // [GL] out-of-bounds imageStore is discarded
                 uint8_t rgb[3];
-                frag_value(s, t, ts, l0b, l1b, l2b, dc, rgb);
+                float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (ts.tex >= 0 && s->textures[ts.tex].mips) {
+                    // texture() derivatives: the neighbouring pixel centres of the fragment's 2x2 quad, on this triangle
+                    auto uv_at = [&](int qx, int qy, float o[2]) {
+                        const float nx = (float)qx + 0.5f, ny = (float)qy + 0.5f;
+                        float f[2];
+                        for (int k = 0; k < 2; ++k) {
+                            const int a = (k + 1) % 3, b = (k + 2) % 3;
+                            const float dx = (wx[b] - wx[a]) * sgn, dy = (wy[b] - wy[a]) * sgn;
+                            f[k] = dx * (ny - wy[a]) - dy * (nx - wx[a]);
+                        }
+                        const float c0 = f[0] / aa, c1 = f[1] / aa, c2 = 1.0f - c0 - c1;
+                        o[0] = c0 * ts.uv[0][0] + c1 * ts.uv[1][0] + c2 * ts.uv[2][0];
+                        o[1] = c0 * ts.uv[0][1] + c1 * ts.uv[1][1] + c2 * ts.uv[2][1];
+                    };
+                    float me[2], nx[2], ny[2];
+                    uv_at(px, py, me);
+                    uv_at(px ^ 1, py, nx);
+                    uv_at(px, py ^ 1, ny);
+                    duv[0] = nx[0] - me[0]; duv[1] = nx[1] - me[1]; duv[2] = ny[0] - me[0]; duv[3] = ny[1] - me[1];
+                }
+                frag_value(s, t, ts, l0b, l1b, l2b, dc, rgb, nullptr, duv);
                 uint8_t* d = l0 + 4 * (((size_t)vp[2] * V + vp[1]) * V + vp[0]);
                 d[0] = rgb[0]; d[1] = rgb[1]; d[2] = rgb[2]; d[3] = 255;   // last writer wins
             }
@@ -809,7 +832,24 @@ void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, 
                                    b0 * ts.dc[0].y + b1 * ts.dc[1].y + b2 * ts.dc[2].y,
                                    b0 * ts.dc[0].z + b1 * ts.dc[1].z + b2 * ts.dc[2].z};
                     float alb[3];
-                    frag_value(s, t, ts, b0, b1, b2, dc, f.rgb, alb);
+                    float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (ts.tex >= 0 && s->textures[ts.tex].mips) {
+                        // no reference code for this mode: the UNCLAMPED barycentrics one voxel further along each
+                        // in-plane axis give the texture coordinate's differences (vct_oracle.h vcto_scene)
+                        auto uv_at = [&](float qx, float qy, float o[2]) {
+                            const float c0 = ((ax1 - qx) * (ay2 - qy) - (ax2 - qx) * (ay1 - qy)) / area;
+                            const float c1 = ((ax2 - qx) * (ay0 - qy) - (ax0 - qx) * (ay2 - qy)) / area;
+                            const float c2 = 1.0f - c0 - c1;
+                            o[0] = c0 * ts.uv[0][0] + c1 * ts.uv[1][0] + c2 * ts.uv[2][0];
+                            o[1] = c0 * ts.uv[0][1] + c1 * ts.uv[1][1] + c2 * ts.uv[2][1];
+                        };
+                        float me[2], nx[2], ny[2];
+                        uv_at(cx, cy, me);
+                        uv_at(cx + 1.0f, cy, nx);
+                        uv_at(cx, cy + 1.0f, ny);
+                        duv[0] = nx[0] - me[0]; duv[1] = nx[1] - me[1]; duv[2] = ny[0] - me[0]; duv[3] = ny[1] - me[1];
+                    }
+                    frag_value(s, t, ts, b0, b1, b2, dc, f.rgb, alb, duv);
                     if (want_attr)
                         for (int c = 0; c < 3; ++c) f.attr[c] = to_unorm8(alb[c]);      // the fragment's albedo
                     f.vox = ((uint64_t)k * V + j) * V + i;

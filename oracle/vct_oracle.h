@@ -129,16 +129,44 @@ void vcto_frag_to_voxel(int V, int axis, float fx, float fy, float fz, int32_t o
  * DepthViewProjectionMatrix (VCT.h:84-86) applied to WORLD positions (the reference applies
  * DepthVP*Model to model positions: the same point).  shadow may be NULL (PCF = 1). */
 /* Material textures (R/Model.h:126-136,141-226 loads them, R/Mesh.h:91-108 binds them).  RGBA8, row 0 at
- * v = 0, texel = byte/255.  Sampling restates texture(sampler2D, uv) as LEVEL 0, BILINEAR, GL_REPEAT:
+ * v = 0, texel = byte/255, wrap GL_REPEAT (R/Model.h:170-171).
+ *
+ * Level-0 sampling (vcto_tex_sample; textures without a mip chain): BILINEAR on level 0,
  *   x = u*W - 0.5, i0 = floor(x), a = x - i0, indices wrapped mod W (same for v), per channel
  *   ((1-a)*(1-b))*t00 + (a*(1-b))*t10 + ((1-a)*b)*t01 + (a*b)*t11 in that order, fp32.
- * (The reference samples a mip-mapped texture with implicit derivatives, R/Model.h:172-175; SURVEY.md A.7
- * allows level 0 for the restatement and asks that it be said: this is where.) */
+ *
+ * Mip-mapped sampling (vcto_tex_sample_lod; textures carrying `mips`): what the reference's sampler state asks for --
+ * glGenerateMipmap + MIN = LINEAR_MIPMAP_LINEAR (R/Model.h:168,172), MAG = LINEAR (the LINEAR_MIPMAP_LINEAR
+ * at :173 is not a valid mag filter: the call is an error and the default stays) -- with the implicit
+ * derivatives of texture() in a fragment shader (S/VoxelConeTracing.fs:114-116,167,209, S/Voxelization.fs:56).
+ * [GL 4.3 8.14] restated with the choices an implementation is free to make written down:
+ *   chain     level k is max(1, W >> k) x max(1, H >> k), down to 1 x 1; a texel is the rounded mean
+ *             (a + b + c + d + 2) >> 2 per channel of parent texels (2x, 2y) .. (2x+1, 2y+1), indices clamped to the
+ *             parent's size (box filter; odd sizes drop the last row / column like the common drivers).
+ *   scale     derivatives are differences inside the fragment's 2x2 pixel quad, evaluated on the fragment's own
+ *             triangle (helper invocations extrapolate): d/dx = f(x ^ 1, y) - f(x, y), d/dy = f(x, y ^ 1) - f(x, y)
+ *             (the sign does not matter below); in texels of level 0: du = ds * W, dv = dt * H.
+ *             m = max(du_dx^2 + dv_dx^2, du_dy^2 + dv_dy^2)  (rho^2),  lambda = 0.5 * log2(m).
+ *   log2      the library-free evaluation vcto_log2_det below (same instruction sequence on the GPU): exponent +
+ *             atanh series of the mantissa, |error| < 1e-6 -- GL leaves the precision of lambda to the implementation.
+ *   filter    m <= 1 (lambda <= 0, also NaN): magnification, BILINEAR on level 0.  lambda >= q = nlev - 1: level q.
+ *             Otherwise d = floor(lambda), f = lambda - d, per channel fma(f, tau(d + 1), (1 - f) * tau(d)).
+ * The level-0 form stays available (config.texture_mipmaps = 0 on the GPU side, textures without `mips` here): the
+ * round-1/2 fixtures were made with it. */
 typedef struct vcto_texture {
-    const uint8_t* rgba;      /* [height*width*4] */
+    const uint8_t* rgba;      /* level 0: [height*width*4] */
     int32_t width, height;
+    const uint8_t* mips;      /* NULL: level-0 sampling; else the chain of vcto_tex_build_mips (level 0 first) */
+    int32_t nlev;             /* levels in `mips` */
 } vcto_texture;
+int vcto_tex_num_levels(int width, int height);
+size_t vcto_tex_level_offset(int width, int height, int level);      /* in texels; level == nlev: the chain's size */
+void vcto_tex_build_mips(const uint8_t* rgba, int width, int height, uint8_t* chain);
+float vcto_log2_det(float x);                                        /* x > 0, normal */
 void vcto_tex_sample(const vcto_texture* t, float u, float v, float out[4]);
+/* ds_dx .. dt_dy: quad differences of the NORMALISED coordinates (s, t) as defined above */
+void vcto_tex_sample_lod(const vcto_texture* t, float u, float v, float ds_dx, float dt_dx, float ds_dy, float dt_dy,
+                         float out[4]);
 
 typedef struct vcto_scene {
     const float* pos;         /* [ntri*9] */
@@ -151,7 +179,11 @@ typedef struct vcto_scene {
     float light_vp[16];
     /* optional (NULL / 0: flat per-material colours): texture coordinates and diffuse textures.  A
      * fragment of a material with a diffuse texture takes albedo = texture(DiffuseTexture, uv) (vox.fs:56),
-     * uv interpolated with the barycentrics the fragment's shadow coordinate is interpolated with. */
+     * uv interpolated with the barycentrics the fragment's shadow coordinate is interpolated with.  Mip-mapped
+     * textures take their derivatives from the voxelization raster: reference mode, the neighbouring pixel centres
+     * (x ^ 1, y) and (x, y ^ 1) of the V x V window evaluated on the fragment's triangle; conservative mode (no
+     * reference code), the UNCLAMPED barycentrics one voxel further along each in-plane axis, (cx + 1, cy) and
+     * (cx, cy + 1). */
     const float* uv;           /* [ntri*6] */
     const int32_t* mat_tex;    /* [nmat*3]: diffuse, specular, height texture index or -1 */
     const vcto_texture* textures;

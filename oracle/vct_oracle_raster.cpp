@@ -40,8 +40,11 @@ inline RVert lerp_vert(const RVert& a, const RVert& b, float t, int nvar) {
     return r;
 }
 
-// One clip-space triangle.  frag(x, y, z, var) is called for every fragment that passes the depth test and
-// returns false to discard it (trace.fs:171): a discarded fragment leaves the depth buffer untouched.
+// One clip-space triangle.  frag(x, y, z, var, duv) is called for every fragment that passes the depth test and
+// returns false to discard it (trace.fs:171): a discarded fragment leaves the depth buffer untouched.  duv[4]
+// (nvar == 14 only) = quad differences of the texture coordinate var[12..13]: (ds_dx, dt_dx, ds_dy, dt_dy) with
+// d/dx = f(x ^ 1, y) - f(x, y), d/dy = f(x, y ^ 1) - f(x, y), the neighbour evaluated on this triangle's own
+// interpolation (a helper invocation when it lies outside) -- vct_oracle.h "Mip-mapped sampling".
 template <class Frag>
 void raster_triangle(const RVert in[3], int nvar, bool cull_back, int W, int H, float* zbuf, Frag frag) {
     RVert poly[4];
@@ -99,7 +102,29 @@ void raster_triangle(const RVert in[3], int nvar, bool cull_back, int W, int H, 
                 float var[kMaxVar];
                 for (int i = 0; i < nvar; ++i)
                     var[i] = (q0 * v[0]->var[i] + q1 * v[1]->var[i] + q2 * v[2]->var[i]) * qs;
-                if (frag(px, py, z, var)) zb = z;
+                float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (nvar == kMaxVar) {
+                    auto uv_at = [&](int qx, int qy, float out[2]) {       // the same interpolation at another pixel centre
+                        const double nx = (double)qx + 0.5, ny = (double)qy + 0.5;
+                        double f[2];
+                        for (int k = 0; k < 2; ++k) {
+                            const int a = (k + 1) % 3, b = (k + 2) % 3;
+                            const double dx = (sx[b] - sx[a]) * sgn, dy = (sy[b] - sy[a]) * sgn;
+                            f[k] = dx * (ny - sy[a]) - dy * (nx - sx[a]);
+                        }
+                        const float c0 = (float)(f[0] / area), c1 = (float)(f[1] / area), c2 = 1.0f - c0 - c1;
+                        const float r0 = c0 * iw[0], r1 = c1 * iw[1], r2 = c2 * iw[2];
+                        const float rs = 1.0f / (r0 + r1 + r2);
+                        for (int i = 0; i < 2; ++i)
+                            out[i] = (r0 * v[0]->var[12 + i] + r1 * v[1]->var[12 + i] + r2 * v[2]->var[12 + i]) * rs;
+                    };
+                    float nx[2], ny[2];
+                    uv_at(px ^ 1, py, nx);
+                    uv_at(px, py ^ 1, ny);
+                    duv[0] = nx[0] - var[12]; duv[1] = nx[1] - var[13];
+                    duv[2] = ny[0] - var[12]; duv[3] = ny[1] - var[13];
+                }
+                if (frag(px, py, z, var, duv)) zb = z;
             }
     }
 }
@@ -125,21 +150,106 @@ inline int tex_of(const vcto_mesh* m, int mat, int slot) {
 
 extern "C" {
 
-void vcto_tex_sample(const vcto_texture* t, float u, float v, float out[4]) {
-    const int W = t->width, H = t->height;
+int vcto_tex_num_levels(int width, int height) {
+    int n = 1;
+    for (int m = width > height ? width : height; m > 1; m >>= 1) ++n;
+    return n;
+}
+
+size_t vcto_tex_level_offset(int width, int height, int level) {
+    size_t off = 0;
+    for (int k = 0; k < level; ++k) {
+        const int w = std::max(1, width >> k), h = std::max(1, height >> k);
+        off += (size_t)w * h;
+    }
+    return off;
+}
+
+void vcto_tex_build_mips(const uint8_t* rgba, int width, int height, uint8_t* chain) {
+    memcpy(chain, rgba, (size_t)width * height * 4);
+    const int nlev = vcto_tex_num_levels(width, height);
+    for (int k = 1; k < nlev; ++k) {
+        const int pw = std::max(1, width >> (k - 1)), ph = std::max(1, height >> (k - 1));
+        const int w = std::max(1, width >> k), h = std::max(1, height >> k);
+        const uint8_t* src = chain + 4 * vcto_tex_level_offset(width, height, k - 1);
+        uint8_t* dst = chain + 4 * vcto_tex_level_offset(width, height, k);
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const int x0 = std::min(2 * x, pw - 1), x1 = std::min(2 * x + 1, pw - 1);
+                const int y0 = std::min(2 * y, ph - 1), y1 = std::min(2 * y + 1, ph - 1);
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t sum = (uint32_t)src[4 * ((size_t)y0 * pw + x0) + c] + src[4 * ((size_t)y0 * pw + x1) + c] +
+                                         src[4 * ((size_t)y1 * pw + x0) + c] + src[4 * ((size_t)y1 * pw + x1) + c];
+                    dst[4 * ((size_t)y * w + x) + c] = (uint8_t)((sum + 2u) >> 2);
+                }
+            }
+    }
+}
+
+// log2 without a math library (the GPU runs the same sequence, csrc/vct_internal.h vct_log2_det): exponent +
+// 2/ln2 * atanh((f - 1) / (f + 1)) of the mantissa f, centred on [sqrt(1/2), sqrt(2)); series to s^9
+float vcto_log2_det(float x) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    int e = (int)(b >> 23) - 127;
+    const uint32_t mb = (b & 0x7fffffu) | 0x3f800000u;
+    float f;
+    memcpy(&f, &mb, 4);
+    if (f > 1.41421354f) { f = f * 0.5f; e += 1; }
+    const float s = (f - 1.0f) / (f + 1.0f);
+    const float s2 = s * s;
+    float p = 0.111111112f;
+    p = fmaf(p, s2, 0.142857149f);
+    p = fmaf(p, s2, 0.2f);
+    p = fmaf(p, s2, 0.333333343f);
+    p = fmaf(p, s2, 1.0f);
+    return fmaf(s * p, 2.88539004f, (float)e);
+}
+
+namespace {
+// [GL] bilinear, GL_REPEAT, on one level (W x H texels at `texels`)
+void tex_bilinear(const uint8_t* texels, int W, int H, float u, float v, float out[4]) {
     const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const float a = x - fx, b = y - fy;
     auto wrap = [](int i, int n) { const int r = i % n; return r < 0 ? r + n : r; };     // GL_REPEAT
     const int i0 = wrap((int)fx, W), i1 = wrap((int)fx + 1, W), j0 = wrap((int)fy, H), j1 = wrap((int)fy + 1, H);
-    const uint8_t* p00 = t->rgba + 4 * ((size_t)j0 * W + i0);
-    const uint8_t* p10 = t->rgba + 4 * ((size_t)j0 * W + i1);
-    const uint8_t* p01 = t->rgba + 4 * ((size_t)j1 * W + i0);
-    const uint8_t* p11 = t->rgba + 4 * ((size_t)j1 * W + i1);
+    const uint8_t* p00 = texels + 4 * ((size_t)j0 * W + i0);
+    const uint8_t* p10 = texels + 4 * ((size_t)j0 * W + i1);
+    const uint8_t* p01 = texels + 4 * ((size_t)j1 * W + i0);
+    const uint8_t* p11 = texels + 4 * ((size_t)j1 * W + i1);
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     for (int c = 0; c < 4; ++c)
         out[c] = w00 * ((float)p00[c] / 255.0f) + w10 * ((float)p10[c] / 255.0f) + w01 * ((float)p01[c] / 255.0f) +
                  w11 * ((float)p11[c] / 255.0f);
+}
+}  // namespace
+
+void vcto_tex_sample(const vcto_texture* t, float u, float v, float out[4]) {
+    tex_bilinear(t->rgba, t->width, t->height, u, v, out);
+}
+
+void vcto_tex_sample_lod(const vcto_texture* t, float u, float v, float ds_dx, float dt_dx, float ds_dy, float dt_dy,
+                         float out[4]) {
+    const int W = t->width, H = t->height;
+    if (!t->mips || t->nlev <= 1) { tex_bilinear(t->rgba, W, H, u, v, out); return; }
+    const float du_dx = ds_dx * (float)W, dv_dx = dt_dx * (float)H;
+    const float du_dy = ds_dy * (float)W, dv_dy = dt_dy * (float)H;
+    const float ax = du_dx * du_dx + dv_dx * dv_dx, ay = du_dy * du_dy + dv_dy * dv_dy;
+    const float m = ax > ay ? ax : ay;
+    auto level = [&](int k, float o[4]) {
+        tex_bilinear(t->mips + 4 * vcto_tex_level_offset(W, H, k), std::max(1, W >> k), std::max(1, H >> k), u, v, o);
+    };
+    if (!(m > 1.0f)) { level(0, out); return; }                // magnification (and NaN)
+    const float lam = 0.5f * vcto_log2_det(m);
+    const int q = t->nlev - 1;
+    if (lam >= (float)q) { level(q, out); return; }
+    const int d = (int)lam;
+    const float f = lam - (float)d, g = 1.0f - f;
+    float t1[4], t2[4];
+    level(d, t1);
+    level(d + 1, t2);
+    for (int c = 0; c < 4; ++c) out[c] = fmaf(f, t2[c], g * t1[c]);
 }
 
 void vcto_render_shadow_map(const vcto_mesh* s, const float light_vp[16], int32_t S, float* depth) {
@@ -151,7 +261,7 @@ void vcto_render_shadow_map(const vcto_mesh* s, const float light_vp[16], int32_
             const float* p = &s->pos[(size_t)t * 9 + 3 * k];
             xform(light_vp, V3{p[0] * s->model_scale, p[1] * s->model_scale, p[2] * s->model_scale}, v[k].c);
         }
-        raster_triangle(v, 0, true, S, S, depth, [](int, int, float, const float*) { return true; });
+        raster_triangle(v, 0, true, S, S, depth, [](int, int, float, const float*, const float*) { return true; });
     }
     const float q = 16777215.0f;                                         // DEPTH_COMPONENT24
     for (size_t i = 0; i < n; ++i) depth[i] = (float)(floor((double)depth[i] * q + 0.5) / q);
@@ -165,6 +275,7 @@ void vcto_render_gbuffer(const vcto_mesh* s, const float view_proj[16], int32_t 
     std::vector<float> zbuf(npix, 1.0f);
     std::vector<int32_t> mat(npix, -1);
     std::vector<float> uvbuf(npix * 2, 0.0f);
+    std::vector<float> duvbuf(npix * 4, 0.0f);      // quad differences of the winning fragment's texture coordinate
     const float ms = s->model_scale;
     for (int t = 0; t < s->ntri; ++t) {
         RVert v[3];
@@ -184,17 +295,18 @@ void vcto_render_gbuffer(const vcto_mesh* s, const float view_proj[16], int32_t 
         }
         const int32_t m = s->material[t];
         const int td = tex_of(s, m, 0);
-        raster_triangle(v, 14, true, W, H, zbuf.data(), [&](int x, int y, float, const float* var) {
+        raster_triangle(v, 14, true, W, H, zbuf.data(), [&](int x, int y, float, const float* var, const float* duv) {
             float alpha = s->albedo[4 * (size_t)m + 3];
             if (td >= 0) {
                 float c[4];
-                vcto_tex_sample(&s->textures[td], var[12], var[13], c);                     // trace.fs:167
+                vcto_tex_sample_lod(&s->textures[td], var[12], var[13], duv[0], duv[1], duv[2], duv[3], c);   // trace.fs:167
                 alpha = c[3];
             }
             if (alpha < 0.5f) return false;                                                  // trace.fs:171 discard
             const size_t i = (size_t)y * W + x;
             for (int k = 0; k < 12; ++k) planes[(size_t)k * npix + i] = var[k];
             uvbuf[2 * i] = var[12]; uvbuf[2 * i + 1] = var[13];
+            for (int k = 0; k < 4; ++k) duvbuf[4 * i + k] = duv[k];
             mat[i] = m;
             return true;
         });
@@ -206,6 +318,11 @@ void vcto_render_gbuffer(const vcto_mesh* s, const float view_proj[16], int32_t 
         const V3 P = {G(0), G(1), G(2)}, N = {G(3), G(4), G(5)}, T = {G(6), G(7), G(8)}, B = {G(9), G(10), G(11)};
         const int m = mat[i];
         const float u = uvbuf[2 * i], v = uvbuf[2 * i + 1];
+        const float* dq = &duvbuf[4 * i];
+        // texture(sampler, tex [+ constant]) with the implicit derivatives of `tex` (a constant offset has none)
+        auto fetch = [&](const vcto_texture* tx, float uu, float vv, float o[4]) {
+            vcto_tex_sample_lod(tx, uu, vv, dq[0], dq[1], dq[2], dq[3], o);
+        };
         const int td = tex_of(s, m, 0), tsp = tex_of(s, m, 1), th = tex_of(s, m, 2);
         const V3 c2 = cross(T, B);
         const float det = dot(T, cross(B, N));
@@ -217,9 +334,9 @@ void vcto_render_gbuffer(const vcto_mesh* s, const float view_proj[16], int32_t 
             const vcto_texture* ht = &s->textures[th];
             const float ox = 1.0f / (float)ht->width, oy = 1.0f / (float)ht->height;   // trace.fs:112
             float c0[4], c1[4], c3[4];
-            vcto_tex_sample(ht, u, v, c0);                                              // :114
-            vcto_tex_sample(ht, u + ox, v, c1);                                         // :115
-            vcto_tex_sample(ht, u, v + oy, c3);                                         // :116
+            fetch(ht, u, v, c0);                                                        // :114
+            fetch(ht, u + ox, v, c1);                                                   // :115
+            fetch(ht, u, v + oy, c3);                                                   // :116
             const float dx = c1[0] - c0[0], dy = c3[0] - c0[0];
             const V3 t1 = normalize(V3{1.0f, 0.0f, dx}), t2 = normalize(V3{0.0f, 1.0f, dy});   // :120-121
             const V3 bump = normalize(cross(t1, t2));                                   // :125
@@ -233,7 +350,7 @@ void vcto_render_gbuffer(const vcto_mesh* s, const float view_proj[16], int32_t 
         }
         if (td >= 0) {
             float c[4];
-            vcto_tex_sample(&s->textures[td], u, v, c);                                 // trace.fs:167
+            fetch(&s->textures[td], u, v, c);                                           // trace.fs:167
             for (int k = 0; k < 4; ++k) G(15 + k) = c[k];
         } else {
             for (int k = 0; k < 4; ++k) G(15 + k) = s->albedo[4 * (size_t)m + k];
@@ -241,7 +358,7 @@ void vcto_render_gbuffer(const vcto_mesh* s, const float view_proj[16], int32_t 
         float sp[3] = {s->specular[3 * (size_t)m], s->specular[3 * (size_t)m + 1], s->specular[3 * (size_t)m + 2]};
         if (tsp >= 0) {
             float c[4];
-            vcto_tex_sample(&s->textures[tsp], u, v, c);                                // trace.fs:209
+            fetch(&s->textures[tsp], u, v, c);                                          // trace.fs:209
             sp[0] = c[0]; sp[1] = c[1]; sp[2] = c[2];
         }
         const bool has_gb = sqrtf(sp[1] * sp[1] + sp[2] * sp[2]) > 0.0f;

@@ -81,9 +81,10 @@ def config1_cornell():
                 steps_hist=np.bincount(r["steps"].reshape(-1), minlength=32).astype(np.int64))
 
 
-def textured_raster():
+def textured_raster(mipmaps=False):
     """The procedurally TEXTURED atrium (diffuse / specular / height maps, alpha cut-outs) through the CPU raster
-    stages: shadow map + G-buffer with matColor / alpha test / CalcBumpNormal / specColor (.rrra) / PCF."""
+    stages: shadow map + G-buffer with matColor / alpha test / CalcBumpNormal / specColor (.rrra) / PCF.
+    mipmaps: textures sampled mip-mapped with implicit derivatives (round 3) or level 0 only (the round-2 fixture)."""
     import vctpkg
     vctpkg.load()
     from voxel_cone_tracing_amd import scene as sc
@@ -93,7 +94,7 @@ def textured_raster():
     scene = sc.Scene(sc.ATRIUM_TEXTURED, 0.1, 7)
     cam = sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
     depth, lvp_row = raster_oracle.shadow_map(sc, scene, light, S)
-    planes = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, lvp_row)
+    planes = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, lvp_row, mipmaps=mipmaps)
     return dict(w=w, h=h, S=S, detail=np.float32(0.1), seed=np.int32(7), shadow=depth, planes=planes,
                 ntri=np.int32(scene.ntri), covered=np.float32((planes[18] >= 0.5).mean()))
 
@@ -102,6 +103,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "textured":      # only the fixture added in round 2
         np.savez_compressed(os.path.join(HERE, "raster_textured_48x32.npz"), **textured_raster())
         print("raster_textured_48x32.npz", os.path.getsize(os.path.join(HERE, "raster_textured_48x32.npz")), "bytes")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "textured-mips":      # only the fixture added in round 3
+        np.savez_compressed(os.path.join(HERE, "raster_textured_mips_48x32.npz"), **textured_raster(mipmaps=True))
+        print("raster_textured_mips_48x32.npz", os.path.getsize(os.path.join(HERE, "raster_textured_mips_48x32.npz")), "bytes")
         return
     # 1. SURVEY.md 8c suggestion: 16^3 volume + 8x8 G-buffer -> 64 RGBA fp32 + 64x7 step counts
     np.savez_compressed(os.path.join(HERE, "trace_v16_8x8_random.npz"),
@@ -137,6 +142,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "config1_cornell_v64_128.npz"), **config1_cornell())
     # 6. the textured raster stages (SURVEY.md 8 f1 with materials)
     np.savez_compressed(os.path.join(HERE, "raster_textured_48x32.npz"), **textured_raster())
+    np.savez_compressed(os.path.join(HERE, "raster_textured_mips_48x32.npz"), **textured_raster(mipmaps=True))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

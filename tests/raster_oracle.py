@@ -5,9 +5,11 @@ import numpy as np
 from oracle import pyoracle
 
 
-def mesh_of(scene, model_scale=0.05):
+# mipmaps: the material textures carry mip chains and are sampled with implicit derivatives (the reference's sampler
+# state and the GPU library's default, config.texture_mipmaps = 1); False = level 0 bilinear (the rounds 1-2 fixtures)
+def mesh_of(scene, model_scale=0.05, mipmaps=True):
     return pyoracle.make_mesh(scene.pos, scene.material, scene.albedo, scene.specular, scene.frames(), scene.uv,
-                              scene.mat_tex, scene.textures, model_scale)
+                              scene.mat_tex, scene.textures, model_scale, mipmaps=mipmaps)
 
 
 def shadow_map(sc, scene, light_dir, size):
@@ -16,14 +18,15 @@ def shadow_map(sc, scene, light_dir, size):
     return pyoracle.render_shadow_map(mesh_of(scene), vp, size), vp.reshape(4, 4).T.copy()
 
 
-def gbuffer(sc, scene, cam, w, h, shadow=None, light_vp_row=None):
+def gbuffer(sc, scene, cam, w, h, shadow=None, light_vp_row=None, mipmaps=True):
     """planes [23, w*h] -- the raster + non-cone fragment work of Render() on the CPU."""
     vp = sc.camera_view_proj(cam, w, h)
     lvp = None if light_vp_row is None else np.ascontiguousarray(np.asarray(light_vp_row, np.float32).T).reshape(16)
-    return pyoracle.render_gbuffer(mesh_of(scene), vp, w, h, shadow, lvp)
+    return pyoracle.render_gbuffer(mesh_of(scene, mipmaps=mipmaps), vp, w, h, shadow, lvp)
 
 
-def oracle_scene(scene, shadow_depth=None, light_vp_row=None):
+def oracle_scene(scene, shadow_depth=None, light_vp_row=None, mipmaps=True):
     """Input of the oracle voxelizers, with the scene's texture coordinates and diffuse textures."""
     return pyoracle.make_scene(scene.pos, scene.material, scene.albedo, shadow_depth=shadow_depth,
-                               light_vp=light_vp_row, uv=scene.uv, mat_tex=scene.mat_tex, textures=scene.textures)
+                               light_vp=light_vp_row, uv=scene.uv, mat_tex=scene.mat_tex, textures=scene.textures,
+                               mipmaps=mipmaps)

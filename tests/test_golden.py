@@ -197,9 +197,17 @@ def test_oracle_reproduces_golden_textured_raster(oracle):
     sc, scene, light, cam = _textured_inputs(g)
     depth, lvp_row = raster_oracle.shadow_map(sc, scene, light, int(g["S"]))
     assert np.array_equal(depth.view(np.uint32), g["shadow"].view(np.uint32))
-    planes = raster_oracle.gbuffer(sc, scene, cam, int(g["w"]), int(g["h"]), depth, lvp_row)
-    assert np.array_equal(planes.view(np.uint32), g["planes"].view(np.uint32))
+    planes = raster_oracle.gbuffer(sc, scene, cam, int(g["w"]), int(g["h"]), depth, lvp_row, mipmaps=False)
+    assert np.array_equal(planes.view(np.uint32), g["planes"].view(np.uint32))     # the round-2 fixture: level-0 sampling
     assert 0.9 < float(g["covered"]) <= 1.0
+    # round 3: the same scene with the reference's sampler state (mip chains, implicit derivatives)
+    gm = np.load(os.path.join(GOLDEN, "raster_textured_mips_48x32.npz"))
+    assert np.array_equal(gm["shadow"].view(np.uint32), g["shadow"].view(np.uint32))
+    planes_m = raster_oracle.gbuffer(sc, scene, cam, int(g["w"]), int(g["h"]), depth, lvp_row, mipmaps=True)
+    assert np.array_equal(planes_m.view(np.uint32), gm["planes"].view(np.uint32))
+    assert not np.array_equal(planes_m[15:22], planes[15:22])                      # minified maps differ from level 0
+    moved = (planes_m[:12].view(np.uint32) != planes[:12].view(np.uint32)).any(0).mean()
+    assert moved < 0.05          # geometry only changes where the mip-mapped alpha test cuts a different silhouette
 
 
 @pytest.mark.gpu
@@ -209,9 +217,10 @@ def test_hip_reproduces_golden_textured_raster():
     g = np.load(os.path.join(GOLDEN, "raster_textured_48x32.npz"))
     sc, scene, light, cam = _textured_inputs(g)
     w, h, S = int(g["w"]), int(g["h"]), int(g["S"])
-    with vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S)) as ctx:
-        ctx.upload_scene(scene)
-        ctx.render_shadow_map(sc.light_view_proj(light))
-        assert np.array_equal(ctx.download_shadow_map().view(np.uint32), g["shadow"].view(np.uint32))
-        ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
-        assert np.array_equal(ctx.download_gbuffer().view(np.uint32), g["planes"].view(np.uint32))
+    for mips, fixture in ((0, g), (1, np.load(os.path.join(GOLDEN, "raster_textured_mips_48x32.npz")))):
+        with vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S, texture_mipmaps=mips)) as ctx:
+            ctx.upload_scene(scene)
+            ctx.render_shadow_map(sc.light_view_proj(light))
+            assert np.array_equal(ctx.download_shadow_map().view(np.uint32), fixture["shadow"].view(np.uint32))
+            ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
+            assert np.array_equal(ctx.download_gbuffer().view(np.uint32), fixture["planes"].view(np.uint32))

@@ -70,10 +70,10 @@ def test_texture_fetch_known_answers(oracle):
     assert abs(float(mid[0]) - (0 + 85 + 255 + 170) / 4 / 255) < 1e-6 and mid[3] == 1.0
 
 
-def textured_pipeline(vct, oracle, scene, cam, V, w, h, S, attrs=0):
+def textured_pipeline(vct, oracle, scene, cam, V, w, h, S, attrs=0, mipmaps=True):
     from voxel_cone_tracing_amd import scene as sc
     ctx = vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=S, debug_outputs=1,
-                                         voxel_attributes=attrs))
+                                         voxel_attributes=attrs, texture_mipmaps=1 if mipmaps else 0))
     ctx.set_camera_position(tuple(cam.position))
     ctx.set_light_direction(LIGHT)
     ctx.upload_scene(scene)
@@ -81,7 +81,7 @@ def textured_pipeline(vct, oracle, scene, cam, V, w, h, S, attrs=0):
     ctx.render_shadow_map(sc.light_view_proj(LIGHT))
     assert np.array_equal(ctx.download_shadow_map().view(np.uint32), depth.view(np.uint32))
     p = oracle.default_params(V, camera_pos=tuple(cam.position), light_dir=LIGHT)
-    osc = raster_oracle.oracle_scene(scene, depth, lvp_row)
+    osc = raster_oracle.oracle_scene(scene, depth, lvp_row, mipmaps=mipmaps)
     # voxelize + inject: the fragment albedo comes from the diffuse texture (vox.fs:56), both modes
     ctx.voxelize(vct.VOX_REFERENCE); ctx.inject_light(); ctx.build_mips()
     assert np.array_equal(ctx.download_chain(), oracle.build_mips(oracle.voxelize_reference(p, osc)))
@@ -95,7 +95,7 @@ def textured_pipeline(vct, oracle, scene, cam, V, w, h, S, attrs=0):
     chain = oracle.build_mips(l0)
     assert np.array_equal(ctx.download_chain(), chain)
     # G-buffer: matColor + alpha test, CalcBumpNormal, specColor
-    want = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, lvp_row)
+    want = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, lvp_row, mipmaps=mipmaps)
     ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
     got = ctx.download_gbuffer()
     bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(0))[0]
@@ -109,7 +109,8 @@ def textured_pipeline(vct, oracle, scene, cam, V, w, h, S, attrs=0):
 
 
 @pytest.mark.gpu
-def test_textured_atrium_every_stage_matches_the_oracle(oracle):
+@pytest.mark.parametrize("mipmaps", [True, False])      # the reference's mip-mapped sampler state; level 0 only (rounds 1-2)
+def test_textured_atrium_every_stage_matches_the_oracle(oracle, mipmaps):
     import torch
     assert torch.cuda.is_available()
     vct = vctpkg.load()
@@ -119,7 +120,7 @@ def test_textured_atrium_every_stage_matches_the_oracle(oracle):
     assert scene.ntri == flat.ntri and len(scene.textures) >= 8 and (scene.mat_tex >= 0).any(0).all()
     cam = sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
     V, w, h, S = 128, 640, 360, 1024
-    ctx, g, l0, chain = textured_pipeline(vct, oracle, scene, cam, V, w, h, S, attrs=1)
+    ctx, g, l0, chain = textured_pipeline(vct, oracle, scene, cam, V, w, h, S, attrs=1, mipmaps=mipmaps)
     # the textures matter: albedo varies inside a material, bump normals leave the interpolated normal, the
     # red-only specular map takes the .rrra rule, lace holes let fragments through
     covered = g[18] >= 0.5
@@ -132,7 +133,7 @@ def test_textured_atrium_every_stage_matches_the_oracle(oracle):
     ctx.bounce()
     pb = oracle.default_params(V, camera_pos=tuple(cam.position), light_dir=LIGHT)
     depth, lvp_row = raster_oracle.shadow_map(sc, scene, LIGHT, S)
-    _, alb, nrmv = oracle.voxelize_conservative_attr(pb, raster_oracle.oracle_scene(scene, depth, lvp_row))
+    _, alb, nrmv = oracle.voxelize_conservative_attr(pb, raster_oracle.oracle_scene(scene, depth, lvp_row, mipmaps=mipmaps))
     l1, steps = oracle.bounce(pb, chain, alb, nrmv, nthreads=8)
     assert ctx.last_step_count() == steps and np.array_equal(ctx.download_chain(), oracle.build_mips(l1))
     l0_flat = oracle.voxelize_conservative(pb, raster_oracle.oracle_scene(flat, depth, lvp_row))

@@ -321,3 +321,69 @@ def test_depth24_dequantisation_needs_no_double():
     got = q.astype(np.float32) / np.float32(16777215.0)
     assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
     assert got.max() == np.float32(1.0) and got.view(np.uint32).max() == 0x3F800000      # fits under the epoch bits
+
+
+# ---- mip-mapped material textures (R/Model.h:168-173; oracle/vct_oracle.h "Mip-mapped sampling") ----------------
+
+def test_texture_mip_chain_is_the_rounded_box_filter(oracle):
+    """glGenerateMipmap restated: level k is max(1, W >> k) x max(1, H >> k); a texel is (a + b + c + d + 2) >> 2 of its
+    2x2 parents, parent indices clamped (odd sizes drop the last row / column), down to 1 x 1."""
+    t = np.zeros((4, 4, 4), np.uint8)
+    t[..., 0] = np.arange(16).reshape(4, 4) * 16
+    t[..., 1] = 255
+    t[..., 3] = [[0, 255, 0, 255]] * 4
+    chain, nlev = oracle.tex_build_mips(t)
+    assert nlev == 3 and chain.shape == (16 + 4 + 1, 4)
+    l1 = oracle.tex_level(t, 1)
+    assert l1.shape == (2, 2, 4)
+    assert l1[0, 0, 0] == (0 + 16 + 64 + 80 + 2) >> 2 and l1[1, 1, 0] == (160 + 176 + 224 + 240 + 2) >> 2
+    assert (l1[..., 1] == 255).all() and (l1[..., 3] == 128).all()          # (0 + 255 + 0 + 255 + 2) >> 2
+    l2 = oracle.tex_level(t, 2)
+    assert l2.shape == (1, 1, 4) and l2[0, 0, 0] == (int(l1[..., 0].astype(int).sum()) + 2) >> 2
+    odd = np.random.default_rng(4).integers(0, 256, (3, 5, 4), dtype=np.uint8)       # 5 x 3 -> 2 x 1 -> 1 x 1
+    chain, nlev = oracle.tex_build_mips(odd)
+    assert nlev == 3 and chain.shape[0] == 15 + 2 + 1
+    a = oracle.tex_level(odd, 1)
+    assert a.shape == (1, 2, 4)
+    for x in range(2):
+        want = (odd[0, 2 * x].astype(int) + odd[0, 2 * x + 1].astype(int) + odd[1, 2 * x].astype(int) + odd[1, 2 * x + 1].astype(int) + 2) >> 2
+        assert np.array_equal(a[0, x], want)
+    b = oracle.tex_level(odd, 2)                                                      # 2 x 1 parent: rows clamp
+    assert np.array_equal(b[0, 0], (2 * a[0, 0].astype(int) + 2 * a[0, 1].astype(int) + 2) >> 2)
+
+
+def test_log2_det_is_exact_on_powers_of_two_and_close_elsewhere(oracle):
+    for k in range(0, 40):
+        assert oracle.log2_det(float(2.0 ** k)) == float(k)
+    xs = np.exp(np.random.default_rng(2).uniform(0.0, 28.0, 4000)).astype(np.float32)
+    err = max(abs(oracle.log2_det(float(x)) - float(np.log2(np.float64(x)))) for x in xs)
+    assert err < 4e-6
+
+
+def test_minified_checker_takes_the_level_lambda_selects(oracle):
+    """A one-texel checkerboard: level 0 alternates 0 / 255, every coarser level is the flat mean 128.  With the
+    coordinate moving 4 texels per pixel lambda = log2(4) = 2 exactly: the sample is the flat level; at <= 1 texel per
+    pixel (lambda <= 0) it is the level-0 bilinear sample; in between, the linear blend of two levels."""
+    n = 64
+    t = np.zeros((n, n, 4), np.uint8)
+    t[..., :3] = (((np.arange(n)[:, None] + np.arange(n)[None, :]) & 1) * 255)[..., None]
+    t[..., 3] = 255
+    assert (oracle.tex_level(t, 1)[..., 0] == 128).all() and (oracle.tex_level(t, 5)[..., 0] == 128).all()
+    u, v = (10 + 0.5) / n, (20 + 0.5) / n                                   # a texel centre: level 0 returns the texel
+    lvl0 = oracle.tex_sample(t, u, v)
+    assert lvl0[0] == np.float32(t[20, 10, 0]) / np.float32(255)
+    flat = np.float32(128) / np.float32(255)
+    for duv in ((4.0 / n, 0, 0, 4.0 / n), (4.0 / n, 0, 0, 0), (0, 0, 0.5 / n, 4.0 / n), (64.0 / n, 0, 0, 0), (1e9, 0, 0, 0)):
+        assert oracle.tex_sample(t, u, v, duv)[0] == flat                   # lambda >= 1: only flat levels contribute
+    for duv in ((1.0 / n, 0, 0, 1.0 / n), (0.3 / n, 0, 0, 0.2 / n), (0, 0, 0, 0), (float("nan"), 0, 0, 0)):
+        assert np.array_equal(oracle.tex_sample(t, u, v, duv), lvl0)        # lambda <= 0 (and NaN): magnification
+    # rho = sqrt(2) texels per pixel: lambda = 0.5, an even blend of level 0 and level 1, fma(f, t2, (1 - f) * t1)
+    lam = np.float32(0.5) * np.float32(oracle.log2_det(2.0))
+    assert lam == np.float32(0.5)
+    got = oracle.tex_sample(t, u, v, (np.sqrt(2.0) / n, 0, 0, 0))
+    m = np.float32((np.float32(np.sqrt(2.0) / n) * np.float32(n)) ** 2)
+    f = np.float32(0.5) * np.float32(oracle.log2_det(float(m)))
+    want = np.float32(np.float64(f) * np.float64(flat) + np.float64(np.float32((np.float32(1) - f) * lvl0[0])))   # fma
+    assert got[0] == want and abs(float(got[0]) - (0.5 * float(flat) + 0.5 * float(lvl0[0]))) < 1e-6
+    # the larger of the two axes' footprints decides (the ideal rho of the GL specification)
+    assert np.array_equal(oracle.tex_sample(t, u, v, (3.0 / n, 0, 0, 1.0 / n)), oracle.tex_sample(t, u, v, (0, 3.0 / n, 1.0 / n, 0)))

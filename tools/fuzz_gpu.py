@@ -102,9 +102,11 @@ while time.time() < t_end:
     lightd = tuple(np.abs(r.normal(size=3)) + 0.1)
     cam = sc.default_camera(position=tuple(r.uniform(-40, 40, 3)), yaw=float(r.uniform(-180, 180)),
                             pitch=float(r.uniform(-60, 60)), zoom=float(r.uniform(20, 45)))
+    mips = bool(r.integers(0, 2))          # material textures mip-mapped (the default) or level 0 only
     dref, lvp_row = raster_oracle.shadow_map(sc, scene, lightd, S)
-    gref = raster_oracle.gbuffer(sc, scene, cam, w, h, dref, lvp_row)
-    with vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S)) as ctx:
+    gref = raster_oracle.gbuffer(sc, scene, cam, w, h, dref, lvp_row, mipmaps=mips)
+    with vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S,
+                                        texture_mipmaps=1 if mips else 0)) as ctx:
         ctx.upload_scene(scene)
         ctx.render_shadow_map(sc.light_view_proj(lightd))
         if not np.array_equal(ctx.download_shadow_map().view(np.uint32), dref.view(np.uint32)): fail("shadow raster", seed)
@@ -121,7 +123,7 @@ while time.time() < t_end:
         ctx.render_gbuffer_rows(sc.camera_view_proj(cam, w, h), r0, r1)
         cam2 = sc.default_camera(position=tuple(r.uniform(-40, 40, 3)), yaw=float(r.uniform(-180, 180)),
                                  pitch=float(r.uniform(-60, 60)), zoom=float(r.uniform(20, 45)))
-        gref2 = raster_oracle.gbuffer(sc, scene, cam2, w, h, dref, lvp_row)
+        gref2 = raster_oracle.gbuffer(sc, scene, cam2, w, h, dref, lvp_row, mipmaps=mips)
         ctx.render_shadow_map(sc.light_view_proj(lightd))
         if not np.array_equal(ctx.download_shadow_map().view(np.uint32), dref.view(np.uint32)): fail("shadow raster (2nd pass)", seed)
         ctx.render_gbuffer(sc.camera_view_proj(cam2, w, h))

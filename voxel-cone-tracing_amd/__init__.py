@@ -25,7 +25,7 @@ GB_PLANES = 23
 GB_LINEAR, GB_TILED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 VOX_CONSERVATIVE_AVG, VOX_REFERENCE = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/vct.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -56,7 +56,7 @@ class Config(C.Structure):
         ("ambient_factor", C.c_float), ("shininess", C.c_float), ("max_distance", C.c_float),
         ("max_alpha", C.c_float), ("tan_diffuse", C.c_float), ("tan_specular", C.c_float),
         ("wrap_repeat", C.c_int32), ("debug_outputs", C.c_int32), ("trace_variant", C.c_int32),
-        ("voxel_attributes", C.c_int32), ("anisotropic_mips", C.c_int32),
+        ("voxel_attributes", C.c_int32), ("anisotropic_mips", C.c_int32), ("texture_mipmaps", C.c_int32),
     ]
 
 

@@ -289,6 +289,7 @@ VctTextures textures_of(const vct_ctx* c) {
     memset(&t, 0, sizeof(t));
     if (c->tex_texels && c->tri_uv && c->mat_tex) {
         t.texels = c->tex_texels; t.desc = c->tex_desc; t.mat_tex = c->mat_tex; t.uv = c->tri_uv; t.ntex = c->ntex;
+        t.mips = c->cfg.texture_mipmaps ? 1 : 0;
     }
     return t;
 }
@@ -443,6 +444,7 @@ int vct_default_config(vct_config* cfg) {
     cfg->trace_variant = 0;
     cfg->voxel_attributes = 0;
     cfg->anisotropic_mips = 0;
+    cfg->texture_mipmaps = 1;        // Model.h:168,172: glGenerateMipmap + LINEAR_MIPMAP_LINEAR
     return VCT_OK;
 }
 
@@ -773,20 +775,32 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
     if (ntex == 0) return VCT_OK;                     // detach: flat colours again
     if (ntex < 0 || !rgba8 || !width || !height || !mat_tex)
         return fail(c, VCT_ERR_INVALID, "vct_upload_textures: null or negative input");
+    // Packed buffer: every texture's level 0, followed (config.texture_mipmaps) by its mip chain down to 1 x 1 --
+    // glGenerateMipmap (R/Model.h:168), built here on the GPU level by level (k_tex_mip).
     std::vector<VctTexDesc> desc((size_t)ntex);
     size_t total = 0;
     for (int32_t i = 0; i < ntex; ++i) {
         if (!rgba8[i] || width[i] <= 0 || height[i] <= 0 || width[i] > 16384 || height[i] > 16384)
             return fail(c, VCT_ERR_INVALID, "vct_upload_textures: bad texture size");
-        desc[(size_t)i].off = (uint32_t)total;
-        desc[(size_t)i].w = width[i];
-        desc[(size_t)i].h = height[i];
+        VctTexDesc& d = desc[(size_t)i];
+        memset(&d, 0, sizeof(d));
+        d.off = (uint32_t)total;
+        d.w = width[i];
+        d.h = height[i];
         const size_t n = (size_t)width[i] * height[i];
         uint32_t flags = 0;
         for (size_t k = 0; k < n; ++k)
             if (rgba8[i][4 * k + 3] != 255) { flags = 1u; break; }
-        desc[(size_t)i].flags = flags;
-        total += n;
+        d.flags = flags;
+        d.nlev = 1;
+        if (c->cfg.texture_mipmaps)
+            for (int m = width[i] > height[i] ? width[i] : height[i]; m > 1; m >>= 1) ++d.nlev;
+        size_t off = 0;
+        for (int k = 0; k < d.nlev; ++k) {
+            d.lvl[k] = (uint32_t)off;
+            off += (size_t)(width[i] >> k > 1 ? width[i] >> k : 1) * (size_t)(height[i] >> k > 1 ? height[i] >> k : 1);
+        }
+        total += off;
         if (total > 0xffffffffull) return fail(c, VCT_ERR_INVALID, "vct_upload_textures: more than 2^32 texels");
     }
     for (int32_t m = 0; m < c->nmat * 3; ++m)
@@ -794,9 +808,17 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
     HIP_TRY(c, hipMalloc(&c->tex_texels, total * 4));
     HIP_TRY(c, hipMalloc(&c->tex_desc, (size_t)ntex * sizeof(VctTexDesc)));
     HIP_TRY(c, hipMalloc(&c->mat_tex, (size_t)c->nmat * 3 * sizeof(int32_t)));
-    for (int32_t i = 0; i < ntex; ++i)
-        HIP_TRY(c, hipMemcpyAsync(c->tex_texels + desc[(size_t)i].off, rgba8[i], (size_t)width[i] * height[i] * 4,
+    for (int32_t i = 0; i < ntex; ++i) {
+        const VctTexDesc& d = desc[(size_t)i];
+        HIP_TRY(c, hipMemcpyAsync(c->tex_texels + d.off, rgba8[i], (size_t)width[i] * height[i] * 4,
                                   hipMemcpyHostToDevice, c->stream));
+        for (int k = 1; k < d.nlev; ++k) {
+            const int pw = d.w >> (k - 1) > 1 ? d.w >> (k - 1) : 1, ph = d.h >> (k - 1) > 1 ? d.h >> (k - 1) : 1;
+            const int w = d.w >> k > 1 ? d.w >> k : 1, h = d.h >> k > 1 ? d.h >> k : 1;
+            HIP_TRY(c, vct_launch_tex_mip(c->tex_texels + d.off + d.lvl[k - 1], pw, ph, c->tex_texels + d.off + d.lvl[k],
+                                          w, h, c->stream));
+        }
+    }
     HIP_TRY(c, hipMemcpyAsync(c->tex_desc, desc.data(), (size_t)ntex * sizeof(VctTexDesc), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->mat_tex, mat_tex, (size_t)c->nmat * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -24,12 +24,17 @@ __device__ __forceinline__ uint32_t vct_float_to_unorm8(float f) {
 #endif
 
 // ---- material textures (R/Model.h:126-136 loads them, R/Mesh.h:91-108 binds them) ---------------------------
-// All textures of a scene live in one packed RGBA8 buffer; texture(sampler2D, uv) is restated as LEVEL 0,
-// BILINEAR, GL_REPEAT with the operation order of oracle/vct_oracle_raster.cpp vcto_tex_sample.
+// All textures of a scene live in one packed RGBA8 buffer, each with its mip chain behind level 0 when
+// config.texture_mipmaps (glGenerateMipmap, R/Model.h:168).  texture(sampler2D, uv) is restated with the operation
+// order of oracle/vct_oracle_raster.cpp: vcto_tex_sample (level 0, BILINEAR, GL_REPEAT) and vcto_tex_sample_lod
+// (LINEAR_MIPMAP_LINEAR with the quad differences of the coordinate; oracle/vct_oracle.h "Mip-mapped sampling").
+#define VCT_TEX_MAX_LEVELS 15       // 16384 x 16384 down to 1 x 1
 struct VctTexDesc {
-    uint32_t off;        // first texel in the packed buffer
+    uint32_t off;        // first texel of level 0 in the packed buffer
     int32_t w, h;
     uint32_t flags;      // bit 0: some texel has alpha != 255 (fragments need the alpha test of trace.fs:169-172)
+    int32_t nlev;        // levels stored (1: level 0 only)
+    uint32_t lvl[VCT_TEX_MAX_LEVELS];     // texel offset of level k behind `off`
 };
 struct VctTextures {
     const uint32_t* texels;    // null: the scene has no textures
@@ -37,6 +42,7 @@ struct VctTextures {
     const int32_t* mat_tex;    // [nmat][3] diffuse / specular / height texture index or -1
     const float* uv;           // [ntri][3][2]
     int32_t ntex;
+    int32_t mips;              // 1: the textures carry mip chains and are sampled with implicit derivatives
 };
 #if defined(__HIPCC__)
 __device__ __forceinline__ int vct_tex_of(const VctTextures& t, int material, int slot) {
@@ -44,15 +50,13 @@ __device__ __forceinline__ int vct_tex_of(const VctTextures& t, int material, in
     const int i = t.mat_tex[3 * (size_t)material + slot];
     return i >= 0 && i < t.ntex ? i : -1;
 }
-__device__ __forceinline__ float4 vct_tex_sample(const VctTextures& t, int ti, float u, float v) {
-    const VctTexDesc d = t.desc[ti];
-    const int W = d.w, H = d.h;
+// [GL] bilinear, GL_REPEAT, on one level of W x H texels
+__device__ __forceinline__ float4 vct_tex_bilinear(const uint32_t* __restrict__ base, int W, int H, float u, float v) {
     const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const float a = x - fx, b = y - fy;
     auto wrap = [](int i, int n) { const int r = i % n; return r < 0 ? r + n : r; };     // GL_REPEAT
     const int i0 = wrap((int)fx, W), i1 = wrap((int)fx + 1, W), j0 = wrap((int)fy, H), j1 = wrap((int)fy + 1, H);
-    const uint32_t* base = t.texels + d.off;
     const uint32_t p00 = base[(size_t)j0 * W + i0], p10 = base[(size_t)j0 * W + i1];
     const uint32_t p01 = base[(size_t)j1 * W + i0], p11 = base[(size_t)j1 * W + i1];
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
@@ -62,6 +66,49 @@ __device__ __forceinline__ float4 vct_tex_sample(const VctTextures& t, int ti, f
            w01 * vct_unorm8_to_float((p01 >> sh) & 0xffu) + w11 * vct_unorm8_to_float((p11 >> sh) & 0xffu);
     VCT_TEXCH(x, 0) VCT_TEXCH(y, 8) VCT_TEXCH(z, 16) VCT_TEXCH(w, 24)
 #undef VCT_TEXCH
+    return o;
+}
+__device__ __forceinline__ float4 vct_tex_sample(const VctTextures& t, int ti, float u, float v) {
+    const VctTexDesc* d = t.desc + ti;
+    return vct_tex_bilinear(t.texels + d->off, d->w, d->h, u, v);
+}
+// log2 without the math library, instruction for instruction oracle/vct_oracle_raster.cpp vcto_log2_det
+__device__ __forceinline__ float vct_log2_det(float x) {
+    const uint32_t b = __float_as_uint(x);
+    int e = (int)(b >> 23) - 127;
+    float f = __uint_as_float((b & 0x7fffffu) | 0x3f800000u);
+    if (f > 1.41421354f) { f = f * 0.5f; e += 1; }
+    const float s = __fdiv_rn(f - 1.0f, f + 1.0f);
+    const float s2 = s * s;
+    float p = 0.111111112f;
+    p = fmaf(p, s2, 0.142857149f);
+    p = fmaf(p, s2, 0.2f);
+    p = fmaf(p, s2, 0.333333343f);
+    p = fmaf(p, s2, 1.0f);
+    return fmaf(s * p, 2.88539004f, (float)e);
+}
+// texture(sampler, (u, v)) with the quad differences (ds_dx, dt_dx, ds_dy, dt_dy) of the normalised coordinate
+__device__ __forceinline__ float4 vct_tex_sample_lod(const VctTextures& t, int ti, float u, float v, float ds_dx,
+                                                     float dt_dx, float ds_dy, float dt_dy) {
+    const VctTexDesc* d = t.desc + ti;
+    const int W = d->w, H = d->h, nlev = d->nlev;
+    const uint32_t* base = t.texels + d->off;
+    if (!t.mips || nlev <= 1) return vct_tex_bilinear(base, W, H, u, v);
+    const float du_dx = ds_dx * (float)W, dv_dx = dt_dx * (float)H;
+    const float du_dy = ds_dy * (float)W, dv_dy = dt_dy * (float)H;
+    const float ax = du_dx * du_dx + dv_dx * dv_dx, ay = du_dy * du_dy + dv_dy * dv_dy;
+    const float m = ax > ay ? ax : ay;
+    if (!(m > 1.0f)) return vct_tex_bilinear(base, W, H, u, v);                     // magnification (and NaN)
+    const float lam = 0.5f * vct_log2_det(m);
+    const int q = nlev - 1;
+    if (lam >= (float)q) return vct_tex_bilinear(base + d->lvl[q], max(1, W >> q), max(1, H >> q), u, v);
+    const int k = (int)lam;
+    const float f = lam - (float)k, g = 1.0f - f;
+    const float4 t1 = vct_tex_bilinear(base + d->lvl[k], max(1, W >> k), max(1, H >> k), u, v);
+    const float4 t2 = vct_tex_bilinear(base + d->lvl[k + 1], max(1, W >> (k + 1)), max(1, H >> (k + 1)), u, v);
+    float4 o;
+    o.x = fmaf(f, t2.x, g * t1.x); o.y = fmaf(f, t2.y, g * t1.y);
+    o.z = fmaf(f, t2.z, g * t1.z); o.w = fmaf(f, t2.w, g * t1.w);
     return o;
 }
 #endif
@@ -238,6 +285,8 @@ hipError_t vct_launch_gbuffer_visibility(const VctRasterArgs& a, const float vie
 hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
                                     const uint32_t* shadow, uint32_t shadow_ebase, int shadow_size,
                                     const float light_vp[16], float* tiled, hipStream_t s);
+// one level of a texture's mip chain from its parent (pw x ph -> w x h), glGenerateMipmap restated as in the oracle
+hipError_t vct_launch_tex_mip(const uint32_t* parent, int pw, int ph, uint32_t* level, int w, int h, hipStream_t s);
 hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s);
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s);

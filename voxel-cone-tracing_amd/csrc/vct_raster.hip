@@ -165,6 +165,26 @@ __device__ __forceinline__ bool cover(const SubTri& s, int px, int py, float& b0
     return z >= 0.0f && z < 1.0f;
 }
 
+// The sub-triangle's perspective-correct interpolation of two per-vertex values at the centre of pixel (qx, qy), with
+// no coverage test: how texture() obtains its implicit derivatives -- the fragment's quad neighbours (qx ^ 1, qy) and
+// (qx, qy ^ 1), helper invocations when they fall outside the triangle (oracle raster_triangle uv_at).
+__device__ __forceinline__ void interp2_at(const SubTri& s, int qx, int qy, const float a[3], const float b[3],
+                                           float& oa, float& ob) {
+    const double cx = (double)qx + 0.5, cy = (double)qy + 0.5;
+    double f[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = (k + 1) % 3, j = (k + 2) % 3;
+        const double dx = (s.sx[j] - s.sx[i]) * s.sgn, dy = (s.sy[j] - s.sy[i]) * s.sgn;
+        f[k] = dx * (cy - s.sy[i]) - dy * (cx - s.sx[i]);
+    }
+    const float c0 = (float)(f[0] / s.area), c1 = (float)(f[1] / s.area), c2 = 1.0f - c0 - c1;
+    const float r0 = c0 * s.iw[0], r1 = c1 * s.iw[1], r2 = c2 * s.iw[2];
+    const float rs = __fdiv_rn(1.0f, r0 + r1 + r2);
+    oa = (r0 * a[0] + r1 * a[1] + r2 * a[2]) * rs;
+    ob = (r0 * b[0] + r1 * b[1] + r2 * b[2]) * rs;
+}
+
 struct RasterParams {
     const float* pos;            // [ntri][9] model space
     int32_t ntri;
@@ -240,7 +260,16 @@ __device__ __forceinline__ void plot(const RasterParams& p, const SubTri& s, int
         const float qs = __fdiv_rn(1.0f, q0 + q1 + q2);
         const float u = (q0 * s.tu[0] + q1 * s.tu[1] + q2 * s.tu[2]) * qs;
         const float v = (q0 * s.tv[0] + q1 * s.tv[1] + q2 * s.tv[2]) * qs;
-        if (vct_tex_sample(p.tex, s.tex, u, v).w < 0.5f) return;                 // trace.fs:171 discard
+        float alpha;
+        if (p.tex.mips) {      // texture(DiffuseTexture, tex) with the quad differences of tex
+            float ux, vx, uy, vy;
+            interp2_at(s, px ^ 1, py, s.tu, s.tv, ux, vx);
+            interp2_at(s, px, py ^ 1, s.tu, s.tv, uy, vy);
+            alpha = vct_tex_sample_lod(p.tex, s.tex, u, v, ux - u, vx - v, uy - u, vy - v).w;
+        } else {
+            alpha = vct_tex_sample(p.tex, s.tex, u, v).w;
+        }
+        if (alpha < 0.5f) return;                                                // trace.fs:171 discard
     }
     if (p.vis32) {        // depth-only pass (shadow map): the nearest depth is all that is kept, as the 24-bit depth
         // the map will show (quantisation is monotonic: the minimum of the quantised depths is the quantised minimum)
@@ -556,6 +585,7 @@ k_gbuffer_shade(const ShadeParams p) {
         const int m = p.material[t];
         const int td = vct_tex_of(p.r.tex, m, 0), tsp = vct_tex_of(p.r.tex, m, 1), th = vct_tex_of(p.r.tex, m, 2);
         float tcu = 0.0f, tcv = 0.0f;                                             // tex (trace.vs:36)
+        float dq[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                   // its quad differences (mip-mapped textures)
         if (td >= 0 || tsp >= 0 || th >= 0) {
             const float* uv = p.r.tex.uv + (size_t)t * 6;
             float vu[3], vv[3];
@@ -573,7 +603,17 @@ k_gbuffer_shade(const ShadeParams p) {
             }
             tcu = (q0 * vu[0] + q1 * vu[1] + q2 * vu[2]) * qs;
             tcv = (q0 * vv[0] + q1 * vv[1] + q2 * vv[2]) * qs;
+            if (p.r.tex.mips) {
+                float ux, vx, uy, vy;
+                interp2_at(s, px ^ 1, py, vu, vv, ux, vx);
+                interp2_at(s, px, py ^ 1, vu, vv, uy, vy);
+                dq[0] = ux - tcu; dq[1] = vx - tcv; dq[2] = uy - tcu; dq[3] = vy - tcv;
+            }
         }
+        // texture(sampler, tex [+ constant]): the implicit derivatives are those of tex
+        auto fetch = [&](int ti, float uu, float vv2) {
+            return vct_tex_sample_lod(p.r.tex, ti, uu, vv2, dq[0], dq[1], dq[2], dq[3]);
+        };
         // TBN = inverse(transpose(mat3(T,B,N))): columns (BxN, NxT, TxB) / det                    trace.fs:175
         const float Tx = g[6], Ty = g[7], Tz = g[8], Bx = g[9], By = g[10], Bz = g[11];
         const float Nx = g[3], Ny = g[4], Nz = g[5];
@@ -589,9 +629,9 @@ k_gbuffer_shade(const ShadeParams p) {
             // CalcBumpNormal (trace.fs:110-128): three HeightTexture taps one texel apart
             const VctTexDesc hd = p.r.tex.desc[th];
             const float ox = __fdiv_rn(1.0f, (float)hd.w), oy = __fdiv_rn(1.0f, (float)hd.h);      // :112
-            const float cur = vct_tex_sample(p.r.tex, th, tcu, tcv).x;                               // :114
-            const float dx = vct_tex_sample(p.r.tex, th, tcu + ox, tcv).x - cur;                     // :115
-            const float dy = vct_tex_sample(p.r.tex, th, tcu, tcv + oy).x - cur;                     // :116
+            const float cur = fetch(th, tcu, tcv).x;                                                 // :114
+            const float dx = fetch(th, tcu + ox, tcv).x - cur;                                       // :115
+            const float dy = fetch(th, tcu, tcv + oy).x - cur;                                       // :116
             // t1 = normalize(1,0,dx), t2 = normalize(0,1,dy)   (host normalize(): a * (1/l))
             const float l1 = __builtin_sqrtf(1.0f * 1.0f + 0.0f * 0.0f + dx * dx), i1 = __fdiv_rn(1.0f, l1);
             const float l2 = __builtin_sqrtf(0.0f * 0.0f + 1.0f * 1.0f + dy * dy), i2 = __fdiv_rn(1.0f, l2);
@@ -616,14 +656,14 @@ k_gbuffer_shade(const ShadeParams p) {
         g[14] = len > 0.0f ? uz * il : 0.0f;
         const float* alb = p.albedo + 4 * (size_t)m;
         if (td >= 0) {
-            const float4 c = vct_tex_sample(p.r.tex, td, tcu, tcv);               // trace.fs:167
+            const float4 c = fetch(td, tcu, tcv);                                 // trace.fs:167
             g[15] = c.x; g[16] = c.y; g[17] = c.z; g[18] = c.w;
         } else {
             g[15] = alb[0]; g[16] = alb[1]; g[17] = alb[2]; g[18] = alb[3];
         }
         float sp[3] = {p.specular[3 * (size_t)m], p.specular[3 * (size_t)m + 1], p.specular[3 * (size_t)m + 2]};
         if (tsp >= 0) {
-            const float4 c = vct_tex_sample(p.r.tex, tsp, tcu, tcv);              // trace.fs:209
+            const float4 c = fetch(tsp, tcu, tcv);                                // trace.fs:209
             sp[0] = c.x; sp[1] = c.y; sp[2] = c.z;
         }
         const bool has_gb = __builtin_sqrtf(sp[1] * sp[1] + sp[2] * sp[2]) > 0.0f;
@@ -696,6 +736,23 @@ k_gbuffer_shade(const ShadeParams p) {
     }
 #pragma unroll
     for (int k = 0; k < VCT_GB_NPLANES; ++k) out[k * VCT_TILE_PIX] = g[k];
+}
+
+// glGenerateMipmap (R/Model.h:168) for one level: rounded mean of the 2x2 parent texels, indices clamped to the parent
+__global__ void __launch_bounds__(256)
+k_tex_mip(const uint32_t* __restrict__ parent, int pw, int ph, uint32_t* __restrict__ level, int w, int h) {
+    const size_t n = (size_t)w * h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / (size_t)w), x = (int)(i - (size_t)y * w);
+        const int x0 = min(2 * x, pw - 1), x1 = min(2 * x + 1, pw - 1), y0 = min(2 * y, ph - 1), y1 = min(2 * y + 1, ph - 1);
+        const uint32_t a = parent[(size_t)y0 * pw + x0], b = parent[(size_t)y0 * pw + x1];
+        const uint32_t c = parent[(size_t)y1 * pw + x0], d = parent[(size_t)y1 * pw + x1];
+        uint32_t o = 0u;
+#pragma unroll
+        for (int sh = 0; sh < 32; sh += 8)
+            o |= ((((a >> sh) & 0xffu) + ((b >> sh) & 0xffu) + ((c >> sh) & 0xffu) + ((d >> sh) & 0xffu) + 2u) >> 2) << sh;
+        level[i] = o;
+    }
 }
 
 // tiled [tile][23][64] -> linear planes [23][h*w] (downloads / tests)
@@ -805,6 +862,13 @@ hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_pro
     const int tiles = p.tile1 - p.tile0;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_gbuffer_shade, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_tex_mip(const uint32_t* parent, int pw, int ph, uint32_t* level, int w, int h, hipStream_t s) {
+    const size_t n = (size_t)w * h;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_tex_mip, dim3(blocks ? blocks : 1u), dim3(256), 0, s, parent, pw, ph, level, w, h);
     return hipGetLastError();
 }
 

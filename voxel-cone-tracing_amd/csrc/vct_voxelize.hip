@@ -153,14 +153,15 @@ struct TriSetup {
 
 // vox.fs:56: the fragment's albedo -- texture(DiffuseTexture, uv) with uv interpolated by the fragment's
 // barycentrics, or the flat material colour when the material has no diffuse texture
+// duv: quad differences of the coordinate in the voxelization raster (mip-mapped textures; oracle/vct_oracle.h vcto_scene)
 template <class Setup>
 __device__ __forceinline__ void frag_albedo(const VctVoxParams& p, const Setup& r, float b0, float b1, float b2,
-                                            float alb[3]) {
+                                            const float duv[4], float alb[3]) {
     alb[0] = r.alb[0]; alb[1] = r.alb[1]; alb[2] = r.alb[2];
     if (r.tex >= 0) {
         const float u = b0 * r.uv[0][0] + b1 * r.uv[1][0] + b2 * r.uv[2][0];
         const float v = b0 * r.uv[0][1] + b1 * r.uv[1][1] + b2 * r.uv[2][1];
-        const float4 c = vct_tex_sample(p.tex, r.tex, u, v);
+        const float4 c = vct_tex_sample_lod(p.tex, r.tex, u, v, duv[0], duv[1], duv[2], duv[3]);
         alb[0] = c.x; alb[1] = c.y; alb[2] = c.z;
     }
 }
@@ -286,7 +287,23 @@ __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& 
         sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f), 25.0f);   // vox.fs:46
     }
     float alb[3];
-    frag_albedo(p, r, b0, b1, b2, alb);                                              // vox.fs:56
+    float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (r.tex >= 0 && p.tex.mips) {
+        // (no reference code for this mode) the UNCLAMPED barycentrics one voxel further along each in-plane axis
+        auto uv_at = [&](float qx, float qy, float& ou, float& ov) {
+            const float c0 = __fdiv_rn((ax1 - qx) * (ay2 - qy) - (ax2 - qx) * (ay1 - qy), r.area);
+            const float c1 = __fdiv_rn((ax2 - qx) * (ay0 - qy) - (ax0 - qx) * (ay2 - qy), r.area);
+            const float c2 = 1.0f - c0 - c1;
+            ou = c0 * r.uv[0][0] + c1 * r.uv[1][0] + c2 * r.uv[2][0];
+            ov = c0 * r.uv[0][1] + c1 * r.uv[1][1] + c2 * r.uv[2][1];
+        };
+        float mu, mv, xu, xv, yu, yv;
+        uv_at(cx, cy, mu, mv);
+        uv_at(cx + 1.0f, cy, xu, xv);
+        uv_at(cx, cy + 1.0f, yu, yv);
+        duv[0] = xu - mu; duv[1] = xv - mv; duv[2] = yu - mu; duv[3] = yv - mv;
+    }
+    frag_albedo(p, r, b0, b1, b2, duv, alb);                                         // vox.fs:56
     const unsigned long long cr = to_unorm8(alb[0] * sh), cg = to_unorm8(alb[1] * sh),
                              cb = to_unorm8(alb[2] * sh);                            // vox.fs:88
     const size_t pv = (size_t)p.brick_slot[vox >> 9] * 512 + (vox & 511u);      // pooled voxel
@@ -475,7 +492,29 @@ __device__ __forceinline__ void ref_fragment(const VctVoxParams& p, const RefSet
         sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f), 25.0f);    // vox.fs:46
     }
     float alb[3];
-    frag_albedo(p, r, l0, l1, l2, alb);                                               // vox.fs:56
+    float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (r.tex >= 0 && p.tex.mips) {
+        // texture() derivatives: the neighbouring pixel centres of the fragment's 2x2 quad, on this triangle
+        auto uv_at = [&](int qx, int qy, float& ou, float& ov) {
+            const float nx = (float)qx + 0.5f, ny = (float)qy + 0.5f;
+            float f[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int a = (k + 1) % 3, b = (k + 2) % 3;
+                const float dx = (r.wx[b] - r.wx[a]) * r.sgn, dy = (r.wy[b] - r.wy[a]) * r.sgn;
+                f[k] = dx * (ny - r.wy[a]) - dy * (nx - r.wx[a]);
+            }
+            const float c0 = __fdiv_rn(f[0], r.area), c1 = __fdiv_rn(f[1], r.area), c2 = 1.0f - c0 - c1;
+            ou = c0 * r.uv[0][0] + c1 * r.uv[1][0] + c2 * r.uv[2][0];
+            ov = c0 * r.uv[0][1] + c1 * r.uv[1][1] + c2 * r.uv[2][1];
+        };
+        float mu, mv, xu, xv, yu, yv;
+        uv_at(px, py, mu, mv);
+        uv_at(px ^ 1, py, xu, xv);
+        uv_at(px, py ^ 1, yu, yv);
+        duv[0] = xu - mu; duv[1] = xv - mv; duv[2] = yu - mu; duv[3] = yv - mv;
+    }
+    frag_albedo(p, r, l0, l1, l2, duv, alb);                                          // vox.fs:56
     const unsigned long long rgb = to_unorm8(alb[0] * sh) | (to_unorm8(alb[1] * sh) << 8) |
                                    (to_unorm8(alb[2] * sh) << 16);                   // vox.fs:88
     atomicMax(p.acc + 2 * ((size_t)p.brick_slot[vox >> 9] * 512 + (vox & 511u)),
