@@ -523,7 +523,12 @@ __device__ __forceinline__ float shadow_fetch(const uint32_t* __restrict__ words
 #ifndef VCT_SHADE_MIN_BLOCKS
 #define VCT_SHADE_MIN_BLOCKS 7       // waves per SIMD; with the rolling PCF window 70 VGPRs, no scratch (G-buffer pass, us: 5: 204, 7: 201, 8: 212)
 #endif
-__global__ void __launch_bounds__(256, VCT_SHADE_MIN_BLOCKS)
+// TEX: the scene has material textures.  Two instantiations because the mip-mapped fetches (two levels x four texels,
+// their derivatives from two more perspective-correct interpolations) do not fit the 72-VGPR budget of 7 waves per
+// SIMD: compiled into one kernel they spilled 76 registers to scratch (560 B per lane) and the pass of the textured
+// atrium took 0.73 ms instead of 0.27.  Flat scenes keep the lean kernel; the textured one gets 96 VGPRs (5 waves).
+template <bool TEX>
+__global__ void __launch_bounds__(256, TEX ? 5 : VCT_SHADE_MIN_BLOCKS)
 k_gbuffer_shade(const ShadeParams p) {
     const int W = p.r.W, H = p.r.H;
     const int tile = p.tile0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -583,10 +588,11 @@ k_gbuffer_shade(const ShadeParams p) {
             g[i] = (q0 * var[0] + q1 * var[1] + q2 * var[2]) * qs;
         }
         const int m = p.material[t];
-        const int td = vct_tex_of(p.r.tex, m, 0), tsp = vct_tex_of(p.r.tex, m, 1), th = vct_tex_of(p.r.tex, m, 2);
+        const int td = TEX ? vct_tex_of(p.r.tex, m, 0) : -1, tsp = TEX ? vct_tex_of(p.r.tex, m, 1) : -1,
+                  th = TEX ? vct_tex_of(p.r.tex, m, 2) : -1;
         float tcu = 0.0f, tcv = 0.0f;                                             // tex (trace.vs:36)
         float dq[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                   // its quad differences (mip-mapped textures)
-        if (td >= 0 || tsp >= 0 || th >= 0) {
+        if (TEX && (td >= 0 || tsp >= 0 || th >= 0)) {
             const float* uv = p.r.tex.uv + (size_t)t * 6;
             float vu[3], vv[3];
             if (whole) {
@@ -611,7 +617,9 @@ k_gbuffer_shade(const ShadeParams p) {
             }
         }
         // texture(sampler, tex [+ constant]): the implicit derivatives are those of tex
-        auto fetch = [&](int ti, float uu, float vv2) {
+        // (always_inline: an out-of-line lambda takes the address of the kernel arguments, and the whole 430-byte
+        // argument block is then copied to scratch at kernel entry)
+        auto fetch = [&](int ti, float uu, float vv2) __attribute__((always_inline)) {
             return vct_tex_sample_lod(p.r.tex, ti, uu, vv2, dq[0], dq[1], dq[2], dq[3]);
         };
         // TBN = inverse(transpose(mat3(T,B,N))): columns (BxN, NxT, TxB) / det                    trace.fs:175
@@ -622,7 +630,7 @@ k_gbuffer_shade(const ShadeParams p) {
         const float det = Tx * bnx + Ty * bny + Tz * bnz;
         const float inv = __fdiv_rn(1.0f, det);
         float ux, uy, uz;
-        if (th < 0) {
+        if (!TEX || th < 0) {
             // CalcBumpNormal with a flat height map: normalize(TBN * (0,0,1))
             ux = c2x * inv; uy = c2y * inv; uz = c2z * inv;
         } else {
@@ -655,14 +663,14 @@ k_gbuffer_shade(const ShadeParams p) {
         g[13] = len > 0.0f ? uy * il : 0.0f;
         g[14] = len > 0.0f ? uz * il : 0.0f;
         const float* alb = p.albedo + 4 * (size_t)m;
-        if (td >= 0) {
+        if (TEX && td >= 0) {
             const float4 c = fetch(td, tcu, tcv);                                 // trace.fs:167
             g[15] = c.x; g[16] = c.y; g[17] = c.z; g[18] = c.w;
         } else {
             g[15] = alb[0]; g[16] = alb[1]; g[17] = alb[2]; g[18] = alb[3];
         }
         float sp[3] = {p.specular[3 * (size_t)m], p.specular[3 * (size_t)m + 1], p.specular[3 * (size_t)m + 2]};
-        if (tsp >= 0) {
+        if (TEX && tsp >= 0) {
             const float4 c = fetch(tsp, tcu, tcv);                                // trace.fs:209
             sp[0] = c.x; sp[1] = c.y; sp[2] = c.z;
         }
@@ -861,7 +869,8 @@ hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_pro
     p.tile1 = row1 * p.tiles_x;
     const int tiles = p.tile1 - p.tile0;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gbuffer_shade, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
+    if (a.tex.texels) hipLaunchKernelGGL(k_gbuffer_shade<true>, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_gbuffer_shade<false>, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
