@@ -53,9 +53,11 @@ def parse():
     ap.add_argument("--voxel-dim", type=int, default=256)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--scene", default="atrium", choices=["atrium", "atrium-textured", "cornell", "noise"],
+    ap.add_argument("--scene", default="atrium", choices=["atrium", "atrium-textured", "bistro", "cornell", "noise"],
                     help="atrium-textured: the same atrium with procedural diffuse / specular / height maps "
-                         "(bump-mapped normals decohere the specular cones)")
+                         "(bump-mapped normals decohere the specular cones); bistro: Bistro-exterior-class street "
+                         "(BASELINE.json configs[4]: 2.8 M triangles at --scene-detail 1, 43 %% alpha-tested foliage "
+                         "cards, clutter, every surface textured with noisy height maps)")
     ap.add_argument("--noise-dense", action="store_true",
                     help="--scene noise: every voxel gets random RGBA bytes (no empty space) -- with --gbuffer random "
                          "at 1024^3 this is the HBM-bound stress: per-lane gathers over a 4.6 GiB chain")
@@ -167,6 +169,12 @@ def build_inputs(args, vct, sc):
         cam = sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
         label = (f"procedural atrium (Sponza-class, {scene.ntri} tris, seed 1234" +
                  (f", {len(scene.textures)} procedural texture maps)" if tex else ")"))
+    elif args.scene == "bistro":
+        scene = sc.Scene(sc.BISTRO, args.scene_detail, 1234)
+        cam = sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0)
+        label = (f"procedural Bistro-exterior-class street ({scene.ntri} tris, "
+                 f"{100.0 * float((scene.material == 5).mean()):.0f} % alpha-tested foliage cards, "
+                 f"{len(scene.textures)} texture maps, seed 1234)")
     else:
         scene = sc.Scene(sc.CORNELL)
         cam = sc.default_camera(position=(0.0, 0.0, 58.0), yaw=-90.0)

@@ -2,8 +2,8 @@
 
   config 2 (configs[1]): Sponza-class atrium (257k triangles), 256^3, 1920x1080, 6+1 cones
   config 3 (configs[2]): the same scene at 512^3, 3840x2160, two bounces (vct_bounce)
-  config 5 (configs[4]): Bistro-class scene (2.75 M triangles), 1024^3, 3840x2160, specular cone at
-                         three apertures (tan 0.07 / 0.105 / 0.2)
+  config 5 (configs[4]): Bistro-exterior-class street (2.8 M triangles, alpha-tested foliage, textured), 1024^3,
+                         3840x2160, specular cone at three apertures (tan 0.07 / 0.105 / 0.2)
 (config 1 is the golden fixture of tests/test_golden.py, config 4 is config 2 cut into slabs:
 tests/test_gpu_fullsize.py, tests/test_slabs_gloo.py, tests/test_gpu_multi.py.)
 
@@ -56,18 +56,17 @@ def vct():
 class Pipeline:
     """Scene + context with every input stage on the GPU, each checked against its CPU counterpart."""
 
-    def __init__(self, vct, oracle, detail, V, w, h, attrs=0, S=4096):
+    def __init__(self, vct, oracle, detail, V, w, h, attrs=0, S=4096, kind=None, cam=None):
         from voxel_cone_tracing_amd import scene as sc
         self.vct, self.oracle, self.sc = vct, oracle, sc
         self.V, self.w, self.h, self.S = V, w, h, S
-        self.scene = sc.Scene(sc.ATRIUM, detail, 1234)
-        self.cam = sc.default_camera(**CAM)
+        self.scene = sc.Scene(sc.ATRIUM if kind is None else kind, detail, 1234)
+        self.cam = sc.default_camera(**(cam or CAM))
         self.ctx = vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=S,
                                                   debug_outputs=1, voxel_attributes=attrs))
         self.ctx.set_camera_position(tuple(self.cam.position))
         self.ctx.set_light_direction(LIGHT)
-        self.ctx.upload_triangles(self.scene.pos, self.scene.material, self.scene.albedo)
-        self.ctx.upload_mesh_attributes(*self.scene.frames(), self.scene.specular)
+        self.ctx.upload_scene(self.scene)        # triangles, frames, and (textured scenes) uvs + mip-mapped texture maps
         self.params = oracle.default_params(V, camera_pos=tuple(self.cam.position), light_dir=LIGHT)
 
     def shadow_map(self):
@@ -185,12 +184,13 @@ def test_config3_512_4k_two_bounces(vct, oracle):
 
 
 def test_config5_1024_4k_three_apertures(vct, oracle):
-    """configs[4]: 2.75 M triangles, 1024^3 (4.57 GiB chain), 3840x2160, specular tan 0.07 / 0.105 / 0.2."""
+    """configs[4]: the Bistro-exterior-class street (2.8 M triangles, 43 % alpha-tested foliage cards, every surface
+    textured and mip-mapped), 1024^3 (4.57 GiB chain), 3840x2160, specular tan 0.07 / 0.105 / 0.2."""
     V, w, h = 1024, 3840, 2160
     apertures = (0.07, 0.105, 0.2)
-    pl = Pipeline(vct, oracle, 3.5, V, w, h)
+    pl = Pipeline(vct, oracle, 1.0, V, w, h, kind=3, cam=dict(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0))
     ctx = pl.ctx
-    assert pl.scene.ntri > 2_500_000
+    assert pl.scene.ntri > 2_700_000 and len(pl.scene.textures) >= 12
     pl.shadow_map()
     pl.gbuffer()
     alive = pl.planes[18] >= 0.5

@@ -174,3 +174,35 @@ def test_alpha_tested_fragments_write_neither_colour_nor_depth(oracle, tmp_path)
     ctx.render_gbuffer(sc.camera_view_proj(cam, 160, 120))
     assert np.array_equal(ctx.download_gbuffer().view(np.uint32), want.view(np.uint32))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_bistro_class_scene_every_stage_matches_the_oracle(oracle):
+    """The Bistro-exterior-class street (BASELINE.json configs[4]) at test size: alpha-tested foliage cards with random
+    orientations, clutter, every material textured (mip-mapped) with noisy height maps -- shadow map, both voxelizers,
+    G-buffer and trace against the oracle, bit for bit / within the north-star tolerance."""
+    import torch
+    assert torch.cuda.is_available()
+    vct = vctpkg.load()
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(sc.BISTRO, 0.14, 1234)
+    leaves = scene.material == 5
+    assert scene.ntri > 80_000 and 0.15 < leaves.mean() < 0.6 and len(scene.textures) >= 12
+    cam = sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0)
+    V, w, h, S = 128, 480, 270, 1024
+    ctx, g, l0, chain = textured_pipeline(vct, oracle, scene, cam, V, w, h, S)
+    covered = g[18] >= 0.5
+    assert 0.6 < covered.mean() < 1.0                       # sky between the roofs, the rest is street and facades
+    # foliage is in the frame, and through its cut-outs one sees what is behind: leaf pixels are scattered, not solid
+    leafy = covered & (g[16] > 1.8 * g[15]) & (g[16] > 1.8 * g[17])
+    assert leafy.mean() > 0.01
+    img = leafy.reshape(h, w)
+    edges = (img[:, 1:] != img[:, :-1]).sum() + (img[1:] != img[:-1]).sum()
+    assert edges > 2.0 * np.sqrt(img.sum())                  # far more boundary than a solid blob of that area has
+    # bump-mapped normals leave the interpolated normal on most covered pixels (noisy height maps)
+    nrm = g[3:6] / np.maximum(np.linalg.norm(g[3:6], axis=0, keepdims=True), 1e-30)
+    assert (np.abs((g[12:15] * nrm).sum(0)[covered]) < 0.9999).mean() > 0.4
+    # the crowns put occupancy INSIDE volumes, not only on surfaces
+    occ = (l0[..., 3] > 0)
+    assert occ.mean() > 0.01
+    ctx.close()

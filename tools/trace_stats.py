@@ -43,6 +43,12 @@ def main():
         ctx.build_mips()
         ctx.trace(inp["planes"])
     out = {"workload": inp["label"], "voxel_dim": V, "width": w, "height": h, "launches": []}
+    if inp["scene"] is not None:
+        sc_ = ctx.stage_counts()
+        nbricks = (V // 8) ** 3
+        out["brick_occupancy"] = {"touched_8x8x8_bricks": sc_["touched_bricks"], "of": nbricks,
+                                  "fraction": round(sc_["touched_bricks"] / nbricks, 5),
+                                  "voxelizer_candidates": sc_["vox_candidates"], "triangles": sc_["triangles"]}
     for ts in (0.07, 0.105, 0.2):
         ctx.set_cone_apertures(0.577, ts)
         ctx.trace_resident()

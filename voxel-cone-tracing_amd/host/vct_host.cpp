@@ -384,6 +384,312 @@ void build_atrium(vcth_scene* s, float detail, uint32_t seed, bool textured) {
     finish(s);
 }
 
+// ---- kind 3: Bistro-exterior-class street scene (BASELINE.json configs[4] names Amazon Bistro exterior; no asset can
+// be fetched here, so its CHARACTER is generated: ~2.8 M triangles at detail 1, about 40 % of them alpha-tested
+// foliage cards with incoherent normals, facades with recessed windows, balconies and awnings, street clutter --
+// tables, chairs, lamps, planters, strings of lights -- and every surface textured, with noisy height maps).
+// A street runs along x between two rows of buildings; the camera stands on it.
+void texture_bistro(vcth_scene* s, const int m[], uint32_t seed) {
+    enum { COBBLE, PLASTER, BRICKM, WOOD, METAL, LEAF, AWNING, GLASS, ROOF, SIDEWALK, LAMP, NMAT };
+    const int cobble_d = add_texture(s, 512, 512, [&](float u, float v, int x, int y, float* c) {
+        const int cx = x / 32, cy = y / 32, ox = (cy & 1) ? 16 : 0;
+        const int lx = (x + ox) % 32, ly = y % 32;
+        const bool gap = lx < 3 || ly < 3;
+        const float tone = 0.75f + 0.5f * (hash01((x + ox) / 32, cy, seed + 31) - 0.5f);
+        const float n = 0.18f * (value_noise(u, v, 128, seed + 32) - 0.5f);
+        const float g = gap ? 0.18f : 0.42f * tone;
+        c[0] = g + n; c[1] = g * 0.97f + n; c[2] = g * 0.92f + n;
+        (void)cx;
+    });
+    const int cobble_h = add_texture(s, 512, 512, [&](float u, float v, int x, int y, float* c) {
+        const int cy = y / 32, ox = (cy & 1) ? 16 : 0;
+        const int lx = (x + ox) % 32, ly = y % 32;
+        const float ex = fminf((float)lx, 31.0f - lx), ey = fminf((float)ly, 31.0f - ly);
+        const float dome = fminf(1.0f, fminf(ex, ey) / 6.0f);
+        c[0] = c[1] = c[2] = 0.15f + 0.6f * dome + 0.25f * value_noise(u, v, 256, seed + 33);     // noisy: bump normals decohere
+    });
+    const int cobble_s = add_texture(s, 128, 128, [&](float u, float v, int, int, float* c) {
+        c[0] = 0.15f + 0.35f * value_noise(u, v, 32, seed + 34); c[1] = 0.0f; c[2] = 0.0f;        // wet patches, .rrra
+    });
+    const int plaster_d = add_texture(s, 512, 512, [&](float u, float v, int, int, float* c) {
+        const float n = 0.5f * value_noise(u, v, 8, seed + 35) + 0.3f * value_noise(u, v, 64, seed + 36) +
+                        0.2f * value_noise(u, v, 256, seed + 37);
+        c[0] = 0.66f + 0.22f * n; c[1] = 0.60f + 0.20f * n; c[2] = 0.48f + 0.18f * n;
+    });
+    const int plaster_h = add_texture(s, 512, 512, [&](float u, float v, int, int, float* c) {
+        c[0] = c[1] = c[2] = 0.4f * value_noise(u, v, 32, seed + 38) + 0.6f * value_noise(u, v, 256, seed + 39);
+    });
+    const int brick_d = add_texture(s, 256, 128, [&](float u, float v, int x, int y, float* c) {
+        const int row = y / 16, xo = x + ((row & 1) ? 16 : 0);
+        const bool mortar = (y % 16) < 2 || (xo % 32) < 2;
+        const float n = 0.12f * (value_noise(u, v, 64, seed + 40) - 0.5f);
+        const float tone = 0.85f + 0.3f * (hash01(xo / 32, row, seed + 41) - 0.5f);
+        if (mortar) { c[0] = 0.50f + n; c[1] = 0.48f + n; c[2] = 0.45f + n; }
+        else { c[0] = 0.50f * tone + n; c[1] = 0.26f * tone + n; c[2] = 0.20f * tone + n; }
+    });
+    const int brick_h = add_texture(s, 256, 128, [&](float u, float v, int x, int y, float* c) {
+        const int row = y / 16, xo = x + ((row & 1) ? 16 : 0);
+        const bool mortar = (y % 16) < 2 || (xo % 32) < 2;
+        c[0] = c[1] = c[2] = mortar ? 0.1f : 0.65f + 0.3f * value_noise(u, v, 128, seed + 42);
+    });
+    const int wood_d = add_texture(s, 256, 256, [&](float u, float v, int, int, float* c) {
+        const float g = 0.5f + 0.5f * sinf(40.0f * v + 6.0f * value_noise(u, v, 16, seed + 43));
+        c[0] = 0.36f + 0.16f * g; c[1] = 0.22f + 0.10f * g; c[2] = 0.11f + 0.06f * g;
+    });
+    const int metal_s = add_texture(s, 64, 64, [&](float u, float v, int, int, float* c) {
+        const float n = 0.6f + 0.4f * value_noise(u, v, 16, seed + 44);
+        c[0] = 0.75f * n; c[1] = 0.75f * n; c[2] = 0.8f * n;
+    });
+    // leaf clusters: several leaves per card, everything else cut out (alpha test, trace.fs:169-172)
+    const int leaf_d = add_texture(s, 256, 256, [&](float u, float v, int, int, float* c) {
+        float a = 0.0f, shade = 0.0f;
+        for (int k = 0; k < 9; ++k) {
+            const float cx = 0.15f + 0.7f * hash01(k, 1, seed + 45), cy = 0.15f + 0.7f * hash01(k, 2, seed + 45);
+            const float ang = 6.2831853f * hash01(k, 3, seed + 45);
+            const float dx = u - cx, dy = v - cy;
+            const float lx = dx * cosf(ang) + dy * sinf(ang), ly = -dx * sinf(ang) + dy * cosf(ang);
+            const float e = (lx * lx) / (0.17f * 0.17f) + (ly * ly) / (0.07f * 0.07f);      // an ellipse per leaf
+            if (e < 1.0f) { a = 1.0f; shade = 0.6f + 0.4f * hash01(k, 4, seed + 45) - 0.25f * fabsf(ly) / 0.07f; }
+        }
+        const float n = 0.15f * (value_noise(u, v, 64, seed + 46) - 0.5f);
+        c[0] = 0.16f * shade + n; c[1] = 0.46f * shade + n; c[2] = 0.10f * shade + n; c[3] = a;
+    });
+    const int awning_d = add_texture(s, 128, 128, [&](float u, float v, int x, int, float* c) {
+        const bool stripe = (x / 16) & 1;
+        const float n = 0.9f + 0.2f * (value_noise(u, v, 32, seed + 47) - 0.5f);
+        if (stripe) { c[0] = 0.80f * n; c[1] = 0.78f * n; c[2] = 0.70f * n; }
+        else { c[0] = 0.70f * n; c[1] = 0.10f * n; c[2] = 0.08f * n; }
+    });
+    const int glass_s = add_texture(s, 32, 32, [&](float u, float v, int, int, float* c) {
+        const float n = 0.85f + 0.15f * value_noise(u, v, 8, seed + 48);
+        c[0] = 0.9f * n; c[1] = 0.9f * n; c[2] = 0.95f * n;
+    });
+    const int roof_d = add_texture(s, 256, 256, [&](float u, float v, int x, int y, float* c) {
+        const int row = y / 16, xo = x + ((row & 1) ? 8 : 0);
+        const float tone = 0.8f + 0.4f * (hash01(xo / 16, row, seed + 49) - 0.5f);
+        const bool edge = (y % 16) < 2;
+        const float n = 0.1f * (value_noise(u, v, 64, seed + 50) - 0.5f);
+        const float g = edge ? 0.12f : 0.30f * tone;
+        c[0] = g * 1.1f + n; c[1] = g * 0.8f + n; c[2] = g * 0.75f + n;
+    });
+    auto set = [&](int mi, int d, int sp, int h) { s->materials[(size_t)mi].tex[0] = d; s->materials[(size_t)mi].tex[1] = sp; s->materials[(size_t)mi].tex[2] = h; };
+    set(m[COBBLE], cobble_d, cobble_s, cobble_h);
+    set(m[SIDEWALK], plaster_d, -1, cobble_h);
+    set(m[PLASTER], plaster_d, -1, plaster_h);
+    set(m[BRICKM], brick_d, -1, brick_h);
+    set(m[WOOD], wood_d, -1, plaster_h);
+    set(m[METAL], -1, metal_s, -1);
+    set(m[LAMP], -1, metal_s, -1);
+    set(m[LEAF], leaf_d, -1, -1);
+    set(m[AWNING], awning_d, -1, -1);
+    set(m[GLASS], -1, glass_s, -1);
+    set(m[ROOF], roof_d, -1, plaster_h);
+    (void)NMAT;
+}
+
+void build_bistro(vcth_scene* s, float detail, uint32_t seed) {
+    enum { COBBLE, PLASTER, BRICKM, WOOD, METAL, LEAF, AWNING, GLASS, ROOF, SIDEWALK, LAMP, NMAT };
+    Builder b{s};
+    uint32_t rng = seed * 2654435761u + 977u;
+    auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return (float)(rng >> 8) / 16777216.0f; };
+    int m[NMAT];
+    m[COBBLE] = add_material(s, 0.40f, 0.39f, 0.37f, 0.25f, 0.25f, 0.25f);
+    m[PLASTER] = add_material(s, 0.74f, 0.68f, 0.55f, 0.08f, 0.08f, 0.08f);
+    m[BRICKM] = add_material(s, 0.50f, 0.28f, 0.22f, 0.08f, 0.08f, 0.08f);
+    m[WOOD] = add_material(s, 0.40f, 0.26f, 0.14f, 0.12f, 0.12f, 0.12f);
+    m[METAL] = add_material(s, 0.30f, 0.30f, 0.32f, 0.75f, 0.75f, 0.8f);
+    m[LEAF] = add_material(s, 0.16f, 0.46f, 0.10f, 0.04f, 0.04f, 0.04f);
+    m[AWNING] = add_material(s, 0.70f, 0.12f, 0.10f, 0.05f, 0.05f, 0.05f);
+    m[GLASS] = add_material(s, 0.06f, 0.07f, 0.09f, 0.9f, 0.9f, 0.95f);
+    m[ROOF] = add_material(s, 0.33f, 0.22f, 0.20f, 0.1f, 0.1f, 0.1f);
+    m[SIDEWALK] = add_material(s, 0.58f, 0.56f, 0.52f, 0.12f, 0.12f, 0.12f);
+    m[LAMP] = add_material(s, 0.95f, 0.9f, 0.7f, 0.9f, 0.85f, 0.6f);
+
+    const float d = std::max(detail, 0.03f);
+    const float cell = 0.235f / d;                // tessellation cell of the large surfaces (world units)
+    auto n = [&](float len) { return std::max(1, (int)lroundf(len / cell)); };
+    const int seg = std::max(6, (int)lroundf(14 * sqrtf(d)));
+    const float X = 68.0f, Y0 = -26.0f, ZS = 10.0f, ZW = 17.0f;      // street half width, facade plane
+
+    // ground: cobbled street, raised sidewalks
+    b.quad({-X, Y0, ZS}, {2 * X, 0, 0}, {0, 0, -2 * ZS}, n(2 * X), n(2 * ZS), m[COBBLE]);
+    for (int side = -1; side <= 1; side += 2) {
+        const float z0 = side < 0 ? -ZW : ZS, z1 = side < 0 ? -ZS : ZW;
+        b.quad({-X, Y0 + 0.4f, z1}, {2 * X, 0, 0}, {0, 0, z0 - z1}, n(2 * X), n(ZW - ZS), m[SIDEWALK]);
+        const float zc = side < 0 ? -ZS : ZS;                               // kerb, facing the street
+        if (side < 0) b.quad({-X, Y0, zc}, {2 * X, 0, 0}, {0, 0.4f, 0}, n(2 * X), 1, m[SIDEWALK]);
+        else b.quad({X, Y0, zc}, {-2 * X, 0, 0}, {0, 0.4f, 0}, n(2 * X), 1, m[SIDEWALK]);
+    }
+    // street ends: walls closing the canyon
+    b.quad({-X, Y0, ZW}, {0, 0, -2 * ZW}, {0, 44.0f, 0}, n(2 * ZW), n(44.0f), m[BRICKM]);
+    b.quad({X, Y0, -ZW}, {0, 0, 2 * ZW}, {0, 44.0f, 0}, n(2 * ZW), n(44.0f), m[BRICKM]);
+
+    // two rows of buildings
+    for (int side = -1; side <= 1; side += 2) {
+        float x = -X;
+        int bi = 0;
+        while (x < X - 1.0f) {
+            const float wdt = std::min(14.0f + 9.0f * rnd(), X - x);
+            const float hgt = 26.0f + 22.0f * rnd();
+            const int wall = (bi % 3 == 1) ? m[BRICKM] : m[PLASTER];
+            const float zf = side * ZW;                       // facade plane; the building extends away from the street
+            const float zb = side * (ZW + 9.0f);
+            // facade (faces the street), roof, the two side walls above the neighbours
+            if (side < 0) b.quad({x, Y0, zf}, {wdt, 0, 0}, {0, hgt, 0}, n(wdt), n(hgt), wall);
+            else b.quad({x + wdt, Y0, zf}, {-wdt, 0, 0}, {0, hgt, 0}, n(wdt), n(hgt), wall);
+            if (side < 0) b.quad({x, Y0 + hgt, zf}, {wdt, 0, 0}, {0, 0, zb - zf}, n(wdt), n(9.0f), m[ROOF]);
+            else b.quad({x, Y0 + hgt, zb}, {wdt, 0, 0}, {0, 0, zf - zb}, n(wdt), n(9.0f), m[ROOF]);
+            b.quad({x, Y0, zb}, {0, 0, zf - zb}, {0, hgt, 0}, n(9.0f), n(hgt), wall);                        // -x side
+            b.quad({x + wdt, Y0, zf}, {0, 0, zb - zf}, {0, hgt, 0}, n(9.0f), n(hgt), wall);                  // +x side
+            // windows: glass pane slightly in front of the wall, wooden frame bars, shutters; balconies on some floors
+            const int floors = std::max(2, (int)(hgt / 7.5f));
+            const int bays = std::max(2, (int)(wdt / 4.5f));
+            for (int f = 0; f < floors; ++f)
+                for (int k = 0; k < bays; ++k) {
+                    const float wx = x + wdt * (k + 0.5f) / bays, wy = Y0 + 2.0f + 7.5f * f + (f == 0 ? 0.5f : 0.0f);
+                    const float ww = 2.2f, wh = f == 0 ? 4.6f : 3.6f;
+                    const float zo = zf - side * 0.12f;       // towards the street
+                    const int gseg = std::max(1, n(ww) / 2);
+                    if (side < 0) b.quad({wx - ww / 2, wy, zo}, {ww, 0, 0}, {0, wh, 0}, gseg, gseg, m[GLASS]);
+                    else b.quad({wx + ww / 2, wy, zo}, {-ww, 0, 0}, {0, wh, 0}, gseg, gseg, m[GLASS]);
+                    const float zfr = zf - side * 0.3f;
+                    const float z0 = std::min(zf, zfr), z1 = std::max(zf, zfr);
+                    b.box({wx - ww / 2 - 0.25f, wy - 0.25f, z0}, {wx + ww / 2 + 0.25f, wy, z1}, cell, m[WOOD]);          // sill
+                    b.box({wx - ww / 2 - 0.25f, wy + wh, z0}, {wx + ww / 2 + 0.25f, wy + wh + 0.25f, z1}, cell, m[WOOD]);   // head
+                    b.box({wx - ww / 2 - 0.25f, wy, z0}, {wx - ww / 2, wy + wh, z1}, cell, m[WOOD]);
+                    b.box({wx + ww / 2, wy, z0}, {wx + ww / 2 + 0.25f, wy + wh, z1}, cell, m[WOOD]);
+                    b.box({wx - 0.06f, wy, z0}, {wx + 0.06f, wy + wh, z1}, cell, m[WOOD]);                                // mullion
+                    if (f > 0 && ((k + f + bi) % 2) == 0) {                                                               // balcony
+                        const float zbal = zf - side * 1.6f;
+                        const float q0 = std::min(zf, zbal), q1 = std::max(zf, zbal);
+                        b.box({wx - 1.9f, wy - 0.6f, q0}, {wx + 1.9f, wy - 0.35f, q1}, cell, m[PLASTER]);
+                        for (int r = 0; r <= 12; ++r) {                                                                   // railing bars
+                            const float rx = wx - 1.85f + 3.7f * r / 12.0f;
+                            b.box({rx - 0.04f, wy - 0.35f, zbal - 0.04f}, {rx + 0.04f, wy + 1.0f, zbal + 0.04f}, 10.0f, m[METAL]);
+                        }
+                        b.box({wx - 1.9f, wy + 1.0f, zbal - 0.06f}, {wx + 1.9f, wy + 1.1f, zbal + 0.06f}, cell, m[METAL]);
+                        // flower box with a small bush of leaf cards
+                        b.box({wx - 1.5f, wy - 0.3f, zbal - 0.35f * 1.0f}, {wx + 1.5f, wy + 0.1f, zbal + 0.35f}, cell, m[WOOD]);
+                        const int cards = std::max(4, (int)lroundf(60 * d));
+                        for (int c = 0; c < cards; ++c) {
+                            const V3 ctr = {wx - 1.4f + 2.8f * rnd(), wy + 0.2f + 0.7f * rnd(), zbal + (rnd() - 0.5f) * 0.8f};
+                            const V3 ax = normalize({rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f});
+                            const V3 up = normalize(cross(ax, {0.3f, 1.0f, 0.2f}));
+                            const float h2 = 0.28f;
+                            const V3 p0 = ctr - ax * h2 - up * h2, du = ax * (2 * h2), dv = up * (2 * h2);
+                            const V3 nn = normalize(cross(du, dv));
+                            b.tri(p0, p0 + du, p0 + du + dv, nn, nn, nn, m[LEAF], {0, 0}, {1, 0}, {1, 1});
+                            b.tri(p0, p0 + du + dv, p0 + dv, nn, nn, nn, m[LEAF], {0, 0}, {1, 1}, {0, 1});
+                            b.tri(p0, p0 + du + dv, p0 + du, nn * -1.0f, nn * -1.0f, nn * -1.0f, m[LEAF], {0, 0}, {1, 1}, {1, 0});
+                            b.tri(p0, p0 + dv, p0 + du + dv, nn * -1.0f, nn * -1.0f, nn * -1.0f, m[LEAF], {0, 0}, {0, 1}, {1, 1});
+                        }
+                    }
+                }
+            // awning over the ground floor of every other building: a sloped striped cloth, both faces
+            if ((bi % 2) == 0) {
+                const float ay = Y0 + 7.4f, ar = 3.2f;
+                const V3 o = side < 0 ? V3{x + 1.0f, ay, zf} : V3{x + wdt - 1.0f, ay, zf};
+                const V3 du = side < 0 ? V3{wdt - 2.0f, 0, 0} : V3{-(wdt - 2.0f), 0, 0};
+                const V3 dv = {0, -1.3f, -side * ar};
+                auto sag = [](float u, float v) { return -0.12f * sinf(u * 25.0f) * v; };
+                auto sag_b = [](float u, float v) { return 0.12f * sinf((1.0f - u) * 25.0f) * v; };
+                b.patch(o, du, dv, n(wdt) * 2, n(ar) * 2, m[AWNING], sag);
+                b.patch(o + du, du * -1.0f, dv, n(wdt) * 2, n(ar) * 2, m[AWNING], sag_b);
+            }
+            x += wdt;
+            ++bi;
+        }
+    }
+
+    // bistro terraces on both sidewalks: tables with chairs
+    auto table = [&](float tx, float tz) {
+        b.cylinder({tx, Y0 + 0.4f, tz}, 0.08f, 1.45f, seg, 2, m[METAL]);
+        b.cylinder({tx, Y0 + 1.85f, tz}, 0.9f, 0.08f, seg * 2, 1, m[WOOD]);
+        b.quad({tx - 0.64f, Y0 + 1.93f, tz + 0.64f}, {1.28f, 0, 0}, {0, 0, -1.28f}, 3, 3, m[WOOD]);      // top disc stand-in
+        for (int c = 0; c < 4; ++c) {
+            const float a = 1.5708f * c + 0.4f * rnd(), cx = tx + 1.5f * cosf(a), cz = tz + 1.5f * sinf(a);
+            b.box({cx - 0.4f, Y0 + 1.2f, cz - 0.4f}, {cx + 0.4f, Y0 + 1.3f, cz + 0.4f}, 10.0f, m[WOOD]);        // seat
+            b.box({cx - 0.4f, Y0 + 1.3f, cz + 0.32f}, {cx + 0.4f, Y0 + 2.3f, cz + 0.4f}, 10.0f, m[WOOD]);       // back
+            for (int l = 0; l < 4; ++l) {
+                const float lx = cx + ((l & 1) ? 0.34f : -0.34f), lz = cz + ((l & 2) ? 0.34f : -0.34f);
+                b.box({lx - 0.04f, Y0 + 0.4f, lz - 0.04f}, {lx + 0.04f, Y0 + 1.2f, lz + 0.04f}, 10.0f, m[METAL]);
+            }
+        }
+    };
+    const int ntables = std::max(2, (int)lroundf(44 * sqrtf(d)));
+    for (int t = 0; t < ntables; ++t) {
+        const int side = (t & 1) ? 1 : -1;
+        const float tx = -60.0f + 120.0f * (t / 2 + 0.5f) / ((ntables + 1) / 2) + (rnd() - 0.5f) * 2.0f;
+        table(tx, side * (ZS + 3.3f + (rnd() - 0.5f)));
+    }
+    // street lamps, bollards, crates
+    for (int i = 0; i < 14; ++i) {
+        const int side = (i & 1) ? 1 : -1;
+        const float lx = -62.0f + 124.0f * i / 13.0f, lz = side * (ZS + 0.8f);
+        b.cylinder({lx, Y0 + 0.4f, lz}, 0.14f, 9.0f, seg, n(9.0f), m[METAL]);
+        b.box({lx - 0.08f, Y0 + 9.3f, std::min(lz, lz - side * 1.6f)}, {lx + 0.08f, Y0 + 9.45f, std::max(lz, lz - side * 1.6f)}, cell, m[METAL]);
+        b.sphere({lx, Y0 + 9.0f, lz - side * 1.6f}, 0.45f, seg * 2, seg, m[LAMP]);
+    }
+    for (int i = 0; i < 40; ++i) {
+        const int side = (i & 1) ? 1 : -1;
+        const float bx = -66.0f + 132.0f * i / 39.0f;
+        b.cylinder({bx, Y0 + 0.4f, side * (ZS + 0.35f)}, 0.16f, 1.1f, seg, 2, m[METAL]);
+    }
+    for (int i = 0; i < 30; ++i) {
+        const int side = rnd() < 0.5f ? -1 : 1;
+        const float cx = -64.0f + 128.0f * rnd(), cz = side * (ZS + 4.5f + 2.0f * rnd()), sz = 0.6f + 0.7f * rnd();
+        b.box({cx, Y0 + 0.4f, cz}, {cx + sz, Y0 + 0.4f + sz, cz + sz}, cell, m[WOOD]);
+    }
+    // strings of lights across the street
+    for (int sidx = 0; sidx < 10; ++sidx) {
+        const float sx = -58.0f + 116.0f * sidx / 9.0f;
+        const int bulbs = 14;
+        for (int k = 0; k <= bulbs; ++k) {
+            const float t = (float)k / bulbs, z = -ZW + 0.5f + (2 * ZW - 1.0f) * t;
+            const float y = Y0 + 15.0f - 2.5f * sinf(3.14159265f * t);
+            b.sphere({sx + 0.6f * sinf(7.0f * t), y, z}, 0.16f, std::max(6, seg), std::max(4, seg / 2), m[LAMP]);
+        }
+    }
+    // trees along both sidewalks: trunk, a few branches, and the foliage -- alpha-tested leaf cards (two faces each)
+    // scattered through an ellipsoidal crown with random orientations: the incoherent normals and the in-volume
+    // occupancy a foliage-heavy exterior has
+    const int ntrees = 14;
+    const int cards_per_tree = std::max(30, (int)lroundf(21000 * d * d));
+    for (int t = 0; t < ntrees; ++t) {
+        const int side = (t & 1) ? 1 : -1;
+        const float tx = -60.0f + 120.0f * t / (ntrees - 1) + (rnd() - 0.5f) * 3.0f, tz = side * (ZS + 1.8f);
+        const float th = 11.0f + 4.0f * rnd();
+        b.cylinder({tx, Y0 + 0.4f, tz}, 0.55f, th, seg * 2, n(th), m[WOOD]);
+        const V3 crown = {tx, Y0 + 0.4f + th + 3.0f, tz - side * 1.0f};
+        const float rx = 6.5f + 1.5f * rnd(), ry = 5.0f + 1.5f * rnd(), rz = 5.5f + 1.0f * rnd();
+        for (int br = 0; br < 5; ++br) {
+            const float a = 6.2831853f * rnd();
+            b.cylinder({tx + 0.8f * cosf(a), Y0 + 0.4f + th * (0.75f + 0.05f * br), tz + 0.8f * sinf(a)}, 0.16f, 4.0f, seg, 2, m[WOOD]);
+        }
+        for (int c = 0; c < cards_per_tree; ++c) {
+            // rejection-free: a point in the unit ball, biased towards the shell like a real crown
+            V3 p;
+            do { p = {2 * rnd() - 1, 2 * rnd() - 1, 2 * rnd() - 1}; } while (dot(p, p) > 1.0f);
+            const float rr = sqrtf(dot(p, p));
+            const float k = rr > 1e-3f ? powf(rr, 0.35f) / rr : 0.0f;
+            const V3 ctr = {crown.x + p.x * k * rx, crown.y + p.y * k * ry, crown.z + p.z * k * rz};
+            const V3 ax = normalize({rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f});
+            V3 up = cross(ax, {rnd() - 0.5f, rnd() + 0.2f, rnd() - 0.5f});
+            if (dot(up, up) < 1e-6f) up = cross(ax, {0, 1, 0});
+            up = normalize(up);
+            const float h2 = 0.55f + 0.25f * rnd();
+            const V3 p0 = ctr - ax * h2 - up * h2, du = ax * (2 * h2), dv = up * (2 * h2);
+            const V3 nn = normalize(cross(du, dv));
+            b.tri(p0, p0 + du, p0 + du + dv, nn, nn, nn, m[LEAF], {0, 0}, {1, 0}, {1, 1});
+            b.tri(p0, p0 + du + dv, p0 + dv, nn, nn, nn, m[LEAF], {0, 0}, {1, 1}, {0, 1});
+            b.tri(p0, p0 + du + dv, p0 + du, nn * -1.0f, nn * -1.0f, nn * -1.0f, m[LEAF], {0, 0}, {1, 1}, {1, 0});
+            b.tri(p0, p0 + dv, p0 + du + dv, nn * -1.0f, nn * -1.0f, nn * -1.0f, m[LEAF], {0, 0}, {0, 1}, {1, 1});
+        }
+    }
+    texture_bistro(s, m, seed);
+    finish(s);
+}
+
 // Image files of an MTL's map_Kd / map_Ks / map_bump (the reference decodes them with stb_image,
 // R/Model.h:141-226): binary PPM (P6, maxval 255) and uncompressed true-colour TGA (type 2, 24 / 32 bpp) --
 // formats that need no entropy decoder.  Rows are stored bottom-up (row 0 at v = 0), which is what the
@@ -457,6 +763,7 @@ vcth_scene* vcth_scene_create(int kind, float detail, uint32_t seed) {
     if (kind == 0) build_cornell(s);
     else if (kind == 1) build_atrium(s, detail, seed, false);
     else if (kind == 2) build_atrium(s, detail, seed, true);
+    else if (kind == 3) build_bistro(s, detail, seed);
     else { delete s; return nullptr; }
     return s;
 }

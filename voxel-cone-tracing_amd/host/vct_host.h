@@ -34,7 +34,11 @@ void vcth_default_camera(vcth_camera* cam);
 /* kind: 0 = Cornell box (~40 tris), 1 = atrium (Sponza-class; `detail` scales tessellation,
  * detail = 1.0 gives ~262k triangles; flat colour per material), 2 = the same atrium with procedural
  * texture maps (checker floor + red-only specular map, brick + height map, stone + noisy height map,
- * bronze specular map, cloth with alpha cut-outs).  Model-space coordinates = world / 0.05 (VCT.h:183). */
+ * bronze specular map, cloth with alpha cut-outs), 3 = Bistro-exterior-class street (BASELINE.json configs[4]; detail
+ * 1.0 gives ~2.8 M triangles: two rows of facades with windows / balconies / awnings, terraces with tables and chairs,
+ * lamps and strings of lights, 14 trees whose crowns are alpha-tested leaf cards with random orientations -- about
+ * 40 % of the triangles -- every surface textured, noisy height maps).  Model-space coordinates = world / 0.05
+ * (VCT.h:183). */
 vcth_scene* vcth_scene_create(int kind, float detail, uint32_t seed);
 /* Wavefront OBJ (+ MTL) reader -- stands where the reference's assimp import stands (R/Model.h:39-61:
  * triangulate, smooth normals, tangent space).  Reads v / vn / vt / f (polygons are fan-triangulated,

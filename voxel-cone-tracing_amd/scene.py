@@ -11,7 +11,7 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} is missing: build it with `make host`")
 _lib = C.CDLL(LIB_PATH)
 
-CORNELL, ATRIUM, ATRIUM_TEXTURED = 0, 1, 2
+CORNELL, ATRIUM, ATRIUM_TEXTURED, BISTRO = 0, 1, 2, 3
 
 
 class Camera(C.Structure):
