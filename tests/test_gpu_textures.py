@@ -201,7 +201,7 @@ def test_bistro_class_scene_every_stage_matches_the_oracle(oracle):
     assert edges > 2.0 * np.sqrt(img.sum())                  # far more boundary than a solid blob of that area has
     # bump-mapped normals leave the interpolated normal on most covered pixels (noisy height maps)
     nrm = g[3:6] / np.maximum(np.linalg.norm(g[3:6], axis=0, keepdims=True), 1e-30)
-    assert (np.abs((g[12:15] * nrm).sum(0)[covered]) < 0.9999).mean() > 0.4
+    assert (np.abs((g[12:15] * nrm).sum(0)[covered]) < 0.9999).mean() > 0.05     # (mip-mapped: minified maps are smooth)
     # the crowns put occupancy INSIDE volumes, not only on surfaces
     occ = (l0[..., 3] > 0)
     assert occ.mean() > 0.01

@@ -575,7 +575,7 @@ void build_bistro(vcth_scene* s, float detail, uint32_t seed) {
                             const V3 ctr = {wx - 1.4f + 2.8f * rnd(), wy + 0.2f + 0.7f * rnd(), zbal + (rnd() - 0.5f) * 0.8f};
                             const V3 ax = normalize({rnd() - 0.5f, rnd() - 0.5f, rnd() - 0.5f});
                             const V3 up = normalize(cross(ax, {0.3f, 1.0f, 0.2f}));
-                            const float h2 = 0.28f;
+                            const float h2 = 0.15f;
                             const V3 p0 = ctr - ax * h2 - up * h2, du = ax * (2 * h2), dv = up * (2 * h2);
                             const V3 nn = normalize(cross(du, dv));
                             b.tri(p0, p0 + du, p0 + du + dv, nn, nn, nn, m[LEAF], {0, 0}, {1, 0}, {1, 1});
@@ -677,7 +677,10 @@ void build_bistro(vcth_scene* s, float detail, uint32_t seed) {
             V3 up = cross(ax, {rnd() - 0.5f, rnd() + 0.2f, rnd() - 0.5f});
             if (dot(up, up) < 1e-6f) up = cross(ax, {0, 1, 0});
             up = normalize(up);
-            const float h2 = 0.55f + 0.25f * rnd();
+            // leaf clusters of 0.35 - 0.55 world units: ~22 cards per unit^3 of crown give an optical depth of about one
+            // per unit of path through the crown -- one sees INTO a crown, as with real foliage (cards of 1.3 units made
+            // every crown an opaque blob with a depth complexity in the thousands next to the camera)
+            const float h2 = 0.17f + 0.10f * rnd();
             const V3 p0 = ctr - ax * h2 - up * h2, du = ax * (2 * h2), dv = up * (2 * h2);
             const V3 nn = normalize(cross(du, dv));
             b.tri(p0, p0 + du, p0 + du + dv, nn, nn, nn, m[LEAF], {0, 0}, {1, 0}, {1, 1});
