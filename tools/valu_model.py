@@ -71,10 +71,14 @@ def main():
         text = open(out).read()
     m = re.search(r"^_ZN12_GLOBAL__N_118k_trace_tile_splitILb1ELb1ELb0EEEv14VctTraceParams:.*?\.end_amdhsa_kernel", text, re.S | re.M)
     body = m.group(0).split("\n")
+    # the specular march = the largest depth-1 inner loop (the diffuse march, inside the cone loop, is depth 2 and has the
+    # same body; small depth-1 loops, if any, are prologue code)
     loops = [i for i, ln in enumerate(body) if "Inner Loop Header: Depth=1" in ln]
-    start = loops[1]                                           # loops[0] is a small prologue loop; [1] = specular march
-    end = next(i for i in range(start + 1, len(body)) if re.match(r"\.LBB\d+_\d+:\s*$", body[i]))   # first label outside the loop
-    loop = body[start:end]
+
+    def loop_at(start):
+        end = next(i for i in range(start + 1, len(body)) if re.match(r"\.LBB\d+_\d+:\s*$", body[i]))   # first label outside the loop
+        return body[start:end]
+    loop = max((loop_at(i) for i in loops), key=len)
     # blocks of the loop, split at labels
     blocks, cur = [], []
     for ln in loop:

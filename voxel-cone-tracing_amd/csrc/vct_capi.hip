@@ -232,7 +232,7 @@ void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chai
     p.n_diffuse = c->n_diffuse;
     p.n_specular = c->n_specular;
     p.step_counter = c->step_counter;
-    p.wave_steps = c->wave_steps;
+    p.tile_steps = c->tile_steps;
 #if defined(VCT_STATS) && VCT_STATS
     p.stats = c->stats;
 #endif
@@ -512,9 +512,9 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     CREATE_TRY(hipMalloc(&c->step_counter, VCT_STEP_COUNTERS * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
     {
-        const size_t nw = (size_t)tiles_x(c) * tiles_y(c) * VCT_TRACE_WAVES;
-        CREATE_TRY(hipMalloc(&c->wave_steps, nw * sizeof(uint32_t)));
-        CREATE_TRY(hipMemsetAsync(c->wave_steps, 0, nw * sizeof(uint32_t), c->stream));
+        const size_t nw = (size_t)tiles_x(c) * tiles_y(c);
+        CREATE_TRY(hipMalloc(&c->tile_steps, nw * sizeof(uint32_t)));
+        CREATE_TRY(hipMemsetAsync(c->tile_steps, 0, nw * sizeof(uint32_t), c->stream));
     }
     CREATE_TRY(hipMalloc(&c->stats, 16 * sizeof(unsigned long long)));
     CREATE_TRY(hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
@@ -546,7 +546,7 @@ void vct_destroy(vct_ctx* c) {
     vct_comm_release(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
-                    c->dbg_cones, c->step_counter, c->wave_steps, c->stats, c->steps_dev, c->spread_lut, c->tri_pos,
+                    c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->steps_dev, c->spread_lut, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->big_list, c->worklist, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_lists[0], c->raster_lists[1],
@@ -1318,10 +1318,10 @@ static int row_steps(vct_ctx* c, std::vector<uint64_t>& rows) {
     rows.assign((size_t)ty, 0);
     const int r0 = c->last_row0, r1 = c->last_row1;
     if (r1 <= r0) return VCT_OK;
-    const size_t per_row = (size_t)tx * VCT_TRACE_WAVES;
+    const size_t per_row = (size_t)tx;
     std::vector<uint32_t> v(per_row * (size_t)(r1 - r0));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(v.data(), c->wave_steps + per_row * (size_t)r0, v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(v.data(), c->tile_steps + per_row * (size_t)r0, v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int r = r0; r < r1; ++r) {
         uint64_t sum = 0;
         const uint32_t* q = v.data() + per_row * (size_t)(r - r0);

@@ -37,7 +37,7 @@ struct vct_ctx {
     uint8_t* dbg_steps = nullptr;
     float* dbg_cones = nullptr;
     unsigned long long* step_counter = nullptr;   // [VCT_STEP_COUNTERS] atomic bank of the bounce kernels (memset before each bounce)
-    uint32_t* wave_steps = nullptr;               // [tiles * VCT_TRACE_WAVES] executed steps per wave of the screen trace
+    uint32_t* tile_steps = nullptr;               // [tiles] executed steps per 8x8 tile of the screen trace
     unsigned long long* stats = nullptr;      // [8] march statistics of instrumented builds (VCT_STATS)
     VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
     uint32_t* spread_lut = nullptr;   // [1024] spread3(i) << 2 (vct_trace.hip: dilated anchor coordinates by scalar load)

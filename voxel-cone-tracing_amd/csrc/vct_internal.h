@@ -142,12 +142,12 @@ __device__ __forceinline__ uint32_t vct_depth24_bits(float z) {
 #define VCT_TILE_PIX 64
 #define VCT_GB_NPLANES 23
 #define VCT_MAX_STEPS 1024
-// Executed steps.  The screen trace STORES each wave's count into its own slot, wave_steps[tile * VCT_TRACE_WAVES + wave]
-// (tile = frame-wide tile index): no atomic, nothing to zero between launches, and the host gets the total (sum over the
-// launched rows) as well as the per-tile-row cost histogram (vct_last_row_steps: load-aware slabs) from the same words.
-// (Device-scope atomicAdd into a shared bank cost 2.5 % of the trace when neighbouring tiles shared addresses.)
-// The bounce kernels, whose waves loop over many voxels, keep a small bank of atomic counters.
-#define VCT_TRACE_WAVES 8       // slots per tile (>= the waves a tile is split over, vct_trace.hip VCT_SPLIT)
+// Executed steps.  The screen trace STORES each tile's count into its own slot, tile_steps[tile] (frame-wide tile
+// index; the tile's waves add theirs in LDS and the last one to arrive stores the sum): no global atomic, nothing to
+// zero between launches, and the host gets the total (sum over the launched rows) as well as the per-tile-row cost
+// histogram (vct_last_row_steps: load-aware slabs) from the same words.  (Device-scope atomicAdd into a shared bank
+// cost 2.5 % of the trace when neighbouring tiles shared addresses.)  The bounce kernels, whose waves loop over many
+// voxels, keep a small bank of atomic counters.
 #define VCT_STEP_COUNTERS 256   // bounce kernels only (power of two)
 
 // One entry per march step of a cone aperture.  The step sequence of trace.fs:90-104 (dist,
@@ -196,7 +196,7 @@ struct VctTraceParams {
     uint8_t* dbg_steps;                 // [npix][7] or null
     float* dbg_cones;                   // [npix][7][4] or null
     unsigned long long* step_counter;   // [VCT_STEP_COUNTERS] bounce kernels: partial sums of executed steps (zero at launch)
-    uint32_t* wave_steps;               // [tiles * VCT_TRACE_WAVES] screen trace: executed steps of each wave (stored, not added)
+    uint32_t* tile_steps;               // [tiles] screen trace: executed steps of each tile (stored, not added)
     unsigned long long* stats;          // [8] wave-level march counters (builds with -DVCT_STATS=1 only)
     // second bounce (k_bounce): per-voxel attributes (pooled like the accumulators: [slot][512]), touched-brick
     // flags, output level 0

@@ -736,9 +736,9 @@ k_trace_tile(const VctTraceParams p) {
         *reinterpret_cast<uint2*>(p.out + pixel_index(fresh_lane()) * 4) = pk;
     }
 #undef VCT_GB
-    // executed-step count: wave reduction, stored into the tile's slot (wave 0 of VCT_TRACE_WAVES; the others are zero)
+    // executed-step count: wave reduction, stored into the tile's slot (a plain store: no atomic, nothing to clear)
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-    if (lane < VCT_TRACE_WAVES) p.wave_steps[(size_t)tile * VCT_TRACE_WAVES + lane] = lane == 0 ? (uint32_t)total : 0u;
+    if (lane == 0) p.tile_steps[tile] = (uint32_t)total;
     flush_stats(p, ms, lane);
 }
 
@@ -758,7 +758,6 @@ k_trace_tile(const VctTraceParams p) {
 // a shorter wave amortises that start-up stall over fewer march steps; 2 waves {0-3, 4-5 + specular} 0.639.
 #define VCT_CONES_PER_WAVE (6 / (VCT_SPLIT - 1))
 static_assert(VCT_SPLIT == 3 || VCT_SPLIT == 4 || VCT_SPLIT == 7, "VCT_SPLIT must be 3, 4 or 7");
-static_assert(VCT_SPLIT <= VCT_TRACE_WAVES, "wave_steps holds VCT_TRACE_WAVES slots per tile");
 #ifndef VCT_ANISO_MIN_WAVES
 #define VCT_ANISO_MIN_WAVES 5     // A/B (ms, 256^3 1080p): 4: 1.61, 5: 1.47, 6: 1.88 (spills), 7: 1.60
 #endif
@@ -771,10 +770,11 @@ k_trace_tile_split(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_SPLIT][ANISO ? 4 : 2][64];   // per wave: level-1 slab, level-2 slab (+ their "-axis" slabs)
     __shared__ float4 lds_cone[7][64];
     __shared__ int lds_done;
+    __shared__ int lds_steps;          // executed steps of the tile's waves, summed here; the last arriver stores the total
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float4* blk = &lds_blk[wave][0][0];
-    if (threadIdx.x == 0) lds_done = 0;
+    if (threadIdx.x == 0) { lds_done = 0; lds_steps = 0; }
     __syncthreads();
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
@@ -858,9 +858,7 @@ k_trace_tile_split(const VctTraceParams p) {
         if (p.dbg_steps && in_frame) p.dbg_steps[pixel_index(fresh_lane()) * 7 + 6] = (uint8_t)st6;
     }
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-    if (lane == 0) p.wave_steps[(size_t)tile * VCT_TRACE_WAVES + wave] = (uint32_t)total;     // a plain store: no atomic, no clear
-    if (VCT_SPLIT < VCT_TRACE_WAVES && wave == 0 && lane >= VCT_SPLIT && lane < VCT_TRACE_WAVES)
-        p.wave_steps[(size_t)tile * VCT_TRACE_WAVES + lane] = 0u;                               // slots no wave of this build owns
+    if (lane == 0) atomicAdd(&lds_steps, total);          // LDS: the last arriver below stores the tile's total
     flush_stats(p, ms, lane);
 
     // arrival: LDS operations of a wave are performed in order, so the cone values are in LDS before
@@ -871,6 +869,7 @@ k_trace_tile_split(const VctTraceParams p) {
     arrived = __builtin_amdgcn_readfirstlane(arrived);
     if (arrived != VCT_SPLIT - 1) return;
     __threadfence_block();
+    if (lane == 0) p.tile_steps[tile] = (uint32_t)lds_steps;      // one plain store per tile: no global atomic, nothing to clear
 
     // composite by the last wave                                                   trace.fs:179-227
     const float* gb3 = gbuf_ptr(fresh_lane());
