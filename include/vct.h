@@ -293,8 +293,8 @@ int vct_last_step_count(vct_ctx* ctx, uint64_t* steps);
  * blocks, [11..15] reserved. */
 int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[16]);
 /* Work-item counts behind the per-stage byte figures of bench.py (`stage_roofline`): [0] triangles uploaded,
- * [1] (triangle, candidate voxel) entries of the voxelizer's work list, [2] triangles of its workgroup-per-triangle
- * pass, [3] accumulator slots = 8^3 bricks a fragment of the mesh can land in, [4] bricks level 0 shows after the last
+ * [1] conservative fragments of the mesh at this grid size (the voxelizer's brick-sorted list), [2] reserved,
+ * [3] brick slots = 8^3 bricks a fragment of the mesh can land in, [4] bricks level 0 shows after the last
  * resolve, [5..7] reserved (0).  Synchronises the stream. */
 int vct_get_stage_counts(vct_ctx* ctx, uint64_t out[8]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */

@@ -461,7 +461,7 @@ class Context:
     def stage_counts(self):
         v = (C.c_uint64 * 8)()
         self._ck(_lib.vct_get_stage_counts(self._h, v), "vct_get_stage_counts")
-        return dict(zip(("triangles", "vox_candidates", "vox_big_triangles", "accumulator_bricks", "touched_bricks"),
+        return dict(zip(("triangles", "vox_candidates", "reserved", "accumulator_bricks", "touched_bricks"),
                         (int(x) for x in v)))
 
     def last_trace_ms(self):

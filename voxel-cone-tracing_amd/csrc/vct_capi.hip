@@ -310,12 +310,14 @@ VctVoxParams vox_params(const vct_ctx* c) {
     memcpy(p.light_vp, c->light_vp, 64);
     p.acc = c->acc;
     p.brick_slot = c->brick_slot;
-    p.worklist = c->worklist;
-    p.n_entries = c->n_entries;
-    p.big_list = c->big_list;
-    p.n_big = c->n_big;
+    p.frag_sorted = c->frag_sorted;
+    p.slot_first = c->slot_first;
+    p.slot_brick = c->slot_brick;
+    p.nslots = c->nslots;
+    p.stage = c->stage;
+    p.stage_albedo = c->stage_albedo;
+    p.stage_normal = c->stage_normal;
     p.brick_flags = c->brick_flags;
-    p.acc_attr = c->acc_attr;
     p.tex = textures_of(c);
     return p;
 }
@@ -333,28 +335,31 @@ void glm_voxel_projections(const vct_ctx* c, float proj[48]) {
     }
 }
 
-// Per-mesh accumulator pools.  The bricks a fragment of this mesh can land in depend only on geometry, V and G
-// (not on the light, the shadow map or the textures), so they are found ONCE per upload by running both
-// voxelizers in mark-only mode -- the very code that later produces the fragments -- and every marked brick
-// gets a slot of 512 accumulators (+ attribute accumulators and resolved attributes when
-// config.voxel_attributes).  Everything is allocated into locals and committed only when every allocation
-// succeeded, so a failed hipMalloc leaves the context without pools (vct_voxelize then reports it) instead
+// Per-mesh brick slots.  The bricks a fragment of this mesh can land in depend only on geometry, V and G (not on the
+// light, the shadow map or the textures), so they are found ONCE per upload -- from the conservative voxelizer's
+// fragment list `frags` and a mark-only run of the reference-mode voxelizer -- and every marked brick gets a slot; the
+// fragment list is then sorted by slot (counting sort) and the staging pool of the north-star pass is allocated (+ the
+// voxel attributes when config.voxel_attributes).  Everything is allocated into locals and committed only when every
+// allocation succeeded, so a failed hipMalloc leaves the context without a plan (vct_voxelize then reports it) instead
 // of half-initialised.
-int build_accumulator_pools(vct_ctx* c) {
+int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
     const uint32_t nbricks = (uint32_t)(nvox / 512);
-    // drop the pools of the previous mesh; level 0 / brick_prev keep describing what the chain shows
-    void** old[] = {(void**)&c->acc, (void**)&c->acc_attr, (void**)&c->attr_albedo, (void**)&c->attr_normal,
-                    (void**)&c->brick_slot};
+    // drop the plan of the previous mesh; level 0 / brick_prev keep describing what the chain shows
+    void** old[] = {(void**)&c->acc, (void**)&c->attr_albedo, (void**)&c->attr_normal, (void**)&c->brick_slot,
+                    (void**)&c->frag_sorted, (void**)&c->slot_first, (void**)&c->slot_brick, (void**)&c->stage,
+                    (void**)&c->stage_albedo, (void**)&c->stage_normal};
     for (void** q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
     c->nslots = 0;
+    c->n_frags = 0;
     c->acc_pending = false;
     c->attrs_valid = false;     // the pooled attributes are indexed by the NEW mesh's slots: nothing resolved into them yet
-    uint32_t *mark = nullptr, *slot = nullptr, *count = nullptr;
-    unsigned long long *acc = nullptr, *acc_attr = nullptr;
-    uint32_t *attr_albedo = nullptr, *attr_normal = nullptr;
+    uint32_t *mark = nullptr, *slot = nullptr, *count = nullptr, *cnt = nullptr, *cursor = nullptr;
+    uint32_t *sorted = nullptr, *first = nullptr, *slot_brick = nullptr, *stage = nullptr, *stage_albedo = nullptr,
+             *stage_normal = nullptr, *attr_albedo = nullptr, *attr_normal = nullptr;
     auto cleanup = [&]() {
-        void* tmp[] = {mark, slot, count, acc, acc_attr, attr_albedo, attr_normal};
+        void* tmp[] = {mark, slot, count, cnt, cursor, sorted, first, slot_brick, stage, stage_albedo, stage_normal,
+                       attr_albedo, attr_normal};
         for (void* q : tmp) if (q) (void)hipFree(q);
     };
 #define POOL_TRY(expr)                                                                                  \
@@ -371,26 +376,45 @@ int build_accumulator_pools(vct_ctx* c) {
     POOL_TRY(hipMalloc(&count, sizeof(uint32_t)));
     POOL_TRY(hipMemsetAsync(mark, 0, (size_t)nbricks * sizeof(uint32_t), c->stream));
     if (!c->ref_big) POOL_TRY(hipMalloc(&c->ref_big, ((size_t)c->ntri + 1) * sizeof(int32_t)));
+    POOL_TRY(vct_launch_frag_mark(frags, nfrags, mark, c->stream));                  // north-star mode's fragments
     VctVoxParams p = vox_params(c);
     p.mark_only = 1;
     p.brick_mark = mark;
     p.shadow = nullptr;
-    p.acc_attr = nullptr;
-    POOL_TRY(vct_launch_voxelize(p, c->stream));                                     // conservative mode
     glm_voxel_projections(c, p.proj);
-    POOL_TRY(vct_launch_voxelize_reference(p, c->ref_big + 1, c->ref_big, c->stream));   // reference mode
+    POOL_TRY(vct_launch_voxelize_reference(p, c->ref_big + 1, c->ref_big, c->stream));   // reference mode's (mark only)
     POOL_TRY(vct_launch_assign_slots(mark, slot, count, nbricks, c->stream));
     uint32_t nslots = 0;
     POOL_TRY(hipMemcpyAsync(&nslots, count, sizeof(nslots), hipMemcpyDeviceToHost, c->stream));
     POOL_TRY(hipStreamSynchronize(c->stream));
-    const size_t pool_vox = (size_t)(nslots ? nslots : 1u) * 512;
-    POOL_TRY(hipMalloc(&acc, pool_vox * 16));
-    POOL_TRY(hipMemsetAsync(acc, 0, pool_vox * 16, c->stream));          // zeroed once: every resolve re-zeroes what it consumed
+    // counting sort of the fragments by slot: per-slot counts -> offsets (host prefix sum: once per mesh) -> scatter
+    const size_t ns = nslots ? nslots : 1u;
+    POOL_TRY(hipMalloc(&cnt, ns * sizeof(uint32_t)));
+    POOL_TRY(hipMalloc(&cursor, ns * sizeof(uint32_t)));
+    POOL_TRY(hipMalloc(&first, (ns + 1) * sizeof(uint32_t)));
+    POOL_TRY(hipMalloc(&slot_brick, ns * sizeof(uint32_t)));
+    POOL_TRY(hipMalloc(&sorted, (size_t)(nfrags ? nfrags : 1u) * sizeof(uint32_t)));
+    POOL_TRY(hipMemsetAsync(cnt, 0, ns * sizeof(uint32_t), c->stream));
+    POOL_TRY(hipMemsetAsync(cursor, 0, ns * sizeof(uint32_t), c->stream));
+    POOL_TRY(hipMemsetAsync(slot_brick, 0, ns * sizeof(uint32_t), c->stream));
+    POOL_TRY(vct_launch_frag_count(frags, nfrags, slot, cnt, c->stream));
+    std::vector<uint32_t> hcnt(ns, 0u), hfirst(ns + 1, 0u);
+    POOL_TRY(hipMemcpyAsync(hcnt.data(), cnt, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    POOL_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < ns; ++i) hfirst[i + 1] = hfirst[i] + hcnt[i];
+    POOL_TRY(hipMemcpyAsync(first, hfirst.data(), (ns + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    POOL_TRY(vct_launch_frag_scatter(frags, nfrags, slot, first, cursor, sorted, slot_brick, c->stream));
+    // staging pool of a pass (+ attributes): written in full by every pass, never cleared
+    const size_t pool_vox = ns * 512;
+    POOL_TRY(hipMalloc(&stage, pool_vox * 4));
+    POOL_TRY(hipMemsetAsync(stage, 0, pool_vox * 4, c->stream));
     if (c->cfg.voxel_attributes) {
-        POOL_TRY(hipMalloc(&acc_attr, pool_vox * 24));
+        POOL_TRY(hipMalloc(&stage_albedo, pool_vox * 4));
+        POOL_TRY(hipMalloc(&stage_normal, pool_vox * 4));
         POOL_TRY(hipMalloc(&attr_albedo, pool_vox * 4));
         POOL_TRY(hipMalloc(&attr_normal, pool_vox * 4));
-        POOL_TRY(hipMemsetAsync(acc_attr, 0, pool_vox * 24, c->stream));
+        POOL_TRY(hipMemsetAsync(stage_albedo, 0, pool_vox * 4, c->stream));
+        POOL_TRY(hipMemsetAsync(stage_normal, 0, pool_vox * 4, c->stream));
         POOL_TRY(hipMemsetAsync(attr_albedo, 0, pool_vox * 4, c->stream));
         POOL_TRY(hipMemsetAsync(attr_normal, 0, pool_vox * 4, c->stream));
     }
@@ -404,11 +428,12 @@ int build_accumulator_pools(vct_ctx* c) {
     POOL_TRY(hipMemsetAsync(c->brick_flags, 0, flag_bytes, c->stream));
     POOL_TRY(hipStreamSynchronize(c->stream));
 #undef POOL_TRY
-    (void)hipFree(mark);
-    (void)hipFree(count);
-    c->acc = acc; c->acc_attr = acc_attr; c->attr_albedo = attr_albedo; c->attr_normal = attr_normal;
+    (void)hipFree(mark); (void)hipFree(count); (void)hipFree(cnt); (void)hipFree(cursor);
+    c->attr_albedo = attr_albedo; c->attr_normal = attr_normal;
     c->brick_slot = slot;
     c->nslots = nslots;
+    c->frag_sorted = sorted; c->n_frags = nfrags; c->slot_first = first; c->slot_brick = slot_brick;
+    c->stage = stage; c->stage_albedo = stage_albedo; c->stage_normal = stage_normal;
     return VCT_OK;
 }
 
@@ -547,8 +572,9 @@ void vct_destroy(vct_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->steps_dev, c->spread_lut, c->tri_pos,
-                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->big_list, c->worklist, c->plan,
-                    c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->acc_attr, c->attr_albedo, c->attr_normal,
+                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->stage,
+                    c->stage_albedo, c->stage_normal, c->plan,
+                    c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_lists[0], c->raster_lists[1],
                     c->raster_counts[0], c->raster_counts[1], c->raster_items[0], c->raster_items[1]};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -611,20 +637,19 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     if (c->tri_pos) { (void)hipFree(c->tri_pos); c->tri_pos = nullptr; }
     if (c->tri_mat) { (void)hipFree(c->tri_mat); c->tri_mat = nullptr; }
     if (c->mat_albedo) { (void)hipFree(c->mat_albedo); c->mat_albedo = nullptr; }
-    if (c->big_list) { (void)hipFree(c->big_list); c->big_list = nullptr; }
-    if (c->worklist) { (void)hipFree(c->worklist); c->worklist = nullptr; }
     for (int k = 0; k < 2; ++k)
         if (c->raster_lists[k]) { (void)hipFree(c->raster_lists[k]); c->raster_lists[k] = nullptr; }   // sized by ntri
     if (c->ref_big) { (void)hipFree(c->ref_big); c->ref_big = nullptr; }
     float** frames[4] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit, &c->tri_uv};       // belong to the old mesh
     for (float** f : frames) if (*f) { (void)hipFree(*f); *f = nullptr; }
     if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }           // indexed by the old materials
-    c->n_entries = 0;
-    c->n_big = 0;
+    if (ntri >= (1 << 23))
+        return fail(c, VCT_ERR_INVALID, "vct_upload_triangles: more than 2^23 - 1 triangles (the voxelizer's fragment "
+                                        "entries carry 23 bits of triangle index)");
     HIP_TRY(c, hipMalloc(&c->tri_pos, (size_t)ntri * 9 * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->tri_mat, (size_t)ntri * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc(&c->mat_albedo, (size_t)nmat * 4 * sizeof(float)));
-    if (!c->plan) HIP_TRY(c, hipMalloc(&c->plan, 2 * sizeof(uint32_t)));
+    if (!c->plan) HIP_TRY(c, hipMalloc(&c->plan, 4 * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpyAsync(c->tri_pos, pos, (size_t)ntri * 9 * sizeof(float),
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->tri_mat, material, (size_t)ntri * sizeof(int32_t),
@@ -633,21 +658,45 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
                               hipMemcpyHostToDevice, c->stream));
     c->ntri = ntri;
     c->nmat = nmat;
-    // voxelization plan: count, allocate, fill (the candidate voxels depend only on the geometry)
+    // Voxelization plan (geometry only): the exact conservative fragments of every triangle -- count, allocate, fill;
+    // triangles with a huge bounding box are enumerated by a workgroup each -- then sorted by brick (build_voxel_slots).
     VctVoxParams p = vox_params(c);
-    uint32_t counts[2] = {0, 0};
-    HIP_TRY(c, hipMemsetAsync(c->plan, 0, 2 * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, vct_launch_vox_plan(p, c->plan, nullptr, nullptr, false, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(counts, c->plan, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (counts[0]) HIP_TRY(c, hipMalloc(&c->worklist, (size_t)counts[0] * sizeof(uint2)));
-    if (counts[1]) HIP_TRY(c, hipMalloc(&c->big_list, (size_t)counts[1] * sizeof(int32_t)));
-    HIP_TRY(c, hipMemsetAsync(c->plan, 0, 2 * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, vct_launch_vox_plan(p, c->plan, c->worklist, c->big_list, true, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->n_entries = counts[0];
-    c->n_big = (int32_t)counts[1];
-    return build_accumulator_pools(c);
+    uint32_t counts[4] = {0, 0, 0, 0};
+    int32_t* big_tmp = nullptr;
+    uint2* frags = nullptr;
+    auto plan_fail = [&](hipError_t e, const char* what) {
+        if (big_tmp) (void)hipFree(big_tmp);
+        if (frags) (void)hipFree(frags);
+        return fail(c, e == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    };
+#define PLAN_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return plan_fail(e_, #expr); } while (0)
+    PLAN_TRY(hipMalloc(&big_tmp, (size_t)ntri * sizeof(int32_t)));
+    PLAN_TRY(hipMemsetAsync(c->plan, 0, 4 * sizeof(uint32_t), c->stream));
+    PLAN_TRY(vct_launch_vox_plan(p, c->plan, nullptr, big_tmp, false, c->stream));
+    PLAN_TRY(hipMemcpyAsync(counts, c->plan, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+    PLAN_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t n_small = counts[0];
+    const int n_big = (int)counts[1];
+    PLAN_TRY(vct_launch_vox_plan_big(p, big_tmp, n_big, c->plan, nullptr, false, c->stream));
+    PLAN_TRY(hipMemcpyAsync(counts, c->plan, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
+    PLAN_TRY(hipStreamSynchronize(c->stream));
+    const unsigned long long total = (unsigned long long)n_small + counts[2];
+    if (total >= (1ull << 32)) {
+        (void)hipFree(big_tmp);
+        return fail(c, VCT_ERR_INVALID, "vct_upload_triangles: the mesh has 2^32 or more conservative fragments at this grid size");
+    }
+    PLAN_TRY(hipMalloc(&frags, (size_t)(total ? total : 1ull) * sizeof(uint2)));
+    const uint32_t restart[4] = {0u, 0u, n_small, 0u};          // small triangles fill [0, n_small), the big ones behind
+    PLAN_TRY(hipMemcpyAsync(c->plan, restart, sizeof(restart), hipMemcpyHostToDevice, c->stream));
+    PLAN_TRY(vct_launch_vox_plan(p, c->plan, frags, nullptr, true, c->stream));
+    PLAN_TRY(vct_launch_vox_plan_big(p, big_tmp, n_big, c->plan, frags, true, c->stream));
+    PLAN_TRY(hipStreamSynchronize(c->stream));
+#undef PLAN_TRY
+    (void)hipFree(big_tmp);
+    big_tmp = nullptr;
+    const int rc = build_voxel_slots(c, frags, (uint32_t)total);
+    (void)hipFree(frags);
+    return rc;
 }
 
 int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const float light_vp[16]) {
@@ -922,15 +971,18 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         return fail(c, VCT_ERR_INVALID, "vct_voxelize: unknown mode");
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_voxelize: no triangles uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->acc || !c->brick_slot)
-        return fail(c, VCT_ERR_NOMEM, "vct_voxelize: the accumulator pools of this mesh could not be allocated "
+    if (!c->brick_slot || !c->stage)
+        return fail(c, VCT_ERR_NOMEM, "vct_voxelize: the voxelization plan of this mesh could not be allocated "
                                       "(vct_upload_triangles reported it)");
-    if (c->acc_pending) {   // a pass that was never resolved: discard it
-        const size_t pool_vox = (size_t)(c->nslots ? c->nslots : 1u) * 512;
-        const size_t nbricks = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512;
+    const size_t pool_vox = (size_t)(c->nslots ? c->nslots : 1u) * 512;
+    const size_t nbricks = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512;
+    if (mode == VCT_VOX_REFERENCE && !c->acc) {       // reference mode's accumulators: allocated on first use, zeroed once
+        HIP_TRY(c, hipMalloc(&c->acc, pool_vox * 16));
         HIP_TRY(c, hipMemsetAsync(c->acc, 0, pool_vox * 16, c->stream));
+    }
+    if (c->acc_pending) {   // a pass that was never resolved: discard it
+        if (c->acc_mode == VCT_VOX_REFERENCE && c->acc) HIP_TRY(c, hipMemsetAsync(c->acc, 0, pool_vox * 16, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->brick_flags, 0, nbricks * sizeof(uint32_t), c->stream));
-        if (c->acc_attr) HIP_TRY(c, hipMemsetAsync(c->acc_attr, 0, pool_vox * 24, c->stream));
     }
     VctVoxParams p = vox_params(c);
     p.mode = mode;
@@ -938,7 +990,7 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         glm_voxel_projections(c, p.proj);
         HIP_TRY(c, vct_launch_voxelize_reference(p, c->ref_big + 1, c->ref_big, c->stream));
     } else {
-        HIP_TRY(c, vct_launch_voxelize(p, c->stream));
+        HIP_TRY(c, vct_launch_voxelize(p, c->stream));      // one workgroup per brick: LDS accumulation + resolve into the staging pool
     }
     c->acc_pending = true;
     c->acc_mode = mode;
@@ -950,8 +1002,8 @@ int vct_inject_light(vct_ctx* c) {
     if (!c->acc_pending) return fail(c, VCT_ERR_INVALID, "vct_inject_light: call vct_voxelize first");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, vct_launch_resolve(c->acc, c->brick_slot, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
-                                  c->level0_dirty, c->acc_attr, c->attr_albedo, c->attr_normal,
-                                  c->acc_mode == VCT_VOX_REFERENCE, c->stream));
+                                  c->level0_dirty, nullptr, c->attr_albedo, c->attr_normal,
+                                  c->acc_mode == VCT_VOX_REFERENCE, c->stage, c->stage_albedo, c->stage_normal, c->stream));
     c->acc_pending = false;
     c->level0_dirty = false;
     c->use_chain_b = false;
@@ -1355,8 +1407,8 @@ int vct_get_stage_counts(vct_ctx* c, uint64_t out[8]) {
     if (!c || !out) return VCT_ERR_INVALID;
     memset(out, 0, 8 * sizeof(uint64_t));
     out[0] = (uint64_t)c->ntri;
-    out[1] = c->n_entries;
-    out[2] = (uint64_t)c->n_big;
+    out[1] = c->n_frags;
+    out[2] = 0;
     out[3] = c->nslots;
     if (c->brick_prev) {
         HIP_TRY(c, hipSetDevice(c->device));

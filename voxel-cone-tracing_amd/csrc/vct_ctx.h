@@ -19,7 +19,6 @@ struct vct_ctx {
     uint32_t* chain = nullptr;        // Morton chain (bounce 0: direct light)
     uint32_t* chain_b = nullptr;      // second chain (bounce 1), allocated by vct_bounce
     bool use_chain_b = false;         // the trace reads chain_b until the next vct_inject_light
-    unsigned long long* acc_attr = nullptr;   // [V^3][3] attribute accumulators (cfg.voxel_attributes)
     uint32_t* attr_albedo = nullptr;  // [V^3] resolved mean albedo, Morton order
     uint32_t* attr_normal = nullptr;  // [V^3] resolved mean normal (biased), Morton order
     bool mips_valid = true;           // levels >= 1 describe level 0 (a fresh chain is all zero)
@@ -89,15 +88,19 @@ struct vct_ctx {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_shadow = nullptr, ev_join = nullptr;
     float light_vp[16];
-    unsigned long long* acc = nullptr;         // accumulator pool [nslots][512][2] (one slot per brick the mesh can touch)
+    unsigned long long* acc = nullptr;         // reference mode only, allocated on first use: [nslots][512][2] ((triangle + 1) << 32 | rgb)
     uint32_t* brick_slot = nullptr;            // [V^3/512] brick -> slot or VCT_NO_SLOT
     uint32_t nslots = 0;
-    // voxelization plan (geometry only; built by vct_upload_triangles) and sparse-resolve state
-    uint2* worklist = nullptr;
-    uint32_t n_entries = 0;
-    int32_t* big_list = nullptr;
-    int32_t n_big = 0;
-    uint32_t* plan = nullptr;          // [2] device counters used while planning
+    // voxelization plan (geometry only; built by vct_upload_triangles): the mesh's conservative fragments sorted by
+    // brick slot, and the staging pool a pass resolves into; sparse-resolve state
+    uint32_t* frag_sorted = nullptr;   // [n_frags] triangle << 9 | voxel inside the brick
+    uint32_t n_frags = 0;
+    uint32_t* slot_first = nullptr;    // [nslots + 1]
+    uint32_t* slot_brick = nullptr;    // [nslots]
+    uint32_t* stage = nullptr;         // [nslots][512] RGBA8 of the pending north-star pass
+    uint32_t* stage_albedo = nullptr;  // [nslots][512] (cfg.voxel_attributes)
+    uint32_t* stage_normal = nullptr;
+    uint32_t* plan = nullptr;          // [4] device counters used while planning
     uint32_t* brick_flags = nullptr;   // [V^3/512] touched in the pending pass
     uint32_t* brick_prev = nullptr;    // [V^3/512] touched in the pass level 0 currently shows
     uint32_t* mip_seen = nullptr;      // [V^3/512] bricks non-empty when the chain's mips were last built

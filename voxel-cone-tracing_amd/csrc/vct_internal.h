@@ -137,6 +137,12 @@ __device__ __forceinline__ uint32_t vct_depth24_bits(float z) {
 }
 #endif
 
+// Six consecutive shadow-map words (one row of a PCF window) as ONE dwordx4 + ONE dwordx2 load: the row starts at any
+// 4-byte boundary (gfx950 under HSA runs with unaligned vector access enabled, and hipcc emits the wide loads for this
+// packed type).  The PCF gathers are bound by the number of load instructions the texture-address unit has to spread
+// over cache lines (36 dword loads per fragment: 70 of the voxelizer's 100 us at configs[1]), not by bytes.
+struct __attribute__((packed, aligned(4))) VctWords6 { uint32_t v[6]; };
+
 #define VCT_NO_SLOT 0xffffffffu
 #define VCT_TILE 8
 #define VCT_TILE_PIX 64
@@ -229,19 +235,24 @@ struct VctVoxParams {
     uint32_t shadow_ebase;     // epoch base of the pass that produced them
     int32_t shadow_size;
     float light_vp[16];
-    // Accumulators live in a POOL of 8^3-voxel slots, one slot per brick that any fragment of the uploaded mesh
-    // can touch (found once per mesh by a mark-only run of the voxelizer itself); brick_slot maps brick ->
-    // slot (VCT_NO_SLOT: no fragment ever lands there).  A 1024^3 grid costs the surface, not 16 GiB.
-    unsigned long long* acc;   // [nslots][512][2]: (sumR | sumG<<32), (sumB | count<<32), Morton order inside the brick
+    // Per brick the uploaded mesh can touch (found once per mesh) there is a SLOT: brick_slot maps brick -> slot
+    // (VCT_NO_SLOT: no fragment ever lands there).  A 1024^3 grid costs the surface, not 16 GiB.
+    // North-star mode: the fragments of the mesh sorted by slot (frag_sorted[slot_first[s] .. slot_first[s + 1]),
+    // entry = triangle << 9 | voxel inside the brick), accumulated in LDS by one workgroup per slot and resolved into
+    // stage[slot][512] (+ the voxel attributes).  Reference mode: acc[nslots][512][2] in HBM, (triangle + 1) << 32 | rgb
+    // by atomicMax.
+    unsigned long long* acc;   // [nslots][512][2] (reference mode)
     const uint32_t* brick_slot;   // [V^3 / 512]
-    uint32_t* brick_mark;      // mark_only: bricks a fragment lands in
+    uint32_t* brick_mark;      // mark_only (reference mode, at upload): bricks a fragment lands in
     int32_t mark_only;
-    const uint2* worklist;     // (triangle, candidate voxel of its bbox), built at upload (k_vox_plan)
-    uint32_t n_entries;
-    const int32_t* big_list;   // triangles with more than VCT_VOX_BIG candidates
-    int32_t n_big;
-    uint32_t* brick_flags;     // [V^3 / 512] raised by fragments, consumed by the sparse resolve
-    unsigned long long* acc_attr;   // [nslots][512][3]: (albR | albG<<32), (albB | nX<<32), (nY | nZ<<32) or null
+    const uint32_t* frag_sorted;  // [nfrag]
+    const uint32_t* slot_first;   // [nslots + 1]
+    const uint32_t* slot_brick;   // [nslots]
+    uint32_t nslots;
+    uint32_t* stage;           // [nslots][512] resolved RGBA8 of the pass (Morton order inside the brick)
+    uint32_t* stage_albedo;    // [nslots][512] or null (config.voxel_attributes)
+    uint32_t* stage_normal;
+    uint32_t* brick_flags;     // [V^3 / 512] raised for bricks written by a pass, consumed by the sparse resolve
     float proj[48];            // ProjX, ProjY, ProjZ (VCT.h:128-134), column-major; reference mode only
     int32_t mode;
     VctTextures tex;           // diffuse textures + texture coordinates (vox.fs:56); texels == null: flat colours
@@ -298,12 +309,21 @@ hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_
 hipError_t vct_launch_build_mips_aniso(const uint32_t* level0, uint32_t* aniso, int V, hipStream_t s);
 hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
                                    hipStream_t s);
-hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* worklist,
+// fragment list of the conservative voxelizer, built at upload: small triangles (+ the list of the big ones), big
+// triangles, then the counting sort by brick slot
+hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* frags,
                                int32_t* big_list, bool write, hipStream_t s);
+hipError_t vct_launch_vox_plan_big(const VctVoxParams& p, const int32_t* big_list, int n_big, uint32_t* plan, uint2* frags,
+                                   bool write, hipStream_t s);
+hipError_t vct_launch_frag_mark(const uint2* frags, uint32_t n, uint32_t* mark, hipStream_t s);
+hipError_t vct_launch_frag_count(const uint2* frags, uint32_t n, const uint32_t* brick_slot, uint32_t* count, hipStream_t s);
+hipError_t vct_launch_frag_scatter(const uint2* frags, uint32_t n, const uint32_t* brick_slot, const uint32_t* first,
+                                   uint32_t* cursor, uint32_t* sorted, uint32_t* slot_brick, hipStream_t s);
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s);
 hipError_t vct_launch_resolve(unsigned long long* acc, const uint32_t* brick_slot, uint32_t* level0, uint32_t* flags,
                               uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
-                              uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, hipStream_t s);
+                              uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, const uint32_t* stage,
+                              const uint32_t* stage_albedo, const uint32_t* stage_normal, hipStream_t s);
 // mark[b] != 0 -> slot[b] = next free slot (order irrelevant), else VCT_NO_SLOT; *count = slots handed out
 hipError_t vct_launch_assign_slots(const uint32_t* mark, uint32_t* slot, uint32_t* count, uint32_t nbricks, hipStream_t s);
 // pooled per-voxel attribute -> dense Morton volume (downloads)

@@ -532,14 +532,17 @@ __device__ __forceinline__ float shadow_fetch(const uint32_t* __restrict__ words
 
 // one thread per pixel, 64 threads = one 8x8 tile of the tiled G-buffer
 #ifndef VCT_SHADE_MIN_BLOCKS
-#define VCT_SHADE_MIN_BLOCKS 7       // waves per SIMD; with the rolling PCF window 70 VGPRs, no scratch (G-buffer pass, us: 5: 204, 7: 201, 8: 212)
+#define VCT_SHADE_MIN_BLOCKS 4       // waves per SIMD (round 2, dword PCF loads, G-buffer pass in us: 5: 204, 7: 201, 8: 212); the wide row loads of round 3 need register tuples: 7 spills
 #endif
 // TEX: the scene has material textures.  Two instantiations because the mip-mapped fetches (two levels x four texels,
 // their derivatives from two more perspective-correct interpolations) do not fit the 72-VGPR budget of 7 waves per
 // SIMD: compiled into one kernel they spilled 76 registers to scratch (560 B per lane) and the pass of the textured
 // atrium took 0.73 ms instead of 0.27.  Flat scenes keep the lean kernel; the textured one gets 96 VGPRs (5 waves).
+#ifndef VCT_SHADE_TEX_MIN_BLOCKS
+#define VCT_SHADE_TEX_MIN_BLOCKS 5
+#endif
 template <bool TEX>
-__global__ void __launch_bounds__(256, TEX ? 5 : VCT_SHADE_MIN_BLOCKS)
+__global__ void __launch_bounds__(256, TEX ? VCT_SHADE_TEX_MIN_BLOCKS : VCT_SHADE_MIN_BLOCKS)
 k_gbuffer_shade(const ShadeParams p) {
     const int W = p.r.W, H = p.r.H;
     const int tile = p.tile0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -726,12 +729,21 @@ k_gbuffer_shade(const ShadeParams p) {
                 // two window rows live at a time (12 registers instead of 36: the kernel is latency-bound and every
                 // resident wave counts); the taps are counted, so their order is free
                 float r0[6], r1[6];
+                const bool wide = col[5] - col[0] == 5;     // six consecutive texels per row: one dwordx4 + one dwordx2 (VctWords6)
+                auto load_row = [&](int rr, float out[6]) __attribute__((always_inline)) {
+                    if (wide) {
+                        const VctWords6 w = *reinterpret_cast<const VctWords6*>(p.shadow + (size_t)rr * S + col[0]);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) r0[i] = vct_shadow_depth(p.shadow[(size_t)row[0] * S + col[i]], p.shadow_ebase);
+                        for (int i = 0; i < 6; ++i) out[i] = vct_shadow_depth(w.v[i], p.shadow_ebase);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) out[i] = vct_shadow_depth(p.shadow[(size_t)rr * S + col[i]], p.shadow_ebase);
+                    }
+                };
+                load_row(row[0], r0);
 #pragma unroll
                 for (int y = 0; y < 5; ++y) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) r1[i] = vct_shadow_depth(p.shadow[(size_t)row[y + 1] * S + col[i]], p.shadow_ebase);
+                    load_row(row[y + 1], r1);
 #pragma unroll
                     for (int x = 0; x < 5; ++x) {
                         const float a = xa[x], b = yb[y];

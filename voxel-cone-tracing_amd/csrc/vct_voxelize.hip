@@ -9,17 +9,20 @@
 // turns them into the rounded mean.  fp32 operation order mirrors the scalar oracle
 // (compile with -ffp-contract=off).
 //
-// Work distribution: fragment-parallel.  The candidate voxels of a triangle (its clipped voxel
-// bounding box) depend only on the geometry, so a work list of (triangle, candidate voxel)
-// entries is built ONCE when the triangles are uploaded (k_vox_plan); every voxelize pass -- e.g.
-// after the light moved -- is then one thread per candidate voxel over that list: neighbouring
-// lanes test neighbouring voxels of the same triangle (coherent PCF taps, balanced waves, 8
-// waves/SIMD of independent fragments to hide the 25-tap shadow fetch latency).  Triangles with
-// more than VCT_VOX_BIG candidates go to a workgroup-per-triangle pass instead of flooding the list.
+// Work distribution (north-star mode): BRICK-parallel, no global atomics.  Which voxels a triangle overlaps depends
+// only on geometry, V and G, so the fragment list is built ONCE when the triangles are uploaded (k_vox_plan*: exact
+// conservative overlap, entries (triangle, Morton voxel)) and sorted by 8^3 brick (counting sort: k_frag_count /
+// k_frag_scatter).  A voxelize pass -- e.g. after the light moved -- is then one workgroup per touched brick
+// (k_voxelize_bricks): its threads evaluate the brick's fragments (PCF, albedo / texture) and add them into the brick's
+// 512 accumulators IN LDS (64-bit ds_add: the exact, order-independent "atomic RGBA average"), then the same workgroup
+// resolves the rounded means and writes the brick's 2 KiB of texels -- coalesced, once.  Rounds 1-2 accumulated with
+// two device-scope 64-bit atomics per fragment into per-brick pools in HBM and resolved in a second kernel: 0.098 +
+// 0.018 ms at configs[1], bound by the atomic unit.  All fragments of a brick lie within 8 voxels of each other, so
+// their 25-tap shadow windows overlap: coherent fetches.
 //
-// Sparse resolve: a fragment also raises its 8^3 brick's flag; k_resolve_sparse visits only bricks
-// flagged in this pass or the previous one (to clear what is no longer covered), writes the rounded
-// mean into level 0 and zeroes the accumulators it read, so they never need a memset again.
+// The texels of a pass go to a staging pool (one 2 KiB slot per brick the mesh can touch); vct_inject_light's sparse
+// resolve (k_resolve_staged) copies the slots of touched bricks into level 0 and clears bricks that are no longer
+// covered -- vct_voxelize evaluates the light, vct_inject_light makes it visible, as before.
 #include "vct_internal.h"
 
 namespace {
@@ -100,10 +103,19 @@ __device__ __forceinline__ int pcf25(const uint32_t* __restrict__ words, uint32_
         for (int k = 0; k < 5; ++k) { col[k] = X.i0[k]; row[k] = Y.i0[k]; }
         col[5] = X.i1[4]; row[5] = Y.i1[4];
         float d[6][6];
+        if (col[5] - col[0] == 5) {       // six consecutive texels per row (no clamped border): two wide loads per row
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+            for (int j = 0; j < 6; ++j) {
+                const VctWords6 w = *reinterpret_cast<const VctWords6*>(words + (size_t)row[j] * S + col[0]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) d[j][i] = vct_shadow_depth(words[(size_t)row[j] * S + col[i]], eb);
+                for (int i = 0; i < 6; ++i) d[j][i] = vct_shadow_depth(w.v[i], eb);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d[j][i] = vct_shadow_depth(words[(size_t)row[j] * S + col[i]], eb);
+        }
 #pragma unroll
         for (int x = 0; x < 5; ++x)
 #pragma unroll
@@ -235,7 +247,7 @@ __device__ __forceinline__ void setup_tri(const VctVoxParams& p, int t, TriSetup
     const float* alb = p.albedo + 4 * (size_t)p.material[t];
     r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
     load_tex_setup(p, t, r);
-    if (p.acc_attr) {
+    if (p.stage_albedo) {
         // front-face unit normal n = normalize(cross(v1-v0, v2-v0)), quantised floor(n*127+.5)+128
         const F3 fn = cross3(sub3(w[1], w[0]), sub3(w[2], w[0]));
         const float fl = __builtin_sqrtf(dot3(fn, fn));
@@ -262,11 +274,10 @@ __device__ __forceinline__ bool overlap(const TriSetup& c, int i, int j, int k) 
     return true;
 }
 
-__device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& r, int i, int j,
-                                         int k) {
-    if (!overlap(r, i, j, k)) return;
-    const uint32_t vox = vct_morton3((uint32_t)i, (uint32_t)j, (uint32_t)k);
-    if (p.mark_only) { p.brick_mark[vox >> 9] = 1u; return; }      // which bricks can this mesh touch at all
+// One conservative fragment of triangle set-up `r` at voxel (i, j, k), known to overlap: the vox.fs:88 value
+// unorm8(albedo * PCF / 25) and, for the second bounce, the fragment's albedo (unorm8) -- vox.fs:18-56.
+struct FragValue { uint32_t r, g, b, ar, ag, ab; };
+__device__ __forceinline__ FragValue frag_eval(const VctVoxParams& p, const TriSetup& r, int i, int j, int k) {
     const F3 ctr = {(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
     const float cx = comp(ctr, r.ua), cy = comp(ctr, r.ub);
     const float ax0 = comp(r.g[0], r.ua), ay0 = comp(r.g[0], r.ub);
@@ -304,21 +315,21 @@ __device__ __forceinline__ void fragment(const VctVoxParams& p, const TriSetup& 
         duv[0] = xu - mu; duv[1] = xv - mv; duv[2] = yu - mu; duv[3] = yv - mv;
     }
     frag_albedo(p, r, b0, b1, b2, duv, alb);                                         // vox.fs:56
-    const unsigned long long cr = to_unorm8(alb[0] * sh), cg = to_unorm8(alb[1] * sh),
-                             cb = to_unorm8(alb[2] * sh);                            // vox.fs:88
-    const size_t pv = (size_t)p.brick_slot[vox >> 9] * 512 + (vox & 511u);      // pooled voxel
-    unsigned long long* a = p.acc + 2 * pv;
-    atomicAdd(a, cr | (cg << 32));
-    atomicAdd(a + 1, cb | (1ull << 32));
-    p.brick_flags[vox >> 9] = 1u;      // benign race: every writer stores the same value
-    if (p.acc_attr) {
-        unsigned long long* q = p.acc_attr + 3 * pv;
-        const uint32_t a0 = r.tex >= 0 ? to_unorm8(alb[0]) : r.attr[0], a1 = r.tex >= 0 ? to_unorm8(alb[1]) : r.attr[1],
-                       a2 = r.tex >= 0 ? to_unorm8(alb[2]) : r.attr[2];              // the fragment's albedo
-        atomicAdd(q, (unsigned long long)a0 | ((unsigned long long)a1 << 32));
-        atomicAdd(q + 1, (unsigned long long)a2 | ((unsigned long long)r.attr[3] << 32));
-        atomicAdd(q + 2, (unsigned long long)r.attr[4] | ((unsigned long long)r.attr[5] << 32));
-    }
+    FragValue f;
+    f.r = to_unorm8(alb[0] * sh); f.g = to_unorm8(alb[1] * sh); f.b = to_unorm8(alb[2] * sh);   // vox.fs:88
+    f.ar = r.tex >= 0 ? to_unorm8(alb[0]) : r.attr[0];                                // the fragment's albedo
+    f.ag = r.tex >= 0 ? to_unorm8(alb[1]) : r.attr[1];
+    f.ab = r.tex >= 0 ? to_unorm8(alb[2]) : r.attr[2];
+    return f;
+}
+
+__device__ __forceinline__ uint32_t resolve_voxel(ulonglong2 a) {
+    const uint32_t c = (uint32_t)(a.y >> 32);
+    if (!c) return 0u;
+    const uint32_t h = c >> 1;
+    const uint32_t r = ((uint32_t)a.x + h) / c, g = ((uint32_t)(a.x >> 32) + h) / c,
+                   b = ((uint32_t)a.y + h) / c;
+    return r | (g << 8) | (b << 16) | 0xff000000u;      // vox.fs:88: a = 1
 }
 
 #define VCT_VOX_BIG 4096
@@ -330,17 +341,17 @@ __device__ __forceinline__ long long tri_candidates(const TriSetup& r) {
     return (long long)nx * ny * nz;
 }
 
-// Builds the work list: one entry (triangle, voxel of its bounding box) per voxel the triangle OVERLAPS.  The overlap
-// test is pure geometry (triangle, V, G), so it runs here, once per uploaded mesh, and a voxelize pass -- after every
-// light move -- spends its threads on fragments only.  (Round 2 listed every voxel of the clipped bounding box and
-// tested in the pass: fine for the wall-and-floor atrium, but an oblique triangle overlaps a thin diagonal slice of its
-// box -- the Bistro-class street's randomly oriented foliage cards at 1024^3: 753 M candidates for ~1/5 as many
-// fragments, 25.9 ms per pass.)  WRITE = false: only totals (plan[0] = list entries, plan[1] = big triangles); WRITE =
-// true: the entries and the big-triangle list.  Entry order is irrelevant (integer accumulation), so workgroups claim
-// ranges with one atomic each.
+// Builds the fragment list: one entry (triangle, Morton index of the voxel) per voxel a triangle OVERLAPS.  The overlap
+// test is pure geometry (triangle, V, G), so it runs here, once per uploaded mesh, and a voxelize pass spends its threads
+// on fragments only.  (Round 2 listed every voxel of the clipped bounding box and tested in the pass: fine for the
+// wall-and-floor atrium, but an oblique triangle overlaps a thin diagonal slice of its box -- the Bistro-class street's
+// randomly oriented foliage cards at 1024^3: 753 M candidates for ~1/5 as many fragments.)  WRITE = false: only totals
+// (plan[0] = fragments of the small triangles, plan[1] = big triangles, listed in big_list: bounding box > VCT_VOX_BIG
+// voxels, enumerated by a workgroup each, k_vox_plan_big); WRITE = true: the entries.  Entry order is
+// irrelevant (integer accumulation), so workgroups claim ranges with one atomic each.
 template <bool WRITE>
 __global__ void __launch_bounds__(256)
-k_vox_plan(const VctVoxParams p, uint32_t* plan, uint2* worklist, int32_t* big_list) {
+k_vox_plan(const VctVoxParams p, uint32_t* plan, uint2* frags, int32_t* big_list) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t block_base;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -376,52 +387,134 @@ k_vox_plan(const VctVoxParams p, uint32_t* plan, uint2* worklist, int32_t* big_l
     }
     if (threadIdx.x == 0) block_base = total ? atomicAdd(&plan[0], total) : 0u;
     __syncthreads();
-    if (big) {
-        const uint32_t slot = atomicAdd(&plan[1], 1u);
-        if (WRITE) big_list[slot] = t;
-    }
+    if (big && !WRITE) big_list[atomicAdd(&plan[1], 1u)] = t;      // (capacity ntri: the count pass lists them)
     if (WRITE && chunks) {
         uint32_t at = block_base + wave_base + incl - chunks;
         for (int k = 0; k < nz; ++k)
             for (int j = 0; j < ny; ++j)
                 for (int i = 0; i < nx; ++i)
                     if (overlap(r, r.lo[0] + i, r.lo[1] + j, r.lo[2] + k))
-                        worklist[at++] = make_uint2((uint32_t)t, (uint32_t)((k * ny + j) * nx + i));
+                        frags[at++] = make_uint2((uint32_t)t, vct_morton3((uint32_t)(r.lo[0] + i), (uint32_t)(r.lo[1] + j),
+                                                                          (uint32_t)(r.lo[2] + k)));
     }
 }
 
-// one thread per candidate voxel
+// fragments of the big triangles, one workgroup per triangle striding its bounding box.  WRITE = false: plan[2] += count;
+// WRITE = true: entries appended at plan[2] (the caller starts it behind the small triangles' entries).
+template <bool WRITE>
 __global__ void __launch_bounds__(256)
-k_voxelize_list(const VctVoxParams p) {
-    const size_t total = (size_t)p.n_entries;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < total;
-         c += (size_t)gridDim.x * blockDim.x) {
-        const uint2 e = p.worklist[c];
-        TriSetup r;
-        setup_tri(p, (int)e.x, r);
-        const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1;
-        const int v = (int)e.y;
-        const int i = r.lo[0] + v % nx;
-        const int j = r.lo[1] + (v / nx) % ny;
-        const int k = r.lo[2] + v / (nx * ny);
-        fragment(p, r, i, j, k);
-    }
-}
-
-__global__ void __launch_bounds__(256)
-k_voxelize_big(const VctVoxParams p) {
-    for (int b = blockIdx.x; b < p.n_big; b += gridDim.x) {
-        const int t = p.big_list[b];
+k_vox_plan_big(const VctVoxParams p, const int32_t* __restrict__ big_list, int n_big, uint32_t* plan, uint2* frags) {
+    const int lane = threadIdx.x & 63;
+    for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const int t = big_list[b];
         TriSetup r;
         setup_tri(p, t, r);
         const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
         const long long cnt = (long long)nx * ny * nz;
-        for (long long v = threadIdx.x; v < cnt; v += blockDim.x) {
-            const int i = r.lo[0] + (int)(v % nx);
-            const int j = r.lo[1] + (int)((v / nx) % ny);
-            const int k = r.lo[2] + (int)(v / ((long long)nx * ny));
-            fragment(p, r, i, j, k);
+        for (long long v0 = 0; v0 < cnt; v0 += blockDim.x) {         // wave-uniform trip count: ballots below
+            const long long v = v0 + threadIdx.x;
+            bool hit = false;
+            int i = 0, j = 0, k = 0;
+            if (v < cnt) {
+                i = r.lo[0] + (int)(v % nx);
+                j = r.lo[1] + (int)((v / nx) % ny);
+                k = r.lo[2] + (int)(v / ((long long)nx * ny));
+                hit = overlap(r, i, j, k);
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m == 0ull) continue;
+            uint32_t base = 0u;
+            const int leader = (int)__ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(&plan[2], (uint32_t)__popcll(m));      // one atomic per wave
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (WRITE && hit)
+                frags[base + __popcll(m & ((1ull << lane) - 1ull))] =
+                    make_uint2((uint32_t)t, vct_morton3((uint32_t)i, (uint32_t)j, (uint32_t)k));
         }
+    }
+}
+
+// counting sort of the fragment list by brick: marks, per-slot counts, scatter
+__global__ void __launch_bounds__(256)
+k_frag_mark(const uint2* __restrict__ frags, uint32_t n, uint32_t* __restrict__ mark) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) mark[frags[i].y >> 9] = 1u;
+}
+__global__ void __launch_bounds__(256)
+k_frag_count(const uint2* __restrict__ frags, uint32_t n, const uint32_t* __restrict__ brick_slot, uint32_t* __restrict__ count) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        atomicAdd(&count[brick_slot[frags[i].y >> 9]], 1u);
+}
+__global__ void __launch_bounds__(256)
+k_frag_scatter(const uint2* __restrict__ frags, uint32_t n, const uint32_t* __restrict__ brick_slot,
+               const uint32_t* __restrict__ first, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted,
+               uint32_t* __restrict__ slot_brick) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 e = frags[i];
+        const uint32_t brick = e.y >> 9, slot = brick_slot[brick];
+        const uint32_t at = first[slot] + atomicAdd(&cursor[slot], 1u);
+        sorted[at] = (e.x << 9) | (e.y & 511u);          // (triangle, voxel inside the brick): 23 + 9 bits
+        slot_brick[slot] = brick;                          // benign race: every writer stores the same value
+    }
+}
+
+// ---- the voxelize pass: one workgroup per brick slot -------------------------------------------------------------
+// acc in LDS: [512][2] u64 (sumR | sumG << 32, sumB | count << 32), + [512][3] for the voxel attributes.
+template <bool ATTR>
+__global__ void __launch_bounds__(256)
+k_voxelize_bricks(const VctVoxParams p) {
+    __shared__ unsigned long long acc[512 * 2];
+    __shared__ unsigned long long acc_attr[ATTR ? 512 * 3 : 1];
+    for (uint32_t slot = blockIdx.x; slot < p.nslots; slot += gridDim.x) {
+        const uint32_t first = p.slot_first[slot], n = p.slot_first[slot + 1] - first;
+        uint32_t* __restrict__ out = p.stage + (size_t)slot * 512;
+        if (n == 0u) {                    // a brick only the reference-mode voxelizer can touch: nothing of this mode
+            for (uint32_t v = threadIdx.x; v < 512u; v += blockDim.x) {
+                out[v] = 0u;
+                if (ATTR) { p.stage_albedo[(size_t)slot * 512 + v] = 0u; p.stage_normal[(size_t)slot * 512 + v] = 0u; }
+            }
+            continue;
+        }
+        for (uint32_t v = threadIdx.x; v < 512u * 2u; v += blockDim.x) acc[v] = 0ull;
+        if (ATTR) for (uint32_t v = threadIdx.x; v < 512u * 3u; v += blockDim.x) acc_attr[v] = 0ull;
+        __syncthreads();
+        const uint32_t brick = p.slot_brick[slot];
+        const uint32_t bm = brick << 9;
+        for (uint32_t f = threadIdx.x; f < n; f += blockDim.x) {
+            const uint32_t e = p.frag_sorted[first + f];
+            const uint32_t local = e & 511u, vox = bm | local;
+            TriSetup r;
+            setup_tri(p, (int)(e >> 9), r);
+            const int i = (int)vct_compact3(vox), j = (int)vct_compact3(vox >> 1), k = (int)vct_compact3(vox >> 2);
+            const FragValue fv = frag_eval(p, r, i, j, k);
+            atomicAdd(&acc[2 * local], (unsigned long long)fv.r | ((unsigned long long)fv.g << 32));       // ds_add_u64
+            atomicAdd(&acc[2 * local + 1], (unsigned long long)fv.b | (1ull << 32));
+            if (ATTR) {
+                atomicAdd(&acc_attr[3 * local], (unsigned long long)fv.ar | ((unsigned long long)fv.ag << 32));
+                atomicAdd(&acc_attr[3 * local + 1], (unsigned long long)fv.ab | ((unsigned long long)r.attr[3] << 32));
+                atomicAdd(&acc_attr[3 * local + 2], (unsigned long long)r.attr[4] | ((unsigned long long)r.attr[5] << 32));
+            }
+        }
+        __syncthreads();
+        for (uint32_t v = threadIdx.x; v < 512u; v += blockDim.x) {
+            const ulonglong2 a = make_ulonglong2(acc[2 * v], acc[2 * v + 1]);
+            out[v] = resolve_voxel(a);
+            if (ATTR) {
+                const uint32_t c = (uint32_t)(a.y >> 32);
+                uint32_t alb = 0u, nrm = 0u;
+                if (c) {
+                    const unsigned long long q0 = acc_attr[3 * v], q1 = acc_attr[3 * v + 1], q2 = acc_attr[3 * v + 2];
+                    const uint32_t h = c >> 1;
+                    alb = (((uint32_t)q0 + h) / c) | ((((uint32_t)(q0 >> 32) + h) / c) << 8) |
+                          ((((uint32_t)q1 + h) / c) << 16) | 0xff000000u;
+                    nrm = (((uint32_t)(q1 >> 32) + h) / c) | ((((uint32_t)q2 + h) / c) << 8) |
+                          ((((uint32_t)(q2 >> 32) + h) / c) << 16) | 0xff000000u;
+                }
+                p.stage_albedo[(size_t)slot * 512 + v] = alb;
+                p.stage_normal[(size_t)slot * 512 + v] = nrm;
+            }
+        }
+        if (threadIdx.x == 0) p.brick_flags[brick] = 1u;
+        __syncthreads();           // the accumulators are re-zeroed for the next slot of this workgroup
     }
 }
 
@@ -569,15 +662,6 @@ k_voxelize_reference_big(const VctVoxParams p, const int32_t* big_list, const in
     }
 }
 
-__device__ __forceinline__ uint32_t resolve_voxel(ulonglong2 a) {
-    const uint32_t c = (uint32_t)(a.y >> 32);
-    if (!c) return 0u;
-    const uint32_t h = c >> 1;
-    const uint32_t r = ((uint32_t)a.x + h) / c, g = ((uint32_t)(a.x >> 32) + h) / c,
-                   b = ((uint32_t)a.y + h) / c;
-    return r | (g << 8) | (b << 16) | 0xff000000u;      // vox.fs:88: a = 1
-}
-
 // accumulators -> RGBA8 level 0 (Morton), rounded mean, a = 255 where any fragment landed.
 // One wave per 8^3 brick (512 voxels, one contiguous 8 KiB run of accumulators); bricks that were
 // touched neither in this pass nor in the previous one are skipped unless `dense`.
@@ -586,7 +670,9 @@ k_resolve_sparse(unsigned long long* __restrict__ acc, const uint32_t* __restric
                  uint32_t* __restrict__ level0,
                  uint32_t* __restrict__ flags, uint32_t* __restrict__ prev, uint32_t nbricks,
                  uint32_t brick_voxels, int dense, unsigned long long* __restrict__ acc_attr,
-                 uint32_t* __restrict__ attr_albedo, uint32_t* __restrict__ attr_normal, int reference) {
+                 uint32_t* __restrict__ attr_albedo, uint32_t* __restrict__ attr_normal, int reference,
+                 const uint32_t* __restrict__ stage, const uint32_t* __restrict__ stage_albedo,
+                 const uint32_t* __restrict__ stage_normal) {
     const int lane = threadIdx.x & 63;
     const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nbricks; b += waves) {
@@ -597,6 +683,15 @@ k_resolve_sparse(unsigned long long* __restrict__ acc, const uint32_t* __restric
         if (slot == VCT_NO_SLOT) {        // no fragment of this mesh can land here: level 0 is empty
             for (uint32_t v = lane; v < brick_voxels; v += 64) l0[v] = 0u;
             if (lane == 0) { prev[b] = 0u; flags[b] = 0u; }
+            continue;
+        }
+        if (stage) {        // north-star mode: k_voxelize_bricks already resolved the brick into its staging slot
+            for (uint32_t v = lane; v < brick_voxels; v += 64) {
+                const size_t vox = (size_t)slot * brick_voxels + v;
+                l0[v] = stage[vox];
+                if (stage_albedo) { attr_albedo[vox] = stage_albedo[vox]; attr_normal[vox] = stage_normal[vox]; }
+            }
+            if (lane == 0) { prev[b] = now; flags[b] = 0u; }
             continue;
         }
         ulonglong2* a2 = reinterpret_cast<ulonglong2*>(acc) + (size_t)slot * brick_voxels;
@@ -667,12 +762,43 @@ hipError_t vct_launch_unpool(const uint32_t* pooled, const uint32_t* brick_slot,
     return hipGetLastError();
 }
 
-hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* worklist,
+hipError_t vct_launch_vox_plan(const VctVoxParams& p, uint32_t* plan, uint2* frags,
                                int32_t* big_list, bool write, hipStream_t s) {
     if (p.ntri <= 0) return hipSuccess;
     const dim3 grid((p.ntri + 255) / 256), block(256);
-    if (write) hipLaunchKernelGGL(k_vox_plan<true>, grid, block, 0, s, p, plan, worklist, big_list);
-    else hipLaunchKernelGGL(k_vox_plan<false>, grid, block, 0, s, p, plan, worklist, big_list);
+    if (write) hipLaunchKernelGGL(k_vox_plan<true>, grid, block, 0, s, p, plan, frags, big_list);
+    else hipLaunchKernelGGL(k_vox_plan<false>, grid, block, 0, s, p, plan, frags, big_list);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_vox_plan_big(const VctVoxParams& p, const int32_t* big_list, int n_big, uint32_t* plan, uint2* frags,
+                                   bool write, hipStream_t s) {
+    if (n_big <= 0) return hipSuccess;
+    const dim3 grid(n_big < 256 * 8 ? n_big : 256 * 8), block(256);
+    if (write) hipLaunchKernelGGL(k_vox_plan_big<true>, grid, block, 0, s, p, big_list, n_big, plan, frags);
+    else hipLaunchKernelGGL(k_vox_plan_big<false>, grid, block, 0, s, p, big_list, n_big, plan, frags);
+    return hipGetLastError();
+}
+
+static unsigned frag_blocks(uint32_t n) {
+    const size_t b = ((size_t)n + 255) / 256;
+    return (unsigned)(b < 256 * 32 ? (b ? b : 1) : 256 * 32);
+}
+hipError_t vct_launch_frag_mark(const uint2* frags, uint32_t n, uint32_t* mark, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_frag_mark, dim3(frag_blocks(n)), dim3(256), 0, s, frags, n, mark);
+    return hipGetLastError();
+}
+hipError_t vct_launch_frag_count(const uint2* frags, uint32_t n, const uint32_t* brick_slot, uint32_t* count, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_frag_count, dim3(frag_blocks(n)), dim3(256), 0, s, frags, n, brick_slot, count);
+    return hipGetLastError();
+}
+hipError_t vct_launch_frag_scatter(const uint2* frags, uint32_t n, const uint32_t* brick_slot, const uint32_t* first,
+                                   uint32_t* cursor, uint32_t* sorted, uint32_t* slot_brick, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_frag_scatter, dim3(frag_blocks(n)), dim3(256), 0, s, frags, n, brick_slot, first, cursor, sorted,
+                       slot_brick);
     return hipGetLastError();
 }
 
@@ -689,31 +815,24 @@ hipError_t vct_launch_voxelize_reference(const VctVoxParams& p, int32_t* big_lis
 }
 
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
-    if (p.n_entries > 0) {
-        const size_t threads = (size_t)p.n_entries;
-        size_t blocks = (threads + 255) / 256;
-        if (blocks > 256 * 32) blocks = 256 * 32;
-        hipLaunchKernelGGL(k_voxelize_list, dim3((unsigned)blocks), dim3(256), 0, s, p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    if (p.n_big > 0) {
-        const int blocks = p.n_big < 256 * 8 ? p.n_big : 256 * 8;
-        hipLaunchKernelGGL(k_voxelize_big, dim3(blocks), dim3(256), 0, s, p);
-        return hipGetLastError();
-    }
-    return hipSuccess;
+    if (p.nslots == 0u) return hipSuccess;
+    const unsigned blocks = p.nslots < 256u * 64u ? p.nslots : 256u * 64u;
+    if (p.stage_albedo) hipLaunchKernelGGL(k_voxelize_bricks<true>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_voxelize_bricks<false>, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 hipError_t vct_launch_resolve(unsigned long long* acc, const uint32_t* brick_slot, uint32_t* level0, uint32_t* flags,
                               uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
-                              uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, hipStream_t s) {
+                              uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, const uint32_t* stage,
+                              const uint32_t* stage_albedo, const uint32_t* stage_normal, hipStream_t s) {
     const uint32_t brick_voxels = V >= 8 ? 512u : (uint32_t)(V * V * V);
     const uint32_t nbricks = (uint32_t)(((size_t)V * V * V) / brick_voxels);
     size_t blocks = ((size_t)nbricks + 3) / 4;      // 4 waves per workgroup, one brick per wave
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_resolve_sparse, dim3((unsigned)blocks), dim3(256), 0, s, acc, brick_slot, level0, flags,
                        prev, nbricks, brick_voxels, dense ? 1 : 0, reference ? nullptr : acc_attr, attr_albedo,
-                       attr_normal, reference ? 1 : 0);
+                       attr_normal, reference ? 1 : 0, reference ? nullptr : stage, reference ? nullptr : stage_albedo,
+                       reference ? nullptr : stage_normal);
     return hipGetLastError();
 }
