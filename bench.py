@@ -341,26 +341,47 @@ def main():
         ctx.trace_gbuffer_rows(r0, r1)
     steps_slab = ctx.last_step_count()
     slab_rows = [vct.slab_partition(h, world, r)[:2] for r in range(world)]
-    if native and world > 1 and args.slabs == "balanced":
+    if native and args.slabs == "balanced":          # (also with the forced 1-rank group: the tests walk this code on one GPU)
         # load-aware slabs: equal rows are not equal work.  The trace counted its executed steps per
         # tile row; the ranks' histograms are summed over the control plane, every rank cuts the same boundaries of
         # equal step cost from them and installs them on its communicator (uneven slabs travel as one fused
         # ncclSend / ncclRecv group, each straight to its rows of the root's frame).  Untimed set-up, like the
         # first frame it is derived from; the gathered frame is checked against the single-GPU frame below.
-        hist = torch.from_numpy(ctx.last_row_steps().astype(np.int64))
+        def install(cost_rows):
+            """Every rank cuts the same boundaries from the same all-reduced per-row cost and re-rasterises its slab."""
+            starts = vct.slab_partition_weighted(np.maximum(cost_rows, 1.0).astype(np.uint64), world)
+            ctx.comm_set_slab_rows(starts)
+            rows = [(int(starts[r]), int(starts[r + 1])) for r in range(world)]
+            a, b = rows[rank]
+            assert ctx.comm_slab() == (a, b)
+            if inp["scene"] is not None:
+                ctx.render_gbuffer_rows(inp["view_proj"], a, b)
+                ctx.trace_gbuffer_rows(a, b)
+            else:
+                ctx.trace(inp["planes"], rows=(a, b))
+            return rows
+
+        hist = torch.from_numpy(ctx.last_row_steps().astype(np.float64))
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
-        starts = vct.slab_partition_weighted(hist.numpy().astype(np.uint64), world)
-        ctx.comm_set_slab_rows(starts)
-        slab_rows = [(int(starts[r]), int(starts[r + 1])) for r in range(world)]
+        slab_rows = install(hist.numpy())
+        # two rounds of feedback: equal steps are not quite equal time (the cost of a step varies with the coherence
+        # of the cones), so each rank prices its rows by the kernel time per executed step it measures on its own slab
+        # (tools/slab_probe.py: slowest 8-way slab 0.1135 -> 0.107 ms on one GPU)
+        for _ in range(2):
+            r0, r1 = slab_rows[rank]
+            for _ in range(8):
+                ctx.trace_gbuffer_rows(r0, r1)
+            ms = []
+            for _ in range(5):
+                ctx.trace_gbuffer_rows(r0, r1)
+                ms.append(ctx.last_trace_ms())
+            mine = ctx.last_row_steps().astype(np.float64)
+            cost = torch.from_numpy(mine * (float(np.median(ms)) * 1e6 / max(float(mine.sum()), 1.0)))
+            dist.all_reduce(cost, op=dist.ReduceOp.SUM)
+            slab_rows = install(cost.numpy())
         r0, r1 = slab_rows[rank]
-        assert ctx.comm_slab() == (r0, r1)
         y0, y1 = r0 * 8, min(r1 * 8, h)
         slab_px = max(0, y1 - y0) * w
-        if inp["scene"] is not None:
-            ctx.render_gbuffer_rows(inp["view_proj"], r0, r1)
-            ctx.trace_gbuffer_rows(r0, r1)
-        else:
-            ctx.trace(inp["planes"], rows=(r0, r1))
         steps_slab = ctx.last_step_count()
 
     comm_stream = torch.cuda.Stream(device=local_rank) if (use_dist and not native) else None

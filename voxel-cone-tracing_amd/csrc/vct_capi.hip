@@ -576,7 +576,8 @@ void vct_destroy(vct_ctx* c) {
                     c->stage_albedo, c->stage_normal, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_lists[0], c->raster_lists[1],
-                    c->raster_counts[0], c->raster_counts[1], c->raster_items[0], c->raster_items[1]};
+                    c->raster_counts[0], c->raster_counts[1], c->raster_items[0], c->raster_items[1], c->raster_recs[0],
+                    c->raster_recs[1]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -637,8 +638,10 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     if (c->tri_pos) { (void)hipFree(c->tri_pos); c->tri_pos = nullptr; }
     if (c->tri_mat) { (void)hipFree(c->tri_mat); c->tri_mat = nullptr; }
     if (c->mat_albedo) { (void)hipFree(c->mat_albedo); c->mat_albedo = nullptr; }
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 2; ++k) {
         if (c->raster_lists[k]) { (void)hipFree(c->raster_lists[k]); c->raster_lists[k] = nullptr; }   // sized by ntri
+        if (c->raster_recs[k]) { (void)hipFree(c->raster_recs[k]); c->raster_recs[k] = nullptr; }
+    }
     if (c->ref_big) { (void)hipFree(c->ref_big); c->ref_big = nullptr; }
     float** frames[4] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit, &c->tri_uv};       // belong to the old mesh
     for (float** f : frames) if (*f) { (void)hipFree(*f); *f = nullptr; }
@@ -736,6 +739,7 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
         c->raster_dirty[k] = true;
     }
     if (!c->raster_lists[k]) HIP_TRY(c, hipMalloc(&c->raster_lists[k], (size_t)c->ntri * 4 * sizeof(int32_t)));
+    if (!c->raster_recs[k]) HIP_TRY(c, hipMalloc(&c->raster_recs[k], (size_t)c->ntri * 2 * 96));
     if (!c->raster_counts[k]) { HIP_TRY(c, hipMalloc(&c->raster_counts[k], 8 * sizeof(uint32_t))); c->raster_dirty[k] = true; }
     // tile work items: 16x16-pixel pieces of large triangles; pixels/16 entries is ~16x the typical
     // demand (sum of visible bounding boxes ~ a few frames' worth of pixels); overflow is handled
@@ -770,6 +774,7 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
     a.group_list = c->raster_lists[k] + (size_t)c->ntri * 2;
     a.group_count = cur + 2;
     a.next_counts = c->raster_counts[k] + 4 * (c->raster_set[k] ^ 1);
+    a.recs = c->raster_recs[k];
     c->raster_set[k] ^= 1;
     a.item_capacity = c->raster_item_capacity[k];
     a.tex = textures_of(c);

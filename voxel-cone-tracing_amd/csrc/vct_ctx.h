@@ -79,6 +79,7 @@ struct vct_ctx {
     // lists / counters / tile items exist twice, [0] for the shadow pass and [1] for the main draw, so that the main
     // draw's visibility raster can run on the second stream WHILE the shadow map is rasterised (vct_gi_pass)
     int32_t* raster_lists[2] = {nullptr, nullptr};     // [2*ntri] wave list, [2*ntri] group list
+    void* raster_recs[2] = {nullptr, nullptr};         // [2*ntri] 96-byte set-up records handed from k_raster_vis to k_raster_mid
     uint32_t* raster_counts[2] = {nullptr, nullptr};   // two sets of [tile work items, wave list, group list, pad]
     int raster_set[2] = {0, 0};                        // the counter set the next pass of that kind uses
     bool raster_dirty[2] = {true, true};

@@ -142,6 +142,9 @@ __device__ __forceinline__ uint32_t vct_depth24_bits(float z) {
 // packed type).  The PCF gathers are bound by the number of load instructions the texture-address unit has to spread
 // over cache lines (36 dword loads per fragment: 70 of the voxelizer's 100 us at configs[1]), not by bytes.
 struct __attribute__((packed, aligned(4))) VctWords6 { uint32_t v[6]; };
+// The nine floats of one triangle in a per-vertex attribute array ([ntri][3][3]: 36 B records at 4-byte alignment) as
+// dwordx4 + dwordx4 + dword instead of nine dword loads -- same reason.
+struct __attribute__((packed, aligned(4))) VctTri9 { float v[9]; };
 
 #define VCT_NO_SLOT 0xffffffffu
 #define VCT_TILE 8
@@ -282,6 +285,7 @@ struct VctRasterArgs {
     uint32_t* item_count;
     uint32_t item_capacity;
     uint32_t* next_counts;       // [3] the other counter set (item, wave, group): zeroed by this pass for the next
+    void* recs;                  // [2 * ntri] 96-byte set-up records of the listed sub-triangles (vct_raster.hip SubTriRec)
     VctTextures tex;             // material textures + texture coordinates (G-buffer pass)
 };
 

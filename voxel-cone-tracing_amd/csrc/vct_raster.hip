@@ -143,6 +143,58 @@ __device__ __forceinline__ void setup_subtri(const RVert* v0, const RVert* v1, c
     s.tex = -1;
 }
 
+// What k_raster_vis hands to k_raster_mid for every sub-triangle it lists: the finished set-up, so that the list consumers
+// do not clip, project and snap the triangle again (that re-derivation -- ~600 instructions, a third of them fp64 -- was
+// more than half of what a 16-lane group spent on a typical 64-pixel triangle).  Window coordinates travel as integers
+// (x 256: they are snapped to 1/256 pixel, so this is exact); the area is recomputed from them by the same expression.
+// A record whose coordinates do not fit (a near-clipped triangle projected far outside the frame) is marked invalid and
+// the consumer falls back to rebuild_subtri.  96 bytes; group entries fill the array from the front, wave entries from
+// the back (a sub-triangle is in at most one list, and there are at most 2 per triangle).
+struct SubTriRec {
+    int32_t fx[3], fy[3];
+    float sz[3], iw[3];
+    int16_t x0, x1, y0, y1;
+    int32_t alpha_tex;          // alpha_mode | (tex + 1) << 2 | valid << 31
+    float tu[3], tv[3];
+    int32_t pad[3];
+};
+static_assert(sizeof(SubTriRec) == 96, "SubTriRec is written and read as six 16-byte words");
+
+__device__ __forceinline__ void pack_subtri(const SubTri& s, SubTriRec& r) {
+    bool fits = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        fits = fits && fabs(s.sx[k]) < 8388607.0 && fabs(s.sy[k]) < 8388607.0;
+        r.fx[k] = (int32_t)(s.sx[k] * 256.0);
+        r.fy[k] = (int32_t)(s.sy[k] * 256.0);
+        r.sz[k] = s.sz[k]; r.iw[k] = s.iw[k];
+        r.tu[k] = s.tu[k]; r.tv[k] = s.tv[k];
+    }
+    fits = fits && s.x1 < 32768 && s.y1 < 32768;
+    r.x0 = (int16_t)s.x0; r.x1 = (int16_t)s.x1; r.y0 = (int16_t)s.y0; r.y1 = (int16_t)s.y1;
+    r.alpha_tex = s.alpha_mode | ((s.tex + 1) << 2) | (fits ? (int32_t)0x80000000 : 0);
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+}
+
+// false: the record is marked invalid (rebuild the set-up from the mesh)
+__device__ __forceinline__ bool unpack_subtri(const SubTriRec& r, SubTri& s) {
+    if (r.alpha_tex >= 0) return false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s.sx[k] = (double)r.fx[k] / 256.0;
+        s.sy[k] = (double)r.fy[k] / 256.0;
+        s.sz[k] = r.sz[k]; s.iw[k] = r.iw[k];
+        s.tu[k] = r.tu[k]; s.tv[k] = r.tv[k];
+    }
+    s.area = (s.sx[1] - s.sx[0]) * (s.sy[2] - s.sy[0]) - (s.sx[2] - s.sx[0]) * (s.sy[1] - s.sy[0]);
+    s.sgn = 1.0;
+    s.x0 = r.x0; s.x1 = r.x1; s.y0 = r.y0; s.y1 = r.y1;
+    s.alpha_mode = r.alpha_tex & 3;
+    s.tex = ((r.alpha_tex & 0x7fffffff) >> 2) - 1;
+    s.ok = true;
+    return true;
+}
+
 // pixel-centre coverage + barycentrics; returns false when the pixel is not covered
 __device__ __forceinline__ bool cover(const SubTri& s, int px, int py, float& b0, float& b1, float& b2,
                                       float& z) {
@@ -203,6 +255,7 @@ struct RasterParams {
     uint32_t* item_count;
     uint32_t item_capacity;
     uint32_t* next_counts;       // [3] the counters the NEXT pass will use: zeroed by this pass (no memset launch)
+    SubTriRec* recs;             // [2 * ntri] set-up records of the listed sub-triangles: group entries from the front, wave entries from the back
     // alpha test of the main draw (null material: depth-only pass, S/Shadow.fs has no alpha test)
     const int32_t* material;
     const float* albedo;
@@ -210,11 +263,10 @@ struct RasterParams {
 };
 
 __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVert in[3]) {
+    const VctTri9 q = *reinterpret_cast<const VctTri9*>(p.pos + (size_t)t * 9);       // three wide loads, not nine
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float* q = p.pos + (size_t)t * 9 + 3 * k;
-        xform4(p.vp, q[0] * p.model_scale, q[1] * p.model_scale, q[2] * p.model_scale, in[k].c);
-    }
+    for (int k = 0; k < 3; ++k)
+        xform4(p.vp, q.v[3 * k] * p.model_scale, q.v[3 * k + 1] * p.model_scale, q.v[3 * k + 2] * p.model_scale, in[k].c);
 }
 
 // Work granularity by bounding-box size (the bench scene: half of the visible triangles cover <= 64
@@ -366,6 +418,8 @@ k_raster_vis(const RasterParams p) {
     for (int f = 1; f <= 2; ++f) {          // a near-clipped triangle is at most a quad: two sub-triangles
         bool big = false, to_group = false, to_wave = false;
         const int id = t * 2 + (f - 1);
+        SubTriRec rec;
+        rec.alpha_tex = 0;
         if (valid && f + 1 < poly.n) {
             SubTri s;
             const FanTri fan = fan_tri(poly, f);
@@ -379,8 +433,10 @@ k_raster_vis(const RasterParams p) {
                         for (int px = s.x0; px <= s.x1; ++px) plot(p, s, px, py, (unsigned long long)(uint32_t)id);
                 } else if (box <= VCT_RASTER_GROUP) {
                     to_group = true;
+                    pack_subtri(s, rec);
                 } else if (box <= VCT_RASTER_WAVE) {
                     to_wave = true;
+                    pack_subtri(s, rec);
                 } else {
                     big = true;
                 }
@@ -389,9 +445,9 @@ k_raster_vis(const RasterParams p) {
         // list appends: ONE atomic per wave and list (a per-lane atomicAdd on the two counters serialises ~10^5
         // same-address atomics in L2: 1.2 ms per pass, measured)
         const uint32_t gslot = wave_append(p.group_count, to_group, lane);
-        if (to_group) p.group_list[gslot] = (int32_t)id;
+        if (to_group) { p.group_list[gslot] = (int32_t)id; p.recs[gslot] = rec; }
         const uint32_t wslot = wave_append(p.wave_count, to_wave, lane);
-        if (to_wave) p.wave_list[wslot] = (int32_t)id;
+        if (to_wave) { p.wave_list[wslot] = (int32_t)id; p.recs[(size_t)2 * p.ntri - 1 - wslot] = rec; }
         if (f == 1) big1 = __builtin_amdgcn_ballot_w64(big); else big2 = __builtin_amdgcn_ballot_w64(big);
     }
     // huge sub-triangles of this wave's 64 triangles, one after the other, all lanes helping (outside the loop
@@ -447,7 +503,7 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
         for (uint32_t g = ((uint32_t)b * blockDim.x + threadIdx.x) >> 4; g < n; g += ngroups) {
             const int id = p.group_list[g];
             SubTri s;
-            if (!rebuild_subtri(p, id, s)) continue;
+            if (!unpack_subtri(p.recs[g], s) && !rebuild_subtri(p, id, s)) continue;
             const int bw = s.x1 - s.x0 + 1;
             const int box = bw * (s.y1 - s.y0 + 1);
             for (int i = l16; i < box; i += 16)
@@ -463,7 +519,7 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
         for (uint32_t w = ((uint32_t)b * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
             const int id = p.wave_list[w];
             SubTri s;
-            if (!rebuild_subtri(p, id, s)) continue;
+            if (!unpack_subtri(p.recs[(size_t)2 * p.ntri - 1 - w], s) && !rebuild_subtri(p, id, s)) continue;
             const int bw = s.x1 - s.x0 + 1;
             const int box = bw * (s.y1 - s.y0 + 1);
             for (int i = lane; i < box; i += 64)
@@ -539,7 +595,7 @@ __device__ __forceinline__ float shadow_fetch(const uint32_t* __restrict__ words
 // SIMD: compiled into one kernel they spilled 76 registers to scratch (560 B per lane) and the pass of the textured
 // atrium took 0.73 ms instead of 0.27.  Flat scenes keep the lean kernel; the textured one gets 96 VGPRs (5 waves).
 #ifndef VCT_SHADE_TEX_MIN_BLOCKS
-#define VCT_SHADE_TEX_MIN_BLOCKS 5
+#define VCT_SHADE_TEX_MIN_BLOCKS 4
 #endif
 template <bool TEX>
 __global__ void __launch_bounds__(256, TEX ? VCT_SHADE_TEX_MIN_BLOCKS : VCT_SHADE_MIN_BLOCKS)
@@ -582,24 +638,30 @@ k_gbuffer_shade(const ShadeParams p) {
         // perspective-correct interpolation of the 12 varyings (trace.vs:27,31-33)
         const float q0 = b0 * s.iw[0], q1 = b1 * s.iw[1], q2 = b2 * s.iw[2];
         const float qs = __fdiv_rn(1.0f, q0 + q1 + q2);
+        // the four per-vertex arrays one after the other, each as one 36-byte record (three wide loads): nine values
+        // live at a time.  A vertex of a near-clipped polygon is picked by selects (a run-time register index would
+        // put the record into scratch).
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            float var[3];
-            auto attr = [&](int vert) -> float {
-                const size_t o = (size_t)t * 9 + 3 * vert + (i % 3);
-                const float* src = i < 3 ? p.r.pos : (i < 6 ? p.nrm : (i < 9 ? p.tan : p.bit));
-                return src[o] * p.r.model_scale;
-            };
-            if (whole) {
-                var[0] = attr(0); var[1] = attr(1); var[2] = attr(2);
-            } else {
+        for (int arr = 0; arr < 4; ++arr) {
+            const float* src = arr == 0 ? p.r.pos : (arr == 1 ? p.nrm : (arr == 2 ? p.tan : p.bit));
+            const VctTri9 rec = *reinterpret_cast<const VctTri9*>(src + (size_t)t * 9);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float va = attr(fan.v[k].a);
-                    var[k] = fan.v[k].b < 0 ? va : va + (attr(fan.v[k].b) - va) * fan.v[k].t;
+            for (int comp = 0; comp < 3; ++comp) {
+                const float a0 = rec.v[comp] * p.r.model_scale, a1 = rec.v[3 + comp] * p.r.model_scale,
+                            a2 = rec.v[6 + comp] * p.r.model_scale;
+                float var[3];
+                if (whole) {
+                    var[0] = a0; var[1] = a1; var[2] = a2;
+                } else {
+                    auto pick = [&](int vert) -> float { return vert == 0 ? a0 : (vert == 1 ? a1 : a2); };
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float va = pick(fan.v[k].a);
+                        var[k] = fan.v[k].b < 0 ? va : va + (pick(fan.v[k].b) - va) * fan.v[k].t;
+                    }
                 }
+                g[3 * arr + comp] = (q0 * var[0] + q1 * var[1] + q2 * var[2]) * qs;
             }
-            g[i] = (q0 * var[0] + q1 * var[1] + q2 * var[2]) * qs;
         }
         const int m = p.material[t];
         const int td = TEX ? vct_tex_of(p.r.tex, m, 0) : -1, tsp = TEX ? vct_tex_of(p.r.tex, m, 1) : -1,
@@ -823,6 +885,7 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
     r.item_count = a.item_count;
     r.item_capacity = a.item_capacity;
     r.next_counts = a.next_counts;
+    r.recs = (SubTriRec*)a.recs;
     r.material = nullptr;
     r.albedo = nullptr;
     memset(&r.tex, 0, sizeof(r.tex));

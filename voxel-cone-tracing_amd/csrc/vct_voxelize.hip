@@ -190,8 +190,10 @@ __device__ __forceinline__ void load_tex_setup(const VctVoxParams& p, int t, Set
 __device__ __forceinline__ void setup_tri(const VctVoxParams& p, int t, TriSetup& r) {
     F3 w[3];
     const float fV = (float)p.V;
+    const VctTri9 rec = *reinterpret_cast<const VctTri9*>(p.pos + (size_t)t * 9);     // three wide loads, not nine
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float* q = p.pos + (size_t)t * 9 + 3 * k;
+        const float* q = rec.v + 3 * k;
         w[k] = {q[0] * p.model_scale, q[1] * p.model_scale, q[2] * p.model_scale};   // vox.vs:21
         const F3 d = xform_point(p.light_vp, w[k]);                                  // vox.vs:18
         r.dc[k] = {d.x * 0.5f + 0.5f, d.y * 0.5f + 0.5f, d.z * 0.5f + 0.5f};          // vox.vs:19
