@@ -1,6 +1,6 @@
 #!/bin/bash
 # ON THE GPU BOX: kernel-trace/stats (+ HBM byte counters) of the non-default BASELINE configurations.
-# Usage: tools/profile_configs.sh <tag>   -> gpurun_out/prof_<tag>_{c3,c5,noise,tex}/
+# Usage: tools/profile_configs.sh <tag>   -> gpurun_out/prof_<tag>_{c3,c5,bistro1080,noise,tex}/   (c5 = the Bistro-class street, BASELINE configs[4])
 set -u
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -22,6 +22,7 @@ run() {   # name, pmc-passes ("yes"/"no"), bench args...
   grep "^{" "$OUT/trace.log" | tail -1 > "$OUT/bench.json"
 }
 run c3 no --voxel-dim 512 --width 3840 --height 2160 --bounces 2
-run c5 yes --voxel-dim 1024 --width 3840 --height 2160 --scene-detail 3.5
+run c5 yes --scene bistro --voxel-dim 1024 --width 3840 --height 2160
+run bistro1080 no --scene bistro
 run tex no --scene atrium-textured
 run noise yes --scene noise --noise-dense --gbuffer random --voxel-dim 1024
