@@ -133,6 +133,10 @@ struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
 #ifndef VCT_UNROLL2
 #define VCT_UNROLL2 1     // A/B: 0.6281 -> 0.6216 ms at 256^3, 2.659 -> 2.623 ms at 512^3 / 4K
 #endif
+#ifndef VCT_FRACT
+#define VCT_FRACT 0       // A/B (round 3, vector pipes binding): 0.6184 / 0.6210 ms without, 0.6194 / 0.6178 ms with: no gain (v_fract and
+                          // v_cvt_flr are 4-cycle operations: 8 cycles per axis against 4 + 2 + 4)
+#endif
 #ifndef VCT_HALF_GATHER
 #define VCT_HALF_GATHER 1     // gather + interpolate the lower z plane, then the upper one (half the texel registers live)
 #endif
@@ -160,9 +164,28 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
     const float fN = lv.fN;
     // ux * fN is exact (power of two), so the fused form is the oracle's (ux*fN) - 0.5f bit for bit
     const float u = fmaf(ux, fN, -0.5f), v = fmaf(uy, fN, -0.5f), w = fmaf(uz, fN, -0.5f);
-    const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
-    const float a = u - fu, b = v - fv, c = w - fw;
-    const int i0 = (int)fu, j0 = (int)fv, k0 = (int)fw;
+    float a, b, c;
+    int i0, j0, k0;
+#if VCT_FRACT
+    if (m != 0) {
+        // Footprint in two instructions per axis instead of three (v_floor + v_sub + v_cvt): v_fract_f32 and
+        // v_cvt_flr_i32_f32.  v_fract returns u - floor(u) except that it never returns 1.0 (it clamps to 1 - 2^-24),
+        // while the subtraction rounds up to 1.0 for u in [-2^-25, 0).  For N >= 2 such a u cannot occur here: u < 0
+        // means ux < 0.5 / N <= 0.25, and ux = fma(q, 0.5, 0.5) with |q| >= 0.5 there, so ux is a multiple of 2^-25
+        // (q's ulp is >= 2^-24 and the sum is exact), u = ux * N - 0.5 is a multiple of 2^-24, and 1 - |u| is
+        // representable: the subtraction is exact and equals v_fract.  The one-texel level (N = 1) keeps the
+        // subtraction.  Bit-exact in every parity test -- and no faster, twice (round 2, round 3): off by default.
+        a = __builtin_amdgcn_fractf(u); b = __builtin_amdgcn_fractf(v); c = __builtin_amdgcn_fractf(w);
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i0) : "v"(u));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(j0) : "v"(v));
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k0) : "v"(w));
+    } else
+#endif
+    {
+        const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+        a = u - fu; b = v - fv; c = w - fw;
+        i0 = (int)fu; j0 = (int)fv; k0 = (int)fw;
+    }
     // Texels are addressed by 32-bit BYTE offsets from the level's first texel (4 * Morton index <= 2^32 - 4 at
     // 1024^3): the dilated-integer arithmetic runs on pre-shifted masks, so no shift and no 64-bit address add
     // is left per load (global_load_dword v, voffset, s[base]).
@@ -534,6 +557,47 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
     return {cr, cg, cb, occ};
 }
 
+// EXPERIMENT (-DVCT_LOCKSTEP=1; round 3): the three diffuse cones of a wave marched in lockstep -- one
+// table entry, one set of level constants per step for all three, three independent dependency chains.  Same bits.
+// Result on MI355X: see profiles/experiments/README.md (the per-step work that is shared is scalar -- the table load
+// and ~8 SALU of loop control -- while every vector instruction of a step depends on the cone's own position; the
+// carried state triples: three accumulator sets + three directions).
+#ifndef VCT_LOCKSTEP
+#define VCT_LOCKSTEP 0
+#endif
+struct ConeAcc { float cr, cg, cb, alpha, occ; int steps; };
+template <bool WRAP, bool FASTDIV, bool COOP>
+__device__ __forceinline__ void cone_march3(const VctTraceParams& p, bool alive, F3 start, const F3 dirs[3],
+                                            const VctStep* tab_global, int n, float4* __restrict__ blk,
+                                            const LaneBlock& lb, ConeAcc out[3], MarchStats& ms) {
+    constexpr bool ANISO = false;
+    const StepTable tab = (StepTable)tab_global;
+    AnisoCone ac = {0.0f, 0.0f, 0.0f, false, false, false};
+    ConeAcc c0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0}, c1 = c0, c2 = c0;
+    const unsigned long long alive_mask = ballot64(alive);
+    auto one = [&](const VctStep& st, const F3 dir, ConeAcc& c) -> bool {
+        float cr = c.cr, cg = c.cg, cb = c.cb, alpha = c.alpha, occ = c.occ;
+        int steps = c.steps;
+        const bool act = alive && (alpha < p.max_alpha);
+        const unsigned long long live = ballot64(alpha < p.max_alpha) & alive_mask;
+        if (live == 0ull) return false;
+        if (VCT_STATS) { ++ms.wave_steps; ms.lane_steps += (uint32_t)__popcll(live); }
+        VCT_MARCH_STEP(st, act, live)
+        c.cr = cr; c.cg = cg; c.cb = cb; c.alpha = alpha; c.occ = occ; c.steps = steps;
+        return true;
+    };
+    VctStep nxt = load_step(tab, 0);
+    for (int k = 0; k < n; ++k) {
+        const VctStep st = nxt;
+        nxt = load_step(tab, k + 1 < n ? k + 1 : k);
+        const bool a = one(st, dirs[0], c0);
+        const bool b = one(st, dirs[1], c1);
+        const bool c = one(st, dirs[2], c2);
+        if (!(a || b || c)) break;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2;
+}
+
 __device__ __forceinline__ uint32_t pack_half2(float a, float b) {
     const __half ha = __float2half_rn(a), hb = __float2half_rn(b);
     return (uint32_t)__half_as_ushort(ha) | ((uint32_t)__half_as_ushort(hb) << 16);
@@ -817,6 +881,31 @@ k_trace_tile_split(const VctTraceParams p) {
             k2 = f3(c2.x * inv_det, c2.y * inv_det, c2.z * inv_det);
             start = f3(P.x + Nw.x * p.vs, P.y + Nw.y * p.vs, P.z + Nw.z * p.vs);       // :92
         }
+#if VCT_LOCKSTEP && VCT_SPLIT == 3
+        if (!ANISO) {
+            F3 dirs[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int i = wave * 3 + j;
+                const float ddx = kConeDirs[3 * i], ddy = kConeDirs[3 * i + 1], ddz = kConeDirs[3 * i + 2];
+                dirs[j] = normalize3(f3(k0.x * ddx + k1.x * ddy + k2.x * ddz, k0.y * ddx + k1.y * ddy + k2.y * ddz,
+                                        k0.z * ddx + k1.z * ddy + k2.z * ddz));
+            }
+            ConeAcc acc3[3];
+            cone_march3<WRAP, FASTDIV, true>(p, alive, start, dirs, p.steps_diffuse, p.n_diffuse, blk, lb, acc3, ms);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int i = wave * 3 + j;
+                total += acc3[j].steps;
+                lds_cone[i][lane] = make_float4(acc3[j].cr, acc3[j].cg, acc3[j].cb, acc3[j].occ);
+                if (p.dbg_cones && alive) {
+                    float* d = p.dbg_cones + pixel_index(fresh_lane()) * 28 + 4 * i;
+                    d[0] = acc3[j].cr; d[1] = acc3[j].cg; d[2] = acc3[j].cb; d[3] = acc3[j].occ;
+                }
+                if (p.dbg_steps && in_frame) p.dbg_steps[pixel_index(fresh_lane()) * 7 + i] = (uint8_t)acc3[j].steps;
+            }
+        } else
+#endif
 #pragma unroll 1
         for (int i = wave * VCT_CONES_PER_WAVE; i < wave * VCT_CONES_PER_WAVE + VCT_CONES_PER_WAVE; ++i) {      // :196-199
             const float ddx = kConeDirs[3 * i], ddy = kConeDirs[3 * i + 1], ddz = kConeDirs[3 * i + 2];
