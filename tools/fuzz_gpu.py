@@ -96,7 +96,7 @@ while time.time() < t_end:
                 fail("bounce", seed)
             counts["bounce"] += 1
     # ---- raster stages ----
-    kind = int(r.integers(0, 3)); w = int(r.integers(8, 640 if BIG else 200)); h = int(r.integers(8, 360 if BIG else 120))
+    kind = int(r.integers(0, 4)); w = int(r.integers(8, 640 if BIG else 200)); h = int(r.integers(8, 360 if BIG else 120))
     S = int(r.choice([256, 1024] if BIG else [64, 256]))
     scene = sc.Scene(kind, 0.3 if BIG else 0.1, seed)
     lightd = tuple(np.abs(r.normal(size=3)) + 0.1)
