@@ -20,7 +20,7 @@
 //   * `VoxelDimensions` / `VoxelGridWorldSize` are plain members (the reference declares them const,
 //     which pins it to 128^3): set them before init_voxel_cone_tracing().
 //   * `model_path` replaces the reference's hard-coded absolute Windows path (VCT.h:77; the reference
-//     ships no assets): "procedural:atrium", "procedural:atrium-textured", "procedural:cornell", or the path of
+//     ships no assets): "procedural:atrium", "procedural:atrium-textured", "procedural:bistro", "procedural:cornell", or the path of
 //     a Wavefront .obj (+ .mtl with map_Kd / map_Ks / map_bump as PPM or TGA).
 //   * Errors keep the reference's print-and-continue behaviour (VCT.h:101-105) and are also
 //     readable through `last_status` / vct_last_error(ctx).
@@ -154,6 +154,7 @@ struct Model {
         if (p == "procedural:cornell") scene = vcth_scene_create(0, 1.0f, 1234u);
         else if (p == "procedural:atrium") scene = vcth_scene_create(1, 1.0f, 1234u);
         else if (p == "procedural:atrium-textured") scene = vcth_scene_create(2, 1.0f, 1234u);
+        else if (p == "procedural:bistro") scene = vcth_scene_create(3, 1.0f, 1234u);        // Bistro-exterior-class street, 2.8 M triangles
         else if (p.size() > 9 && p.compare(p.size() - 9, 9, ".vctscene") == 0) scene = vcth_scene_load_cache(p.c_str(), err);
         else scene = vcth_scene_load_obj(p.c_str(), err);             // R/Model.h:39-61
         if (!scene) printf("ERROR::MODEL: cannot load '%s' (%s; or use procedural:atrium | procedural:cornell)\n",

@@ -4,7 +4,7 @@
 // window and swap-buffers it renders N frames, prints a checksum of the last RGBA16F frame and
 // optionally writes it as a tonemapped PPM.
 //
-//   vct_demo [--scene procedural:atrium|procedural:cornell] [--voxels 128] [--size 1280x720]
+//   vct_demo [--scene procedural:atrium|procedural:atrium-textured|procedural:bistro|procedural:cornell] [--voxels 128] [--size 1280x720]
 //            [--shadow 4096] [--frames 3] [--bounces 1|2] [--ppm out.ppm] [--gpus N] [--dynamic-light]
 //
 // --dynamic-light: every Render() re-runs the whole GI pass (shadow map, voxelize, inject, mips, G-buffer, trace)
