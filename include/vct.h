@@ -307,6 +307,11 @@ int vct_last_trace_ms(vct_ctx* ctx, float* ms);
  * trace kernel relies on (vct_trace.hip shows why the march never leaves that domain in a way that
  * could change a result). */
 int vct_selftest_const_divide(vct_ctx* ctx, float d, uint64_t* mismatches);
+/* Self-test of the rasteriser's shared-reciprocal division (csrc/vct_raster.hip div_area: the barycentrics' x / area
+ * as two FMA corrections of x * RN(1/area), correctly rounded by Markstein's theorem): `count` pseudo-random pairs of
+ * the operands' form (integers of 1..53 bits scaled by 2^-16) next to the IEEE division; returns the number of pairs
+ * whose quotients differ in any bit (0 expected; the raster stages' equality with the oracle rests on it). */
+int vct_selftest_area_divide(vct_ctx* ctx, uint64_t seed, uint64_t count, uint64_t* mismatches);
 int vct_get_stream(vct_ctx* ctx, void** hip_stream);
 int vct_get_frame_device(vct_ctx* ctx, void** rgba16f_dev, size_t* bytes);
 

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "vct_download_chain_rgba8", "vct_chain_texels", "vct_trace", "vct_trace_slab",
     "vct_trace_resident", "vct_synchronize", "vct_download_steps", "vct_download_cones",
     "vct_last_step_count", "vct_last_trace_ms", "vct_get_stream", "vct_get_frame_device",
-    "vct_selftest_const_divide", "vct_set_frame_target", "vct_bounce",
+    "vct_selftest_const_divide", "vct_selftest_area_divide", "vct_set_frame_target", "vct_bounce",
     "vct_download_voxel_attributes", "vct_download_aniso_rgba8", "vct_upload_mesh_attributes", "vct_render_shadow_map",
     "vct_download_shadow_map", "vct_render_gbuffer", "vct_download_gbuffer", "vct_trace_current", "vct_trace_resident_rows",
     "vct_last_trace_stats", "vct_download_frame", "vct_render_gbuffer_rows",
@@ -109,6 +109,7 @@ _lib.vct_trace_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.
 _lib.vct_get_frame_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.vct_set_frame_target.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_selftest_const_divide.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+_lib.vct_selftest_area_divide.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
 _lib.vct_render_gbuffer_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
 _lib.vct_slab_partition.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.vct_comm_get_unique_id.argtypes = [C.c_void_p]
@@ -472,6 +473,11 @@ class Context:
     def selftest_const_divide(self, d):
         v = C.c_uint64()
         self._ck(_lib.vct_selftest_const_divide(self._h, float(d), C.byref(v)), "vct_selftest_const_divide")
+        return v.value
+
+    def selftest_area_divide(self, seed, count):
+        v = C.c_uint64()
+        self._ck(_lib.vct_selftest_area_divide(self._h, int(seed), int(count), C.byref(v)), "vct_selftest_area_divide")
         return v.value
 
     def stream(self):

@@ -1481,6 +1481,24 @@ int vct_selftest_const_divide(vct_ctx* c, float d, uint64_t* mismatches) {
     return VCT_OK;
 }
 
+int vct_selftest_area_divide(vct_ctx* c, uint64_t seed, uint64_t count, uint64_t* mismatches) {
+    if (!c || !mismatches) return VCT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, vct_launch_area_divide_selftest(seed, count, c->stats, c->stream));
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(v, c->stats, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *mismatches = v[0];
+    if (v[0]) {
+        char msg[96];
+        snprintf(msg, sizeof(msg), "area divide: %llu mismatches, e.g. sample %llu of seed %llu", v[0], v[1],
+                 (unsigned long long)seed);
+        c->err = msg;
+    }
+    return VCT_OK;
+}
+
 int vct_get_stream(vct_ctx* c, void** s) {
     if (!c || !s) return VCT_ERR_INVALID;
     *s = (void*)c->stream;

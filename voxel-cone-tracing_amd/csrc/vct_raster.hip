@@ -196,20 +196,90 @@ __device__ __forceinline__ bool unpack_subtri(const SubTriRec& r, SubTri& s) {
 }
 
 // pixel-centre coverage + barycentrics; returns false when the pixel is not covered
-__device__ __forceinline__ bool cover(const SubTri& s, int px, int py, float& b0, float& b1, float& b2,
-                                      float& z) {
-    const double cx = (double)px + 0.5, cy = (double)py + 0.5;
-    double e[3];
+// The three edge functions as plane equations, for the list consumers' inner loops: e_k(cx, cy) = a_k*cx + b_k*cy + c_k
+// with the top-left rule folded into c_k (an edge that does not own its boundary gets c_k - 2^-16, so that "inside" is
+// e'_k >= 0 for every edge; bias_k restores e_k for the barycentrics).  EXACT -- the same real numbers as the
+// difference-of-products form of cover(), which the oracle states -- as long as every window coordinate is below
+// 2^16 in magnitude: coordinates are multiples of 2^-8, pixel centres of 2^-1, so every product and partial sum is a
+// multiple of 2^-16 below 2^37 and fits a double's 53 bits.  Sub-triangles that reach further (near-clipped ones
+// projected far outside the frame) keep the general form, whose roundings the fast form could not reproduce.
+#ifndef VCT_FAST_COVER
+#define VCT_FAST_COVER 1      // 0: every sub-triangle takes the general form (A/B measurements)
+#endif
+struct FastEdges {
+    double a[3], b[3], c[3], bias[3];
+    double rcp;              // RN(1 / area)
+    bool ok;
+};
+// x / area, correctly rounded, from the sub-triangle's correctly rounded reciprocal y = RN(1 / area): two
+// Newton-Raphson corrections of q = x * y, each with the exact remainder of an FMA.  The first leaves q within one ulp of
+// the quotient (|x*y - x/area| <= |x/area| * 2^-53 before the product's own rounding); Markstein's theorem (IBM J. Res.
+// Dev. 34(1), 1990; restated in Muller et al., Handbook of Floating-Point Arithmetic, ch. "Division") then makes
+// RN(q + r * y), r = x - area * q, THE correctly rounded quotient -- the value the `/` of the general form and of the
+// oracle returns -- for every x, with no case distinction (no overflow or underflow can occur: |x|, area are
+// multiples of 2^-16 below 2^37).  Five FMA-rate operations instead of the ~11 (one of them a quarter-rate
+// v_rcp_f64) of an IEEE division; the six divisions of an alpha-tested fragment share the reciprocal.
+__device__ __forceinline__ double div_area(double x, double area, double y) {
+    double q = x * y;
+    q = fma(fma(-area, q, x), y, q);
+    q = fma(fma(-area, q, x), y, q);
+    // x = -0: the corrections turn the quotient into +0 (-0 + +0), the division keeps -0 -- and the sign of a zero
+    // barycentric does reach the G-buffer (a sum of zero products keeps it).  area > 0, so the quotient's sign is x's.
+    return copysign(q, x);
+}
+// the general form's companion: only the reciprocal
+__device__ __forceinline__ FastEdges slow_edges(const SubTri& s) {
+    FastEdges f;
+    f.ok = false;
+    f.rcp = 1.0 / s.area;
+    return f;
+}
+__device__ __forceinline__ void make_fast(const SubTri& s, FastEdges& f) {
+    f.ok = VCT_FAST_COVER != 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f.ok = f.ok && fabs(s.sx[k]) < 65536.0 && fabs(s.sy[k]) < 65536.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int a = (k + 1) % 3, b = (k + 2) % 3;
-        const double dx = (s.sx[b] - s.sx[a]) * s.sgn, dy = (s.sy[b] - s.sy[a]) * s.sgn;
-        e[k] = dx * (cy - s.sy[a]) - dy * (cx - s.sx[a]);
+        const int i = (k + 1) % 3, j = (k + 2) % 3;
+        const double dx = (s.sx[j] - s.sx[i]) * s.sgn, dy = (s.sy[j] - s.sy[i]) * s.sgn;
         const bool top_left = (dy > 0.0) || (dy == 0.0 && dx < 0.0);
-        if (e[k] < 0.0 || (e[k] == 0.0 && !top_left)) return false;
+        f.bias[k] = top_left ? 0.0 : 0x1p-16;
+        f.a[k] = -dy;
+        f.b[k] = dx;
+        f.c[k] = (dy * s.sx[i] - dx * s.sy[i]) - f.bias[k];
     }
-    b0 = (float)(e[0] / s.area);
-    b1 = (float)(e[1] / s.area);
+    f.rcp = 1.0 / s.area;
+}
+
+// pixel-centre coverage + barycentrics; returns false when the pixel is not covered
+template <bool FAST>
+__device__ __forceinline__ bool cover(const SubTri& s, const FastEdges& f, int px, int py, float& b0, float& b1,
+                                      float& b2, float& z, double& e0, double& e1) {
+    const double cx = (double)px + 0.5, cy = (double)py + 0.5;
+    double e[3];
+    if (FAST) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) e[k] = fma(f.a[k], cx, fma(f.b[k], cy, f.c[k]));
+        if (e[0] < 0.0 || e[1] < 0.0 || e[2] < 0.0) return false;
+        // (an edge function that is exactly zero may come out as +0 here and as -0 in the general form, or the other
+        // way round.  The plane-equation form is only used by plot(), whose results are the depth -- normalised below,
+        // and a zero product never changes a non-zero sum -- and the alpha test, which a zero's sign cannot change
+        // either; k_gbuffer_shade, whose interpolated attributes DO keep the sign of a zero, uses the general form.)
+        e[0] += f.bias[0];
+        e[1] += f.bias[1];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int a = (k + 1) % 3, b = (k + 2) % 3;
+            const double dx = (s.sx[b] - s.sx[a]) * s.sgn, dy = (s.sy[b] - s.sy[a]) * s.sgn;
+            e[k] = dx * (cy - s.sy[a]) - dy * (cx - s.sx[a]);
+            const bool top_left = (dy > 0.0) || (dy == 0.0 && dx < 0.0);
+            if (e[k] < 0.0 || (e[k] == 0.0 && !top_left)) return false;
+        }
+    }
+    b0 = (float)div_area(e[0], s.area, f.rcp);
+    b1 = (float)div_area(e[1], s.area, f.rcp);
+    e0 = e[0]; e1 = e[1];
     b2 = 1.0f - b0 - b1;
     z = b0 * s.sz[0] + b1 * s.sz[1] + b2 * s.sz[2];
     z = z + 0.0f;      // -0 -> +0: depth is ordered through its bit pattern below
@@ -217,11 +287,47 @@ __device__ __forceinline__ bool cover(const SubTri& s, int px, int py, float& b0
     return z >= 0.0f && z < 1.0f;
 }
 
+// vct_selftest_area_divide: div_area next to the IEEE division on `count` pseudo-random (x, area) pairs -- integers of
+// 1..53 bits (every width equally often, so small and large operands and all alignments of the quotient's rounding
+// bit occur) scaled by 2^-16, x of either sign, area > 0.  A superset of what the raster feeds it.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256)
+k_area_divide_selftest(uint64_t seed, uint64_t count, unsigned long long* out) {
+    unsigned long long bad = 0ull, example = 0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t h0 = mix64(seed + 3ull * i), h1 = mix64(seed + 3ull * i + 1ull), h2 = mix64(seed + 3ull * i + 2ull);
+        const int bx = 1 + (int)(h2 % 53ull), ba = 1 + (int)((h2 >> 8) % 53ull);
+        const uint64_t xi = h0 & ((1ull << bx) - 1ull);
+        const uint64_t ai = (h1 & ((1ull << ba) - 1ull)) | (1ull << (ba - 1));
+        const double x = ((h2 >> 16) & 1ull) ? -(double)xi * 0x1p-16 : (double)xi * 0x1p-16;       // -0 included
+        const double area = (double)ai * 0x1p-16;
+        const double want = x / area, got = div_area(x, area, 1.0 / area);
+        if (__double_as_longlong(want) != __double_as_longlong(got)) { ++bad; example = i; }
+    }
+    if (bad) { atomicAdd(out, bad); out[1] = example; }
+}
+
+// perspective-correct interpolation of two per-vertex values from the first two barycentrics (as doubles, before their
+// conversion to float)
+__device__ __forceinline__ void interp2_from(const SubTri& s, double q0, double q1, const float a[3], const float b[3],
+                                             float& oa, float& ob) {
+    const float c0 = (float)q0, c1 = (float)q1, c2 = 1.0f - c0 - c1;
+    const float r0 = c0 * s.iw[0], r1 = c1 * s.iw[1], r2 = c2 * s.iw[2];
+    const float rs = __fdiv_rn(1.0f, r0 + r1 + r2);
+    oa = (r0 * a[0] + r1 * a[1] + r2 * a[2]) * rs;
+    ob = (r0 * b[0] + r1 * b[1] + r2 * b[2]) * rs;
+}
+
 // The sub-triangle's perspective-correct interpolation of two per-vertex values at the centre of pixel (qx, qy), with
 // no coverage test: how texture() obtains its implicit derivatives -- the fragment's quad neighbours (qx ^ 1, qy) and
 // (qx, qy ^ 1), helper invocations when they fall outside the triangle (oracle raster_triangle uv_at).
-__device__ __forceinline__ void interp2_at(const SubTri& s, int qx, int qy, const float a[3], const float b[3],
-                                           float& oa, float& ob) {
+__device__ __forceinline__ void interp2_at(const SubTri& s, double rcp, int qx, int qy, const float a[3],
+                                           const float b[3], float& oa, float& ob) {
     const double cx = (double)qx + 0.5, cy = (double)qy + 0.5;
     double f[2];
 #pragma unroll
@@ -230,11 +336,7 @@ __device__ __forceinline__ void interp2_at(const SubTri& s, int qx, int qy, cons
         const double dx = (s.sx[j] - s.sx[i]) * s.sgn, dy = (s.sy[j] - s.sy[i]) * s.sgn;
         f[k] = dx * (cy - s.sy[i]) - dy * (cx - s.sx[i]);
     }
-    const float c0 = (float)(f[0] / s.area), c1 = (float)(f[1] / s.area), c2 = 1.0f - c0 - c1;
-    const float r0 = c0 * s.iw[0], r1 = c1 * s.iw[1], r2 = c2 * s.iw[2];
-    const float rs = __fdiv_rn(1.0f, r0 + r1 + r2);
-    oa = (r0 * a[0] + r1 * a[1] + r2 * a[2]) * rs;
-    ob = (r0 * b[0] + r1 * b[1] + r2 * b[2]) * rs;
+    interp2_from(s, div_area(f[0], s.area, rcp), div_area(f[1], s.area, rcp), a, b, oa, ob);
 }
 
 struct RasterParams {
@@ -302,11 +404,13 @@ __device__ __forceinline__ void setup_alpha(const RasterParams& p, int t, const 
     }
 }
 
-__device__ __forceinline__ void plot(const RasterParams& p, const SubTri& s, int px, int py,
+template <bool FAST>
+__device__ __forceinline__ void plot(const RasterParams& p, const SubTri& s, const FastEdges& fe, int px, int py,
                                      unsigned long long id) {
     float b0, b1, b2, z;
+    double e0 = 0.0, e1 = 0.0;         // FAST: the fragment's first two edge functions, for the quad neighbours below
     if (s.alpha_mode == 1) return;
-    if (!cover(s, px, py, b0, b1, b2, z)) return;
+    if (!cover<FAST>(s, fe, px, py, b0, b1, b2, z, e0, e1)) return;
     const size_t pix = (size_t)py * p.W + px;
     if (p.vis32) {        // depth-only pass (shadow map): the nearest depth is all that is kept, as the 24-bit depth
         // the map will show (quantisation is monotonic: the minimum of the quantised depths is the quantised minimum)
@@ -331,8 +435,16 @@ __device__ __forceinline__ void plot(const RasterParams& p, const SubTri& s, int
         float alpha;
         if (p.tex.mips) {      // texture(DiffuseTexture, tex) with the quad differences of tex
             float ux, vx, uy, vy;
-            interp2_at(s, px ^ 1, py, s.tu, s.tv, ux, vx);
-            interp2_at(s, px, py ^ 1, s.tu, s.tv, uy, vy);
+            if (FAST) {     // one pixel to the side: e_k changes by exactly a_k (b_k), the same numbers interp2_at forms
+                const double sx = (px & 1) ? -1.0 : 1.0, sy = (py & 1) ? -1.0 : 1.0;
+                interp2_from(s, div_area(fma(sx, fe.a[0], e0), s.area, fe.rcp),
+                             div_area(fma(sx, fe.a[1], e1), s.area, fe.rcp), s.tu, s.tv, ux, vx);
+                interp2_from(s, div_area(fma(sy, fe.b[0], e0), s.area, fe.rcp),
+                             div_area(fma(sy, fe.b[1], e1), s.area, fe.rcp), s.tu, s.tv, uy, vy);
+            } else {
+                interp2_at(s, fe.rcp, px ^ 1, py, s.tu, s.tv, ux, vx);
+                interp2_at(s, fe.rcp, px, py ^ 1, s.tu, s.tv, uy, vy);
+            }
             alpha = vct_tex_sample_lod(p.tex, s.tex, u, v, ux - u, vx - v, uy - u, vy - v).w;
         } else {
             alpha = vct_tex_sample(p.tex, s.tex, u, v).w;
@@ -374,8 +486,9 @@ __device__ __forceinline__ void emit_big_wave(const RasterParams& p, int id, int
         }
         const int x0 = max(s.x0, tx * VCT_RTILE), x1 = min(s.x1, tx * VCT_RTILE + VCT_RTILE - 1);
         const int y0 = max(s.y0, ty * VCT_RTILE), y1 = min(s.y1, ty * VCT_RTILE + VCT_RTILE - 1);
+        const FastEdges fe = slow_edges(s);
         for (int py = y0; py <= y1; ++py)
-            for (int px = x0; px <= x1; ++px) plot(p, s, px, py, (unsigned long long)(uint32_t)id);
+            for (int px = x0; px <= x1; ++px) plot<false>(p, s, fe, px, py, (unsigned long long)(uint32_t)id);
     }
 }
 
@@ -429,8 +542,9 @@ k_raster_vis(const RasterParams p) {
             if (s.ok && s.alpha_mode != 1) {
                 const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
                 if (box <= VCT_RASTER_SMALL) {
+                    const FastEdges fe = slow_edges(s);
                     for (int py = s.y0; py <= s.y1; ++py)
-                        for (int px = s.x0; px <= s.x1; ++px) plot(p, s, px, py, (unsigned long long)(uint32_t)id);
+                        for (int px = s.x0; px <= s.x1; ++px) plot<false>(p, s, fe, px, py, (unsigned long long)(uint32_t)id);
                 } else if (box <= VCT_RASTER_GROUP) {
                     to_group = true;
                     pack_subtri(s, rec);
@@ -506,8 +620,21 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
             if (!unpack_subtri(p.recs[g], s) && !rebuild_subtri(p, id, s)) continue;
             const int bw = s.x1 - s.x0 + 1;
             const int box = bw * (s.y1 - s.y0 + 1);
-            for (int i = l16; i < box; i += 16)
-                plot(p, s, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+            FastEdges fe;
+            make_fast(s, fe);
+            // the box is walked in strides of 16 without a division per pixel: (x, y) advance by (16 % bw, 16 / bw)
+            const int qs = 16 / bw, rs = 16 - qs * bw;
+            int x = l16 % bw, y = l16 / bw;
+            if (fe.ok) {
+                for (int i = l16; i < box; i += 16) {
+                    plot<true>(p, s, fe, s.x0 + x, s.y0 + y, (unsigned long long)(uint32_t)id);
+                    x += rs; y += qs;
+                    if (x >= bw) { x -= bw; ++y; }
+                }
+            } else {
+                for (int i = l16; i < box; i += 16)
+                    plot<false>(p, s, fe, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+            }
         }
         return;
     }
@@ -522,8 +649,20 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
             if (!unpack_subtri(p.recs[(size_t)2 * p.ntri - 1 - w], s) && !rebuild_subtri(p, id, s)) continue;
             const int bw = s.x1 - s.x0 + 1;
             const int box = bw * (s.y1 - s.y0 + 1);
-            for (int i = lane; i < box; i += 64)
-                plot(p, s, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+            FastEdges fe;
+            make_fast(s, fe);
+            const int qs = 64 / bw, rs = 64 - qs * bw;
+            int x = lane % bw, y = lane / bw;
+            if (fe.ok) {
+                for (int i = lane; i < box; i += 64) {
+                    plot<true>(p, s, fe, s.x0 + x, s.y0 + y, (unsigned long long)(uint32_t)id);
+                    x += rs; y += qs;
+                    if (x >= bw) { x -= bw; ++y; }
+                }
+            } else {
+                for (int i = lane; i < box; i += 64)
+                    plot<false>(p, s, fe, s.x0 + i % bw, s.y0 + i / bw, (unsigned long long)(uint32_t)id);
+            }
         }
         return;
     }
@@ -537,7 +676,10 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
         const int px = (int)(e.y & 0xffffu) * VCT_RTILE + (int)(threadIdx.x % VCT_RTILE);
         const int py = (int)(e.y >> 16) * VCT_RTILE + (int)(threadIdx.x / VCT_RTILE);
         if (px < s.x0 || px > s.x1 || py < s.y0 || py > s.y1) continue;
-        plot(p, s, px, py, (unsigned long long)e.x);
+        FastEdges fe;
+        make_fast(s, fe);
+        if (fe.ok) plot<true>(p, s, fe, px, py, (unsigned long long)e.x);
+        else plot<false>(p, s, fe, px, py, (unsigned long long)e.x);
     }
 }
 
@@ -634,7 +776,9 @@ k_gbuffer_shade(const ShadeParams p) {
             setup_subtri(&fan.v[0].v, &fan.v[1].v, &fan.v[2].v, W, H, 0, H, s);
         }
         float b0, b1, b2, z;
-        cover(s, px, py, b0, b1, b2, z);
+        double e0, e1;
+        const FastEdges fe = slow_edges(s);
+        cover<false>(s, fe, px, py, b0, b1, b2, z, e0, e1);
         // perspective-correct interpolation of the 12 varyings (trace.vs:27,31-33)
         const float q0 = b0 * s.iw[0], q1 = b1 * s.iw[1], q2 = b2 * s.iw[2];
         const float qs = __fdiv_rn(1.0f, q0 + q1 + q2);
@@ -687,8 +831,8 @@ k_gbuffer_shade(const ShadeParams p) {
             tcv = (q0 * vv[0] + q1 * vv[1] + q2 * vv[2]) * qs;
             if (p.r.tex.mips) {
                 float ux, vx, uy, vy;
-                interp2_at(s, px ^ 1, py, vu, vv, ux, vx);
-                interp2_at(s, px, py ^ 1, vu, vv, uy, vy);
+                interp2_at(s, fe.rcp, px ^ 1, py, vu, vv, ux, vx);
+                interp2_at(s, fe.rcp, px, py ^ 1, vu, vv, uy, vy);
                 dq[0] = ux - tcu; dq[1] = vx - tcv; dq[2] = uy - tcu; dq[3] = vy - tcv;
             }
         }
@@ -970,5 +1114,10 @@ hipError_t vct_launch_tex_mip(const uint32_t* parent, int pw, int ph, uint32_t* 
 hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s) {
     const int tx = (w + VCT_TILE - 1) / VCT_TILE;
     hipLaunchKernelGGL(k_untile_gbuffer, dim3(256 * 8), dim3(256), 0, s, tiled, planes_linear, w, h, tx);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_area_divide_selftest(uint64_t seed, uint64_t count, unsigned long long* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_area_divide_selftest, dim3(256 * 16), dim3(256), 0, s, seed, count, out);
     return hipGetLastError();
 }

@@ -140,6 +140,9 @@ struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
 #ifndef VCT_HALF_GATHER
 #define VCT_HALF_GATHER 1     // gather + interpolate the lower z plane, then the upper one (half the texel registers live)
 #endif
+#ifndef VCT_TWO_BLOCKS
+#define VCT_TWO_BLOCKS 0      // 1: a second cooperative block before the per-lane gather (profiles/experiments/README.md)
+#endif
 struct MarchStats {
     uint32_t wave_steps;       // march-loop iterations executed by the wave
     uint32_t lane_steps;       // sum over those iterations of the live lanes (== executed cone steps)
@@ -149,6 +152,7 @@ struct MarchStats {
     uint32_t fallback_lanes;   // live lanes in those
     uint32_t fallback_fits;    // per-lane samples whose live footprints WOULD fit one 4x4x4 block (anchored at their minimum)
     uint32_t greedy_blocks, greedy_le2, greedy_le3, greedy_le4;   // blocks a greedy multi-anchor cover of them would need
+    uint32_t two_blocks;       // level samples served by two cooperative blocks (VCT_TWO_BLOCKS)
 };
 
 // [GL] tri(level): trilinear, texel centres, REPEAT (or clamp).  `level` is wave-uniform; must be
@@ -195,6 +199,10 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
     F4 r = {0.0f, 0.0f, 0.0f, 0.0f};
     bool coop = false;
     int ax = 0, ay = 0, az = 0, dx = 0, dy = 0, dz = 0;
+#if VCT_TWO_BLOCKS
+    bool two = false, mine = act, mine2 = false;   // mine: this lane's footprint lies in the block being fetched
+    int ex = 0, ey = 0, ez = 0;                    // second anchor - first anchor
+#endif
     if (COOP) {
         // anchor = footprint of the tile's centre pixel (lane 27) if it is live, else the first live lane
         const int src = ((am >> 27) & 1ull) ? 27 : (int)__ffsll((long long)am) - 1;
@@ -203,9 +211,32 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         az = __builtin_amdgcn_readlane(k0, src) - 1;
         dx = i0 - ax; dy = j0 - ay; dz = k0 - az;
         const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
-        coop = (ballot64(far > 2u) & am) == 0ull;
+        const unsigned long long out = ballot64(far > 2u) & am;
+        coop = out == 0ull;
+#if VCT_TWO_BLOCKS
+        if (!coop) {
+            // Second chance before the per-lane gather: a second block anchored at the first live lane the first one
+            // misses.  If the two blocks hold every live footprint, each is fetched cooperatively in turn and a lane
+            // gathers from the one that holds its footprint (any block that holds the 8 texels gives the same bits).
+            const int s2 = (int)__ffsll((long long)out) - 1;
+            ex = __builtin_amdgcn_readlane(dx, s2) - 1;
+            ey = __builtin_amdgcn_readlane(dy, s2) - 1;
+            ez = __builtin_amdgcn_readlane(dz, s2) - 1;
+            const uint32_t far2 = max(max((uint32_t)(dx - ex), (uint32_t)(dy - ey)), (uint32_t)(dz - ez));
+            two = (ballot64(far2 > 2u) & out) == 0ull;
+            coop = two;
+            mine = act && far <= 2u;
+            mine2 = act && far > 2u;
+        }
+#endif
     }
+#if VCT_TWO_BLOCKS
+    if (COOP && coop)
+#pragma unroll 1
+    for (int pass = 0;; ++pass) {
+#else
     if (COOP && coop) {
+#endif
         uint32_t idx;
         if (WRAP) {
             // scalar unit: dilate the anchor; vector unit: one dilated add per axis
@@ -232,6 +263,9 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             d.w = unorm8(t >> 24);
             blk[lb.lane] = d;
             wave_sync();
+#if VCT_TWO_BLOCKS
+            if (mine) {
+#endif
             const int slot = act ? (dz * 4 + dy) * 4 + dx : 0;
             const float4* q = blk + slot;
             const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
@@ -267,7 +301,17 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
 #undef VCT_ACC
 #endif
+#if VCT_TWO_BLOCKS
+            }                              // a lane of the other block keeps what it has
+#endif
         }
+#if VCT_TWO_BLOCKS
+        if (!two || pass == 1) break;
+        if (VCT_STATS) ++ms.two_blocks;
+        ax += ex; ay += ey; az += ez;
+        dx -= ex; dy -= ey; dz -= ez;
+        mine = mine2;
+#endif
     } else {
       if (VCT_STATS) {
           ++ms.fallback; ms.fallback_lanes += (uint32_t)__popcll(am);
