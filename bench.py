@@ -309,6 +309,7 @@ def main():
     # kernel write this rank's slab straight into one of them (full-frame addressing, no copies) and issues
     # the ONE gather of the frame on a communication stream while the next frame's trace fills the other.
     use_dist = world > 1 or force_dist
+    native_fallback, fallback_group = None, None
     r0, r1, _per = vct.slab_partition(h, world, rank)
     y0, y1 = r0 * 8, min(r1 * 8, h)
     slab_px = max(0, y1 - y0) * w
@@ -321,18 +322,40 @@ def main():
         sys.stdout.flush()                   # RCCL prints a version banner on stdout when a communicator forms
         saved_fd = os.dup(1)
         os.dup2(2, 1)
+        native_err = None
         try:
+            if os.environ.get("VCT_BENCH_FAIL_NATIVE") == "1":       # tests: walk the fallback below
+                raise RuntimeError("VCT_BENCH_FAIL_NATIVE=1")
             ctx.comm_init(bytes(idt.numpy().tobytes()), rank, world)
+        except Exception as e:               # noqa: BLE001 -- whatever went wrong, the ranks must agree on what to do next
+            native_err = f"rank {rank}: {e}"
         finally:
             ctypes.CDLL(None).fflush(None)   # the banner sits in the C library's stdout buffer
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+        # all-or-nothing across the ranks: vct_comm_init is all-or-nothing per rank (a failed init leaves no
+        # communicator behind); if any rank could not form the communicator, every rank drops to the Python-paced
+        # step below with torch.distributed's own RCCL gather, and the line says so.  A run that cannot use the native
+        # step is worth more than no run.
+        errs = [None] * world
+        dist.all_gather_object(errs, native_err)
+        errs = [e for e in errs if e]
+        if errs:
+            print(f"[bench] native communicator unavailable ({errs[0]}); falling back to torch.distributed gather",
+                  file=sys.stderr)
+            if native_err is None:
+                ctx.comm_destroy()
+            native = False
+            native_fallback = errs[0]
+            if backend == "nccl" and world > 1:
+                fallback_group = dist.new_group(backend="nccl")
+    if native:
         assert ctx.comm_slab() == (r0, r1)
         if inp["scene"] is not None and world > 1:
             ctx.render_gbuffer_rows(inp["view_proj"], r0, r1)   # each rank rasterises only its slab from now on
     else:
         nbuf = 2 if use_dist else 1
-        fgs = [slabs.FrameGather(h, w, world, rank, f"cuda:{local_rank}") for _ in range(nbuf)]
+        fgs = [slabs.FrameGather(h, w, world, rank, f"cuda:{local_rank}", group=fallback_group) for _ in range(nbuf)]
         bases = [f.slab.data_ptr() - y0 * w * 8 for f in fgs]
         ctx.set_frame_target(bases[0])
     if inp["scene"] is None:
@@ -508,8 +531,10 @@ def main():
                        "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7, "bounces": args.bounces,
                        "anisotropic_mips": bool(args.anisotropic),
                        "parallelism": "single GPU" if world == 1 else
-                       f"{world} screen-tile slabs ({args.slabs if native else 'equal'}) + 1 RCCL gather (native vct_frame_step)" +
-                       ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]"),
+                       f"{world} screen-tile slabs ({args.slabs if native else 'equal'}) + 1 RCCL gather " +
+                       ("(native vct_frame_step)" if native else "(Python-paced step, torch.distributed gather)") +
+                       ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]") +
+                       ("" if not native_fallback else f" [native communicator unavailable: {native_fallback}]"),
                        "trace_variant": args.variant,
                        "slab_tile_rows": [b - a for a, b in slab_rows]},
             "cone_steps_per_frame": total_steps,

@@ -273,3 +273,21 @@ def test_row_step_histogram_and_load_aware_slabs(vct):
     assert np.array_equal(ctx.comm_download_frame(), frame)
     ctx.comm_destroy()
     ctx.close()
+
+
+def test_bench_falls_back_when_the_native_communicator_cannot_form():
+    """If vct_comm_init fails on any rank (here: forced), every rank drops to the Python-paced step with
+    torch.distributed's gather, the frame is still the single-GPU frame, and the line says what happened -- an N-GPU
+    run that cannot use the native step still produces a number instead of nothing."""
+    env = dict(os.environ, VCT_BENCH_FORCE_DIST="1", VCT_BENCH_FAIL_NATIVE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29617")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--width", "320",
+           "--height", "180", "--voxel-dim", "64", "--scene-detail", "0.15", "--shadow-size", "512",
+           "--cpu-seconds", "0", "--no-sweep"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["gathered_frame_equals_single_gpu_frame"] is True and d["value"] > 0
+    assert "falling back" in out.stderr
