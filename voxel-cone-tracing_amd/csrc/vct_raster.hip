@@ -505,7 +505,10 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred, in
 
 // one thread per triangle: clip, cull, classify; tiny sub-triangles are rasterised inline, huge ones are cut into
 // tile work items by the wave, the rest go to the group / wave lists of k_raster_mid
-__global__ void __launch_bounds__(256, 3)
+#ifndef VCT_VIS_MIN_BLOCKS
+#define VCT_VIS_MIN_BLOCKS 3
+#endif
+__global__ void __launch_bounds__(256, VCT_VIS_MIN_BLOCKS)
 k_raster_vis(const RasterParams p) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -607,7 +610,10 @@ __device__ __forceinline__ bool rebuild_subtri(const RasterParams& p, int id, Su
 //          cover <= 64 pixels: a whole wave per triangle would leave most lanes idle after the first iteration)
 //   wave:  one wave per medium sub-triangle, 64 bounding-box pixels per iteration
 //   tile:  one workgroup per 16x16-pixel work item of a huge sub-triangle, one pixel per thread
-__global__ void __launch_bounds__(256)
+#ifndef VCT_MID_MIN_BLOCKS
+#define VCT_MID_MIN_BLOCKS 4
+#endif
+__global__ void __launch_bounds__(256, VCT_MID_MIN_BLOCKS)
 k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
     int b = blockIdx.x;
     if (b < gblocks) {
