@@ -938,24 +938,8 @@ k_gbuffer_shade(const ShadeParams p) {
 #pragma unroll
                 for (int k = 0; k < 5; ++k) { col[k] = xi0[k]; row[k] = yj0[k]; }
                 col[5] = xi1[4]; row[5] = yj1[4];
-                // two window rows live at a time (12 registers instead of 36: the kernel is latency-bound and every
-                // resident wave counts); the taps are counted, so their order is free
-                float r0[6], r1[6];
                 const bool wide = col[5] - col[0] == 5;     // six consecutive texels per row: one dwordx4 + one dwordx2 (VctWords6)
-                auto load_row = [&](int rr, float out[6]) __attribute__((always_inline)) {
-                    if (wide) {
-                        const VctWords6 w = *reinterpret_cast<const VctWords6*>(p.shadow + (size_t)rr * S + col[0]);
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) out[i] = vct_shadow_depth(w.v[i], p.shadow_ebase);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) out[i] = vct_shadow_depth(p.shadow[(size_t)rr * S + col[i]], p.shadow_ebase);
-                    }
-                };
-                load_row(row[0], r0);
-#pragma unroll
-                for (int y = 0; y < 5; ++y) {
-                    load_row(row[y + 1], r1);
+                auto tap_row = [&](int y, const float r0[6], const float r1[6]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int x = 0; x < 5; ++x) {
                         const float a = xa[x], b = yb[y];
@@ -963,8 +947,37 @@ k_gbuffer_shade(const ShadeParams p) {
                                           (1.0f - a) * b * r1[x] + a * b * r1[x + 1];
                         if (cur <= tap) cnt += 1.0f;
                     }
+                };
+                if (wide) {
+                    // all six rows in flight at once (round 3: the rows used to be fetched one after the other, two
+                    // live at a time to save registers -- six dependent round trips per pixel were the price, 36 of
+                    // the pass's 188 us); the taps are counted, so their order is free
+                    VctWords6 w[6];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) r0[i] = r1[i];
+                    for (int y = 0; y < 6; ++y) w[y] = *reinterpret_cast<const VctWords6*>(p.shadow + (size_t)row[y] * S + col[0]);
+                    float r0[6], r1[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) r0[i] = vct_shadow_depth(w[0].v[i], p.shadow_ebase);
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) r1[i] = vct_shadow_depth(w[y + 1].v[i], p.shadow_ebase);
+                        tap_row(y, r0, r1);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) r0[i] = r1[i];
+                    }
+                } else {       // a window at a clamped border: texel by texel, two rows live at a time
+                    float r0[6], r1[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) r0[i] = vct_shadow_depth(p.shadow[(size_t)row[0] * S + col[i]], p.shadow_ebase);
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) r1[i] = vct_shadow_depth(p.shadow[(size_t)row[y + 1] * S + col[i]], p.shadow_ebase);
+                        tap_row(y, r0, r1);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) r0[i] = r1[i];
+                    }
                 }
             } else {
                 for (int x = -2; x <= 2; ++x)
