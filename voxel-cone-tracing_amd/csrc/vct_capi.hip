@@ -1067,9 +1067,10 @@ int vct_bounce(vct_ctx* c) {
         c->bounce_list_cap = (uint32_t)(nvox / 8);
         HIP_TRY(c, hipMalloc(&c->bounce_list, ((size_t)c->bounce_list_cap + 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&c->brick_over, nbricks * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(c->brick_over, 0, nbricks * sizeof(uint32_t), c->stream));   // k_bounce_bricks resets what it serves
     }
-    HIP_TRY(c, hipMemsetAsync(c->bounce_list, 0, sizeof(uint32_t), c->stream));        // the counter
-    HIP_TRY(c, hipMemsetAsync(c->bounce_list + 1, 0xff, (size_t)c->bounce_list_cap * sizeof(uint32_t), c->stream));
+    // only the counter: the list itself needs no clear (the one brick that can straddle its end marks its tail empty)
+    HIP_TRY(c, hipMemsetAsync(c->bounce_list, 0, sizeof(uint32_t), c->stream));
     VctTraceParams p;
     fill_march_params(c, p, c->chain);
     p.attr_albedo = c->attr_albedo;
@@ -1079,6 +1080,8 @@ int vct_bounce(vct_ctx* c) {
     p.bounce_seen = c->mip_seen_b;
     p.bounce_out = c->chain_b;
     p.nbricks = (uint32_t)(nvox / 512);
+    p.slot_brick = c->slot_brick;
+    p.nslots = c->nslots;
     p.bounce_list_count = c->bounce_list;
     p.bounce_list = c->bounce_list + 1;
     p.bounce_list_cap = c->bounce_list_cap;

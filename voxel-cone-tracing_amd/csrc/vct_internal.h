@@ -216,6 +216,8 @@ struct VctTraceParams {
     const uint32_t* bounce_seen;        // bricks the bounce chain showed when its mips were last built
     uint32_t* bounce_out;
     uint32_t nbricks;
+    const uint32_t* slot_brick;         // [nslots] the bricks a fragment of the mesh can land in (the voxelizer's slots)
+    uint32_t nslots;
     // anisotropic option: six directional chains (levels >= 1), Morton per level, each
     // `aniso_stride` texels; level k of a direction at texel offset level_off[k] - level_off[1]
     const uint32_t* aniso;

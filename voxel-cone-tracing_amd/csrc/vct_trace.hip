@@ -1063,10 +1063,11 @@ __device__ __forceinline__ uint32_t to_unorm8_dev(float f) {     // [GL] float -
 }
 
 // Second bounce (oracle/vct_oracle.h vcto_bounce), three kernels:
-//   k_bounce_list   one wave per touched 8^3 brick: copies the brick into the bounce chain (untouched
-//                   voxels keep their bounce-0 value), compacts its occupied voxels (ballot +
-//                   popcount through LDS) and appends them to a global voxel list -- bricks stay
-//                   contiguous in the list, so neighbouring entries are Morton-adjacent voxels;
+//   k_bounce_list   one wave per touched 8^3 brick (found through the voxelizer's slot table): copies the brick
+//                   into the bounce chain (untouched voxels keep their bounce-0 value), compacts its occupied
+//                   voxels (ballot + popcount through LDS) and appends them to a global voxel list, one
+//                   reservation per workgroup of 16 bricks -- bricks stay contiguous in the list and follow
+//                   each other in Morton order, so neighbouring entries are Morton-adjacent voxels;
 //   k_bounce_march  one wave per 64 list entries, lane = voxel, the 6 diffuse cones marched with the
 //                   same cone_march as the screen trace (voxels of a locally flat surface trace
 //                   near-parallel cones, so the cooperative sampler applies);
@@ -1136,51 +1137,83 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
 
 // compaction of one brick into `list` (LDS); returns the number of occupied voxels
 __device__ __forceinline__ int compact_brick(const VctTraceParams& p, uint32_t b, int lane, uint16_t* list) {
+    // a brick without a slot holds nothing of the current mesh (the host refuses the bounce when the attributes
+    // are stale, vct_capi.hip attrs_valid; this keeps the index in bounds regardless)
+    const uint32_t slot = p.brick_slot[b];
+    const bool has = slot != VCT_NO_SLOT;
+    const uint32_t* __restrict__ src = p.chain + (size_t)b * 512 + lane;
+    const uint32_t* __restrict__ nrm = p.attr_normal + (size_t)(has ? slot : 0u) * 512 + lane;
+    // all sixteen loads of the brick in flight before the first ballot (one round trip, not eight)
+    uint32_t t[8], a[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { t[it] = src[it * 64]; a[it] = nrm[it * 64]; }
     int n = 0;
+#pragma unroll
     for (int it = 0; it < 8; ++it) {
-        const uint32_t v = (uint32_t)(it * 64 + lane);
-        const size_t vox = (size_t)b * 512 + v;
-        const uint32_t src0 = p.chain[vox];
-        p.bounce_out[vox] = src0;
-        // a brick without a slot holds nothing of the current mesh (the host refuses the bounce when the attributes
-        // are stale, vct_capi.hip attrs_valid; this keeps the index in bounds regardless)
-        const uint32_t slot = p.brick_slot[b];
-        const bool occ = (src0 >> 24) != 0u && slot != VCT_NO_SLOT &&
-                         (p.attr_normal[(size_t)(slot == VCT_NO_SLOT ? 0u : slot) * 512 + v] & 0xffffffu) != 0x808080u;
+        p.bounce_out[(size_t)b * 512 + it * 64 + lane] = t[it];
+        const bool occ = (t[it] >> 24) != 0u && has && (a[it] & 0xffffffu) != 0x808080u;
         const unsigned long long m = ballot64(occ);
-        if (occ) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)v;
+        if (occ) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(it * 64 + lane);
         n += __popcll(m);
     }
     return n;
 }
 
-__global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK)
+// 16 waves per workgroup: the list positions of a workgroup's 16 bricks are reserved with ONE atomic on the list's
+// counter.  One atomic per brick meant ~10^4 returning atomics on one address at 512^3, which the L2 executes one after
+// the other (~12 ns each): they, not the bricks, were the 0.12-0.14 ms this kernel took (round 3).
+#define VCT_BLIST_WAVES 16
+__global__ void __launch_bounds__(64 * VCT_BLIST_WAVES)
 k_bounce_list(const VctTraceParams p) {
-    __shared__ uint16_t lds_list[VCT_WAVES_PER_BLOCK][512];
+    __shared__ uint16_t lds_list[VCT_BLIST_WAVES][512];
+    __shared__ uint32_t lds_n[VCT_BLIST_WAVES];
+    __shared__ uint32_t lds_base;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint16_t* list = &lds_list[wave][0];
-    const uint32_t nwaves = gridDim.x * VCT_WAVES_PER_BLOCK;
-    for (uint32_t b = blockIdx.x * VCT_WAVES_PER_BLOCK + wave; b < p.nbricks; b += nwaves) {
-        p.brick_over[b] = 0u;
-        if (!p.brick_prev[b]) {
-            // nothing here now; if the bounce chain still shows an older pass, clear it
-            if (p.bounce_seen[b])
-                for (int it = 0; it < 8; ++it) p.bounce_out[(size_t)b * 512 + it * 64 + lane] = 0u;
-            continue;
+    const uint32_t nwaves = gridDim.x * VCT_BLIST_WAVES;
+    // (1) bricks the bounce chain still shows from an older pass and that hold nothing now are cleared.  The flags
+    // are scanned 64 bricks at a time, one per lane (a 512^3 grid has 262,144 bricks, 2 % of them touched).
+    const uint32_t nchunks = (p.nbricks + 63u) >> 6;
+    for (uint32_t c = blockIdx.x * VCT_BLIST_WAVES + wave; c < nchunks; c += nwaves) {
+        const uint32_t mine = c * 64u + (uint32_t)lane;
+        const bool stale = mine < p.nbricks && p.brick_prev[mine] == 0u && p.bounce_seen[mine] != 0u;
+        for (unsigned long long m = ballot64(stale); m != 0ull; m &= m - 1ull) {
+            const uint32_t b = c * 64u + (uint32_t)(__ffsll((long long)m) - 1);
+            for (int it = 0; it < 8; ++it) p.bounce_out[(size_t)b * 512 + it * 64 + lane] = 0u;
         }
-        const int n = compact_brick(p, b, lane, list);
-        wave_sync();
-        if (n == 0) continue;
-        uint32_t off = 0;
-        if (lane == 0) off = atomicAdd(p.bounce_list_count, (uint32_t)n);
-        off = __builtin_amdgcn_readfirstlane(off);
-        if (off + (uint32_t)n > p.bounce_list_cap) {      // does not fit: k_bounce_bricks takes this brick
-            if (lane == 0) p.brick_over[b] = 1u;
-        } else {
-            for (int i = lane; i < n; i += 64) p.bounce_list[off + i] = b * 512u + list[i];
+    }
+    // (2) the touched bricks, one wave each, found through the voxelizer's slot table (every brick level 0 can show
+    // content in has a slot) instead of a scan of the grid
+    for (uint32_t s0 = blockIdx.x * VCT_BLIST_WAVES; s0 < p.nslots; s0 += nwaves) {        // workgroup-uniform trip count
+        const uint32_t sl = s0 + (uint32_t)wave;
+        uint32_t b = 0u;
+        int n = 0;
+        if (sl < p.nslots) {
+            b = p.slot_brick[sl];
+            if (p.brick_prev[b]) n = compact_brick(p, b, lane, list);
         }
-        wave_sync();
+        if (lane == 0) lds_n[wave] = (uint32_t)n;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0u;
+            for (int w = 0; w < VCT_BLIST_WAVES; ++w) total += lds_n[w];
+            lds_base = total ? atomicAdd(p.bounce_list_count, total) : 0u;
+        }
+        __syncthreads();
+        if (n != 0) {
+            uint32_t off = lds_base;
+            for (int w = 0; w < wave; ++w) off += lds_n[w];
+            if (off + (uint32_t)n > p.bounce_list_cap) {
+                // does not fit: k_bounce_bricks takes this brick (and resets the flag).  At most one brick straddles the
+                // end of the list; it marks the entries it reserved there as empty, so the list needs no clear.
+                if (lane == 0) p.brick_over[b] = 1u;
+                for (uint32_t i = off + (uint32_t)lane; i < p.bounce_list_cap; i += 64u) p.bounce_list[i] = 0xffffffffu;
+            } else {
+                for (int i = lane; i < n; i += 64) p.bounce_list[off + i] = b * 512u + list[i];
+            }
+        }
+        __syncthreads();           // lds_n / lds_base / the lists are reused by the next round
     }
 }
 
@@ -1218,20 +1251,28 @@ k_bounce_bricks(const VctTraceParams p) {
     uint16_t* list = &lds_list[wave][0];
     unsigned long long wave_steps = 0;
     const uint32_t nwaves = gridDim.x * VCT_WAVES_PER_BLOCK;
-    for (uint32_t b = blockIdx.x * VCT_WAVES_PER_BLOCK + wave; b < p.nbricks; b += nwaves) {
-        if (!p.brick_over[b]) continue;
-        const int n = compact_brick(p, b, lane, list);
-        wave_sync();
-        for (int base = 0; base < n; base += 64) {
-            const bool alive = base + lane < n;
-            const size_t vox = (size_t)b * 512 + (alive ? list[base + lane] : list[base]);
-            int total;
-            bounce_voxels(p, alive, vox, total, [&](bool al, F3 start, F3 dir, int& st) {
-                return cone_march<WRAP, FASTDIV, true>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st, ms);
-            });
-            wave_steps += (unsigned long long)total;
+    // flags of the slots scanned 64 at a time, one per lane; a served brick's flag is reset for the next pass
+    const uint32_t nchunks = (p.nslots + 63u) >> 6;
+    for (uint32_t c = blockIdx.x * VCT_WAVES_PER_BLOCK + wave; c < nchunks; c += nwaves) {
+        const uint32_t sl = c * 64u + (uint32_t)lane;
+        const uint32_t mine = sl < p.nslots ? p.slot_brick[sl] : 0u;
+        const bool over = sl < p.nslots && p.brick_over[mine] != 0u;
+        if (over) p.brick_over[mine] = 0u;
+        for (unsigned long long m = ballot64(over); m != 0ull; m &= m - 1ull) {
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)mine, __ffsll((long long)m) - 1);
+            const int n = compact_brick(p, b, lane, list);
+            wave_sync();
+            for (int base = 0; base < n; base += 64) {
+                const bool alive = base + lane < n;
+                const size_t vox = (size_t)b * 512 + (alive ? list[base + lane] : list[base]);
+                int total;
+                bounce_voxels(p, alive, vox, total, [&](bool al, F3 start, F3 dir, int& st) {
+                    return cone_march<WRAP, FASTDIV, true>(p, al, start, dir, p.steps_diffuse, p.n_diffuse, blk, lb, st, ms);
+                });
+                wave_steps += (unsigned long long)total;
+            }
+            wave_sync();
         }
-        wave_sync();
     }
     if (lane == 0 && wave_steps)
         atomicAdd(p.step_counter + ((blockIdx.x * VCT_WAVES_PER_BLOCK + wave) & (VCT_STEP_COUNTERS - 1)), wave_steps);
@@ -1289,7 +1330,10 @@ hipError_t launch_bounce(const VctTraceParams& p, hipStream_t s) {
     uint32_t blocks = (p.nbricks + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
     if (blocks > 256u * 64u) blocks = 256u * 64u;
     const dim3 block(64 * VCT_WAVES_PER_BLOCK);
-    hipLaunchKernelGGL(k_bounce_list, dim3(blocks), block, 0, s, p);
+    uint32_t lblocks = (p.nslots + VCT_BLIST_WAVES - 1) / VCT_BLIST_WAVES;               // one wave per touched brick
+    if (lblocks > 256u * 8u) lblocks = 256u * 8u;
+    if (lblocks < 64u) lblocks = 64u;
+    hipLaunchKernelGGL(k_bounce_list, dim3(lblocks), dim3(64 * VCT_BLIST_WAVES), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_bounce_march<WRAP, FASTDIV>), dim3(256 * 24), block, 0, s, p);
