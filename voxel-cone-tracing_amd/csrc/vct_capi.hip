@@ -767,12 +767,14 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
     a.vis32 = nullptr;          // vct_render_shadow_map points it at the shadow-map words
     a.vis32_ebase = 0u;
     a.items = c->raster_items[k];
+    // [wave, group, item, -]: the wave and group counters are one 8-byte-aligned pair, k_raster_vis reserves both lists
+    // of a workgroup with a single 64-bit atomic
     uint32_t* cur = c->raster_counts[k] + 4 * c->raster_set[k];
-    a.item_count = cur;
     a.wave_list = c->raster_lists[k];
-    a.wave_count = cur + 1;
+    a.wave_count = cur;
     a.group_list = c->raster_lists[k] + (size_t)c->ntri * 2;
-    a.group_count = cur + 2;
+    a.group_count = cur + 1;
+    a.item_count = cur + 2;
     a.next_counts = c->raster_counts[k] + 4 * (c->raster_set[k] ^ 1);
     a.recs = c->raster_recs[k];
     c->raster_set[k] ^= 1;

@@ -510,6 +510,8 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred, in
 #endif
 __global__ void __launch_bounds__(256, VCT_VIS_MIN_BLOCKS)
 k_raster_vis(const RasterParams p) {
+    __shared__ uint32_t lds_cnt[4][2];
+    __shared__ unsigned long long lds_base;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if (t == 0) { p.next_counts[0] = 0u; p.next_counts[1] = 0u; p.next_counts[2] = 0u; }
@@ -559,11 +561,36 @@ k_raster_vis(const RasterParams p) {
                 }
             }
         }
-        // list appends: ONE atomic per wave and list (a per-lane atomicAdd on the two counters serialises ~10^5
-        // same-address atomics in L2: 1.2 ms per pass, measured)
-        const uint32_t gslot = wave_append(p.group_count, to_group, lane);
+        // List appends.  Returning atomics on ONE address are executed by the L2 one after the other (~10 ns each): a
+        // per-lane atomicAdd on the two counters was 1.2 ms per pass (round 2), one per wave and list still 4,000
+        // (atrium) to 90,000 (the street's 2.8 M triangles) in a row -- 40 us and 0.5 ms, most of this kernel's time
+        // (round 3, found on the second bounce's list).  Now the workgroup's four waves pool their counts in LDS and
+        // ONE 64-bit atomic reserves both lists for all 256 triangles (wave count low, group count high: neither can
+        // carry, the lists hold at most 2 * ntri entries).  The second sub-triangle exists only for near-clipped
+        // triangles: rare, it keeps the per-wave append.
+        uint32_t gslot, wslot;
+        if (f == 1) {
+            const unsigned long long mg = __builtin_amdgcn_ballot_w64(to_group), mw = __builtin_amdgcn_ballot_w64(to_wave);
+            const int wv = (int)(threadIdx.x >> 6);
+            if (lane == 0) { lds_cnt[wv][0] = (uint32_t)__popcll(mg); lds_cnt[wv][1] = (uint32_t)__popcll(mw); }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tg = 0u, tw = 0u;
+                for (int w = 0; w < 4; ++w) { tg += lds_cnt[w][0]; tw += lds_cnt[w][1]; }
+                lds_base = (tg | tw) ? atomicAdd(reinterpret_cast<unsigned long long*>(p.wave_count),
+                                                 (unsigned long long)tw | ((unsigned long long)tg << 32)) : 0ull;
+            }
+            __syncthreads();
+            const unsigned long long base = lds_base;
+            uint32_t gb = (uint32_t)(base >> 32), wb = (uint32_t)base;
+            for (int w = 0; w < wv; ++w) { gb += lds_cnt[w][0]; wb += lds_cnt[w][1]; }
+            gslot = gb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mg, 0u));
+            wslot = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
+        } else {
+            gslot = wave_append(p.group_count, to_group, lane);
+            wslot = wave_append(p.wave_count, to_wave, lane);
+        }
         if (to_group) { p.group_list[gslot] = (int32_t)id; p.recs[gslot] = rec; }
-        const uint32_t wslot = wave_append(p.wave_count, to_wave, lane);
         if (to_wave) { p.wave_list[wslot] = (int32_t)id; p.recs[(size_t)2 * p.ntri - 1 - wslot] = rec; }
         if (f == 1) big1 = __builtin_amdgcn_ballot_w64(big); else big2 = __builtin_amdgcn_ballot_w64(big);
     }
