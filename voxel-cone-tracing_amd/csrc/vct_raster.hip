@@ -203,6 +203,9 @@ __device__ __forceinline__ bool unpack_subtri(const SubTriRec& r, SubTri& s) {
 // 2^16 in magnitude: coordinates are multiples of 2^-8, pixel centres of 2^-1, so every product and partial sum is a
 // multiple of 2^-16 below 2^37 and fits a double's 53 bits.  Sub-triangles that reach further (near-clipped ones
 // projected far outside the frame) keep the general form, whose roundings the fast form could not reproduce.
+#ifndef VCT_SHADE_PREFETCH
+#define VCT_SHADE_PREFETCH 1
+#endif
 #ifndef VCT_FAST_COVER
 #define VCT_FAST_COVER 1      // 0: every sub-triangle takes the general form (A/B measurements)
 #endif
@@ -795,6 +798,25 @@ k_gbuffer_shade(const ShadeParams p) {
         const int t = id >> 1, f = (id & 1) + 1;
         RVert in[3];
         load_clip_tri(p.r, t, in);
+#if VCT_SHADE_PREFETCH
+        // Everything that depends on the triangle index only is requested NOW, ahead of the fp64 set-up: the four
+        // per-vertex records (the position once more: the clip-space copy above is consumed by the set-up) and the
+        // material index.  The kernel is a chain of dependent round trips (visibility word -> records -> material ->
+        // colours -> shadow window); these used to be five of its eight.
+        VctTri9 recs4[4];
+#pragma unroll
+        for (int arr = 0; arr < 4; ++arr) {
+            const float* src = arr == 0 ? p.r.pos : (arr == 1 ? p.nrm : (arr == 2 ? p.tan : p.bit));
+            recs4[arr] = *reinterpret_cast<const VctTri9*>(src + (size_t)t * 9);
+        }
+        const int m_early = p.material[t];
+        // ... and the material's colours as soon as the index is there (it arrives with the records), so that they too
+        // travel during the set-up
+        const float alb_early[4] = {p.albedo[4 * (size_t)m_early], p.albedo[4 * (size_t)m_early + 1],
+                                    p.albedo[4 * (size_t)m_early + 2], p.albedo[4 * (size_t)m_early + 3]};
+        const float sp_early[3] = {p.specular[3 * (size_t)m_early], p.specular[3 * (size_t)m_early + 1],
+                                   p.specular[3 * (size_t)m_early + 2]};
+#endif
         const bool whole = unclipped(in);
         FanTri fan;
         SubTri s;
@@ -820,8 +842,12 @@ k_gbuffer_shade(const ShadeParams p) {
         // put the record into scratch).
 #pragma unroll
         for (int arr = 0; arr < 4; ++arr) {
+#if VCT_SHADE_PREFETCH
+            const VctTri9 rec = recs4[arr];
+#else
             const float* src = arr == 0 ? p.r.pos : (arr == 1 ? p.nrm : (arr == 2 ? p.tan : p.bit));
             const VctTri9 rec = *reinterpret_cast<const VctTri9*>(src + (size_t)t * 9);
+#endif
 #pragma unroll
             for (int comp = 0; comp < 3; ++comp) {
                 const float a0 = rec.v[comp] * p.r.model_scale, a1 = rec.v[3 + comp] * p.r.model_scale,
@@ -840,7 +866,11 @@ k_gbuffer_shade(const ShadeParams p) {
                 g[3 * arr + comp] = (q0 * var[0] + q1 * var[1] + q2 * var[2]) * qs;
             }
         }
+#if VCT_SHADE_PREFETCH
+        const int m = m_early;
+#else
         const int m = p.material[t];
+#endif
         const int td = TEX ? vct_tex_of(p.r.tex, m, 0) : -1, tsp = TEX ? vct_tex_of(p.r.tex, m, 1) : -1,
                   th = TEX ? vct_tex_of(p.r.tex, m, 2) : -1;
         float tcu = 0.0f, tcv = 0.0f;                                             // tex (trace.vs:36)
@@ -915,14 +945,22 @@ k_gbuffer_shade(const ShadeParams p) {
         g[12] = len > 0.0f ? ux * il : 0.0f;
         g[13] = len > 0.0f ? uy * il : 0.0f;
         g[14] = len > 0.0f ? uz * il : 0.0f;
+#if VCT_SHADE_PREFETCH
+        const float* alb = alb_early;
+#else
         const float* alb = p.albedo + 4 * (size_t)m;
+#endif
         if (TEX && td >= 0) {
             const float4 c = fetch(td, tcu, tcv);                                 // trace.fs:167
             g[15] = c.x; g[16] = c.y; g[17] = c.z; g[18] = c.w;
         } else {
             g[15] = alb[0]; g[16] = alb[1]; g[17] = alb[2]; g[18] = alb[3];
         }
+#if VCT_SHADE_PREFETCH
+        float sp[3] = {sp_early[0], sp_early[1], sp_early[2]};
+#else
         float sp[3] = {p.specular[3 * (size_t)m], p.specular[3 * (size_t)m + 1], p.specular[3 * (size_t)m + 2]};
+#endif
         if (TEX && tsp >= 0) {
             const float4 c = fetch(tsp, tcu, tcv);                                // trace.fs:209
             sp[0] = c.x; sp[1] = c.y; sp[2] = c.z;
