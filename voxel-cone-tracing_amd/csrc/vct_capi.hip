@@ -313,6 +313,13 @@ VctVoxParams vox_params(const vct_ctx* c) {
     p.frag_sorted = c->frag_sorted;
     p.slot_first = c->slot_first;
     p.slot_brick = c->slot_brick;
+    p.items = (const uint4*)c->vox_items;
+    p.nitems = c->n_vox_items;
+    p.chunk = c->vox_chunk;
+    p.acc2 = c->vox_acc2;
+    p.acc2_attr = c->vox_acc2_attr;
+    p.multi_slot = c->vox_multi_slot;
+    p.nmulti = c->n_vox_multi;
     p.nslots = c->nslots;
     p.stage = c->stage;
     p.stage_albedo = c->stage_albedo;
@@ -348,18 +355,23 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     // drop the plan of the previous mesh; level 0 / brick_prev keep describing what the chain shows
     void** old[] = {(void**)&c->acc, (void**)&c->attr_albedo, (void**)&c->attr_normal, (void**)&c->brick_slot,
                     (void**)&c->frag_sorted, (void**)&c->slot_first, (void**)&c->slot_brick, (void**)&c->stage,
-                    (void**)&c->stage_albedo, (void**)&c->stage_normal};
+                    (void**)&c->stage_albedo, (void**)&c->stage_normal, (void**)&c->vox_items, (void**)&c->vox_acc2,
+                    (void**)&c->vox_acc2_attr, (void**)&c->vox_multi_slot};
     for (void** q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
     c->nslots = 0;
     c->n_frags = 0;
+    c->n_vox_items = 0;
+    c->n_vox_multi = 0;
     c->acc_pending = false;
     c->attrs_valid = false;     // the pooled attributes are indexed by the NEW mesh's slots: nothing resolved into them yet
     uint32_t *mark = nullptr, *slot = nullptr, *count = nullptr, *cnt = nullptr, *cursor = nullptr;
     uint32_t *sorted = nullptr, *first = nullptr, *slot_brick = nullptr, *stage = nullptr, *stage_albedo = nullptr,
-             *stage_normal = nullptr, *attr_albedo = nullptr, *attr_normal = nullptr;
+             *stage_normal = nullptr, *attr_albedo = nullptr, *attr_normal = nullptr, *multi_slot = nullptr;
+    void* items = nullptr;
+    unsigned long long *acc2 = nullptr, *acc2_attr = nullptr;
     auto cleanup = [&]() {
         void* tmp[] = {mark, slot, count, cnt, cursor, sorted, first, slot_brick, stage, stage_albedo, stage_normal,
-                       attr_albedo, attr_normal};
+                       attr_albedo, attr_normal, multi_slot, items, acc2, acc2_attr};
         for (void* q : tmp) if (q) (void)hipFree(q);
     };
 #define POOL_TRY(expr)                                                                                  \
@@ -404,6 +416,39 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     for (size_t i = 0; i < ns; ++i) hfirst[i + 1] = hfirst[i] + hcnt[i];
     POOL_TRY(hipMemcpyAsync(first, hfirst.data(), (ns + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     POOL_TRY(vct_launch_frag_scatter(frags, nfrags, slot, first, cursor, sorted, slot_brick, c->stream));
+    // Work items of the pass, the heaviest slots first, slots above VCT_VOX_CHUNK fragments cut into chunks.  Fragments
+    // per slot are uneven (atrium at 256^3: 425 on average, 1,918 at most; the street at 256^3: 4,138 and 23,128): with
+    // one workgroup per slot in slot order the pass ended when an unluckily late heavy slot did.  Longest-first alone:
+    // atrium 0.068 -> 0.049 ms, street at 1024^3 1.41 -> 1.27 ms; cutting the few very heavy slots as well: street at
+    // 256^3 0.64 -> 0.31 ms.  (Smaller chunks cost more in accumulator atomics than they balance: 1024: 1.43 ms.)
+    std::vector<uint32_t> order(ns);
+    for (size_t i = 0; i < ns; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hcnt[a] > hcnt[b]; });
+    std::vector<uint32_t> hitems;
+    hitems.reserve(ns * 4 + 64);
+    std::vector<uint32_t> hmulti;
+    uint32_t nmulti = 0;
+    const uint32_t CH = VCT_VOX_CHUNK;
+    c->vox_chunk = CH;
+    if (nslots)
+        for (uint32_t sl : order) {
+            const uint32_t chunks = hcnt[sl] ? (hcnt[sl] + CH - 1u) / CH : 1u;
+            const uint32_t mi = chunks > 1u ? nmulti++ : 0xffffffffu;
+            if (chunks > 1u) hmulti.push_back(sl);
+            for (uint32_t ch = 0; ch < chunks; ++ch) { hitems.push_back(sl); hitems.push_back(ch); hitems.push_back(chunks); hitems.push_back(mi); }
+        }
+    const uint32_t nitems = (uint32_t)(hitems.size() / 4);
+    POOL_TRY(hipMalloc(&items, (size_t)(nitems ? nitems : 1u) * 16));
+    if (nitems) POOL_TRY(hipMemcpyAsync(items, hitems.data(), (size_t)nitems * 16, hipMemcpyHostToDevice, c->stream));
+    const size_t nm = nmulti ? nmulti : 1u;
+    POOL_TRY(hipMalloc(&acc2, nm * 512 * 2 * sizeof(unsigned long long)));
+    POOL_TRY(hipMemsetAsync(acc2, 0, nm * 512 * 2 * sizeof(unsigned long long), c->stream));
+    POOL_TRY(hipMalloc(&multi_slot, nm * sizeof(uint32_t)));
+    if (nmulti) POOL_TRY(hipMemcpyAsync(multi_slot, hmulti.data(), (size_t)nmulti * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (c->cfg.voxel_attributes) {
+        POOL_TRY(hipMalloc(&acc2_attr, nm * 512 * 3 * sizeof(unsigned long long)));
+        POOL_TRY(hipMemsetAsync(acc2_attr, 0, nm * 512 * 3 * sizeof(unsigned long long), c->stream));
+    }
     // staging pool of a pass (+ attributes): written in full by every pass, never cleared
     const size_t pool_vox = ns * 512;
     POOL_TRY(hipMalloc(&stage, pool_vox * 4));
@@ -434,6 +479,7 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     c->nslots = nslots;
     c->frag_sorted = sorted; c->n_frags = nfrags; c->slot_first = first; c->slot_brick = slot_brick;
     c->stage = stage; c->stage_albedo = stage_albedo; c->stage_normal = stage_normal;
+    c->vox_items = items; c->n_vox_items = nitems; c->vox_acc2 = acc2; c->vox_acc2_attr = acc2_attr; c->vox_multi_slot = multi_slot; c->n_vox_multi = nmulti;
     return VCT_OK;
 }
 
@@ -572,7 +618,7 @@ void vct_destroy(vct_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->steps_dev, c->spread_lut, c->tri_pos,
-                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->stage,
+                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->vox_items, c->vox_acc2, c->vox_acc2_attr, c->vox_multi_slot, c->stage,
                     c->stage_albedo, c->stage_normal, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_lists[0], c->raster_lists[1],

@@ -98,6 +98,13 @@ struct vct_ctx {
     uint32_t n_frags = 0;
     uint32_t* slot_first = nullptr;    // [nslots + 1]
     uint32_t* slot_brick = nullptr;    // [nslots]
+    void* vox_items = nullptr;         // [n_vox_items] uint4 work items of the voxelize pass (VctVoxParams::items)
+    uint32_t n_vox_items = 0;
+    uint32_t vox_chunk = VCT_VOX_CHUNK;
+    unsigned long long* vox_acc2 = nullptr;       // accumulators of the multi-chunk slots (+ attributes), arrival counters
+    unsigned long long* vox_acc2_attr = nullptr;
+    uint32_t* vox_multi_slot = nullptr;          // [n_vox_multi] slot of every multi-chunk slot
+    uint32_t n_vox_multi = 0;
     uint32_t* stage = nullptr;         // [nslots][512] RGBA8 of the pending north-star pass
     uint32_t* stage_albedo = nullptr;  // [nslots][512] (cfg.voxel_attributes)
     uint32_t* stage_normal = nullptr;

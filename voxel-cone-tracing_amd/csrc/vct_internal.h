@@ -229,6 +229,7 @@ struct VctTraceParams {
     uint32_t* brick_over;               // bricks whose voxels did not fit the list
 };
 
+#define VCT_VOX_CHUNK 4096u       // most fragments one work item (workgroup) of the voxelize pass takes (vct_capi.hip build_voxel_slots)
 struct VctVoxParams {
     int32_t V;
     float G, model_scale;
@@ -254,6 +255,17 @@ struct VctVoxParams {
     const uint32_t* slot_first;   // [nslots + 1]
     const uint32_t* slot_brick;   // [nslots]
     uint32_t nslots;
+    // Work items of the pass: a slot's fragments in chunks of at most VCT_VOX_CHUNK, one workgroup per chunk, heaviest
+    // slots first (built on the host once per mesh).  A slot of one chunk is accumulated and resolved in LDS; the chunks of a
+    // larger one add their LDS partial sums to the slot's accumulators in HBM (acc2: [multi][512][2], acc2_attr:
+    // [multi][512][3]); a second small kernel resolves those slots (multi_slot[multi]) and re-zeroes the accumulators.
+    const uint4* items;        // [nitems] (slot, chunk, chunks of the slot, index among the multi-chunk slots)
+    uint32_t nitems;
+    uint32_t chunk;            // fragments per work item
+    unsigned long long* acc2;
+    unsigned long long* acc2_attr;
+    const uint32_t* multi_slot;
+    uint32_t nmulti;
     uint32_t* stage;           // [nslots][512] resolved RGBA8 of the pass (Morton order inside the brick)
     uint32_t* stage_albedo;    // [nslots][512] or null (config.voxel_attributes)
     uint32_t* stage_normal;

@@ -459,23 +459,43 @@ k_frag_scatter(const uint2* __restrict__ frags, uint32_t n, const uint32_t* __re
     }
 }
 
-// ---- the voxelize pass: one workgroup per brick slot -------------------------------------------------------------
+// ---- the voxelize pass: one workgroup per work item = up to VCT_VOX_CHUNK fragments of one brick slot ------------
 // acc in LDS: [512][2] u64 (sumR | sumG << 32, sumB | count << 32), + [512][3] for the voxel attributes.
+// A slot of one chunk (most) is resolved from LDS by its workgroup.  The chunks of a heavier slot add their non-empty
+// LDS sums to the slot's accumulators in HBM (integer sums: any order gives the same bits) and count themselves in;
+// the last one reads the totals back (device-scope loads: the other chunks' atomics executed outside this CU's
+// caches), resolves, and leaves accumulators and counter zero for the next pass.
+__device__ __forceinline__ void resolve_attr(uint32_t c, unsigned long long q0, unsigned long long q1, unsigned long long q2,
+                                             uint32_t& alb, uint32_t& nrm) {
+    alb = 0u; nrm = 0u;
+    if (c) {
+        const uint32_t h = c >> 1;
+        alb = (((uint32_t)q0 + h) / c) | ((((uint32_t)(q0 >> 32) + h) / c) << 8) |
+              ((((uint32_t)q1 + h) / c) << 16) | 0xff000000u;
+        nrm = (((uint32_t)(q1 >> 32) + h) / c) | ((((uint32_t)q2 + h) / c) << 8) |
+              ((((uint32_t)(q2 >> 32) + h) / c) << 16) | 0xff000000u;
+    }
+}
+
 template <bool ATTR>
 __global__ void __launch_bounds__(256)
 k_voxelize_bricks(const VctVoxParams p) {
     __shared__ unsigned long long acc[512 * 2];
     __shared__ unsigned long long acc_attr[ATTR ? 512 * 3 : 1];
-    for (uint32_t slot = blockIdx.x; slot < p.nslots; slot += gridDim.x) {
-        const uint32_t first = p.slot_first[slot], n = p.slot_first[slot + 1] - first;
+    for (uint32_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
+        const uint4 w = p.items[it];
+        const uint32_t slot = w.x, chunks = w.z, mi = w.w;
+        const uint32_t first0 = p.slot_first[slot], ntot = p.slot_first[slot + 1] - first0;
         uint32_t* __restrict__ out = p.stage + (size_t)slot * 512;
-        if (n == 0u) {                    // a brick only the reference-mode voxelizer can touch: nothing of this mode
+        if (ntot == 0u) {                 // a brick only the reference-mode voxelizer can touch: nothing of this mode
             for (uint32_t v = threadIdx.x; v < 512u; v += blockDim.x) {
                 out[v] = 0u;
                 if (ATTR) { p.stage_albedo[(size_t)slot * 512 + v] = 0u; p.stage_normal[(size_t)slot * 512 + v] = 0u; }
             }
             continue;
         }
+        const uint32_t first = first0 + w.y * p.chunk;
+        const uint32_t n = min(p.chunk, ntot - w.y * p.chunk);
         for (uint32_t v = threadIdx.x; v < 512u * 2u; v += blockDim.x) acc[v] = 0ull;
         if (ATTR) for (uint32_t v = threadIdx.x; v < 512u * 3u; v += blockDim.x) acc_attr[v] = 0ull;
         __syncthreads();
@@ -497,26 +517,64 @@ k_voxelize_bricks(const VctVoxParams p) {
             }
         }
         __syncthreads();
+        if (chunks == 1u) {
+            for (uint32_t v = threadIdx.x; v < 512u; v += blockDim.x) {
+                const ulonglong2 a = make_ulonglong2(acc[2 * v], acc[2 * v + 1]);
+                out[v] = resolve_voxel(a);
+                if (ATTR) {
+                    uint32_t alb, nrm;
+                    resolve_attr((uint32_t)(a.y >> 32), acc_attr[3 * v], acc_attr[3 * v + 1], acc_attr[3 * v + 2], alb, nrm);
+                    p.stage_albedo[(size_t)slot * 512 + v] = alb;
+                    p.stage_normal[(size_t)slot * 512 + v] = nrm;
+                }
+            }
+            if (threadIdx.x == 0) p.brick_flags[brick] = 1u;
+        } else {
+            unsigned long long* __restrict__ g = p.acc2 + (size_t)mi * 1024;
+            unsigned long long* __restrict__ ga = ATTR ? p.acc2_attr + (size_t)mi * 1536 : nullptr;
+            for (uint32_t v = threadIdx.x; v < 512u; v += blockDim.x) {
+                const unsigned long long a1 = acc[2 * v + 1];
+                if ((a1 >> 32) == 0ull) continue;                    // no fragment of this chunk in the voxel
+                atomicAdd(&g[2 * v], acc[2 * v]);
+                atomicAdd(&g[2 * v + 1], a1);
+                if (ATTR) {
+                    atomicAdd(&ga[3 * v], acc_attr[3 * v]);
+                    atomicAdd(&ga[3 * v + 1], acc_attr[3 * v + 1]);
+                    atomicAdd(&ga[3 * v + 2], acc_attr[3 * v + 2]);
+                }
+            }
+            // (k_vox_resolve_multi, the next launch, turns the sums into texels: a "last chunk resolves" scheme needs a
+            // device-scope release / acquire pair per workgroup, which on this GPU is a write-back and an invalidate of the
+            // XCD's L2 -- measured: the pass four times slower)
+        }
+        __syncthreads();           // the accumulators are re-zeroed for the next work item of this workgroup
+    }
+}
+
+// the multi-chunk slots of the pass: sums -> texels (+ attributes), accumulators back to zero
+template <bool ATTR>
+__global__ void __launch_bounds__(256)
+k_vox_resolve_multi(const VctVoxParams p, const uint32_t* __restrict__ multi_slot, uint32_t nmulti) {
+    for (uint32_t mi = blockIdx.x; mi < nmulti; mi += gridDim.x) {
+        const uint32_t slot = multi_slot[mi];
+        unsigned long long* __restrict__ g = p.acc2 + (size_t)mi * 1024;
+        unsigned long long* __restrict__ ga = ATTR ? p.acc2_attr + (size_t)mi * 1536 : nullptr;
         for (uint32_t v = threadIdx.x; v < 512u; v += blockDim.x) {
-            const ulonglong2 a = make_ulonglong2(acc[2 * v], acc[2 * v + 1]);
-            out[v] = resolve_voxel(a);
+            const ulonglong2 a = make_ulonglong2(g[2 * v], g[2 * v + 1]);
+            p.stage[(size_t)slot * 512 + v] = resolve_voxel(a);
+            const bool any = (a.y >> 32) != 0ull;
+            if (any) { g[2 * v] = 0ull; g[2 * v + 1] = 0ull; }
             if (ATTR) {
-                const uint32_t c = (uint32_t)(a.y >> 32);
                 uint32_t alb = 0u, nrm = 0u;
-                if (c) {
-                    const unsigned long long q0 = acc_attr[3 * v], q1 = acc_attr[3 * v + 1], q2 = acc_attr[3 * v + 2];
-                    const uint32_t h = c >> 1;
-                    alb = (((uint32_t)q0 + h) / c) | ((((uint32_t)(q0 >> 32) + h) / c) << 8) |
-                          ((((uint32_t)q1 + h) / c) << 16) | 0xff000000u;
-                    nrm = (((uint32_t)(q1 >> 32) + h) / c) | ((((uint32_t)q2 + h) / c) << 8) |
-                          ((((uint32_t)(q2 >> 32) + h) / c) << 16) | 0xff000000u;
+                if (any) {
+                    resolve_attr((uint32_t)(a.y >> 32), ga[3 * v], ga[3 * v + 1], ga[3 * v + 2], alb, nrm);
+                    ga[3 * v] = 0ull; ga[3 * v + 1] = 0ull; ga[3 * v + 2] = 0ull;
                 }
                 p.stage_albedo[(size_t)slot * 512 + v] = alb;
                 p.stage_normal[(size_t)slot * 512 + v] = nrm;
             }
         }
-        if (threadIdx.x == 0) p.brick_flags[brick] = 1u;
-        __syncthreads();           // the accumulators are re-zeroed for the next slot of this workgroup
+        if (threadIdx.x == 0) p.brick_flags[p.slot_brick[slot]] = 1u;
     }
 }
 
@@ -817,10 +875,15 @@ hipError_t vct_launch_voxelize_reference(const VctVoxParams& p, int32_t* big_lis
 }
 
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
-    if (p.nslots == 0u) return hipSuccess;
-    const unsigned blocks = p.nslots < 256u * 64u ? p.nslots : 256u * 64u;
+    if (p.nslots == 0u || p.nitems == 0u) return hipSuccess;
+    const unsigned blocks = p.nitems < 256u * 64u ? p.nitems : 256u * 64u;
     if (p.stage_albedo) hipLaunchKernelGGL(k_voxelize_bricks<true>, dim3(blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_voxelize_bricks<false>, dim3(blocks), dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || p.nmulti == 0u) return e;
+    const unsigned mblocks = p.nmulti < 256u * 16u ? p.nmulti : 256u * 16u;
+    if (p.stage_albedo) hipLaunchKernelGGL(k_vox_resolve_multi<true>, dim3(mblocks), dim3(256), 0, s, p, p.multi_slot, p.nmulti);
+    else hipLaunchKernelGGL(k_vox_resolve_multi<false>, dim3(mblocks), dim3(256), 0, s, p, p.multi_slot, p.nmulti);
     return hipGetLastError();
 }
 
