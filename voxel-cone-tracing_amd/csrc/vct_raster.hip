@@ -376,9 +376,15 @@ __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVer
 
 // Work granularity by bounding-box size (the bench scene: half of the visible triangles cover <= 64
 // pixels, 91-100 % <= 256, the largest ~2k; a Cornell wall covers the whole frame):
+#ifndef VCT_RASTER_SMALL
 #define VCT_RASTER_SMALL 16      // <= this many pixels: rasterised inline by the triangle's own thread
+#endif
+#ifndef VCT_RASTER_GROUP
 #define VCT_RASTER_GROUP 256     // <= this many: a 16-lane group (4 sub-triangles per wave), lanes stride the box
+#endif
+#ifndef VCT_RASTER_WAVE
 #define VCT_RASTER_WAVE 4096     // <= this many: one wave, lanes stride the bounding box
+#endif
 #define VCT_RTILE 16             // larger: cut into 16x16-pixel work items by the wave that met the triangle
 
 // Decides how fragments of triangle t are alpha-tested and, for the per-fragment case, loads the texture
