@@ -684,12 +684,12 @@ def stage_roofline(args, gi, counts, trace_ms, trace_bytes, npix):
     upper = sum((V >> l) ** 3 for l in range(3, V.bit_length()))          # levels >= 3: dense (tiny)
     stage_bytes = {
         # triangles in, one depth word per shadow-map texel out
-        "shadow_map_raster": (ntri * 36 + S * S * 4, "fp64 triangle set-up and coverage tests + L2 atomics (latency)"),
+        "shadow_map_raster": (ntri * 36 + S * S * 4, "latency: per-triangle fp64 set-up, then dependent loads and L2 atomics of the coverage loops"),
         # triangles in, per pixel 8 B visibility word + 92 B G-buffer out
         "gbuffer_raster": (ntri * 36 + npix * 100, "L2 atomics (visibility), then ALU + dependent fetches (shade)"),
         # per fragment a 4 B list entry + its triangle's 36 B (re-read per fragment, cache-served: counted once per
         # triangle), per touched brick 2 KiB of staged texels out; accumulation happens in LDS
-        "voxelize": (ntri * 36 + cand * 4 + bricks * 2048, "PCF gathers (texture-address unit) + per-fragment set-up; LDS atomics"),
+        "voxelize": (ntri * 36 + cand * 4 + bricks * 2048, "VALU instructions per fragment (triangle set-up, 25-tap PCF, albedo): ~1,200 per 64 fragments; accumulation in LDS"),
         # per voxel of a touched brick: staged texel read, level-0 texel written
         "inject_resolve": (bricks * 512 * 8, "hbm"),
         # per touched brick 2 KiB read, 1/8 + 1/64 + 1/512 of it written; dense above level 2
