@@ -383,6 +383,42 @@ def test_second_bounce_matches_oracle(vct, oracle, with_shadow):
         check_frame(vct, oracle, ctx, chain0, planes, w, h)
 
 
+def test_second_bounce_visits_brick_zero_once(vct, oracle):
+    """Found by tools/fuzz_gpu.py (seeds 2857, 1268 of round 3): the second bounce walks the voxelizer's brick slots, and a
+    slot that only the mark-only run of the reference-mode voxelizer created (rare: its pixel-centre raster + depth
+    quantisation can name a voxel in a brick the conservative mode does not touch) had no brick recorded -- it read as
+    brick 0, so a scene with content in brick 0 marched that brick's voxels once more per such slot: same chain, too many
+    cone steps.  A soup of the fuzzer's kind that has such a slot (searched on the CPU) + a triangle in the grid's corner."""
+    V = 64
+    r = np.random.default_rng(48)
+    ntri = int(r.integers(50, 400))
+    c = r.uniform(-1300, 1300, (ntri, 1, 3))
+    pos = (c + r.normal(scale=r.choice([10.0, 40.0, 150.0]), size=(ntri, 3, 3))).astype(np.float32)
+    if r.random() < 0.5:
+        pos[: ntri // 8] = np.round(pos[: ntri // 8] / 58.59375) * 58.59375      # vertices on voxel corners
+    mat = r.integers(0, 4, ntri).astype(np.int32)
+    alb = r.uniform(0.05, 1.0, (4, 4)).astype(np.float32)
+    pos[5] = [[-1450.0, -1430.0, -1400.0], [-1250.0, -1440.0, -1350.0], [-1400.0, -1200.0, -1420.0]]
+    p = oracle.default_params(V)
+    sc = oracle.make_scene(pos, mat, alb)
+    l0, want_alb, want_nrm = oracle.voxelize_conservative_attr(p, sc)
+    nb = V // 8
+
+    def bricks(level0):
+        return level0[..., 3].reshape(nb, 8, nb, 8, nb, 8).any(axis=(1, 3, 5))
+    assert l0[:8, :8, :8, 3].any()                               # brick 0 (voxels 0..7 on every axis) holds content
+    assert (bricks(oracle.voxelize_reference(p, sc)) & ~bricks(l0)).any()      # a brick only the reference mode touches
+    chain0 = oracle.build_mips(l0)
+    want_l1, want_steps = oracle.bounce(p, chain0, want_alb, want_nrm, nthreads=8)
+    with make_ctx(vct, V, 8, 8, voxel_attributes=1) as ctx:
+        ctx.upload_triangles(pos, mat, alb)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        assert ctx.stage_counts()["accumulator_bricks"] > int(bricks(l0).sum())     # slots without a conservative fragment
+        ctx.bounce()
+        assert ctx.last_step_count() == want_steps
+        assert np.array_equal(ctx.download_chain(), oracle.build_mips(want_l1))
+
+
 def test_second_bounce_dense_scene_overflows_the_voxel_list(vct, oracle):
     """More than 1/8 of the grid occupied: the compacted list of occupied voxels (capacity V^3 / 8) overflows and the
     bricks that did not fit are marched brick by brick (k_bounce_bricks).  Same level 0, chain and step count."""

@@ -1,5 +1,6 @@
 """ON THE GPU BOX: randomized parity sweep -- many seeds of every stage against its CPU checker.
 Usage: python tools/fuzz_gpu.py [seconds]   (exit code 1 on the first mismatch, with the seed)."""
+import os
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -29,7 +30,7 @@ def rnd_scene(r, ntri):
     return pos, mat, alb
 
 
-seed = 1000
+seed = int(os.environ.get("FUZZ_SEED0", "1000"))      # FUZZ_SEED0=n: start behind seed n (reproduce a reported seed n + 1)
 while time.time() < t_end:
     seed += 1
     r = np.random.default_rng(seed)
@@ -92,8 +93,14 @@ while time.time() < t_end:
         if r.random() < 0.5:
             l1, st = oracle.bounce(p, c0, a_alb, a_nrm, nthreads=8)
             ctx.bounce()
-            if ctx.last_step_count() != st or not np.array_equal(ctx.download_chain(), oracle.build_mips(l1)):
-                fail("bounce", seed)
+            got_steps, got_chain = ctx.last_step_count(), ctx.download_chain()
+            if got_steps != st or not np.array_equal(got_chain, oracle.build_mips(l1)):
+                want = oracle.build_mips(l1)
+                nv = V ** 3
+                bad = np.nonzero((got_chain[:nv] != want[:nv]).reshape(nv, -1).any(1))[0] if got_chain.ndim > 1 else \
+                    np.nonzero(got_chain[:nv] != want[:nv])[0]
+                fail("bounce", seed, f"V={V} ntri={ntri} steps {got_steps} vs {st}; level-0 texels differing: {bad.size}, "
+                                     f"first {bad[:8]} bricks {np.unique(bad[:64] >> 9)}")
             counts["bounce"] += 1
     # ---- raster stages ----
     kind = int(r.integers(0, 4)); w = int(r.integers(8, 640 if BIG else 200)); h = int(r.integers(8, 360 if BIG else 120))

@@ -409,6 +409,7 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     POOL_TRY(hipMemsetAsync(cnt, 0, ns * sizeof(uint32_t), c->stream));
     POOL_TRY(hipMemsetAsync(cursor, 0, ns * sizeof(uint32_t), c->stream));
     POOL_TRY(hipMemsetAsync(slot_brick, 0, ns * sizeof(uint32_t), c->stream));
+    POOL_TRY(vct_launch_slot_bricks(slot, nbricks, slot_brick, c->stream));      // every slot names its brick
     POOL_TRY(vct_launch_frag_count(frags, nfrags, slot, cnt, c->stream));
     std::vector<uint32_t> hcnt(ns, 0u), hfirst(ns + 1, 0u);
     POOL_TRY(hipMemcpyAsync(hcnt.data(), cnt, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

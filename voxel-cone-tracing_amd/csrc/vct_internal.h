@@ -345,6 +345,7 @@ hipError_t vct_launch_resolve(unsigned long long* acc, const uint32_t* brick_slo
                               const uint32_t* stage_albedo, const uint32_t* stage_normal, hipStream_t s);
 // mark[b] != 0 -> slot[b] = next free slot (order irrelevant), else VCT_NO_SLOT; *count = slots handed out
 hipError_t vct_launch_assign_slots(const uint32_t* mark, uint32_t* slot, uint32_t* count, uint32_t nbricks, hipStream_t s);
+hipError_t vct_launch_slot_bricks(const uint32_t* slot, uint32_t nbricks, uint32_t* slot_brick, hipStream_t s);
 // pooled per-voxel attribute -> dense Morton volume (downloads)
 hipError_t vct_launch_unpool(const uint32_t* pooled, const uint32_t* brick_slot, uint32_t* dense, uint32_t nbricks, hipStream_t s);
 hipError_t vct_launch_voxelize_reference(const VctVoxParams& p, int32_t* big_list, int32_t* big_count,

@@ -793,6 +793,17 @@ k_assign_slots(const uint32_t* __restrict__ mark, uint32_t* __restrict__ slot, u
         slot[b] = mark[b] ? atomicAdd(count, 1u) : VCT_NO_SLOT;
 }
 
+// slot -> brick for EVERY slot (k_frag_scatter only names the bricks that hold a conservative fragment; a slot the
+// mark-only run of the reference-mode voxelizer created would keep pointing at brick 0 -- the slot-driven loops of the
+// second bounce then visited brick 0 once per such slot: found by the fuzzer as an over-count of cone steps)
+__global__ void __launch_bounds__(256)
+k_slot_bricks(const uint32_t* __restrict__ slot, uint32_t nbricks, uint32_t* __restrict__ slot_brick) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nbricks; b += gridDim.x * blockDim.x) {
+        const uint32_t s = slot[b];
+        if (s != VCT_NO_SLOT) slot_brick[s] = b;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_unpool(const uint32_t* __restrict__ pooled, const uint32_t* __restrict__ brick_slot, uint32_t* __restrict__ dense,
          uint32_t nbricks) {
@@ -812,6 +823,12 @@ hipError_t vct_launch_assign_slots(const uint32_t* mark, uint32_t* slot, uint32_
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_assign_slots, dim3((nbricks + 255) / 256 < 4096 ? (nbricks + 255) / 256 : 4096), dim3(256), 0, s,
                        mark, slot, count, nbricks);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_slot_bricks(const uint32_t* slot, uint32_t nbricks, uint32_t* slot_brick, hipStream_t s) {
+    hipLaunchKernelGGL(k_slot_bricks, dim3((nbricks + 255) / 256 < 4096 ? (nbricks + 255) / 256 : 4096), dim3(256), 0, s,
+                       slot, nbricks, slot_brick);
     return hipGetLastError();
 }
 
