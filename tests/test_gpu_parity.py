@@ -419,6 +419,47 @@ def test_second_bounce_visits_brick_zero_once(vct, oracle):
         assert np.array_equal(ctx.download_chain(), oracle.build_mips(want_l1))
 
 
+@pytest.mark.parametrize("with_shadow", [False, True])
+def test_heavy_bricks_are_cut_into_chunks(vct, oracle, with_shadow):
+    """The voxelize pass takes a brick slot's fragments heaviest-first and cuts a slot above 4096 fragments into chunks
+    whose LDS sums meet in HBM accumulators, resolved by a second kernel.  8,000 small triangles crowded
+    into a few bricks: slots far above the limit, with voxel attributes, twice in a row (the accumulators must
+    come back to zero), then the second bounce on top."""
+    V = 32
+    r = np.random.default_rng(5)
+    ntri = 8000
+    c = np.array([[[-300.0, 150.0, 420.0]]]) + r.normal(scale=60.0, size=(ntri, 1, 3))
+    pos = (c + r.normal(scale=70.0, size=(ntri, 3, 3))).astype(np.float32)
+    mat = r.integers(0, 5, ntri).astype(np.int32)
+    alb = r.uniform(0.1, 1.0, (5, 4)).astype(np.float32)
+    depth, vp = light_setup(128, 9) if with_shadow else (None, None)
+    p = oracle.default_params(V)
+    sc = oracle.make_scene(pos, mat, alb, shadow_depth=depth, light_vp=vp)
+    l0, want_alb, want_nrm = oracle.voxelize_conservative_attr(p, sc)
+    chain0 = oracle.build_mips(l0)
+    with make_ctx(vct, V, 8, 8, voxel_attributes=1) as ctx:
+        ctx.upload_triangles(pos, mat, alb)
+        if with_shadow:
+            ctx.upload_shadow_map(depth, vp)
+        counts = ctx.stage_counts()
+        assert counts["vox_candidates"] > 4096 * counts["accumulator_bricks"]      # pigeonhole: a slot above the limit
+        for _ in range(2):
+            ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+            assert np.array_equal(ctx.download_chain(), chain0)
+            got_alb, got_nrm = ctx.voxel_attributes()
+            assert np.array_equal(got_alb, want_alb) and np.array_equal(got_nrm, want_nrm)
+        want_l1, want_steps = oracle.bounce(p, chain0, want_alb, want_nrm, nthreads=8)
+        ctx.bounce()
+        assert ctx.last_step_count() == want_steps
+        assert np.array_equal(ctx.download_chain(), oracle.build_mips(want_l1))
+    with make_ctx(vct, V, 8, 8) as ctx:                          # and without attributes
+        ctx.upload_triangles(pos, mat, alb)
+        if with_shadow:
+            ctx.upload_shadow_map(depth, vp)
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        assert np.array_equal(ctx.download_chain(), chain0)
+
+
 def test_second_bounce_dense_scene_overflows_the_voxel_list(vct, oracle):
     """More than 1/8 of the grid occupied: the compacted list of occupied voxels (capacity V^3 / 8) overflows and the
     bricks that did not fit are marched brick by brick (k_bounce_bricks).  Same level 0, chain and step count."""
