@@ -136,4 +136,4 @@ while time.time() < t_end:
         ctx.render_gbuffer(sc.camera_view_proj(cam2, w, h))
         if not np.array_equal(ctx.download_gbuffer().view(np.uint32), gref2.view(np.uint32)): fail("gbuffer raster (2nd pose)", seed)
         counts["raster"] += 1
-print("fuzz ok:", counts, "seeds", seed - 1000)
+print("fuzz ok:", counts, "seeds", counts["trace"], "last seed", seed)
