@@ -55,8 +55,16 @@ __device__ __forceinline__ float4 vct_tex_bilinear(const uint32_t* __restrict__ 
     const float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
     const float fx = floorf(x), fy = floorf(y);
     const float a = x - fx, b = y - fy;
-    auto wrap = [](int i, int n) { const int r = i % n; return r < 0 ? r + n : r; };     // GL_REPEAT
-    const int i0 = wrap((int)fx, W), i1 = wrap((int)fx + 1, W), j0 = wrap((int)fy, H), j1 = wrap((int)fy + 1, H);
+    // GL_REPEAT.  An integer remainder by a run-time divisor is ~25 instructions on this GPU and a bilinear tap used to
+    // take four: the upper index follows from the lower one ((i + 1) mod n = wrap(i) + 1, or 0 at the end), and a size
+    // that is a power of two (most maps) wraps with a mask -- the same integers either way.
+    auto wrap = [](int i, int n) {
+        if ((n & (n - 1)) == 0) return i & (n - 1);
+        const int r = i % n;
+        return r < 0 ? r + n : r;
+    };
+    const int i0 = wrap((int)fx, W), j0 = wrap((int)fy, H);
+    const int i1 = i0 + 1 == W ? 0 : i0 + 1, j1 = j0 + 1 == H ? 0 : j0 + 1;
     const uint32_t p00 = base[(size_t)j0 * W + i0], p10 = base[(size_t)j0 * W + i1];
     const uint32_t p01 = base[(size_t)j1 * W + i0], p11 = base[(size_t)j1 * W + i1];
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
