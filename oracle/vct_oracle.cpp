@@ -276,6 +276,10 @@ void vcto_sample(const vcto_params* p, const uint8_t* chain, const float pos[3],
     sample_voxels(p, chain, v3(pos), lod, out);
 }
 
+void vcto_texture_lod(const vcto_params* p, const uint8_t* chain, const float uvw[3], float lod, float out[4]) {
+    texture_lod(p, chain, uvw[0], uvw[1], uvw[2], lod, out);
+}
+
 int vcto_cone(const vcto_params* p, const uint8_t* chain, const float P[3], const float Nw[3],
               const float dir[3], float tan_half, float out[4]) {
     return cone_trace(p, chain, v3(P), v3(Nw), v3(dir), tan_half, out);

@@ -80,6 +80,9 @@ void vcto_build_mips(uint8_t* chain, int V);
 /* trace.fs:59-66 + [GL] A.2 textureLod with LINEAR_MIPMAP_LINEAR / LINEAR. */
 void vcto_sample(const vcto_params* p, const uint8_t* chain, const float pos[3], float lod,
                  float out[4]);
+/* [GL] A.2 textureLod(VoxelTexture, uvw, lod) alone -- the sampler behind vcto_sample, for tests that evaluate the
+ * reference's shader text through their own GLSL stand-in (tests/test_shader_crosscheck.py). */
+void vcto_texture_lod(const vcto_params* p, const uint8_t* chain, const float uvw[3], float lod, float out[4]);
 /* trace.fs:82-107.  Returns the executed step count. */
 int vcto_cone(const vcto_params* p, const uint8_t* chain, const float P[3], const float Nw[3],
               const float dir[3], float tan_half, float out[4]);

@@ -1,0 +1,156 @@
+"""Independent cross-check of the oracle's gather + composite against the reference's own shader TEXT.
+
+The reference's cone-trace fragment shader (S/VoxelConeTracing.fs) is read from /root/reference at run time -- it is
+never stored in this repository -- rewritten mechanically into C++ (qualifiers dropped, GLSL array constructors ->
+braces, multi-component swizzles -> calls, `discard` -> a flag) and compiled against tests/glsl_shim.h, a minimal
+GLSL stand-in written for this test.  `main()` of the shader then runs on 10^4 random G-buffer pixels next to
+oracle/vct_oracle.cpp vcto_shade_pixel on the same inputs.
+
+What it shows: the oracle's restatement of trace.fs:82-107 (march), :165-228 (frame, 6 + 1 cones, composite, the .rrra
+rule, discard) agrees with the shader as written -- operation by operation but for rounding (the stand-in uses the GLSL
+definitions of normalize / reflect / inverse and no fused multiply-adds; the oracle fixes its own fp32 order).
+What it does NOT show: parity stays UNPINNED -- `textureLod` here is the oracle's own sampler (no GL driver exists in
+this container), the material / height / shadow samplers are per-pixel constants (the G-buffer contract takes those
+fetches as inputs), and nothing in the reference pins a single output value.
+Runs in the build container only: the reference tree does not travel to the GPU box."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_FS = "/root/reference/Voxel_Cone_Tracing_Final/Shader/VoxelConeTracing.fs"
+ORACLE = os.path.join(ROOT, "oracle", "libvct_oracle.so")
+
+HARNESS = r'''
+ShimState g_shim;
+}  // namespace glsl
+extern "C" int vcto_shade_pixel(const void* p, const unsigned char* chain, const float gb[23], float out[4],
+                                unsigned char steps[7], float cones[28]);
+using namespace glsl;
+// gbin [n][23] (bump normal slots ignored: CalcBumpNormal of the shader fills them), spec_raw [n][4], shadow_k [n];
+// outputs: shader colour [n][4], oracle colour [n][4], steps of both [n][7], the G-buffer as fed to the oracle [n][23]
+extern "C" int run_pixels(const void* params, const unsigned char* chain, int V, float G, const float cam[3],
+                          const float light[3], float ambient, float shininess, int n, const float* gbin,
+                          const float* spec_raw, const int* shadow_k, float* out_shader, float* out_oracle,
+                          int* steps_shader, int* steps_oracle, float* gb_used, int* discarded) {
+    VoxelGridWorldSize = G; VoxelDimensions = V; ambientFactor = ambient; Shininess = shininess; Opacity = 1.0f;
+    LightDirection = vec3(light[0], light[1], light[2]);
+    ShadowMapSize = 4096; HeightTextureSize = vec2(64.0, 64.0);
+    DiffuseTexture.which = 0; SpecularTexture.which = 1; MaskTexture.which = 2; HeightTexture.which = 3; ShadowMap.which = 4;
+    for (int i = 0; i < n; ++i) {
+        const float* g = gbin + 23 * i;
+        Position_world = vec3(g[0], g[1], g[2]);
+        Normal_world = vec3(g[3], g[4], g[5]);
+        Tangent_world = vec3(g[6], g[7], g[8]);
+        BiTangent_world = vec3(g[9], g[10], g[11]);
+        CameraDirection_world = vec3(cam[0], cam[1], cam[2]) - Position_world;      // trace.vs:34
+        Position_depth = vec4(0.5, 0.5, 0.5, 1.0);
+        tex = vec2(0.25, 0.75);
+        g_shim = ShimState();
+        g_shim.params = params; g_shim.chain = chain;
+        g_shim.diffuse = vec4(g[15], g[16], g[17], g[18]);
+        g_shim.specular = vec4(spec_raw[4 * i], spec_raw[4 * i + 1], spec_raw[4 * i + 2], spec_raw[4 * i + 3]);
+        g_shim.height = 0.5f;
+        g_shim.shadow_pass = shadow_k[i];
+        color = vec4(-1.0);
+        shader_main();
+        discarded[i] = g_shim.discarded ? 1 : 0;
+        out_shader[4 * i] = color.x; out_shader[4 * i + 1] = color.y; out_shader[4 * i + 2] = color.z; out_shader[4 * i + 3] = color.w;
+        for (int k = 0; k < 7; ++k) steps_shader[7 * i + k] = g_shim.cone_steps[k];
+        if (g_shim.ncones > 7) steps_shader[7 * i] = -1;
+        // the oracle's G-buffer: the same pixel with the shader's own bump normal, the resolved specular colour
+        // (trace.fs:210) and the shader's shadow term as INPUTS (SURVEY.md 8 a5)
+        float gb[23];
+        for (int k = 0; k < 23; ++k) gb[k] = g[k];
+        const mat3 TBN = inverse(transpose(mat3(Tangent_world, BiTangent_world, Normal_world)));
+        const vec3 N = CalcBumpNormal(TBN);
+        gb[12] = N.x; gb[13] = N.y; gb[14] = N.z;
+        const vec4 sp = g_shim.specular;
+        const bool has_gb = length(sp.gb()) > 0.0f;
+        gb[19] = sp.x; gb[20] = has_gb ? sp.y : sp.x; gb[21] = has_gb ? sp.z : sp.x;
+        g_shim.shadow_calls = 0;
+        gb[22] = PCF_Shadow_Mapping(0.002f);
+        for (int k = 0; k < 23; ++k) gb_used[23 * i + k] = gb[k];
+        unsigned char st[7];
+        vcto_shade_pixel(params, chain, gb, out_oracle + 4 * i, st, nullptr);
+        for (int k = 0; k < 7; ++k) steps_oracle[7 * i + k] = st[k];
+    }
+    return 0;
+}
+'''
+
+
+def glsl_to_cpp(src):
+    """The mechanical rewrites; anything else in the text is compiled as it stands."""
+    out = []
+    for line in src.splitlines():
+        if line.lstrip().startswith("#version"):
+            continue
+        line = re.sub(r"^\s*(in|out|uniform)\s+", "", line)                  # storage qualifiers -> plain globals
+        out.append(line)
+    s = "\n".join(out)
+    s = re.sub(r"=\s*float\[\]\s*\(([^;]*)\)\s*;", r"= {\1};", s)           # float[](...)  -> {...}
+    s = re.sub(r"=\s*vec3\[\]\s*\(([^;]*)\)\s*;", r"= {\1};", s, flags=re.S)  # vec3[](...)   -> {...}
+    s = re.sub(r"\.(rgb|gb|rrra|xy)\b", r".\1()", s)                        # multi-component swizzles (reads only)
+    s = re.sub(r"\bdiscard\s*;", "{ g_shim.discarded = true; return; }", s)
+    s = re.sub(r"\bvoid\s+main\s*\(\s*\)", "void shader_main()", s)
+    # instrumentation: count the textureLod calls of each Voxel_Cone_Tracing invocation (= its executed steps)
+    s, k = re.subn(r"(vec4\s+Voxel_Cone_Tracing\s*\([^)]*\)\s*\{)", r"\1 shim_cone_begin();", s)
+    assert k == 1
+    return s
+
+
+@pytest.mark.skipif(not os.path.exists(REF_FS), reason="the reference tree is not present on this box")
+def test_oracle_agrees_with_the_reference_shader_text(tmp_path):
+    import synth
+    from oracle import pyoracle
+    cpp = tmp_path / "shader_gen.cpp"
+    cpp.write_text(f'#include "{ROOT}/tests/glsl_shim.h"\nnamespace glsl {{\n' + glsl_to_cpp(open(REF_FS).read()) + HARNESS)
+    so = tmp_path / "libshader_check.so"
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-w", "-o", str(so), str(cpp),
+                        ORACLE, f"-Wl,-rpath,{os.path.dirname(ORACLE)}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lib = C.CDLL(str(so))
+    for V, seed in ((32, 11), (64, 12)):
+        n = 5000
+        l0 = synth.noise_volume(V, seed=seed)
+        chain = np.ascontiguousarray(pyoracle.build_mips(l0))
+        planes = synth.random_gbuffer(n, seed=seed, discard_frac=0.05)           # [23][n]
+        gb = np.ascontiguousarray(planes.T.astype(np.float32))                   # [n][23]
+        rng = np.random.default_rng(seed)
+        spec_raw = rng.uniform(0.0, 1.0, (n, 4)).astype(np.float32)
+        spec_raw[rng.random(n) < 0.3, 1:3] = 0.0                                 # red-only maps: the .rrra rule (trace.fs:210)
+        shadow_k = rng.integers(0, 26, n).astype(np.int32)
+        p = pyoracle.default_params(V)
+        outs = np.zeros((n, 4), np.float32); outo = np.zeros((n, 4), np.float32)
+        ss = np.zeros((n, 7), np.int32); so_ = np.zeros((n, 7), np.int32)
+        gbu = np.zeros((n, 23), np.float32); disc = np.zeros(n, np.int32)
+        cam = np.array(p.camera_pos, np.float32); light = np.array(p.light_dir, np.float32)
+        rc = lib.run_pixels(C.byref(p), chain.ctypes.data_as(C.c_void_p), C.c_int(V), C.c_float(p.G),
+                            cam.ctypes.data_as(C.c_void_p), light.ctypes.data_as(C.c_void_p), C.c_float(p.ambient_factor),
+                            C.c_float(p.shininess), C.c_int(n), gb.ctypes.data_as(C.c_void_p),
+                            spec_raw.ctypes.data_as(C.c_void_p), shadow_k.ctypes.data_as(C.c_void_p),
+                            outs.ctypes.data_as(C.c_void_p), outo.ctypes.data_as(C.c_void_p),
+                            ss.ctypes.data_as(C.c_void_p), so_.ctypes.data_as(C.c_void_p),
+                            gbu.ctypes.data_as(C.c_void_p), disc.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        live = disc == 0
+        # discard: the shader discards exactly the pixels the oracle does not shade (alpha < 0.5, trace.fs:169-172)
+        assert np.array_equal(disc == 1, gb[:, 18] < np.float32(0.5))
+        assert live.sum() > 0.9 * n
+        # executed steps, cone by cone
+        same = (ss[live] == so_[live]).all(axis=1)
+        print(f"V={V}: {live.sum()} live pixels, step counts differ on {np.count_nonzero(~same)}, steps {so_[live].sum()}")
+        assert same.mean() > 0.999, f"step counts differ on {np.count_nonzero(~same)} of {live.sum()} pixels"
+        a, b = outs[live][same], outo[live][same]
+        rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+        assert rel.max() <= 1e-5, rel.max()
+        # (a pixel whose alpha lands within an ulp of MAX_ALPHA may take one step more in one of the two evaluations --
+        # the stand-in has no fused multiply-add, the oracle's accumulation has: still within the frame tolerance)
+        if (~same).any():
+            assert synth.rel_l2(outs[live][~same], outo[live][~same]) <= 1e-3
+        assert so_[live].sum() > 20 * live.sum()                                # the march really ran

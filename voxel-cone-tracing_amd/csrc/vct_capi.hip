@@ -342,6 +342,25 @@ void glm_voxel_projections(const vct_ctx* c, float proj[48]) {
     }
 }
 
+// Drops the voxelization plan of the previous mesh (slots, sorted fragments, work items, staging pool, pooled
+// attributes, reference-mode accumulators and big-triangle list): everything indexed by the OLD mesh's triangles or
+// slots.  Called by vct_upload_triangles BEFORE any step that can fail, so that a failed upload leaves the context
+// without a plan (vct_voxelize then refuses) instead of with the old mesh's plan over the new mesh's triangles.
+// Level 0 / brick_prev keep describing what the chain shows.
+void drop_voxel_plan(vct_ctx* c) {
+    void** old[] = {(void**)&c->acc, (void**)&c->attr_albedo, (void**)&c->attr_normal, (void**)&c->brick_slot,
+                    (void**)&c->frag_sorted, (void**)&c->slot_first, (void**)&c->slot_brick, (void**)&c->stage,
+                    (void**)&c->stage_albedo, (void**)&c->stage_normal, (void**)&c->vox_items, (void**)&c->vox_acc2,
+                    (void**)&c->vox_acc2_attr, (void**)&c->vox_multi_slot, (void**)&c->ref_big};
+    for (void** q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    c->nslots = 0;
+    c->n_frags = 0;
+    c->n_vox_items = 0;
+    c->n_vox_multi = 0;
+    c->acc_pending = false;
+    c->attrs_valid = false;     // the pooled attributes are indexed by the NEW mesh's slots: nothing resolved into them yet
+}
+
 // Per-mesh brick slots.  The bricks a fragment of this mesh can land in depend only on geometry, V and G (not on the
 // light, the shadow map or the textures), so they are found ONCE per upload -- from the conservative voxelizer's
 // fragment list `frags` and a mark-only run of the reference-mode voxelizer -- and every marked brick gets a slot; the
@@ -352,18 +371,7 @@ void glm_voxel_projections(const vct_ctx* c, float proj[48]) {
 int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
     const uint32_t nbricks = (uint32_t)(nvox / 512);
-    // drop the plan of the previous mesh; level 0 / brick_prev keep describing what the chain shows
-    void** old[] = {(void**)&c->acc, (void**)&c->attr_albedo, (void**)&c->attr_normal, (void**)&c->brick_slot,
-                    (void**)&c->frag_sorted, (void**)&c->slot_first, (void**)&c->slot_brick, (void**)&c->stage,
-                    (void**)&c->stage_albedo, (void**)&c->stage_normal, (void**)&c->vox_items, (void**)&c->vox_acc2,
-                    (void**)&c->vox_acc2_attr, (void**)&c->vox_multi_slot};
-    for (void** q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
-    c->nslots = 0;
-    c->n_frags = 0;
-    c->n_vox_items = 0;
-    c->n_vox_multi = 0;
-    c->acc_pending = false;
-    c->attrs_valid = false;     // the pooled attributes are indexed by the NEW mesh's slots: nothing resolved into them yet
+    drop_voxel_plan(c);         // (vct_upload_triangles already did, before its first fallible step)
     uint32_t *mark = nullptr, *slot = nullptr, *count = nullptr, *cnt = nullptr, *cursor = nullptr;
     uint32_t *sorted = nullptr, *first = nullptr, *slot_brick = nullptr, *stage = nullptr, *stage_albedo = nullptr,
              *stage_normal = nullptr, *attr_albedo = nullptr, *attr_normal = nullptr, *multi_slot = nullptr;
@@ -566,6 +574,13 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     }
     CREATE_TRY(hipEventCreate(&c->ev0));
     CREATE_TRY(hipEventCreate(&c->ev1));
+    {
+        // VCT_RASTER_PATH=binned | direct: the tile-binned visibility (round 4) or the direct form of rounds 2-3 (one
+        // device-scope atomicMin per covered pixel) for both raster passes -- same results.  Unset: the direct form
+        // (the binned one is selected per pass once it wins there; see render_gbuffer_rows_on).
+        const char* rp = getenv("VCT_RASTER_PATH");
+        c->raster_binned = rp && rp[0] == 'b';
+    }
     const int V = cfg->voxel_dim;
     c->nlev = vct_ilog2(V) + 1;
     c->chain_texels = vct_chain_texels(V);
@@ -626,6 +641,10 @@ void vct_destroy(vct_ctx* c) {
                     c->raster_counts[0], c->raster_counts[1], c->raster_items[0], c->raster_items[1], c->raster_recs[0],
                     c->raster_recs[1]};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (int k = 0; k < 2; ++k) {
+        void* bb[] = {c->bin_recs[k], c->bin_entries[k], c->bin_count[k], c->bin_items[k], c->bin_huge[k]};
+        for (void* b : bb) if (b) (void)hipFree(b);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -688,8 +707,11 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     for (int k = 0; k < 2; ++k) {
         if (c->raster_lists[k]) { (void)hipFree(c->raster_lists[k]); c->raster_lists[k] = nullptr; }   // sized by ntri
         if (c->raster_recs[k]) { (void)hipFree(c->raster_recs[k]); c->raster_recs[k] = nullptr; }
+        void** bb[] = {&c->bin_recs[k], (void**)&c->bin_entries[k], (void**)&c->bin_items[k]};
+        for (void** b : bb) if (*b) { (void)hipFree(*b); *b = nullptr; }
+        c->bin_rec_cap[k] = c->bin_entry_cap[k] = c->bin_item_cap[k] = 0u;
     }
-    if (c->ref_big) { (void)hipFree(c->ref_big); c->ref_big = nullptr; }
+    drop_voxel_plan(c);     // before anything below can fail: the old plan indexes the old mesh
     float** frames[4] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit, &c->tri_uv};       // belong to the old mesh
     for (float** f : frames) if (*f) { (void)hipFree(*f); *f = nullptr; }
     if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }           // indexed by the old materials
@@ -731,7 +753,9 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     PLAN_TRY(hipMemcpyAsync(counts, c->plan, sizeof(counts), hipMemcpyDeviceToHost, c->stream));
     PLAN_TRY(hipStreamSynchronize(c->stream));
     const unsigned long long total = (unsigned long long)n_small + counts[2];
-    if (total >= (1ull << 32)) {
+    // counts[3]: one of the 32-bit device counters wrapped while counting (k_vox_plan / k_vox_plan_big flag it) -- the
+    // totals above would then look small
+    if (total >= (1ull << 32) || counts[3] != 0u) {
         (void)hipFree(big_tmp);
         return fail(c, VCT_ERR_INVALID, "vct_upload_triangles: the mesh has 2^32 or more conservative fragments at this grid size");
     }
@@ -776,8 +800,9 @@ int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const fl
 // ---- raster input stages ------------------------------------------------------------------
 
 // Scratch of one raster pass on stream `s`: `pixels` 64-bit visibility words (main draw) or 32-bit ones (depth_only).
-static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s, VctRasterArgs& a) {
+static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, hipStream_t s, VctRasterArgs& a) {
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "no triangles uploaded");
+    const size_t pixels = (size_t)side_w * side_h;
     const int k = depth_only ? 0 : 1;
     if (!depth_only && c->vis_words < pixels) {
         if (c->vis) { (void)hipFree(c->vis); c->vis = nullptr; c->vis_words = 0; }
@@ -785,24 +810,80 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
         c->vis_words = pixels;
         c->raster_dirty[k] = true;
     }
-    if (!c->raster_lists[k]) HIP_TRY(c, hipMalloc(&c->raster_lists[k], (size_t)c->ntri * 4 * sizeof(int32_t)));
-    if (!c->raster_recs[k]) HIP_TRY(c, hipMalloc(&c->raster_recs[k], (size_t)c->ntri * 2 * 96));
-    if (!c->raster_counts[k]) { HIP_TRY(c, hipMalloc(&c->raster_counts[k], 8 * sizeof(uint32_t))); c->raster_dirty[k] = true; }
-    // tile work items: 16x16-pixel pieces of large triangles; pixels/16 entries is ~16x the typical
-    // demand (sum of visible bounding boxes ~ a few frames' worth of pixels); overflow is handled
-    const size_t want_items = pixels / 16 + 4096;
-    if (c->raster_item_capacity[k] < want_items) {
-        if (c->raster_items[k]) { (void)hipFree(c->raster_items[k]); c->raster_items[k] = nullptr; }
-        HIP_TRY(c, hipMalloc(&c->raster_items[k], want_items * sizeof(uint2)));
-        c->raster_item_capacity[k] = (uint32_t)want_items;
+    const bool binned = c->raster_binned;
+    const uint32_t bins = (uint32_t)(((size_t)side_w + 15) / 16 * (((size_t)side_h + 15) / 16));
+    if (binned) {
+        // Scratch of the tile-binned form (vct_raster.hip).  One 160-byte record per visible sub-triangle (back faces are
+        // always culled, a near-clipped triangle is two sub-triangles: ntri + 4096 holds every scene that is not mostly
+        // near-clipped) and one 8-byte entry per (sub-triangle, 16x16 bin) overlap -- 3.3 per visible sub-triangle on the
+        // Bistro-class street at 4K -- plus the bins' counters.  Whatever does not fit takes the huge list or is
+        // rasterised in place (k_bin_setup), so these are sizes, not limits.  ~200 B per triangle and pass kind,
+        // replicated per rank of a multi-GPU frame.
+        const uint32_t want_recs = (uint32_t)c->ntri + 4096u;
+        const size_t want_ent_sz = (size_t)c->ntri * 4 + (size_t)bins * 4 + 65536;
+        const uint32_t want_ent = (uint32_t)(want_ent_sz < 0x7fffffffull ? want_ent_sz : 0x7fffffffull);
+        if (c->bin_rec_cap[k] < want_recs) {
+            if (c->bin_recs[k]) { (void)hipFree(c->bin_recs[k]); c->bin_recs[k] = nullptr; c->bin_rec_cap[k] = 0u; }
+            HIP_TRY(c, hipMalloc(&c->bin_recs[k], (size_t)want_recs * 160));
+            c->bin_rec_cap[k] = want_recs;
+        }
+        if (c->bin_entry_cap[k] < want_ent) {
+            if (c->bin_entries[k]) { (void)hipFree(c->bin_entries[k]); c->bin_entries[k] = nullptr; c->bin_entry_cap[k] = 0u; }
+            HIP_TRY(c, hipMalloc(&c->bin_entries[k], (size_t)want_ent * sizeof(uint2)));
+            c->bin_entry_cap[k] = want_ent;
+        }
+        const uint32_t want_items = bins + c->bin_entry_cap[k] / 512u + 1u;      // sum over bins of ceil(entries / slice)
+        if (c->bin_item_cap[k] < want_items) {
+            if (c->bin_items[k]) { (void)hipFree(c->bin_items[k]); c->bin_items[k] = nullptr; c->bin_item_cap[k] = 0u; }
+            HIP_TRY(c, hipMalloc(&c->bin_items[k], (size_t)want_items * sizeof(uint4)));
+            c->bin_item_cap[k] = want_items;
+        }
+        if (c->bin_bins[k] < bins) {
+            if (c->bin_count[k]) { (void)hipFree(c->bin_count[k]); c->bin_count[k] = nullptr; c->bin_bins[k] = 0u; }
+            HIP_TRY(c, hipMalloc(&c->bin_count[k], (size_t)bins * 2 * VCT_BIN_CSTRIDE * sizeof(uint32_t)));
+            c->bin_bins[k] = bins;
+            c->raster_dirty[k] = true;
+        }
+        if (!c->bin_huge[k]) {
+            HIP_TRY(c, hipMalloc(&c->bin_huge[k], (size_t)(VCT_BIN_HUGE_CAP + 16 + 32) * sizeof(uint32_t)));
+            c->raster_dirty[k] = true;
+        }
+    } else {
+        if (!c->raster_lists[k]) HIP_TRY(c, hipMalloc(&c->raster_lists[k], (size_t)c->ntri * 4 * sizeof(int32_t)));
+        if (!c->raster_recs[k]) HIP_TRY(c, hipMalloc(&c->raster_recs[k], (size_t)c->ntri * 2 * 96));
+        if (!c->raster_counts[k]) { HIP_TRY(c, hipMalloc(&c->raster_counts[k], 8 * sizeof(uint32_t))); c->raster_dirty[k] = true; }
+        // tile work items: 16x16-pixel pieces of large triangles; pixels/16 entries is ~16x the typical
+        // demand (sum of visible bounding boxes ~ a few frames' worth of pixels); overflow is handled
+        const size_t want_items = pixels / 16 + 4096;
+        if (c->raster_item_capacity[k] < want_items) {
+            if (c->raster_items[k]) { (void)hipFree(c->raster_items[k]); c->raster_items[k] = nullptr; }
+            HIP_TRY(c, hipMalloc(&c->raster_items[k], want_items * sizeof(uint2)));
+            c->raster_item_capacity[k] = (uint32_t)want_items;
+        }
     }
     if (c->raster_dirty[k]) {   // first pass, resized buffers, or a pass that failed half way: clear this kind's state once
         if (depth_only) c->shadow_passes = 0u;      // the shadow words restart their epoch cycle with a memset (below)
         else HIP_TRY(c, hipMemsetAsync(c->vis, 0xff, c->vis_words * sizeof(unsigned long long), s));
-        HIP_TRY(c, hipMemsetAsync(c->raster_counts[k], 0, 8 * sizeof(uint32_t), s));
+        if (binned) {
+            HIP_TRY(c, hipMemsetAsync(c->bin_count[k], 0, (size_t)c->bin_bins[k] * 2 * VCT_BIN_CSTRIDE * sizeof(uint32_t), s));
+            HIP_TRY(c, hipMemsetAsync(c->bin_huge[k] + VCT_BIN_HUGE_CAP, 0, (16 + 32) * sizeof(uint32_t), s));
+        } else {
+            HIP_TRY(c, hipMemsetAsync(c->raster_counts[k], 0, 8 * sizeof(uint32_t), s));
+        }
         c->raster_dirty[k] = false;
     }
     memset(&a, 0, sizeof(a));
+    a.binned = binned ? 1 : 0;
+    if (binned) {
+        a.bin_recs = c->bin_recs[k]; a.bin_rec_cap = c->bin_rec_cap[k];
+        a.bin_entries = c->bin_entries[k]; a.bin_entry_cap = c->bin_entry_cap[k];
+        a.bin_count = c->bin_count[k]; a.bin_cursor = c->bin_count[k] + (size_t)c->bin_bins[k] * VCT_BIN_CSTRIDE;
+        a.bin_items = c->bin_items[k]; a.bin_item_cap = c->bin_item_cap[k];
+        a.bin_huge = c->bin_huge[k]; a.bin_huge_cap = VCT_BIN_HUGE_CAP;
+        a.bin_ctr = c->bin_huge[k] + VCT_BIN_HUGE_CAP + 8 * c->bin_set[k];
+        a.bin_next_ctr = c->bin_huge[k] + VCT_BIN_HUGE_CAP + 8 * (c->bin_set[k] ^ 1);
+        c->bin_set[k] ^= 1;
+    }
     a.pos = c->tri_pos;
     a.nrm = c->tri_nrm; a.tan = c->tri_tan; a.bit = c->tri_bit;
     a.material = c->tri_mat;
@@ -813,19 +894,21 @@ static int raster_args(vct_ctx* c, size_t pixels, bool depth_only, hipStream_t s
     a.vis = c->vis;
     a.vis32 = nullptr;          // vct_render_shadow_map points it at the shadow-map words
     a.vis32_ebase = 0u;
-    a.items = c->raster_items[k];
-    // [wave, group, item, -]: the wave and group counters are one 8-byte-aligned pair, k_raster_vis reserves both lists
-    // of a workgroup with a single 64-bit atomic
-    uint32_t* cur = c->raster_counts[k] + 4 * c->raster_set[k];
-    a.wave_list = c->raster_lists[k];
-    a.wave_count = cur;
-    a.group_list = c->raster_lists[k] + (size_t)c->ntri * 2;
-    a.group_count = cur + 1;
-    a.item_count = cur + 2;
-    a.next_counts = c->raster_counts[k] + 4 * (c->raster_set[k] ^ 1);
-    a.recs = c->raster_recs[k];
-    c->raster_set[k] ^= 1;
-    a.item_capacity = c->raster_item_capacity[k];
+    if (!binned) {
+        a.items = c->raster_items[k];
+        // [wave, group, item, -]: the wave and group counters are one 8-byte-aligned pair, k_raster_vis reserves both
+        // lists of a workgroup with a single 64-bit atomic
+        uint32_t* cur = c->raster_counts[k] + 4 * c->raster_set[k];
+        a.wave_list = c->raster_lists[k];
+        a.wave_count = cur;
+        a.group_list = c->raster_lists[k] + (size_t)c->ntri * 2;
+        a.group_count = cur + 1;
+        a.item_count = cur + 2;
+        a.next_counts = c->raster_counts[k] + 4 * (c->raster_set[k] ^ 1);
+        a.recs = c->raster_recs[k];
+        c->raster_set[k] ^= 1;
+        a.item_capacity = c->raster_item_capacity[k];
+    }
     a.tex = textures_of(c);
     return VCT_OK;
 }
@@ -942,7 +1025,7 @@ int vct_render_shadow_map(vct_ctx* c, const float light_vp[16]) {
     }
     c->shadow_size = S;
     VctRasterArgs a;
-    int rc = raster_args(c, (size_t)S * S, true, c->stream, a);
+    int rc = raster_args(c, S, S, true, c->stream, a);
     if (rc) return rc;
     // The pass's atomicMin words ARE the map (vct_internal.h "shadow map words"): epoch 3, 2, 1, 0, then one memset
     // and 3 again -- a new pass overwrites older epochs by itself, readers see them as depth 1.0.
@@ -983,7 +1066,7 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
         return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer_rows: tile-row range outside the frame");
     HIP_TRY(c, hipSetDevice(c->device));
     VctRasterArgs a;
-    int rc = raster_args(c, (size_t)c->cfg.width * c->cfg.height, false, s, a);
+    int rc = raster_args(c, c->cfg.width, c->cfg.height, false, s, a);
     if (rc) return rc;
     hipError_t e = vct_launch_gbuffer_visibility(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, s);
     if (e == hipSuccess && shadow_ready) e = hipStreamWaitEvent(s, shadow_ready, 0);
@@ -995,6 +1078,20 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     c->last_row0 = row0;
     c->last_row1 = row1;
     c->have_gbuffer = true;
+#if defined(VCT_BIN_STATS) && VCT_BIN_STATS
+    if (c->raster_binned && getenv("VCT_BIN_STATS_DUMP")) {       // instrumented builds only (tools/r04_binstats.sh)
+        uint32_t st[48];
+        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, hipMemcpy(st, c->bin_huge[1] + VCT_BIN_HUGE_CAP, sizeof(st), hipMemcpyDeviceToHost));
+        const uint32_t* cur = st + 8 * (c->bin_set[1] ^ 1);
+        fprintf(stderr, "binstats: entries %u records %u items %u huge %u | ", cur[0], cur[1], cur[2], cur[4]);
+        static const char* names[] = {"entries_zrejected", "entries_processed", "steps_hiz_skipped", "steps_run", "frag_inside",
+                                      "frag_cov_open", "frag_queued", "flushes", "frag_fetched", "-", "lanes_inbox", "lanes_open", "steps_with_cov"};
+        for (int k = 0; k < 13; ++k) fprintf(stderr, "%s %u ", names[k], st[16 + k]);
+        fprintf(stderr, "\n");
+        HIP_TRY(c, hipMemset(c->bin_huge[1] + VCT_BIN_HUGE_CAP + 16, 0, 32 * sizeof(uint32_t)));
+    }
+#endif
     return VCT_OK;
 }
 
@@ -1025,7 +1122,7 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         return fail(c, VCT_ERR_INVALID, "vct_voxelize: unknown mode");
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_voxelize: no triangles uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->brick_slot || !c->stage)
+    if (!c->brick_slot || !c->stage || (mode == VCT_VOX_REFERENCE && !c->ref_big))
         return fail(c, VCT_ERR_NOMEM, "vct_voxelize: the voxelization plan of this mesh could not be allocated "
                                       "(vct_upload_triangles reported it)");
     const size_t pool_vox = (size_t)(c->nslots ? c->nslots : 1u) * 512;

@@ -85,6 +85,18 @@ struct vct_ctx {
     bool raster_dirty[2] = {true, true};
     uint2* raster_items[2] = {nullptr, nullptr};
     uint32_t raster_item_capacity[2] = {0, 0};
+    // tile-binned visibility (vct_raster.hip): scratch per pass kind ([0] shadow pass, [1] main draw), see VctRasterArgs
+    bool raster_binned = false;                        // VCT_RASTER_PATH=binned at vct_create: the tile-binned form for both passes
+    void* bin_recs[2] = {nullptr, nullptr};
+    uint32_t bin_rec_cap[2] = {0, 0};
+    uint2* bin_entries[2] = {nullptr, nullptr};
+    uint32_t bin_entry_cap[2] = {0, 0};
+    uint32_t* bin_count[2] = {nullptr, nullptr};       // count + cursor, [2 * bins * VCT_BIN_CSTRIDE]
+    uint32_t bin_bins[2] = {0, 0};
+    uint4* bin_items[2] = {nullptr, nullptr};
+    uint32_t bin_item_cap[2] = {0, 0};
+    uint32_t* bin_huge[2] = {nullptr, nullptr};        // huge list [VCT_BIN_HUGE_CAP] + two counter sets [16] behind it
+    int bin_set[2] = {0, 0};
     // second stream: vct_gi_pass runs the G-buffer raster beside the voxel stages
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_shadow = nullptr, ev_join = nullptr;
@@ -101,7 +113,7 @@ struct vct_ctx {
     void* vox_items = nullptr;         // [n_vox_items] uint4 work items of the voxelize pass (VctVoxParams::items)
     uint32_t n_vox_items = 0;
     uint32_t vox_chunk = VCT_VOX_CHUNK;
-    unsigned long long* vox_acc2 = nullptr;       // accumulators of the multi-chunk slots (+ attributes), arrival counters
+    unsigned long long* vox_acc2 = nullptr;       // HBM accumulators of the multi-chunk slots (+ attributes): chunks add, k_vox_resolve_multi resolves and re-zeroes
     unsigned long long* vox_acc2_attr = nullptr;
     uint32_t* vox_multi_slot = nullptr;          // [n_vox_multi] slot of every multi-chunk slot
     uint32_t n_vox_multi = 0;

@@ -154,6 +154,8 @@ struct __attribute__((packed, aligned(4))) VctWords6 { uint32_t v[6]; };
 // dwordx4 + dwordx4 + dword instead of nine dword loads -- same reason.
 struct __attribute__((packed, aligned(4))) VctTri9 { float v[9]; };
 
+#define VCT_BIN_CSTRIDE 32          // words between the counters of two bins (vct_raster.hip)
+#define VCT_BIN_HUGE_CAP 1024u      // records the tile-binned raster lets every bin scan (vct_raster.hip k_bin_setup)
 #define VCT_NO_SLOT 0xffffffffu
 #define VCT_TILE 8
 #define VCT_TILE_PIX 64
@@ -309,6 +311,22 @@ struct VctRasterArgs {
     uint32_t* next_counts;       // [3] the other counter set (item, wave, group): zeroed by this pass for the next
     void* recs;                  // [2 * ntri] 96-byte set-up records of the listed sub-triangles (vct_raster.hip SubTriRec)
     VctTextures tex;             // material textures + texture coordinates (G-buffer pass)
+    // Tile-binned visibility (vct_raster.hip "Tile-binned visibility"; binned == 0: the direct form above).  Scratch of
+    // one pass kind: records, (bin, record) pairs, per-bin entry ranges, work items, the list of huge records, and two
+    // alternating sets of eight counters (a pass zeroes the other set; bin_count is left zero by k_bin_alloc).
+    int32_t binned;
+    void* bin_recs;              // [bin_rec_cap] 160-byte BinRec
+    uint32_t bin_rec_cap;
+    uint2* bin_entries;          // [bin_entry_cap] one per (sub-triangle, 16x16 bin) overlap
+    uint32_t bin_entry_cap;
+    uint32_t* bin_count;         // [bins * VCT_BIN_CSTRIDE] (a bin's counter has a cache line to itself)
+    uint32_t* bin_cursor;        // [bins * VCT_BIN_CSTRIDE]
+    uint4* bin_items;            // [bin_item_cap]
+    uint32_t bin_item_cap;
+    uint32_t* bin_huge;          // [bin_huge_cap]
+    uint32_t bin_huge_cap;
+    uint32_t* bin_ctr;           // [8] this pass's counters
+    uint32_t* bin_next_ctr;      // [8] the next pass's
 };
 
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, hipStream_t s);

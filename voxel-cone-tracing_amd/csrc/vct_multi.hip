@@ -357,13 +357,18 @@ int vct_comm_sync(vct_ctx* c) {
     if (!m) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_sync: call vct_comm_init first");
     if (m->broken) return vct_fail(c, VCT_ERR_DEVICE, "vct_comm_sync: the communicator was aborted");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // BOTH streams are polled under the deadline: with frames issued back to back the context stream itself waits on
+    // gathered[k] (vct_frame_step), i.e. behind a collective a dead peer never finishes -- a blocking
+    // hipStreamSynchronize(c->stream) here would hang before the deadline loop was ever reached.
+    // After the abort below the stuck collective's kernel ends, its event completes and both streams drain.
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
     while (true) {
+        const hipError_t qc = hipStreamQuery(c->stream);
+        if (qc != hipSuccess && qc != hipErrorNotReady) HIP_TRY(c, qc);
         const hipError_t q = hipStreamQuery(m->comm_stream);
-        if (q == hipSuccess) return VCT_OK;
-        if (q != hipErrorNotReady) HIP_TRY(c, q);
+        if (q == hipSuccess && qc == hipSuccess) return VCT_OK;
+        if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(c, q);
         ncclResult_t async = ncclSuccess;
         if (m->comm && rccl()->CommGetAsyncError && rccl()->CommGetAsyncError(m->comm, &async) == ncclSuccess &&
             async != ncclSuccess && async != ncclInProgress)

@@ -18,6 +18,7 @@
 // shading pass then re-derives the winning fragment from its triangle; nothing per-fragment is
 // stored besides the 8-byte visibility word (4 bytes of depth in the shadow pass).  A pass is two dependent launches
 // (k_raster_vis, k_raster_mid) and no clear: consumers reset the words they read, the counters alternate.
+#include <stddef.h>
 #include <string.h>
 
 #include "vct_internal.h"
@@ -725,6 +726,639 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
     }
 }
 
+
+// ====================================================================================================================
+// Tile-binned visibility (round 4; SURVEY.md 8 f1 / f2, R/Voxel_Cone_Tracing.h:146-190,192-211).
+//
+// The direct form above resolves visibility with one L2 atomicMin per covered pixel and pays, per listed sub-triangle
+// and 16-lane group, for a set-up that every lane repeats.  On the Bistro-class street (BASELINE configs[4]: 1.27 M
+// visible sub-triangles whose bounding boxes add up to 305 M pixels at 4K, 80 % of them alpha-tested foliage) that was
+// 2.4 of the 3.45 ms G-buffer pass.  The binned form is four dependent launches:
+//
+//   k_bin_setup   one thread per triangle: clip, cull, set up (exactly as k_raster_vis), write ONE 160-byte record per
+//                 visible sub-triangle -- plane equations of the three edge functions, reciprocal area, depths, 1/w,
+//                 alpha-test state -- and count it into every 16x16-pixel bin its bounding box overlaps (fire-and-
+//                 forget atomics on counters a cache line apart).  Sub-triangles over more than VCT_BIN_INLINE bins
+//                 are counted by the whole wave, those over more than VCT_BIN_HUGE (a Cornell wall) go to a short
+//                 list that every bin scans.
+//   k_bin_alloc   one thread per bin: its range of the entry array (wave-aggregated cursor), its work items -- slices of
+//                 at most VCT_BIN_SLICE entries -- and the bin counter back to zero.
+//   k_bin_fill    one thread per record: an 8-byte entry (sort key | quadrants touched | record) into each of its bins.
+//   k_bin_raster  one workgroup per work item; wave w owns the 8x8-pixel quadrant w of the bin, LANE = PIXEL.  The
+//                 entries ARE the sort keys: opaque first, then alpha-tested front to back by a lower bound of the
+//                 sub-triangle's depth (bitonic in LDS, only when the slice has alpha-tested entries).  Records are
+//                 gathered into LDS 64 at a time by the whole workgroup (one round trip per chunk instead of one per
+//                 entry) and read back as broadcasts: the coverage test of 64 pixels is nine fp64 operations on
+//                 wave-uniform operands instead of a per-lane set-up.  A pixel's visibility word lives in ITS lane's
+//                 registers: no atomic, and the early depth test in front of the alpha fetch costs nothing.  An entry
+//                 whose depth bound lies behind everything the quadrant already shows is dropped before its record is
+//                 touched.  texture()'s implicit derivatives are what they are in hardware: the quad neighbours' own
+//                 interpolations, exchanged by DPP (lanes are laid out so that a 2x2 quad is four consecutive lanes)
+//                 -- the same numbers as the oracle's helper invocations, because a lane evaluates the identical
+//                 expression at its own centre.  One plain 8-byte store per visible pixel at the end (atomicMin only
+//                 where several slices share a bin).
+//
+// Every arithmetic step that decides a result (snapping, edge functions, barycentrics, depth, alpha) is the code of the
+// direct form, so the two are bit-identical; VCT_RASTER_PATH=direct keeps the old path selectable for A/B runs.
+#define VCT_BIN 16
+#define VCT_BIN_SHIFT 4
+#define VCT_BIN_SLICE 512           // entries per work item of k_bin_raster (LDS: 4 KiB of sort keys)
+#define VCT_BIN_CHUNK 64            // records staged in LDS at a time (10 KiB)
+#define VCT_BIN_INLINE 16           // bins a thread counts / fills by itself
+#define VCT_BIN_HUGE 2048           // above: the record goes to the huge list instead of one entry per bin
+// VCT_BIN_CSTRIDE (vct_internal.h): words between two bins' counters -- device-scope atomics on one line queue up
+
+struct BinRec {
+    double ea[3], eb[3], ec[3];     // fast: e_k(cx, cy) = ea*cx + eb*cy + ec (top-left bias folded in); general: sx[3], sy[3], -
+    double area, rcp;
+    float sz[3], iw[3];
+    float tu[3], tv[3];
+    uint32_t id;                    // triangle * 2 + sub-triangle: the tie-breaker of the visibility word
+    uint32_t pad;
+    // the next four are one aligned 16-byte word: all k_bin_fill reads of a record
+    uint32_t flags;                 // 0-1 alpha_mode, 2-26 texture + 1, 27 "has per-bin entries", 28-30 "edge k does not own its boundary", 31 fast form
+    uint32_t xx, yy;                // x0 | x1 << 16, y0 | y1 << 16 (clipped to the frame and the scissor)
+    uint32_t zmin_bits;             // float bits of a lower bound of every depth the sub-triangle can produce (>= 0)
+};
+static_assert(sizeof(BinRec) == 160, "BinRec is staged as ten 16-byte words");
+static_assert(offsetof(BinRec, flags) == 144, "flags / xx / yy / zmin_bits are read as one dwordx4");
+#define VCT_BINREC_BINNED 0x08000000u
+
+struct BinParams {
+    RasterParams r;
+    BinRec* recs;
+    uint32_t rec_cap;
+    uint2* entries;                 // [entry_cap] (record | quadrants << 28, alpha-tested << 31 | depth bound), bin after bin
+    uint32_t entry_cap;
+    uint32_t* bin_count;            // [nbins * VCT_BIN_CSTRIDE] zero between passes
+    uint32_t* bin_cursor;           // [nbins * VCT_BIN_CSTRIDE]
+    uint4* items;                   // (bin, first entry, entries, flags: 1 = the bin has several slices, 2 = first slice)
+    uint32_t item_cap;
+    uint32_t* huge;                 // records every bin scans
+    uint32_t huge_cap;
+    // [0] entries promised, [1] records (one 64-bit word), [2] items, [3] entry cursor (one 64-bit word), [4] huge
+    // records, [5] "something was rasterised in place" (capacity overflow): k_bin_raster must merge with atomicMin
+    uint32_t* ctr;
+    uint32_t* next_ctr;             // the other counter set: zeroed by this pass for the next
+    int32_t bins_x, bins_y;
+};
+
+__device__ __forceinline__ void pack_binrec(const SubTri& s, int id, bool binned, BinRec& r) {
+    FastEdges fe;
+    make_fast(s, fe);
+    uint32_t nb = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (fe.ok) { r.ea[k] = fe.a[k]; r.eb[k] = fe.b[k]; r.ec[k] = fe.c[k]; }
+        else { r.ea[k] = s.sx[k]; r.eb[k] = s.sy[k]; r.ec[k] = 0.0; }
+        if (fe.bias[k] != 0.0) nb |= 1u << (28 + k);
+        r.sz[k] = s.sz[k]; r.iw[k] = s.iw[k];
+        r.tu[k] = s.alpha_mode == 2 ? s.tu[k] : 0.0f; r.tv[k] = s.alpha_mode == 2 ? s.tv[k] : 0.0f;
+    }
+    r.area = s.area;
+    r.rcp = fe.rcp;
+    r.id = (uint32_t)id;
+    r.pad = 0u;
+    r.flags = (uint32_t)s.alpha_mode | ((uint32_t)(s.tex + 1) << 2) | nb | (fe.ok ? 0x80000000u : 0u) | (binned ? VCT_BINREC_BINNED : 0u);
+    r.xx = (uint32_t)s.x0 | ((uint32_t)s.x1 << 16);
+    r.yy = (uint32_t)s.y0 | ((uint32_t)s.y1 << 16);
+    // z = b0*sz0 + b1*sz1 + b2*sz2 with b0, b1 in [0, 1] and b2 = 1 - b0 - b1 >= -2^-23: within 1e-6 of a convex
+    // combination for |sz| <= 2; the bound is only used to DROP entries that cannot win, so it errs low
+    const float lo = fminf(fminf(s.sz[0], s.sz[1]), s.sz[2]);
+    const float lb = (lo > -2.0f && lo < 2.0f) ? lo - 4e-6f : 0.0f;
+    r.zmin_bits = lb > 0.0f ? __float_as_uint(lb) : 0u;
+}
+
+#ifndef VCT_BINSETUP_MIN_BLOCKS
+#define VCT_BINSETUP_MIN_BLOCKS 3
+#endif
+__global__ void __launch_bounds__(256, VCT_BINSETUP_MIN_BLOCKS)
+k_bin_setup(const BinParams p) {
+    __shared__ uint32_t lds_cnt[4][2];
+    __shared__ unsigned long long lds_base;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p.next_ctr[k] = 0u;
+    }
+    const bool valid = t < p.r.ntri;
+    RVert in[3];
+    ClipPoly poly;
+    poly.n = 0;
+    bool whole = false;
+    if (valid) {
+        load_clip_tri(p.r, t, in);
+        whole = unclipped(in);
+        poly.n = 3;
+        if (!whole) clip_near(in, poly);
+    }
+    if (whole || !valid) {
+        poly.p0.v.c[0] = poly.p0.v.c[1] = poly.p0.v.c[2] = poly.p0.v.c[3] = 0.0f;
+        poly.p0.a = 0; poly.p0.b = -1; poly.p0.t = 0.0f;
+        poly.p1 = poly.p0; poly.p2 = poly.p0; poly.p3 = poly.p0;
+    }
+    // sub-triangles whose bins the wave counts together (more than VCT_BIN_INLINE): first bin, bins per row | bins
+    unsigned long long coop[2] = {0ull, 0ull};
+    uint32_t coop_b0[2] = {0u, 0u}, coop_wn[2] = {0u, 0u};
+    uint32_t in_place = 0u;       // sub-triangles that found neither a record, entry room nor a slot of the huge list
+#pragma unroll
+    for (int f = 1; f <= 2; ++f) {
+        const int id = t * 2 + (f - 1);
+        bool have = false;
+        SubTri s;
+        s.ok = false;
+        if (valid && f + 1 < poly.n) {
+            const FanTri fan = fan_tri(poly, f);
+            if (whole) setup_subtri(&in[0], &in[1], &in[2], p.r.W, p.r.H, p.r.ys0, p.r.ys1, s);
+            else setup_subtri(&fan.v[0].v, &fan.v[1].v, &fan.v[2].v, p.r.W, p.r.H, p.r.ys0, p.r.ys1, s);
+            if (s.ok) setup_alpha(p.r, t, whole ? nullptr : &fan, s);
+            have = s.ok && s.alpha_mode != 1;
+        }
+        int bx0 = 0, by0 = 0, bw = 0, nb = 0;
+        if (have) {
+            bx0 = s.x0 >> VCT_BIN_SHIFT; by0 = s.y0 >> VCT_BIN_SHIFT;
+            bw = (s.x1 >> VCT_BIN_SHIFT) - bx0 + 1;
+            nb = bw * ((s.y1 >> VCT_BIN_SHIFT) - by0 + 1);
+        }
+        const uint32_t np = (have && nb <= VCT_BIN_HUGE) ? (uint32_t)nb : 0u;      // entries this sub-triangle asks for
+        // Reservation of the record and of room in the entry array.  Returning atomics on one address execute one
+        // after the other (~11 ns each): one 64-bit atomic per WORKGROUP (entries low, records high) for the first
+        // sub-triangle; the second exists for near-clipped triangles only and keeps a per-wave reservation.
+        const unsigned long long mh = __builtin_amdgcn_ballot_w64(have);
+        uint32_t incl = np;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const uint32_t wave_ent = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t rslot, eslot;
+        if (f == 1) {
+            if (lane == 0) { lds_cnt[wv][0] = wave_ent; lds_cnt[wv][1] = (uint32_t)__popcll(mh); }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t te = 0u, tr = 0u;
+                for (int w = 0; w < 4; ++w) { te += lds_cnt[w][0]; tr += lds_cnt[w][1]; }
+                lds_base = (te | tr) ? atomicAdd(reinterpret_cast<unsigned long long*>(p.ctr),
+                                                 (unsigned long long)te | ((unsigned long long)tr << 32)) : 0ull;
+            }
+            __syncthreads();
+            const unsigned long long base = lds_base;
+            uint32_t eb = (uint32_t)base, rb = (uint32_t)(base >> 32);
+            for (int w = 0; w < wv; ++w) { eb += lds_cnt[w][0]; rb += lds_cnt[w][1]; }
+            eslot = eb + incl - np;
+            rslot = rb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u));
+        } else {
+            unsigned long long base = 0ull;
+            if (mh != 0ull) {       // wave-uniform
+                if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned long long*>(p.ctr),
+                                                (unsigned long long)wave_ent | ((unsigned long long)__popcll(mh) << 32));
+                base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+            }
+            eslot = (uint32_t)base + incl - np;
+            rslot = (uint32_t)(base >> 32) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u));
+        }
+        bool wave_bins = false;
+        if (have) {
+            if (rslot >= p.rec_cap) {
+                in_place |= 1u << (f - 1);
+            } else {
+                // the promise of entry room holds when the whole promised range lies inside the array: then every
+                // entry k_bin_fill writes for this record has a place (the bins' ranges are packed by k_bin_alloc)
+                const bool room = np != 0u && eslot + np <= p.entry_cap && eslot + np >= eslot;
+                bool listed = false;
+                if (!room) {                                             // huge, or the entry array is full
+                    const uint32_t h = atomicAdd(&p.ctr[4], 1u);
+                    if (h < p.huge_cap) { p.huge[h] = rslot; listed = true; }
+                }
+                pack_binrec(s, id, room, p.recs[rslot]);
+                if (room) {
+                    if (nb <= VCT_BIN_INLINE) {
+                        int bx = 0, by = 0;
+                        for (int j = 0; j < nb; ++j) {
+                            const uint32_t bin = (uint32_t)((by0 + by) * p.bins_x + bx0 + bx);
+                            atomicAdd(&p.bin_count[(size_t)bin * VCT_BIN_CSTRIDE], 1u);        // result unused: no round trip
+                            if (++bx == bw) { bx = 0; ++by; }
+                        }
+                    } else {
+                        wave_bins = true;
+                        coop_b0[f - 1] = (uint32_t)bx0 | ((uint32_t)by0 << 16);
+                        coop_wn[f - 1] = (uint32_t)bw | ((uint32_t)nb << 16);
+                    }
+                } else if (!listed) {
+                    in_place |= 1u << (f - 1);
+                }
+            }
+        }
+        coop[f - 1] = __builtin_amdgcn_ballot_w64(wave_bins);
+    }
+    // sub-triangles over many bins, one after the other, 64 bins per step
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        unsigned long long pending = coop[k];
+        while (pending != 0ull) {
+            const int src = (int)__ffsll((long long)pending) - 1;
+            pending &= pending - 1ull;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)coop_b0[k], src);
+            const uint32_t wn = (uint32_t)__builtin_amdgcn_readlane((int)coop_wn[k], src);
+            const int bx0 = (int)(b0 & 0xffffu), by0 = (int)(b0 >> 16), bw = (int)(wn & 0xffffu), nb = (int)(wn >> 16);
+            for (int j = lane; j < nb; j += 64)
+                atomicAdd(&p.bin_count[(size_t)((by0 + j / bw) * p.bins_x + bx0 + j % bw) * VCT_BIN_CSTRIDE], 1u);
+        }
+    }
+    // Last resort (every capacity exhausted): the owner rasterises in place with global atomics -- correct, slow -- and
+    // raises the flag that makes k_bin_raster merge its words with atomicMin instead of storing them.
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+        if (!((in_place >> k) & 1u)) continue;
+        SubTri s;
+        if (!rebuild_subtri(p.r, t * 2 + k, s)) continue;
+        p.ctr[5] = 1u;
+        const FastEdges fe = slow_edges(s);
+        for (int py = s.y0; py <= s.y1; ++py)
+            for (int px = s.x0; px <= s.x1; ++px) plot<false>(p.r, s, fe, px, py, (unsigned long long)(uint32_t)(t * 2 + k));
+    }
+}
+
+// one thread per bin: entry range, work items, counter reset
+__global__ void __launch_bounds__(256)
+k_bin_alloc(const BinParams p) {
+    const int nbins = p.bins_x * p.bins_y;
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t nhuge = min(p.ctr[4], p.huge_cap);
+    uint32_t n = 0u;
+    bool rows = false;
+    if (bin < nbins) {
+        n = p.bin_count[(size_t)bin * VCT_BIN_CSTRIDE];
+        p.bin_count[(size_t)bin * VCT_BIN_CSTRIDE] = 0u;
+        const int y = (bin / p.bins_x) << VCT_BIN_SHIFT;
+        rows = y < p.r.ys1 && y + VCT_BIN > p.r.ys0;
+    }
+    // a bin without entries still gets one item while the huge list is not empty (a Cornell wall covers every bin)
+    const uint32_t ni = n ? (n + VCT_BIN_SLICE - 1u) / VCT_BIN_SLICE : ((nhuge && rows) ? 1u : 0u);
+    uint32_t in_n = n, in_i = ni;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = __shfl_up(in_n, off), b = __shfl_up(in_i, off);
+        if (lane >= off) { in_n += a; in_i += b; }
+    }
+    const uint32_t tot_n = (uint32_t)__builtin_amdgcn_readlane((int)in_n, 63), tot_i = (uint32_t)__builtin_amdgcn_readlane((int)in_i, 63);
+    unsigned long long base = 0ull;
+    if (tot_i != 0u) {
+        if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned long long*>(p.ctr + 2),
+                                        (unsigned long long)tot_i | ((unsigned long long)tot_n << 32));
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    }
+    const uint32_t ebase = (uint32_t)(base >> 32) + in_n - n, ibase = (uint32_t)base + in_i - ni;
+    if (bin < nbins) p.bin_cursor[(size_t)bin * VCT_BIN_CSTRIDE] = ebase;
+    for (uint32_t sl = 0; sl < ni; ++sl) {
+        const uint32_t at = ibase + sl;
+        const uint32_t cnt = n ? min((uint32_t)VCT_BIN_SLICE, n - sl * VCT_BIN_SLICE) : 0u;
+        if (at < p.item_cap) p.items[at] = make_uint4((uint32_t)bin, ebase + sl * VCT_BIN_SLICE, cnt, (ni > 1u ? 1u : 0u) | (sl == 0u ? 2u : 0u));
+    }
+}
+
+// the entry of record `rec` (header q = flags, xx, yy, zmin_bits) in bin (bx, by): sort key high, quadrants | record low
+__device__ __forceinline__ uint2 bin_entry(uint32_t rec, const uint4& q, int bx, int by, bool depth_only) {
+    const int x0 = (int)(q.y & 0xffffu), x1 = (int)(q.y >> 16), y0 = (int)(q.z & 0xffffu), y1 = (int)(q.z >> 16);
+    const int ox = bx << VCT_BIN_SHIFT, oy = by << VCT_BIN_SHIFT;
+    const bool l = x0 <= ox + 7, r = x1 >= ox + 8, u = y0 <= oy + 7, d = y1 >= oy + 8;      // halves of the bin the box reaches
+    const uint32_t qm = (l && u ? 1u : 0u) | (r && u ? 2u : 0u) | (l && d ? 4u : 0u) | (r && d ? 8u : 0u);
+    const bool alpha = !depth_only && (q.x & 3u) == 2u;
+    return make_uint2((qm << 28) | rec, (alpha ? 0x80000000u : 0u) | q.w);
+}
+
+// one wave per 64 records: its lanes load the headers, then share the records' (record, bin) pairs evenly -- pair k of
+// the wave belongs to the record whose prefix range holds k (binary search over the 64 prefix sums in LDS).  One
+// returning atomic + one 8-byte store per pair and lane, every lane busy whatever the records' bin counts are
+// (a thread looping over its own record's bins waited for each store in turn: 200 us on the street).
+__global__ void __launch_bounds__(256)
+k_bin_fill(const BinParams p) {
+    __shared__ uint32_t s_pre[4][64];
+    __shared__ uint4 s_hdr[4][64];
+    const uint32_t nrec = min(p.ctr[1], p.rec_cap);
+    const bool depth_only = p.r.vis32 != nullptr;
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const uint32_t nround = (nrec + 63u) & ~63u;          // whole waves
+    for (uint32_t rec = blockIdx.x * blockDim.x + threadIdx.x; rec < nround; rec += gridDim.x * blockDim.x) {
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (rec < nrec) q = *reinterpret_cast<const uint4*>(&p.recs[rec].flags);
+        const bool binned = (q.x & VCT_BINREC_BINNED) != 0u;
+        const int bx0 = (int)(q.y & 0xffffu) >> VCT_BIN_SHIFT, by0 = (int)(q.z & 0xffffu) >> VCT_BIN_SHIFT;
+        const int bw = ((int)(q.y >> 16) >> VCT_BIN_SHIFT) - bx0 + 1;
+        const uint32_t nb = binned ? (uint32_t)(bw * (((int)(q.z >> 16) >> VCT_BIN_SHIFT) - by0 + 1)) : 0u;
+        uint32_t incl = nb;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        s_pre[wv][lane] = incl;                        // inclusive: pair k belongs to the first lane with incl > k
+        s_hdr[wv][lane] = q;
+        // (LDS operations of one wave execute in order: no barrier between these writes and the reads below)
+        const uint32_t rec0 = rec - (uint32_t)lane;
+        for (uint32_t k = (uint32_t)lane; k < total; k += 64u) {
+            int lo = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (s_pre[wv][lo + step - 1] <= k) lo += step;
+            const uint4 h = s_hdr[wv][lo];
+            const uint32_t j = k - (lo ? s_pre[wv][lo - 1] : 0u);
+            const int hx0 = (int)(h.y & 0xffffu) >> VCT_BIN_SHIFT, hy0 = (int)(h.z & 0xffffu) >> VCT_BIN_SHIFT;
+            const int hw = ((int)(h.y >> 16) >> VCT_BIN_SHIFT) - hx0 + 1;
+            const int by = hy0 + (int)j / hw, bx = hx0 + (int)j % hw;
+            const uint32_t at = atomicAdd(&p.bin_cursor[(size_t)(by * p.bins_x + bx) * VCT_BIN_CSTRIDE], 1u);
+            if (at < p.entry_cap) p.entries[at] = bin_entry(rec0 + (uint32_t)lo, h, bx, by, depth_only);
+        }
+    }
+}
+
+// edge functions of the sub-triangle at this lane's pixel centre: inside?, and the first two (unbiased) for the
+// barycentrics -- the arithmetic of cover<FAST>, split so that lanes outside the triangle keep their values too
+// (they are the helper invocations of the alpha test's texture fetch)
+template <bool FAST>
+__device__ __forceinline__ bool edges_at(const SubTri& s, const FastEdges& f, int px, int py, double& e0, double& e1) {
+    const double cx = (double)px + 0.5, cy = (double)py + 0.5;
+    double e[3];
+    bool in = true;
+    if (FAST) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) e[k] = fma(f.a[k], cx, fma(f.b[k], cy, f.c[k]));
+        in = !(e[0] < 0.0 || e[1] < 0.0 || e[2] < 0.0);
+        e0 = e[0] + f.bias[0];
+        e1 = e[1] + f.bias[1];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int a = (k + 1) % 3, b = (k + 2) % 3;
+            const double dx = (s.sx[b] - s.sx[a]) * s.sgn, dy = (s.sy[b] - s.sy[a]) * s.sgn;
+            e[k] = dx * (cy - s.sy[a]) - dy * (cx - s.sx[a]);
+            const bool top_left = (dy > 0.0) || (dy == 0.0 && dx < 0.0);
+            if (e[k] < 0.0 || (e[k] == 0.0 && !top_left)) in = false;
+        }
+        e0 = e[0];
+        e1 = e[1];
+    }
+    return in;
+}
+
+__device__ __forceinline__ float dpp_quad_x(float v) {      // the value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_quad_y(float v) {      // the value of lane ^ 2 (quad_perm [2,3,0,1])
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+}
+// maximum over the wave, result uniform (quad permutes, half-row / row mirrors, then the four rows through readlane)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));     // row_half_mirror
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));     // row_mirror
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+#ifndef VCT_BINRASTER_MIN_BLOCKS
+#define VCT_BINRASTER_MIN_BLOCKS 2
+#endif
+#ifndef VCT_BINRASTER_GRID
+#define VCT_BINRASTER_GRID 16384u    // workgroups of k_bin_raster: each strides the work items
+#endif
+#if defined(VCT_BIN_STATS) && VCT_BIN_STATS
+#define BIN_STAT(k, v) do { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); if ((int)(threadIdx.x & 63) == (int)__ffsll((long long)m_) - 1) atomicAdd(&p.huge[p.huge_cap + 16 + (k)], (uint32_t)(v)); } while (0)
+#else
+#define BIN_STAT(k, v) do { } while (0)
+#endif
+#define VCT_VIS_PITCH 17             // words per row of the bin's visibility words in LDS (a quad's two rows on different banks)
+// ceil(1024 / w) for w = 1 .. 8: q / w == (q * kBinInv[w]) >> 10 for q < 64
+__constant__ uint32_t kBinInv[9] = {0u, 1024u, 512u, 342u, 256u, 205u, 171u, 147u, 128u};
+
+// alpha-test queue of ONE wave: fragments that passed coverage and the early depth test, waiting for a FULL wave of
+// texture fetches (a fetch issued per entry ran with one lane in twelve busy on the street's foliage)
+struct BinAlphaQueue {
+    unsigned long long word[64];
+    float uv[64][6];                                      // u, v, du/dx, dv/dx, du/dy, dv/dy
+    uint32_t pix_tex[64];                                 // pixel slot in the bin's words | texture << 16
+};
+
+// fetches the alpha of the queued fragments -- one per lane -- and merges the survivors into the bin's words
+__device__ __forceinline__ void bin_flush_alpha(const BinParams& p, BinAlphaQueue& Q, unsigned long long* vis, int lane, int qn) {
+    BIN_STAT(7, 1);
+    if (lane < qn) {
+        const unsigned long long word = Q.word[lane];
+        const uint32_t pt = Q.pix_tex[lane];
+        unsigned long long* slot = &vis[pt & 0xffffu];
+        if (word < *(volatile unsigned long long*)slot) {       // still in front of what the pixel shows now
+            const float u = Q.uv[lane][0], v = Q.uv[lane][1];
+            float alpha;
+            if (p.r.tex.mips) alpha = vct_tex_sample_lod(p.r.tex, (int)(pt >> 16), u, v, Q.uv[lane][2], Q.uv[lane][3], Q.uv[lane][4], Q.uv[lane][5]).w;
+            else alpha = vct_tex_sample(p.r.tex, (int)(pt >> 16), u, v).w;
+#if defined(VCT_BIN_STATS) && VCT_BIN_STATS
+            { const int n_f = (int)__popcll(__builtin_amdgcn_ballot_w64(true)); BIN_STAT(8, n_f); }
+#endif
+            if (!(alpha < 0.5f)) atomicMin(slot, word);                                       // trace.fs:171 discard
+        }
+    }
+}
+
+template <bool DEPTH_ONLY>
+__global__ void __launch_bounds__(256, VCT_BINRASTER_MIN_BLOCKS)
+k_bin_raster(const BinParams p) {
+    __shared__ unsigned long long s_kv[VCT_BIN_SLICE];
+    __shared__ uint4 s_rec[VCT_BIN_CHUNK * 10];
+    __shared__ unsigned long long s_vis[VCT_BIN * VCT_VIS_PITCH];
+    __shared__ BinAlphaQueue s_q[DEPTH_ONLY ? 1 : 4];
+    const uint32_t nitems = min(p.ctr[2], p.item_cap);
+    const bool any_in_place = p.ctr[5] != 0u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    BinAlphaQueue& Q = s_q[DEPTH_ONLY ? 0 : wave];
+    const uint4* rec16 = reinterpret_cast<const uint4*>(p.recs);
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const uint4 it = p.items[item];
+        const int bin = (int)it.x, n = (int)it.z;
+        const uint32_t first = it.y;
+        const int by = bin / p.bins_x, bx = bin - by * p.bins_x;
+        const int ox = bx << VCT_BIN_SHIFT, oy = by << VCT_BIN_SHIFT;
+        // ---- the slice's entries ARE the sort keys; sorted when the slice holds alpha-tested ones ----
+        int m = 1;
+        while (m < n) m <<= 1;
+        bool alpha_here = false;
+        for (int i = (int)threadIdx.x; i < m && n > 0; i += 256) {
+            unsigned long long kv = ~0ull;
+            if (i < n) {
+                const uint2 e = p.entries[first + (uint32_t)i];
+                kv = ((unsigned long long)e.y << 32) | e.x;
+                alpha_here = alpha_here || (e.y >> 31);
+            }
+            s_kv[i] = kv;
+        }
+        // this thread's pixel of the bin (output, and the "how far does the bin reach" reduction)
+        const int tx = (int)(threadIdx.x & 15), ty = (int)(threadIdx.x >> 4);
+        const bool inscr = ox + tx < p.r.W && oy + ty >= p.r.ys0 && oy + ty < p.r.ys1;
+        s_vis[ty * VCT_VIS_PITCH + tx] = ~0ull;
+        if (__syncthreads_or(alpha_here ? 1 : 0) && n > 1) {     // opaque first, then alpha-tested front to back
+            for (int k = 2; k <= m; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = (int)threadIdx.x; i < m; i += 256) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const unsigned long long a = s_kv[i], b = s_kv[l];
+                            if ((a > b) == ((i & k) == 0)) { s_kv[i] = b; s_kv[l] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        uint32_t zmax = 0xffffffffu;            // bits of the farthest depth the bin shows (all ones while a pixel is open)
+        const uint32_t nh = (it.w & 2u) ? min(p.ctr[4], p.huge_cap) : 0u;
+        const int total = n + (int)nh;
+        int qn = 0;                             // fragments in this wave's alpha queue
+        for (int c0 = 0; c0 < total; c0 += VCT_BIN_CHUNK) {
+            const int cn = min(VCT_BIN_CHUNK, total - c0);
+            // ---- the chunk's records into LDS: ten 16-byte words each, all 256 threads, one round trip ----
+            __syncthreads();        // the previous chunk has been consumed
+            for (int w = (int)threadIdx.x; w < cn * 10; w += 256) {
+                const int j = w / 10, part = w - j * 10;
+                const int i = c0 + j;
+                const uint32_t e = i < n ? ((uint32_t)s_kv[i] & 0x0fffffffu) : p.huge[i - n];
+                s_rec[w] = rec16[(size_t)e * 10 + part];
+            }
+            if (c0 != 0) {          // what the bin shows after the previous chunks (every wave computes the same value)
+                uint32_t far = 0u;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int x2 = lane & 15, y2 = 4 * o + (lane >> 4);
+                    const bool in2 = ox + x2 < p.r.W && oy + y2 >= p.r.ys0 && oy + y2 < p.r.ys1;
+                    const unsigned long long v2 = s_vis[y2 * VCT_VIS_PITCH + x2];
+                    far = max(far, in2 ? (uint32_t)(DEPTH_ONLY ? v2 : v2 >> 32) : 0u);
+                }
+                zmax = wave_max_u32(far);
+            }
+            __syncthreads();
+            // ---- entries of the chunk in turn, one wave each; LANES = the pixels of the entry's box inside the bin,
+            //      quad by quad (a 2x2 quad is four consecutive lanes), 16 quads per step ----
+            for (int j = wave; j < cn; j += 4) {
+                const int i = c0 + j;
+                if (i < n) {
+                    const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s_kv[i] >> 32));
+                    if ((key & 0x7fffffffu) > zmax) { BIN_STAT(0, 1); continue; }              // behind everything the bin shows
+                }
+                const uint4* R = s_rec + j * 10;
+                const uint4 hd = R[9];                                     // flags, xx, yy, zmin_bits
+                const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.x);
+                const uint32_t xx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.y), yy = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.z);
+                const uint32_t zmin_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.w);
+                const int x0 = max((int)(xx & 0xffffu), ox), x1 = min((int)(xx >> 16), ox + VCT_BIN - 1);
+                const int y0 = max((int)(yy & 0xffffu), oy), y1 = min((int)(yy >> 16), oy + VCT_BIN - 1);
+                if (x1 < x0 || y1 < y0 || zmin_bits > zmax) { BIN_STAT(0, 1); continue; }        // (a record of the huge list that misses this bin)
+                BIN_STAT(1, 1);
+                const int qx0 = x0 >> 1, qy0 = y0 >> 1, qw = (x1 >> 1) - qx0 + 1, nq = qw * ((y1 >> 1) - qy0 + 1);
+                const uint32_t inv = kBinInv[qw];
+                const double* D = reinterpret_cast<const double*>(R);      // ea[3], eb[3], ec[3], area, rcp
+                const float* F = reinterpret_cast<const float*>(R) + 22;   // sz[3], iw[3], tu[3], tv[3], id
+                bool loaded = false;
+                SubTri s;
+                FastEdges fe;
+                uint32_t id = 0u;
+                for (int q0 = 0; q0 < nq; q0 += 16) {
+                    const int q = q0 + (lane >> 2);
+                    const int qy = (int)(((uint32_t)q * inv) >> 10), qx = q - qy * qw;
+                    const int px = ((qx0 + qx) << 1) | (lane & 1), py = ((qy0 + qy) << 1) | ((lane >> 1) & 1);
+                    const bool inbox = q < nq && px >= x0 && px <= x1 && py >= y0 && py <= y1;
+                    const int vslot = inbox ? (py - oy) * VCT_VIS_PITCH + (px - ox) : 0;
+                    // Hierarchical depth test of the step: a pixel that already shows something nearer than the
+                    // sub-triangle's nearest point cannot be won -- and where that holds for every pixel of the step
+                    // (the inside of a tree crown after its front layers) the coverage arithmetic is skipped whole.
+                    const unsigned long long cur = *(volatile unsigned long long*)&s_vis[vslot];
+                    const bool open = inbox && (uint32_t)(DEPTH_ONLY ? cur : cur >> 32) >= zmin_bits;
+                    if (__builtin_amdgcn_ballot_w64(open) == 0ull) { BIN_STAT(2, 1); continue; }
+                    BIN_STAT(3, 1);
+                    if (!loaded) {
+                        loaded = true;
+                        s.area = D[9]; s.sgn = 1.0;
+                        fe.rcp = D[10];
+                        fe.ok = (flags >> 31) != 0u;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            s.sz[k] = F[k];
+                            fe.a[k] = D[k]; fe.b[k] = D[3 + k]; fe.c[k] = D[6 + k];
+                            fe.bias[k] = ((flags >> (28 + k)) & 1u) ? 0x1p-16 : 0.0;
+                            s.sx[k] = fe.a[k]; s.sy[k] = fe.b[k];
+                        }
+                        id = __float_as_uint(F[12]);
+                    }
+                    double e0, e1;
+                    const bool in = fe.ok ? edges_at<true>(s, fe, px, py, e0, e1) : edges_at<false>(s, fe, px, py, e0, e1);
+                    const bool cov = in && open;
+#if defined(VCT_BIN_STATS) && VCT_BIN_STATS
+                    { const int n_in = (int)__popcll(__builtin_amdgcn_ballot_w64(in && inbox)), n_box = (int)__popcll(__builtin_amdgcn_ballot_w64(inbox)),
+                                n_open = (int)__popcll(__builtin_amdgcn_ballot_w64(open)), n_cov = (int)__popcll(__builtin_amdgcn_ballot_w64(cov));
+                      BIN_STAT(4, n_in); BIN_STAT(5, n_cov); BIN_STAT(10, n_box); BIN_STAT(11, n_open); }
+#endif
+                    if (__builtin_amdgcn_ballot_w64(cov) == 0ull) continue;
+                    BIN_STAT(12, 1);
+                    const float b0 = (float)div_area(e0, s.area, fe.rcp), b1 = (float)div_area(e1, s.area, fe.rcp);
+                    const float b2 = 1.0f - b0 - b1;
+                    float z = b0 * s.sz[0] + b1 * s.sz[1] + b2 * s.sz[2];
+                    z = z + 0.0f;
+                    bool pass = cov && z >= 0.0f && z < 1.0f;
+                    if (DEPTH_ONLY) {
+                        if (pass) atomicMin(&s_vis[vslot], (unsigned long long)__float_as_uint(z));
+                    } else {
+                        const unsigned long long word = ((unsigned long long)__float_as_uint(z) << 32) | id;
+                        pass = pass && word < cur;             // the exact early depth test (another wave may lower the word meanwhile: the atomic decides)
+                        if ((flags & 3u) != 2u) {
+                            if (pass) atomicMin(&s_vis[vslot], word);
+                            continue;
+                        }
+                        // alpha-tested: into the queue
+                        const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass);
+                        if (mp == 0ull) continue;
+                        // every lane interpolates the texture coordinate at its own centre (helper invocations included)
+                        const float w0 = b0 * F[3], w1 = b1 * F[4], w2 = b2 * F[5];
+                        const float ws = __fdiv_rn(1.0f, w0 + w1 + w2);
+                        const float u = (w0 * F[6] + w1 * F[7] + w2 * F[8]) * ws;
+                        const float v = (w0 * F[9] + w1 * F[10] + w2 * F[11]) * ws;
+                        const float ux = dpp_quad_x(u), vx = dpp_quad_x(v), uy = dpp_quad_y(u), vy = dpp_quad_y(v);
+                        const int cnt = (int)__popcll(mp);
+                        BIN_STAT(6, cnt);
+                        if (qn + cnt > 64) { bin_flush_alpha(p, Q, s_vis, lane, qn); qn = 0; }
+                        if (pass) {
+                            const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mp, 0u));
+                            Q.word[at] = word;
+                            Q.uv[at][0] = u; Q.uv[at][1] = v;
+                            Q.uv[at][2] = ux - u; Q.uv[at][3] = vx - v; Q.uv[at][4] = uy - u; Q.uv[at][5] = vy - v;
+                            Q.pix_tex[at] = (uint32_t)vslot | ((((flags >> 2) & 0x1ffffffu) - 1u) << 16);
+                        }
+                        qn += cnt;
+                    }
+                }
+            }
+            // a fragment waiting in the queue does not yet hide what lies behind it: resolve the fuller queues before the
+            // next chunk's "how far does the bin reach"
+            if (!DEPTH_ONLY && qn >= 32) { bin_flush_alpha(p, Q, s_vis, lane, qn); qn = 0; }
+        }
+        if (!DEPTH_ONLY && qn > 0) { bin_flush_alpha(p, Q, s_vis, lane, qn); qn = 0; }
+        __syncthreads();
+        // ---- one word per visible pixel ----
+        const unsigned long long best = s_vis[ty * VCT_VIS_PITCH + tx];
+        if (inscr && best != ~0ull) {
+            const bool merge = (it.w & 1u) || any_in_place;
+            const size_t pix = (size_t)(oy + ty) * p.r.W + (ox + tx);
+            if (DEPTH_ONLY) {
+                const uint32_t word = vct_depth24_bits(__uint_as_float((uint32_t)best)) + p.r.vis32_ebase;
+                if (merge) atomicMin(&p.r.vis32[pix], word); else p.r.vis32[pix] = word;
+            } else {
+                if (merge) atomicMin(&p.r.vis[pix], best); else p.r.vis[pix] = best;
+            }
+        }
+        __syncthreads();        // s_kv / s_vis are reused by the next item
+    }
+}
+
 // float depths in [0, 1] <-> shadow-map words of epoch base `ebase`
 __global__ void __launch_bounds__(256)
 k_shadow_encode(const float* __restrict__ depth, uint32_t* __restrict__ words, size_t n, uint32_t ebase) {
@@ -1141,13 +1775,43 @@ hipError_t run_visibility(const RasterParams& r, hipStream_t s) {
     return hipGetLastError();
 }
 
+// The tile-binned form of run_visibility: four dependent launches (set-up + pairs, bin ranges + work items, scatter,
+// raster).  Same caller guarantees; the counters of the next pass are zeroed by k_bin_setup, the bins' counters by
+// k_bin_alloc.
+hipError_t run_visibility_binned(const VctRasterArgs& a, const RasterParams& r, hipStream_t s) {
+    BinParams p;
+    p.r = r;
+    p.recs = (BinRec*)a.bin_recs; p.rec_cap = a.bin_rec_cap;
+    p.entries = a.bin_entries; p.entry_cap = a.bin_entry_cap;
+    p.bin_count = a.bin_count; p.bin_cursor = a.bin_cursor;
+    p.items = a.bin_items; p.item_cap = a.bin_item_cap;
+    p.huge = a.bin_huge; p.huge_cap = a.bin_huge_cap;
+    p.ctr = a.bin_ctr; p.next_ctr = a.bin_next_ctr;
+    p.bins_x = (r.W + VCT_BIN - 1) / VCT_BIN;
+    p.bins_y = (r.H + VCT_BIN - 1) / VCT_BIN;
+    if (r.ys1 <= r.ys0 || r.ntri <= 0) return hipMemsetAsync(p.next_ctr, 0, 8 * sizeof(uint32_t), s);
+    const int nbins = p.bins_x * p.bins_y;
+    hipLaunchKernelGGL(k_bin_setup, dim3((r.ntri + 255) / 256), dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bin_alloc, dim3((nbins + 255) / 256), dim3(256), 0, s, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const uint32_t fill_blocks = p.rec_cap / 256u + 1u < 4096u ? p.rec_cap / 256u + 1u : 4096u;
+    hipLaunchKernelGGL(k_bin_fill, dim3(fill_blocks), dim3(256), 0, s, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    const uint32_t raster_blocks = p.item_cap < VCT_BINRASTER_GRID ? p.item_cap : VCT_BINRASTER_GRID;
+    if (r.vis32) hipLaunchKernelGGL(k_bin_raster<true>, dim3(raster_blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_bin_raster<false>, dim3(raster_blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp[16], int S, hipStream_t s) {
     RasterParams r = make_raster(a, light_vp, S, S, 0, S);
     r.vis32 = a.vis32;                                  // depth only, straight into the shadow-map words
     r.vis32_ebase = a.vis32_ebase;
-    return run_visibility(r, s);
+    return a.binned ? run_visibility_binned(a, r, s) : run_visibility(r, s);
 }
 
 hipError_t vct_launch_shadow_encode(const float* depth, uint32_t* words, size_t n, uint32_t ebase, hipStream_t s) {
@@ -1172,7 +1836,7 @@ static ShadeParams make_shade(const VctRasterArgs& a, const float view_proj[16],
 hipError_t vct_launch_gbuffer_visibility(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
                                          hipStream_t s) {
     const ShadeParams p = make_shade(a, view_proj, W, H, row0, row1);
-    return run_visibility(p.r, s);
+    return a.binned ? run_visibility_binned(a, p.r, s) : run_visibility(p.r, s);
 }
 
 hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,

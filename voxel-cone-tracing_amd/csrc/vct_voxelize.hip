@@ -387,7 +387,10 @@ k_vox_plan(const VctVoxParams p, uint32_t* plan, uint2* frags, int32_t* big_list
         if (w < wave) wave_base += wave_tot[w];
         total += wave_tot[w];
     }
-    if (threadIdx.x == 0) block_base = total ? atomicAdd(&plan[0], total) : 0u;
+    if (threadIdx.x == 0) {
+        block_base = total ? atomicAdd(&plan[0], total) : 0u;
+        if (block_base + total < block_base) plan[3] = 1u;      // the 32-bit counter wrapped: the caller rejects the mesh
+    }
     __syncthreads();
     if (big && !WRITE) big_list[atomicAdd(&plan[1], 1u)] = t;      // (capacity ntri: the count pass lists them)
     if (WRITE && chunks) {
@@ -427,7 +430,10 @@ k_vox_plan_big(const VctVoxParams p, const int32_t* __restrict__ big_list, int n
             if (m == 0ull) continue;
             uint32_t base = 0u;
             const int leader = (int)__ffsll((long long)m) - 1;
-            if (lane == leader) base = atomicAdd(&plan[2], (uint32_t)__popcll(m));      // one atomic per wave
+            if (lane == leader) {
+                base = atomicAdd(&plan[2], (uint32_t)__popcll(m));      // one atomic per wave
+                if (base + (uint32_t)__popcll(m) < base) plan[3] = 1u;  // wrapped (see k_vox_plan)
+            }
             base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
             if (WRITE && hit)
                 frags[base + __popcll(m & ((1ull << lane) - 1ull))] =
@@ -462,9 +468,10 @@ k_frag_scatter(const uint2* __restrict__ frags, uint32_t n, const uint32_t* __re
 // ---- the voxelize pass: one workgroup per work item = up to VCT_VOX_CHUNK fragments of one brick slot ------------
 // acc in LDS: [512][2] u64 (sumR | sumG << 32, sumB | count << 32), + [512][3] for the voxel attributes.
 // A slot of one chunk (most) is resolved from LDS by its workgroup.  The chunks of a heavier slot add their non-empty
-// LDS sums to the slot's accumulators in HBM (integer sums: any order gives the same bits) and count themselves in;
-// the last one reads the totals back (device-scope loads: the other chunks' atomics executed outside this CU's
-// caches), resolves, and leaves accumulators and counter zero for the next pass.
+// LDS sums to the slot's accumulators in HBM (acc2 / acc2_attr; integer sums: any order gives the same bits); a SECOND
+// small launch, k_vox_resolve_multi, turns those sums into texels and re-zeroes them for the next pass.  (A "last
+// chunk resolves" variant with an arrival counter needs a device-scope release / acquire per workgroup -- a write-back
+// and invalidate of the XCD's L2 on this GPU -- and ran 4x slower.)
 __device__ __forceinline__ void resolve_attr(uint32_t c, unsigned long long q0, unsigned long long q1, unsigned long long q2,
                                              uint32_t& alb, uint32_t& nrm) {
     alb = 0u; nrm = 0u;
