@@ -3,6 +3,7 @@
 TAG=${1:-a}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 [ "$2" = direct ] && export VCT_RASTER_PATH=direct
+[ -z "$VCT_RASTER_PATH" ] && export VCT_RASTER_PATH=binned
 cd /tmp; export TMPDIR=/tmp
 for cfg in "atrium 1920 1080" "bistro 1920 1080" "bistro 3840 2160"; do
   set -- $cfg

@@ -576,10 +576,11 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     CREATE_TRY(hipEventCreate(&c->ev1));
     {
         // VCT_RASTER_PATH=binned | direct: the tile-binned visibility (round 4) or the direct form of rounds 2-3 (one
-        // device-scope atomicMin per covered pixel) for both raster passes -- same results.  Unset: the direct form
-        // (the binned one is selected per pass once it wins there; see render_gbuffer_rows_on).
+        // device-scope atomicMin per covered pixel) for both raster passes -- same results.  Unset: chosen per scene by
+        // measurement (vct_ctx.h raster_mode).
         const char* rp = getenv("VCT_RASTER_PATH");
-        c->raster_binned = rp && rp[0] == 'b';
+        c->raster_mode = !rp ? 0 : (rp[0] == 'b' ? 2 : (rp[0] == 'd' ? 1 : 0));
+        for (int k = 0; k < 4; ++k) CREATE_TRY(hipEventCreate(&c->ev_auto[k]));
     }
     const int V = cfg->voxel_dim;
     c->nlev = vct_ilog2(V) + 1;
@@ -650,6 +651,7 @@ void vct_destroy(vct_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_shadow) (void)hipEventDestroy(c->ev_shadow);
+    for (int k = 0; k < 4; ++k) if (c->ev_auto[k]) (void)hipEventDestroy(c->ev_auto[k]);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -711,6 +713,7 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
         for (void** b : bb) if (*b) { (void)hipFree(*b); *b = nullptr; }
         c->bin_rec_cap[k] = c->bin_entry_cap[k] = c->bin_item_cap[k] = 0u;
     }
+    c->auto_state = 0; c->auto_choice = -1;       // the raster form is measured again for the new mesh
     drop_voxel_plan(c);     // before anything below can fail: the old plan indexes the old mesh
     float** frames[4] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit, &c->tri_uv};       // belong to the old mesh
     for (float** f : frames) if (*f) { (void)hipFree(*f); *f = nullptr; }
@@ -800,7 +803,7 @@ int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const fl
 // ---- raster input stages ------------------------------------------------------------------
 
 // Scratch of one raster pass on stream `s`: `pixels` 64-bit visibility words (main draw) or 32-bit ones (depth_only).
-static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, hipStream_t s, VctRasterArgs& a) {
+static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, bool binned, hipStream_t s, VctRasterArgs& a) {
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "no triangles uploaded");
     const size_t pixels = (size_t)side_w * side_h;
     const int k = depth_only ? 0 : 1;
@@ -810,7 +813,6 @@ static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, hipS
         c->vis_words = pixels;
         c->raster_dirty[k] = true;
     }
-    const bool binned = c->raster_binned;
     const uint32_t bins = (uint32_t)(((size_t)side_w + 15) / 16 * (((size_t)side_h + 15) / 16));
     if (binned) {
         // Scratch of the tile-binned form (vct_raster.hip).  One 160-byte record per visible sub-triangle (back faces are
@@ -829,7 +831,7 @@ static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, hipS
         }
         if (c->bin_entry_cap[k] < want_ent) {
             if (c->bin_entries[k]) { (void)hipFree(c->bin_entries[k]); c->bin_entries[k] = nullptr; c->bin_entry_cap[k] = 0u; }
-            HIP_TRY(c, hipMalloc(&c->bin_entries[k], (size_t)want_ent * sizeof(uint2)));
+            HIP_TRY(c, hipMalloc(&c->bin_entries[k], ((size_t)want_ent + 1) * sizeof(uint2)));      // + the spare entry k_bin_fill's idle lanes write
             c->bin_entry_cap[k] = want_ent;
         }
         const uint32_t want_items = bins + c->bin_entry_cap[k] / 512u + 1u;      // sum over bins of ceil(entries / slice)
@@ -958,6 +960,8 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
     if (c->tex_desc) { (void)hipFree(c->tex_desc); c->tex_desc = nullptr; }
     if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }
     c->ntex = 0;
+    c->has_alpha_textures = false;
+    c->auto_state = 0; c->auto_choice = -1;
     if (ntex == 0) return VCT_OK;                     // detach: flat colours again
     if (ntex < 0 || !rgba8 || !width || !height || !mat_tex)
         return fail(c, VCT_ERR_INVALID, "vct_upload_textures: null or negative input");
@@ -1009,6 +1013,8 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
     HIP_TRY(c, hipMemcpyAsync(c->mat_tex, mat_tex, (size_t)c->nmat * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ntex = ntex;
+    for (int32_t m = 0; m < c->nmat; ++m)         // a diffuse map with non-opaque texels: its fragments are alpha-tested
+        if (mat_tex[3 * m] >= 0 && (desc[(size_t)mat_tex[3 * m]].flags & 1u)) c->has_alpha_textures = true;
     return VCT_OK;
 }
 
@@ -1025,7 +1031,7 @@ int vct_render_shadow_map(vct_ctx* c, const float light_vp[16]) {
     }
     c->shadow_size = S;
     VctRasterArgs a;
-    int rc = raster_args(c, S, S, true, c->stream, a);
+    int rc = raster_args(c, S, S, true, c->raster_mode == 2, c->stream, a);
     if (rc) return rc;
     // The pass's atomicMin words ARE the map (vct_internal.h "shadow map words"): epoch 3, 2, 1, 0, then one memset
     // and 3 again -- a new pass overwrites older epochs by itself, readers see them as depth 1.0.
@@ -1065,10 +1071,26 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     if (row0 < 0 || row1 > tiles_y(c) || row0 > row1)
         return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer_rows: tile-row range outside the frame");
     HIP_TRY(c, hipSetDevice(c->device));
+    // the form of the visibility stage (vct_ctx.h raster_mode)
+    bool binned = c->raster_mode == 2;
+    int sample = -1;            // 0 / 1: this pass is the timed sample of the direct / the binned form
+    if (c->raster_mode == 0 && c->has_alpha_textures) {
+        if (c->auto_state == 2 && c->auto_choice < 0 && hipEventQuery(c->ev_auto[3]) == hipSuccess) {
+            float td = 0.0f, tb = 0.0f;
+            if (hipEventElapsedTime(&td, c->ev_auto[0], c->ev_auto[1]) == hipSuccess &&
+                hipEventElapsedTime(&tb, c->ev_auto[2], c->ev_auto[3]) == hipSuccess)
+                c->auto_choice = tb < td ? 1 : 0;
+        }
+        const bool whole = row0 == 0 && row1 == tiles_y(c);
+        if (c->auto_choice >= 0) binned = c->auto_choice == 1;
+        else if (whole && c->auto_state < 2) { sample = c->auto_state; binned = sample == 1; }
+    }
     VctRasterArgs a;
-    int rc = raster_args(c, c->cfg.width, c->cfg.height, false, s, a);
+    int rc = raster_args(c, c->cfg.width, c->cfg.height, false, binned, s, a);
     if (rc) return rc;
+    if (sample >= 0) HIP_TRY(c, hipEventRecord(c->ev_auto[2 * sample], s));
     hipError_t e = vct_launch_gbuffer_visibility(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, s);
+    if (sample >= 0 && e == hipSuccess) { e = hipEventRecord(c->ev_auto[2 * sample + 1], s); c->auto_state = sample + 1; }
     if (e == hipSuccess && shadow_ready) e = hipStreamWaitEvent(s, shadow_ready, 0);
     if (e == hipSuccess)
         e = vct_launch_gbuffer_shade(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow, c->shadow_ebase,
@@ -1079,7 +1101,7 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     c->last_row1 = row1;
     c->have_gbuffer = true;
 #if defined(VCT_BIN_STATS) && VCT_BIN_STATS
-    if (c->raster_binned && getenv("VCT_BIN_STATS_DUMP")) {       // instrumented builds only (tools/r04_binstats.sh)
+    if (binned && getenv("VCT_BIN_STATS_DUMP")) {       // instrumented builds only (tools/r04_binstats.sh)
         uint32_t st[48];
         HIP_TRY(c, hipStreamSynchronize(s));
         HIP_TRY(c, hipMemcpy(st, c->bin_huge[1] + VCT_BIN_HUGE_CAP, sizeof(st), hipMemcpyDeviceToHost));

@@ -86,7 +86,15 @@ struct vct_ctx {
     uint2* raster_items[2] = {nullptr, nullptr};
     uint32_t raster_item_capacity[2] = {0, 0};
     // tile-binned visibility (vct_raster.hip): scratch per pass kind ([0] shadow pass, [1] main draw), see VctRasterArgs
-    bool raster_binned = false;                        // VCT_RASTER_PATH=binned at vct_create: the tile-binned form for both passes
+    // Which form the MAIN draw's visibility takes (the shadow pass is opaque and sparse: the direct form won every
+    // measurement).  raster_mode 0 = auto: scenes without alpha-tested textures keep the direct form; otherwise the first
+    // whole-frame pass runs direct, the second binned, both between events, and the faster one is kept until the mesh,
+    // the textures or the frame size change.  1 / 2 = VCT_RASTER_PATH=direct / binned (both passes), for A/B runs.
+    int raster_mode = 0;
+    int auto_state = 0;                                // 0: sample the direct form next, 1: the binned form, 2: both sampled
+    int auto_choice = -1;                              // -1 undecided, 0 direct, 1 binned
+    hipEvent_t ev_auto[4] = {nullptr, nullptr, nullptr, nullptr};     // direct begin / end, binned begin / end
+    bool has_alpha_textures = false;
     void* bin_recs[2] = {nullptr, nullptr};
     uint32_t bin_rec_cap[2] = {0, 0};
     uint2* bin_entries[2] = {nullptr, nullptr};

@@ -788,8 +788,11 @@ struct BinParams {
     RasterParams r;
     BinRec* recs;
     uint32_t rec_cap;
-    uint2* entries;                 // [entry_cap] (record | quadrants << 28, alpha-tested << 31 | depth bound), bin after bin
+    uint2* entries;                 // [entry_cap + 1] (record | quadrants << 28, alpha-tested << 31 | depth bound), bin after bin; the last is a spare
     uint32_t entry_cap;
+    // A bin's counter / cursor has 128 bytes to itself: atomics of several XCDs on one cache line make the line migrate
+    // between their L2s (~11 ns each); with the counters of neighbouring bins -- the bins a tree crown covers -- in one
+    // line, k_bin_setup took 0.52 ms instead of 0.27 on the Bistro-class street.
     uint32_t* bin_count;            // [nbins * VCT_BIN_CSTRIDE] zero between passes
     uint32_t* bin_cursor;           // [nbins * VCT_BIN_CSTRIDE]
     uint4* items;                   // (bin, first entry, entries, flags: 1 = the bin has several slices, 2 = first slice)
@@ -1030,6 +1033,9 @@ __device__ __forceinline__ uint2 bin_entry(uint32_t rec, const uint4& q, int bx,
     return make_uint2((qm << 28) | rec, (alpha ? 0x80000000u : 0u) | q.w);
 }
 
+// (Measured and dropped: counters per class of workgroups (blockIdx % 8, one XCD each) with the slots of k_bin_setup's
+// returning atomics stored per record, so that this kernel is a pure permutation -- it fell to 0.10 ms, but k_bin_setup
+// rose from 0.27 to 0.44 ms waiting for its atomics' results: 4.1 M returning atomics cost ~0.18 ms wherever they are.)
 // one wave per 64 records: its lanes load the headers, then share the records' (record, bin) pairs evenly -- pair k of
 // the wave belongs to the record whose prefix range holds k (binary search over the 64 prefix sums in LDS).  One
 // returning atomic + one 8-byte store per pair and lane, every lane busy whatever the records' bin counts are
@@ -1059,18 +1065,32 @@ k_bin_fill(const BinParams p) {
         s_hdr[wv][lane] = q;
         // (LDS operations of one wave execute in order: no barrier between these writes and the reads below)
         const uint32_t rec0 = rec - (uint32_t)lane;
-        for (uint32_t k = (uint32_t)lane; k < total; k += 64u) {
-            int lo = 0;
+        // four pairs per lane in flight: their atomics are issued together, and the stores are unconditional (a pair that
+        // does not exist writes the spare entry behind the array) -- a store under a branch waits for the one before it
+        for (uint32_t k0 = 0u; k0 < total; k0 += 256u) {
+            uint32_t at[4];
+            uint2 ent[4];
 #pragma unroll
-            for (int step = 32; step > 0; step >>= 1)
-                if (s_pre[wv][lo + step - 1] <= k) lo += step;
-            const uint4 h = s_hdr[wv][lo];
-            const uint32_t j = k - (lo ? s_pre[wv][lo - 1] : 0u);
-            const int hx0 = (int)(h.y & 0xffffu) >> VCT_BIN_SHIFT, hy0 = (int)(h.z & 0xffffu) >> VCT_BIN_SHIFT;
-            const int hw = ((int)(h.y >> 16) >> VCT_BIN_SHIFT) - hx0 + 1;
-            const int by = hy0 + (int)j / hw, bx = hx0 + (int)j % hw;
-            const uint32_t at = atomicAdd(&p.bin_cursor[(size_t)(by * p.bins_x + bx) * VCT_BIN_CSTRIDE], 1u);
-            if (at < p.entry_cap) p.entries[at] = bin_entry(rec0 + (uint32_t)lo, h, bx, by, depth_only);
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
+                at[u] = p.entry_cap;
+                ent[u] = make_uint2(0u, 0u);
+                if (k < total) {
+                    int lo = 0;
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (s_pre[wv][lo + step - 1] <= k) lo += step;
+                    const uint4 h = s_hdr[wv][lo];
+                    const uint32_t j = k - (lo ? s_pre[wv][lo - 1] : 0u);
+                    const int hx0 = (int)(h.y & 0xffffu) >> VCT_BIN_SHIFT, hy0 = (int)(h.z & 0xffffu) >> VCT_BIN_SHIFT;
+                    const int hw = ((int)(h.y >> 16) >> VCT_BIN_SHIFT) - hx0 + 1;
+                    const int by = hy0 + (int)j / hw, bx = hx0 + (int)j % hw;
+                    ent[u] = bin_entry(rec0 + (uint32_t)lo, h, bx, by, depth_only);
+                    at[u] = atomicAdd(&p.bin_cursor[(size_t)(by * p.bins_x + bx) * VCT_BIN_CSTRIDE], 1u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p.entries[at[u] < p.entry_cap ? at[u] : p.entry_cap] = ent[u];
         }
     }
 }
@@ -1133,8 +1153,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #define BIN_STAT(k, v) do { } while (0)
 #endif
 #define VCT_VIS_PITCH 17             // words per row of the bin's visibility words in LDS (a quad's two rows on different banks)
-// ceil(1024 / w) for w = 1 .. 8: q / w == (q * kBinInv[w]) >> 10 for q < 64
-__constant__ uint32_t kBinInv[9] = {0u, 1024u, 512u, 342u, 256u, 205u, 171u, 147u, 128u};
+
+// The bin's visibility words live in LDS and are read / lowered by the four waves at once.  (A `volatile` access through
+// a plain pointer compiles to a FLAT load with system scope and a wait for every outstanding memory operation -- on the
+// critical path of every step; these stay ds_read_b64 / ds_min_u64.)
+__device__ __forceinline__ unsigned long long lds_peek(const unsigned long long* w) {
+    return *(const volatile __attribute__((address_space(3))) unsigned long long*)w;      // w points into __shared__ memory
+}
+__device__ __forceinline__ void lds_lower(unsigned long long* w, unsigned long long v) {
+    (void)__hip_atomic_fetch_min(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // alpha-test queue of ONE wave: fragments that passed coverage and the early depth test, waiting for a FULL wave of
 // texture fetches (a fetch issued per entry ran with one lane in twelve busy on the street's foliage)
@@ -1145,13 +1173,14 @@ struct BinAlphaQueue {
 };
 
 // fetches the alpha of the queued fragments -- one per lane -- and merges the survivors into the bin's words
-__device__ __forceinline__ void bin_flush_alpha(const BinParams& p, BinAlphaQueue& Q, unsigned long long* vis, int lane, int qn) {
+template <class Vis>
+__device__ __forceinline__ void bin_flush_alpha(const BinParams& p, BinAlphaQueue& Q, Vis& vis, int lane, int qn) {
     BIN_STAT(7, 1);
     if (lane < qn) {
         const unsigned long long word = Q.word[lane];
         const uint32_t pt = Q.pix_tex[lane];
         unsigned long long* slot = &vis[pt & 0xffffu];
-        if (word < *(volatile unsigned long long*)slot) {       // still in front of what the pixel shows now
+        if (word < lds_peek(slot)) {       // still in front of what the pixel shows now
             const float u = Q.uv[lane][0], v = Q.uv[lane][1];
             float alpha;
             if (p.r.tex.mips) alpha = vct_tex_sample_lod(p.r.tex, (int)(pt >> 16), u, v, Q.uv[lane][2], Q.uv[lane][3], Q.uv[lane][4], Q.uv[lane][5]).w;
@@ -1159,7 +1188,7 @@ __device__ __forceinline__ void bin_flush_alpha(const BinParams& p, BinAlphaQueu
 #if defined(VCT_BIN_STATS) && VCT_BIN_STATS
             { const int n_f = (int)__popcll(__builtin_amdgcn_ballot_w64(true)); BIN_STAT(8, n_f); }
 #endif
-            if (!(alpha < 0.5f)) atomicMin(slot, word);                                       // trace.fs:171 discard
+            if (!(alpha < 0.5f)) lds_lower(slot, word);                                       // trace.fs:171 discard
         }
     }
 }
@@ -1169,19 +1198,21 @@ __global__ void __launch_bounds__(256, VCT_BINRASTER_MIN_BLOCKS)
 k_bin_raster(const BinParams p) {
     __shared__ unsigned long long s_kv[VCT_BIN_SLICE];
     __shared__ uint4 s_rec[VCT_BIN_CHUNK * 10];
-    __shared__ unsigned long long s_vis[VCT_BIN * VCT_VIS_PITCH];
+    __shared__ unsigned long long s_mail[4][64];          // per wave: what its alpha-queue flushes won, by pixel
     __shared__ BinAlphaQueue s_q[DEPTH_ONLY ? 1 : 4];
     const uint32_t nitems = min(p.ctr[2], p.item_cap);
     const bool any_in_place = p.ctr[5] != 0u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
     BinAlphaQueue& Q = s_q[DEPTH_ONLY ? 0 : wave];
+    unsigned long long* mail = s_mail[wave];
+    // LANE = PIXEL of the wave's 8x8 quadrant of the bin; a 2x2 quad is four consecutive lanes
+    const int lx = (lane & 1) | ((lane >> 1) & 6), ly = ((lane >> 1) & 1) | ((lane >> 3) & 6);
     const uint4* rec16 = reinterpret_cast<const uint4*>(p.recs);
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         const uint4 it = p.items[item];
         const int bin = (int)it.x, n = (int)it.z;
         const uint32_t first = it.y;
         const int by = bin / p.bins_x, bx = bin - by * p.bins_x;
-        const int ox = bx << VCT_BIN_SHIFT, oy = by << VCT_BIN_SHIFT;
         // ---- the slice's entries ARE the sort keys; sorted when the slice holds alpha-tested ones ----
         int m = 1;
         while (m < n) m <<= 1;
@@ -1195,10 +1226,7 @@ k_bin_raster(const BinParams p) {
             }
             s_kv[i] = kv;
         }
-        // this thread's pixel of the bin (output, and the "how far does the bin reach" reduction)
-        const int tx = (int)(threadIdx.x & 15), ty = (int)(threadIdx.x >> 4);
-        const bool inscr = ox + tx < p.r.W && oy + ty >= p.r.ys0 && oy + ty < p.r.ys1;
-        s_vis[ty * VCT_VIS_PITCH + tx] = ~0ull;
+        mail[lane] = ~0ull;
         if (__syncthreads_or(alpha_here ? 1 : 0) && n > 1) {     // opaque first, then alpha-tested front to back
             for (int k = 2; k <= m; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
@@ -1212,7 +1240,12 @@ k_bin_raster(const BinParams p) {
                     __syncthreads();
                 }
         }
-        uint32_t zmax = 0xffffffffu;            // bits of the farthest depth the bin shows (all ones while a pixel is open)
+        const int qx0 = (bx << VCT_BIN_SHIFT) + (wave & 1) * 8, qy0 = (by << VCT_BIN_SHIFT) + (wave >> 1) * 8;
+        const int px = qx0 + lx, py = qy0 + ly;
+        const double cx = (double)px + 0.5, cy = (double)py + 0.5;
+        const bool inscr = px < p.r.W && py >= p.r.ys0 && py < p.r.ys1;
+        unsigned long long best = ~0ull;        // this pixel's visibility word (DEPTH_ONLY: the depth's float bits in the low word)
+        uint32_t zmax = 0xffffffffu;            // bits of the farthest depth the quadrant shows (all ones while a pixel is open)
         const uint32_t nh = (it.w & 2u) ? min(p.ctr[4], p.huge_cap) : 0u;
         const int total = n + (int)nh;
         int qn = 0;                             // fragments in this wave's alpha queue
@@ -1226,95 +1259,66 @@ k_bin_raster(const BinParams p) {
                 const uint32_t e = i < n ? ((uint32_t)s_kv[i] & 0x0fffffffu) : p.huge[i - n];
                 s_rec[w] = rec16[(size_t)e * 10 + part];
             }
-            if (c0 != 0) {          // what the bin shows after the previous chunks (every wave computes the same value)
-                uint32_t far = 0u;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const int x2 = lane & 15, y2 = 4 * o + (lane >> 4);
-                    const bool in2 = ox + x2 < p.r.W && oy + y2 >= p.r.ys0 && oy + y2 < p.r.ys1;
-                    const unsigned long long v2 = s_vis[y2 * VCT_VIS_PITCH + x2];
-                    far = max(far, in2 ? (uint32_t)(DEPTH_ONLY ? v2 : v2 >> 32) : 0u);
-                }
-                zmax = wave_max_u32(far);
-            }
             __syncthreads();
-            // ---- entries of the chunk in turn, one wave each; LANES = the pixels of the entry's box inside the bin,
-            //      quad by quad (a 2x2 quad is four consecutive lanes), 16 quads per step ----
-            for (int j = wave; j < cn; j += 4) {
-                const int i = c0 + j;
-                if (i < n) {
-                    const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s_kv[i] >> 32));
-                    if ((key & 0x7fffffffu) > zmax) { BIN_STAT(0, 1); continue; }              // behind everything the bin shows
-                }
+            // Lane j looks at entry j of the chunk: its header, and whether the entry concerns this wave at all (its box
+            // reaches the quadrant; it does not lie behind everything the quadrant shows).  The wave then walks the set
+            // bits -- an entry that does not concern it costs nothing, the others one v_readlane per header word.
+            uint4 hd_l = make_uint4(0u, 0u, 0u, 0xffffffffu);
+            bool mine = false;
+            if (lane < cn) {
+                hd_l = s_rec[lane * 10 + 9];                               // flags, xx, yy, zmin_bits
+                const int x0 = (int)(hd_l.y & 0xffffu), x1 = (int)(hd_l.y >> 16), y0 = (int)(hd_l.z & 0xffffu), y1 = (int)(hd_l.z >> 16);
+                mine = x1 >= qx0 && x0 <= qx0 + 7 && y1 >= qy0 && y0 <= qy0 + 7 && hd_l.w <= zmax;
+            }
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(mine);
+            while (todo != 0ull) {
+                const int j = (int)__ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t zmin_bits = (uint32_t)__builtin_amdgcn_readlane((int)hd_l.w, j);
+                if (zmin_bits > zmax) continue;                            // the quadrant closed meanwhile
+                const uint32_t xx = (uint32_t)__builtin_amdgcn_readlane((int)hd_l.y, j), yy = (uint32_t)__builtin_amdgcn_readlane((int)hd_l.z, j);
+                const int x0 = (int)(xx & 0xffffu), x1 = (int)(xx >> 16), y0 = (int)(yy & 0xffffu), y1 = (int)(yy >> 16);
                 const uint4* R = s_rec + j * 10;
-                const uint4 hd = R[9];                                     // flags, xx, yy, zmin_bits
-                const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.x);
-                const uint32_t xx = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.y), yy = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.z);
-                const uint32_t zmin_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.w);
-                const int x0 = max((int)(xx & 0xffffu), ox), x1 = min((int)(xx >> 16), ox + VCT_BIN - 1);
-                const int y0 = max((int)(yy & 0xffffu), oy), y1 = min((int)(yy >> 16), oy + VCT_BIN - 1);
-                if (x1 < x0 || y1 < y0 || zmin_bits > zmax) { BIN_STAT(0, 1); continue; }        // (a record of the huge list that misses this bin)
-                BIN_STAT(1, 1);
-                const int qx0 = x0 >> 1, qy0 = y0 >> 1, qw = (x1 >> 1) - qx0 + 1, nq = qw * ((y1 >> 1) - qy0 + 1);
-                const uint32_t inv = kBinInv[qw];
+                // Hierarchical depth test, in registers: a pixel that already shows something nearer than the
+                // sub-triangle's nearest point cannot be won; where that holds for every pixel the box reaches (the
+                // inside of a tree crown after its front layers) the record is not even unpacked.
+                const bool open = px >= x0 && px <= x1 && py >= y0 && py <= y1 && (uint32_t)(DEPTH_ONLY ? best : best >> 32) >= zmin_bits;
+                if (__builtin_amdgcn_ballot_w64(open) == 0ull) continue;
+                const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)hd_l.x, j);
                 const double* D = reinterpret_cast<const double*>(R);      // ea[3], eb[3], ec[3], area, rcp
                 const float* F = reinterpret_cast<const float*>(R) + 22;   // sz[3], iw[3], tu[3], tv[3], id
-                bool loaded = false;
-                SubTri s;
-                FastEdges fe;
-                uint32_t id = 0u;
-                for (int q0 = 0; q0 < nq; q0 += 16) {
-                    const int q = q0 + (lane >> 2);
-                    const int qy = (int)(((uint32_t)q * inv) >> 10), qx = q - qy * qw;
-                    const int px = ((qx0 + qx) << 1) | (lane & 1), py = ((qy0 + qy) << 1) | ((lane >> 1) & 1);
-                    const bool inbox = q < nq && px >= x0 && px <= x1 && py >= y0 && py <= y1;
-                    const int vslot = inbox ? (py - oy) * VCT_VIS_PITCH + (px - ox) : 0;
-                    // Hierarchical depth test of the step: a pixel that already shows something nearer than the
-                    // sub-triangle's nearest point cannot be won -- and where that holds for every pixel of the step
-                    // (the inside of a tree crown after its front layers) the coverage arithmetic is skipped whole.
-                    const unsigned long long cur = *(volatile unsigned long long*)&s_vis[vslot];
-                    const bool open = inbox && (uint32_t)(DEPTH_ONLY ? cur : cur >> 32) >= zmin_bits;
-                    if (__builtin_amdgcn_ballot_w64(open) == 0ull) { BIN_STAT(2, 1); continue; }
-                    BIN_STAT(3, 1);
-                    if (!loaded) {
-                        loaded = true;
-                        s.area = D[9]; s.sgn = 1.0;
-                        fe.rcp = D[10];
-                        fe.ok = (flags >> 31) != 0u;
+                bool in;
+                double e0, e1;
+                if (flags >> 31) {       // plane equations (every coordinate below 2^16)
+                    const double f0 = fma(D[0], cx, fma(D[3], cy, D[6])), f1 = fma(D[1], cx, fma(D[4], cy, D[7]));
+                    const double f2 = fma(D[2], cx, fma(D[5], cy, D[8]));
+                    in = !(f0 < 0.0 || f1 < 0.0 || f2 < 0.0);
+                    e0 = f0 + (((flags >> 28) & 1u) ? 0x1p-16 : 0.0);
+                    e1 = f1 + (((flags >> 29) & 1u) ? 0x1p-16 : 0.0);
+                } else {                 // the general form on the snapped coordinates (sx in ea, sy in eb)
+                    SubTri s;
+                    FastEdges fe;
+                    s.sgn = 1.0;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            s.sz[k] = F[k];
-                            fe.a[k] = D[k]; fe.b[k] = D[3 + k]; fe.c[k] = D[6 + k];
-                            fe.bias[k] = ((flags >> (28 + k)) & 1u) ? 0x1p-16 : 0.0;
-                            s.sx[k] = fe.a[k]; s.sy[k] = fe.b[k];
-                        }
-                        id = __float_as_uint(F[12]);
-                    }
-                    double e0, e1;
-                    const bool in = fe.ok ? edges_at<true>(s, fe, px, py, e0, e1) : edges_at<false>(s, fe, px, py, e0, e1);
-                    const bool cov = in && open;
-#if defined(VCT_BIN_STATS) && VCT_BIN_STATS
-                    { const int n_in = (int)__popcll(__builtin_amdgcn_ballot_w64(in && inbox)), n_box = (int)__popcll(__builtin_amdgcn_ballot_w64(inbox)),
-                                n_open = (int)__popcll(__builtin_amdgcn_ballot_w64(open)), n_cov = (int)__popcll(__builtin_amdgcn_ballot_w64(cov));
-                      BIN_STAT(4, n_in); BIN_STAT(5, n_cov); BIN_STAT(10, n_box); BIN_STAT(11, n_open); }
-#endif
-                    if (__builtin_amdgcn_ballot_w64(cov) == 0ull) continue;
-                    BIN_STAT(12, 1);
-                    const float b0 = (float)div_area(e0, s.area, fe.rcp), b1 = (float)div_area(e1, s.area, fe.rcp);
-                    const float b2 = 1.0f - b0 - b1;
-                    float z = b0 * s.sz[0] + b1 * s.sz[1] + b2 * s.sz[2];
-                    z = z + 0.0f;
-                    bool pass = cov && z >= 0.0f && z < 1.0f;
-                    if (DEPTH_ONLY) {
-                        if (pass) atomicMin(&s_vis[vslot], (unsigned long long)__float_as_uint(z));
-                    } else {
-                        const unsigned long long word = ((unsigned long long)__float_as_uint(z) << 32) | id;
-                        pass = pass && word < cur;             // the exact early depth test (another wave may lower the word meanwhile: the atomic decides)
-                        if ((flags & 3u) != 2u) {
-                            if (pass) atomicMin(&s_vis[vslot], word);
-                            continue;
-                        }
-                        // alpha-tested: into the queue
+                    for (int k = 0; k < 3; ++k) { s.sx[k] = D[k]; s.sy[k] = D[3 + k]; }
+                    in = edges_at<false>(s, fe, px, py, e0, e1);
+                }
+                const bool cov = in && open;
+                if (__builtin_amdgcn_ballot_w64(cov) == 0ull) continue;
+                const double area = D[9], rcp = D[10];
+                const float b0 = (float)div_area(e0, area, rcp), b1 = (float)div_area(e1, area, rcp);
+                const float b2 = 1.0f - b0 - b1;
+                float z = b0 * F[0] + b1 * F[1] + b2 * F[2];
+                z = z + 0.0f;
+                bool pass = cov && z >= 0.0f && z < 1.0f;
+                if (DEPTH_ONLY) {
+                    const unsigned long long word = (unsigned long long)__float_as_uint(z);
+                    pass = pass && word < best;
+                    if (pass) best = word;
+                } else {
+                    const unsigned long long word = ((unsigned long long)__float_as_uint(z) << 32) | __float_as_uint(F[12]);
+                    pass = pass && word < best;        // the exact early depth test, for free
+                    if ((flags & 3u) == 2u) {
                         const unsigned long long mp = __builtin_amdgcn_ballot_w64(pass);
                         if (mp == 0ull) continue;
                         // every lane interpolates the texture coordinate at its own centre (helper invocations included)
@@ -1324,30 +1328,43 @@ k_bin_raster(const BinParams p) {
                         const float v = (w0 * F[9] + w1 * F[10] + w2 * F[11]) * ws;
                         const float ux = dpp_quad_x(u), vx = dpp_quad_x(v), uy = dpp_quad_y(u), vy = dpp_quad_y(v);
                         const int cnt = (int)__popcll(mp);
-                        BIN_STAT(6, cnt);
-                        if (qn + cnt > 64) { bin_flush_alpha(p, Q, s_vis, lane, qn); qn = 0; }
+                        if (qn + cnt > 64) {
+                            bin_flush_alpha(p, Q, mail, lane, qn);
+                            qn = 0;
+                            best = min(best, lds_peek(&mail[lane]));
+                        }
                         if (pass) {
                             const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mp, 0u));
                             Q.word[at] = word;
                             Q.uv[at][0] = u; Q.uv[at][1] = v;
                             Q.uv[at][2] = ux - u; Q.uv[at][3] = vx - v; Q.uv[at][4] = uy - u; Q.uv[at][5] = vy - v;
-                            Q.pix_tex[at] = (uint32_t)vslot | ((((flags >> 2) & 0x1ffffffu) - 1u) << 16);
+                            Q.pix_tex[at] = (uint32_t)lane | ((((flags >> 2) & 0x1ffffffu) - 1u) << 16);
                         }
                         qn += cnt;
+                        continue;
                     }
+                    if (pass) best = word;
                 }
+                if (__builtin_amdgcn_ballot_w64(pass) != 0ull)
+                    zmax = wave_max_u32(inscr ? (uint32_t)(DEPTH_ONLY ? best : best >> 32) : 0u);
             }
-            // a fragment waiting in the queue does not yet hide what lies behind it: resolve the fuller queues before the
-            // next chunk's "how far does the bin reach"
-            if (!DEPTH_ONLY && qn >= 32) { bin_flush_alpha(p, Q, s_vis, lane, qn); qn = 0; }
+            // a fragment waiting in the queue does not yet hide what lies behind it: resolve the fuller queues between chunks
+            if (!DEPTH_ONLY && qn >= 32) {
+                bin_flush_alpha(p, Q, mail, lane, qn);
+                qn = 0;
+                best = min(best, lds_peek(&mail[lane]));
+                zmax = wave_max_u32(inscr ? (uint32_t)(best >> 32) : 0u);
+            }
         }
-        if (!DEPTH_ONLY && qn > 0) { bin_flush_alpha(p, Q, s_vis, lane, qn); qn = 0; }
-        __syncthreads();
+        if (!DEPTH_ONLY && qn > 0) {
+            bin_flush_alpha(p, Q, mail, lane, qn);
+            qn = 0;
+            best = min(best, lds_peek(&mail[lane]));
+        }
         // ---- one word per visible pixel ----
-        const unsigned long long best = s_vis[ty * VCT_VIS_PITCH + tx];
         if (inscr && best != ~0ull) {
             const bool merge = (it.w & 1u) || any_in_place;
-            const size_t pix = (size_t)(oy + ty) * p.r.W + (ox + tx);
+            const size_t pix = (size_t)py * p.r.W + px;
             if (DEPTH_ONLY) {
                 const uint32_t word = vct_depth24_bits(__uint_as_float((uint32_t)best)) + p.r.vis32_ebase;
                 if (merge) atomicMin(&p.r.vis32[pix], word); else p.r.vis32[pix] = word;
@@ -1355,7 +1372,7 @@ k_bin_raster(const BinParams p) {
                 if (merge) atomicMin(&p.r.vis[pix], best); else p.r.vis[pix] = best;
             }
         }
-        __syncthreads();        // s_kv / s_vis are reused by the next item
+        __syncthreads();        // s_kv is reused by the next item
     }
 }
 
