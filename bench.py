@@ -80,7 +80,7 @@ def parse():
                     help="skip the 3-aperture roughness sweep (profiling runs: keeps every trace launch identical)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the oracle baseline sample (0 disables)")
-    ap.add_argument("--slabs", default="balanced", choices=["balanced", "equal"],
+    ap.add_argument("--slabs", default="balanced", choices=["balanced", "equal", "interleaved"],
                     help="N > 1: balanced = slab boundaries of equal cone-step cost from the first frame's per-row step "
                          "histogram (vct_slab_partition_weighted), equal = ceil(tile_rows / N) rows per rank")
     ap.add_argument("--timeout", type=float, default=float(os.environ.get("VCT_BENCH_TIMEOUT_S", "900")),
@@ -407,6 +407,19 @@ def main():
         slab_px = max(0, y1 - y0) * w
         steps_slab = ctx.last_step_count()
 
+    if native and args.slabs == "interleaved":
+        # interleaved slabs: tile row r belongs to rank r % world -- every rank samples the whole frame,
+        # so the slabs cost the same by construction (no histogram, no feedback rounds); one equal-count ncclGather,
+        # the root de-interleaves behind it.  Every rank keeps the whole G-buffer resident.
+        ty_all = (h + 7) // 8
+        ctx.comm_set_interleaved(True)
+        if inp["scene"] is not None:
+            ctx.render_gbuffer(inp["view_proj"])
+        ctx.trace_gbuffer_strided(min(rank, ty_all), ty_all, world)
+        steps_slab = ctx.last_step_count()
+        slab_rows = [(r, r + len(range(r, ty_all, world))) for r in range(world)]       # (first row, first row + rows)
+        slab_px = sum(min(8, h - 8 * r) for r in range(rank, ty_all, world)) * w
+
     comm_stream = torch.cuda.Stream(device=local_rank) if (use_dist and not native) else None
     traced = [torch.cuda.Event() for _ in range(len(fgs))]
     gathered = [torch.cuda.Event() for _ in range(len(fgs))]
@@ -535,7 +548,10 @@ def main():
                        ("(native vct_frame_step)" if native else "(Python-paced step, torch.distributed gather)") +
                        ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]") +
                        ("" if not native_fallback else f" [native communicator unavailable: {native_fallback}]"),
+                       "slabs": args.slabs if (native and use_dist) else ("equal" if use_dist else None),
                        "trace_variant": args.variant,
+                       # compute units kept away from the trace for the gather's stream (VCT_COMM_RESERVED_CUS; 0: none)
+                       "comm_reserved_cus": ctx.stage_counts().get("comm_reserved_cus", 0),
                        "slab_tile_rows": [b - a for a, b in slab_rows]},
             "cone_steps_per_frame": total_steps,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
@@ -568,6 +584,34 @@ def main():
                               "Mcones_per_s": round(cones / (float(np.mean(ms)) * 1e-3) / 1e6, 1)})
             ctx.set_cone_apertures(0.577, 0.07)
             result["roughness_sweep"] = sweep
+        if world == 1 and not args.no_sweep and args.variant == 0 and not args.anisotropic:
+            # What bit-exactness with the oracle costs: the same kernel with a one-multiply unorm8 decode and
+            # reciprocal-multiply divisions (config.trace_variant 3 -- opt-in, never the default, not `value`)
+            exact = ctx.trace_current().copy()
+            exact_steps = ctx.last_step_count()
+            ms_e, ms_l = [], []
+            for _ in range(5):
+                ctx.trace_resident()
+                ms_e.append(ctx.last_trace_ms())
+            ctx.set_trace_variant(3)
+            for _ in range(5):
+                ctx.trace_resident()
+                ms_l.append(ctx.last_trace_ms())
+            loose = ctx.trace_current().copy()
+            loose_steps = ctx.last_step_count()
+            ctx.set_trace_variant(0)
+            a = vct.half_to_float(exact.reshape(-1, 4)).astype(np.float64)
+            b = vct.half_to_float(loose.reshape(-1, 4)).astype(np.float64)
+            result["exactness_tax"] = {
+                "exact_trace_kernel_ms": round(float(np.mean(ms_e)), 4),
+                "loose_trace_kernel_ms": round(float(np.mean(ms_l)), 4),
+                "exact_over_loose": round(float(np.mean(ms_e)) / float(np.mean(ms_l)), 4),
+                "rel_l2_loose_vs_exact_frame": float(np.sqrt(((a - b) ** 2).sum() / max((a ** 2).sum(), 1e-30))),
+                "halves_that_differ": int((exact != loose).sum()),
+                "cone_steps_exact": int(exact_steps), "cone_steps_loose": int(loose_steps),
+                "note": "loose = config.trace_variant 3: unorm8 * RN(1/255) (wrong in the last bit for 126 bytes), x * RN(1/d) "
+                        "for the constant divisions; opt-in, never `value`",
+            }
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(args, inp, ctx, vct)
         print(json.dumps(result), flush=True)

@@ -86,7 +86,12 @@ typedef struct vct_config {
     int32_t wrap_repeat;       /* 1 = GL_REPEAT (VCT.h:110-113 leaves the GL default) */
     int32_t debug_outputs;     /* 1 = also keep per-cone step counts and raw cone vec4s */
     int32_t trace_variant;     /* 0 = default (cooperative sampler, tile split over 3 waves); A/B variants with
-                                  identical results: 1 = per-lane sampler, 2 = one wave per tile */
+                                  identical results: 1 = per-lane sampler, 2 = one wave per tile.  3 = the default
+                                  kernel with a one-multiply unorm8 decode and reciprocal-multiply divisions: NOT
+                                  bit-exact (within the 1e-3 frame tolerance), never a default -- it exists to
+                                  measure what the exactness costs (bench.py exactness_tax).  4 = the
+                                  default kernel over a live-pixel compaction of 16x16 super-tiles (identical
+                                  results; experiment, profiles/experiments/README.md) */
     int32_t voxel_attributes;  /* 1 = the voxelizer also keeps per-voxel mean albedo + face normal
                                   (needed by vct_bounce; 24 B/voxel of extra accumulators) */
     int32_t anisotropic_mips;  /* 1 = also keep six directional (pre-integrated) mip chains and sample
@@ -119,6 +124,8 @@ int vct_set_camera_position(vct_ctx* ctx, const float pos[3]);
 int vct_set_light_direction(vct_ctx* ctx, const float dir[3]);
 int vct_set_ambient_factor(vct_ctx* ctx, float ambient);
 int vct_set_cone_apertures(vct_ctx* ctx, float tan_diffuse, float tan_specular);
+/* config.trace_variant of the following traces (0 .. 4, see vct_config) */
+int vct_set_trace_variant(vct_ctx* ctx, int32_t variant);
 
 /* Scene upload -- replaces Model/Mesh VBO setup (R/Mesh.h:49-82) for the two attributes the
  * voxelizer reads (vox.vs:3-4).  pos: [ntri][3][3] model-space fp32; material: [ntri];
@@ -214,6 +221,9 @@ int vct_trace_resident(vct_ctx* ctx);
 /* Same for the tile-row slab [tile_row0, tile_row1) of the resident G-buffer; later
  * vct_trace_resident calls repeat this slab. */
 int vct_trace_resident_rows(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
+/* every `stride`-th tile row of [tile_row0, tile_row1), starting with tile_row0 (the rows rank tile_row0 of `stride`
+ * ranks traces under interleaved slabs, vct_comm_set_interleaved); the pixels land at their own place in the frame */
+int vct_trace_resident_strided(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1, int32_t stride);
 /* One whole GI pass for a light AND a camera that moved -- init_voxel_cone_tracing's DrawDepthTexture +
  * DrawVoxelTexture (VCT.h:138-139) followed by Render (VCT.h:146-190) -- issued as one call:
  *   { shadow map -> voxelize(mode) -> inject -> mips }  ||  { G-buffer visibility -> (shadow map ready) -> shade }  -> trace.
@@ -274,6 +284,14 @@ int vct_comm_set_timeout_ms(vct_ctx* ctx, int32_t milliseconds);
 int vct_last_row_steps(vct_ctx* ctx, uint64_t* rows, int32_t nrows);
 int vct_slab_partition_weighted(const uint64_t* row_cost, int32_t tile_rows, int32_t world, int32_t* starts);
 int vct_comm_set_slab_rows(vct_ctx* ctx, const int32_t* starts);
+/* Collective: interleaved slabs -- tile row r belongs to rank r % world, so every rank samples the whole frame and the
+ * slabs cost the same by construction (SURVEY.md 8e "interleaved tile assignment ... with a de-interleave after the
+ * gather").  The frame still travels as ONE equal-count ncclGather; the root de-interleaves behind it.  on = 0 returns
+ * to contiguous equal slabs.  A rank's G-buffer must cover the whole frame (vct_render_gbuffer; vct_gi_pass does). */
+int vct_comm_set_interleaved(vct_ctx* ctx, int32_t on);
+/* One-GPU check of the interleaved data path for any world size: strided + packed traces of every emulated rank, the
+ * root's de-interleave, compared with the frame of one launch; *mismatches = differing pixels. */
+int vct_selftest_interleaved(vct_ctx* ctx, int32_t world, uint64_t* mismatches);
 /* Root only: the last gathered frame (device pointer valid until the next-but-one vct_frame_step) / a host copy. */
 int vct_comm_frame(vct_ctx* ctx, void** rgba16f_dev, size_t* bytes);
 int vct_comm_download_frame(vct_ctx* ctx, void* out_rgba16f_host);

@@ -107,6 +107,39 @@ def test_two_ranks_sharing_the_gpu_gather_the_single_gpu_frame():
     assert d["cone_steps_per_frame"] > 0
 
 
+def test_interleaved_rows_data_path_for_emulated_ranks(vct):
+    """Interleaved slabs (tile row r -> rank r % world; vct_comm_set_interleaved).  No multi-GPU box: the data path of
+    `world` ranks is walked on one GPU -- (1) a strided trace puts exactly the rank's rows at their places, (2) the
+    library's self-test traces every emulated rank's rows strided + packed, runs the root's de-interleave kernel and
+    compares with the frame of one launch, (3) the native step with a 1-rank communicator in interleaved mode."""
+    w, h = 200, 123                                 # 16 tile rows, the last one ragged
+    ctx, vp = small_pipeline(vct, w=w, h=h)
+    ctx.render_gbuffer(vp)
+    want = ctx.trace_current()
+    total = ctx.last_step_count()
+    ty = (h + 7) // 8
+    for world in (2, 3, 8):
+        steps = 0
+        for rank in range(world):
+            ctx.trace_gbuffer_strided(rank, ty, world)
+            steps += ctx.last_step_count()
+        assert steps == total                                   # every tile row traced exactly once over the ranks
+        assert ctx.selftest_interleaved(world) == 0
+    ctx.comm_init(vct.comm_unique_id(), 0, 1)
+    ctx.comm_set_interleaved(True)
+    assert ctx.comm_slab() == (0, ty)
+    for _ in range(3):
+        ctx.frame_step()
+    ctx.comm_sync()
+    assert np.array_equal(ctx.comm_download_frame(), want)
+    ctx.comm_set_interleaved(False)
+    ctx.frame_step()
+    ctx.comm_sync()
+    assert np.array_equal(ctx.comm_download_frame(), want)
+    ctx.comm_destroy()
+    ctx.close()
+
+
 def test_native_bench_loop_with_forced_one_rank_group():
     """The pipelined native step loop of bench.py (what N > 1 runs) with a 1-rank RCCL communicator."""
     env = dict(os.environ, VCT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613")
@@ -117,6 +150,17 @@ def test_native_bench_loop_with_forced_one_rank_group():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["gathered_frame_equals_single_gpu_frame"] is True and d["host_issue_us_per_step"] > 0
+
+
+def test_native_bench_loop_interleaved_with_forced_one_rank_group():
+    env = dict(os.environ, VCT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29614")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--width", "320",
+           "--height", "180", "--voxel-dim", "64", "--scene-detail", "0.15", "--shadow-size", "512",
+           "--cpu-seconds", "0", "--no-sweep", "--slabs", "interleaved"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["gathered_frame_equals_single_gpu_frame"] is True and d["config"]["slabs"] == "interleaved"
 
 
 def test_cpp_caller_multi_gpu_launcher(vct):

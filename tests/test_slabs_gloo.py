@@ -71,6 +71,38 @@ def _worker(rank, world, port, w, h, V, q):
         dist.destroy_process_group()
 
 
+def _worker_interleaved(rank, world, port, w, h, V, q):
+    """Interleaved assignment (tile row r -> rank r % world): every rank traces its rows, packs them back to back, ONE
+    gather, the root de-interleaves."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pyoracle
+    slabs = _load_slabs()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        chain = pyoracle.build_mips(synth.noise_volume(V, seed=8, occupancy=0.1))
+        planes = synth.random_gbuffer(w * h, seed=12, discard_frac=0.1)
+        p = pyoracle.default_params(V)
+        fg = slabs.FrameGather(h, w, world, rank, "cpu")
+        mine = torch.zeros((h, w, 4), dtype=torch.float16)               # this rank's rows at their own places
+        for r in slabs.interleaved_rows(h, world, rank):
+            y0, y1 = r * 8, min(r * 8 + 8, h)
+            part = pyoracle.trace(p, chain, planes[:, y0 * w:y1 * w])["rgba16f"]
+            mine[y0:y1] = torch.from_numpy(part.view(np.float16).reshape(y1 - y0, w, 4))
+        fg.pack_interleaved(mine)
+        frame = fg.gather_interleaved()
+        if rank == 0:
+            full = pyoracle.trace(p, chain, planes)["rgba16f"].reshape(h, w, 4)
+            q.put(bool(np.array_equal(frame.numpy().view(np.uint16), full)))
+        else:
+            assert frame is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -83,6 +115,24 @@ def test_slab_gather_equals_single_process_frame(world, h):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, 24, h, 16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("world,h", [(2, 72), (3, 43), (4, 20)])
+def test_interleaved_gather_equals_single_process_frame(world, h):
+    slabs = _load_slabs()
+    rows = [slabs.interleaved_rows(h, world, r) for r in range(world)]
+    assert sorted(sum(rows, [])) == list(range(slabs.tile_rows(h)))           # every tile row exactly once
+    assert max(len(x) for x in rows) - min(len(x) for x in rows) <= 1          # balanced to one row
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_interleaved, args=(r, world, port, 24, h, 16, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -31,6 +31,20 @@ for world, balanced in ((2, False), (4, False), (8, False), (2, True), (4, True)
     print(world, "slabs" + (" balanced" if balanced else " equal") + ": steps max/mean", round(max(steps) / np.mean(steps), 3), "kernel ms max", max(t), "mean", round(float(np.mean(t)), 4), "sum", round(sum(t), 4), t)
 
 
+# interleaved slabs (tile row r -> rank r % world): balanced by construction, no histogram and no feedback
+ty = (h + 7) // 8
+for world in (2, 4, 8):
+    t, steps = [], []
+    for rank in range(world):
+        for _ in range(30): ctx.trace_gbuffer_strided(rank, ty, world)
+        ctx.synchronize()
+        ms = []
+        for _ in range(10):
+            ctx.trace_gbuffer_strided(rank, ty, world); ctx.synchronize(); ms.append(ctx.last_trace_ms())
+        t.append(round(float(np.median(ms)), 4)); steps.append(ctx.last_step_count())
+    print(world, "slabs interleaved: steps max/mean", round(max(steps) / np.mean(steps), 3), "kernel ms max", max(t), "mean", round(float(np.mean(t)), 4), "sum", round(sum(t), 4), t)
+
+
 # time-feedback balancing (what bench.py --slabs balanced does over the control plane): rows are re-weighted by the
 # measured kernel time per executed step of the slab they were in, the boundaries re-cut, a few rounds
 def measure(r0, r1):

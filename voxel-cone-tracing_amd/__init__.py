@@ -31,7 +31,8 @@ ABI_VERSION = 6
 ABI_SYMBOLS = [
     "vct_default_config", "vct_create", "vct_destroy", "vct_last_error", "vct_get_config",
     "vct_set_camera_position", "vct_set_light_direction", "vct_set_ambient_factor",
-    "vct_set_cone_apertures", "vct_upload_triangles", "vct_upload_shadow_map", "vct_voxelize",
+    "vct_set_cone_apertures", "vct_set_trace_variant", "vct_trace_resident_strided", "vct_comm_set_interleaved",
+    "vct_selftest_interleaved", "vct_upload_triangles", "vct_upload_shadow_map", "vct_voxelize",
     "vct_inject_light", "vct_build_mips", "vct_upload_volume_rgba8", "vct_upload_chain_rgba8",
     "vct_download_chain_rgba8", "vct_chain_texels", "vct_trace", "vct_trace_slab",
     "vct_trace_resident", "vct_synchronize", "vct_download_steps", "vct_download_cones",
@@ -89,6 +90,10 @@ for _n in ("vct_set_camera_position", "vct_set_light_direction", "vct_upload_vol
     getattr(_lib, _n).argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_set_ambient_factor.argtypes = [C.c_void_p, C.c_float]
 _lib.vct_set_cone_apertures.argtypes = [C.c_void_p, C.c_float, C.c_float]
+_lib.vct_set_trace_variant.argtypes = [C.c_void_p, C.c_int32]
+_lib.vct_trace_resident_strided.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+_lib.vct_comm_set_interleaved.argtypes = [C.c_void_p, C.c_int32]
+_lib.vct_selftest_interleaved.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 _lib.vct_upload_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                       C.c_int32]
 _lib.vct_upload_shadow_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -228,6 +233,9 @@ class Context:
     def set_cone_apertures(self, td, ts):
         self._ck(_lib.vct_set_cone_apertures(self._h, float(td), float(ts)), "vct_set_cone_apertures")
 
+    def set_trace_variant(self, variant):
+        self._ck(_lib.vct_set_trace_variant(self._h, int(variant)), "vct_set_trace_variant")
+
     # --- scene / volume
     def upload_triangles(self, pos, material, albedo):
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 9)
@@ -327,6 +335,20 @@ class Context:
         """Collective: load-aware slab boundaries [world + 1] in tile rows (None: the equal partition)."""
         a = None if starts is None else np.ascontiguousarray(starts, np.int32)
         self._ck(_lib.vct_comm_set_slab_rows(self._h, _ptr(a)), "vct_comm_set_slab_rows")
+
+    def comm_set_interleaved(self, on=True):
+        """Collective: tile row r belongs to rank r % world (every rank needs the whole G-buffer resident)."""
+        self._ck(_lib.vct_comm_set_interleaved(self._h, 1 if on else 0), "vct_comm_set_interleaved")
+
+    def selftest_interleaved(self, world):
+        """Pixels that differ between the de-interleaved frame of `world` emulated ranks and the frame of one launch."""
+        bad = C.c_uint64(0)
+        self._ck(_lib.vct_selftest_interleaved(self._h, int(world), C.byref(bad)), "vct_selftest_interleaved")
+        return bad.value
+
+    def trace_gbuffer_strided(self, row0, row1, stride):
+        """Asynchronous trace of every stride-th tile row of [row0, row1) of the resident G-buffer."""
+        self._ck(_lib.vct_trace_resident_strided(self._h, row0, row1, stride), "vct_trace_resident_strided")
 
     def last_row_steps(self):
         """Executed cone steps per 8-pixel tile row of the last screen trace (uint64 [ceil(height / 8)])."""
@@ -462,8 +484,8 @@ class Context:
     def stage_counts(self):
         v = (C.c_uint64 * 8)()
         self._ck(_lib.vct_get_stage_counts(self._h, v), "vct_get_stage_counts")
-        return dict(zip(("triangles", "vox_candidates", "reserved", "accumulator_bricks", "touched_bricks"),
-                        (int(x) for x in v)))
+        return dict(zip(("triangles", "vox_candidates", "reserved", "accumulator_bricks", "touched_bricks",
+                         "comm_reserved_cus"), (int(x) for x in v)))
 
     def last_trace_ms(self):
         v = C.c_float()

@@ -241,7 +241,7 @@ void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chai
 // `out_base`: where the kernel writes (full-frame addressing); null = the caller's vct_set_frame_target or the
 // context-owned frame.  vct_frame_step passes its gather buffer here instead of re-pointing c->frame_target, which
 // on a non-root rank would leave a pointer BEFORE a one-slab allocation behind for every later full-frame call.
-int launch_trace(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr) {
+int launch_trace(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr, int row_stride = 1, bool pack_rows = false) {
     // the reference rebuilds the mips right after every voxelization (VCT.h:248); tracing a chain whose
     // coarse levels describe an older level 0 would return wrong GI without any sign of it
     if (!c->mips_valid)
@@ -261,7 +261,12 @@ int launch_trace(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr) {
     p.tiles_y = tiles_y(c);
     p.tile_row0 = row0;
     p.tile_row1 = row1;
-    p.spec_prio = (row1 - row0) * 2 <= tiles_y(c) ? 1 : 0;
+    p.row_stride = row_stride;
+    p.pack_rows = pack_rows ? 1 : 0;
+    p.ntiles = ((row1 - row0 + (row_stride > 1 ? row_stride : 1) - 1) / (row_stride > 1 ? row_stride : 1)) * tiles_x(c);
+    if ((row_stride > 1 || pack_rows) && (c->cfg.trace_variant == 1 || c->cfg.trace_variant == 2 || c->cfg.trace_variant == 4))
+        return fail(c, VCT_ERR_INVALID, "interleaved tile rows need the default trace kernel (config.trace_variant 0 or 3)");
+    p.spec_prio = ((row1 - row0) / (row_stride > 1 ? row_stride : 1)) * 2 <= tiles_y(c) ? 1 : 0;
     const int variant = c->cfg.trace_variant;
     p.gbuf = c->gb_current;
     p.aniso = c->cfg.anisotropic_mips ? c->aniso : nullptr;
@@ -273,11 +278,19 @@ int launch_trace(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr) {
 #if defined(VCT_STATS) && VCT_STATS
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 16 * sizeof(unsigned long long), c->stream));
 #endif
+    if (variant == 4 && !c->cfg.anisotropic_mips) {       // live-pixel compaction (experiment): list + counter, zeroed per launch
+        const size_t nt = (size_t)tiles_x(c) * tiles_y(c);
+        if (!c->vt_pix) HIP_TRY(c, hipMalloc(&c->vt_pix, (nt * 64 + 4) * sizeof(uint32_t)));
+        p.vt_pix = c->vt_pix;
+        p.vt_count = c->vt_pix + nt * 64;
+        HIP_TRY(c, hipMemsetAsync(p.vt_count, 0, sizeof(uint32_t), c->stream));
+    }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_trace(p, variant, c->stream));       // an empty row range (a rank without rows) launches nothing
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->last_row0 = row0;
     c->last_row1 = row1;
+    c->last_row_stride = row_stride > 1 ? row_stride : 1;
     c->have_trace = true;
     c->last_was_screen_trace = true;
     return VCT_OK;
@@ -495,7 +508,19 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
 }  // namespace
 
 int vct_fail(vct_ctx* c, int code, const std::string& msg) { return fail(c, code, msg); }
-int vct_launch_trace_rows(vct_ctx* c, int row0, int row1, uint16_t* out_base) { return launch_trace(c, row0, row1, out_base); }
+
+hipError_t vct_create_masked_stream(hipStream_t* s, int device, int first_cu, int last_cu) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return e;
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int cu = first_cu < 0 ? 0 : first_cu; cu < last_cu && cu < ncu; ++cu) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+    return hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data());
+}
+int vct_launch_trace_rows(vct_ctx* c, int row0, int row1, uint16_t* out_base, int row_stride, bool pack_rows) {
+    return launch_trace(c, row0, row1, out_base, row_stride, pack_rows);
+}
 int vct_tiles_x(const vct_ctx* c) { return tiles_x(c); }
 int vct_tiles_y(const vct_ctx* c) { return tiles_y(c); }
 void vct_comm_release(vct_ctx* c);      // vct_multi.hip
@@ -567,7 +592,16 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
         // VCT_STREAM_PRIORITY = high | low: experiments with two contexts sharing a GPU (tools/overlap_probe.py)
         int lo = 0, hi = 0;
         const char* pr = getenv("VCT_STREAM_PRIORITY");
-        if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+        // VCT_COMM_RESERVED_CUS = k: the context's streams leave the device's last k compute units alone; the multi-GPU
+        // step's communication stream gets exactly those (vct_ctx.h vct_create_masked_stream)
+        const char* rc_ = getenv("VCT_COMM_RESERVED_CUS");
+        c->reserved_cus = rc_ ? atoi(rc_) : 0;
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, dev));
+        if (c->reserved_cus < 0 || c->reserved_cus >= prop.multiProcessorCount) c->reserved_cus = 0;
+        if (c->reserved_cus > 0)
+            CREATE_TRY(vct_create_masked_stream(&c->stream, dev, 0, prop.multiProcessorCount - c->reserved_cus));
+        else if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
             CREATE_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo));
         else
             CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -634,7 +668,7 @@ void vct_destroy(vct_ctx* c) {
     vct_comm_release(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
-                    c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->steps_dev, c->spread_lut, c->tri_pos,
+                    c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->vt_pix, c->steps_dev, c->spread_lut, c->tri_pos,
                     c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->vox_items, c->vox_acc2, c->vox_acc2_attr, c->vox_multi_slot, c->stage,
                     c->stage_albedo, c->stage_normal, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->attr_albedo, c->attr_normal,
@@ -689,6 +723,13 @@ int vct_set_cone_apertures(vct_ctx* c, float td, float ts) {
     c->cfg.tan_diffuse = td;
     c->cfg.tan_specular = ts;
     c->steps_dirty = true;
+    return VCT_OK;
+}
+
+int vct_set_trace_variant(vct_ctx* c, int32_t variant) {
+    if (!c) return VCT_ERR_INVALID;
+    if (variant < 0 || variant > 4) return fail(c, VCT_ERR_INVALID, "vct_set_trace_variant: 0 .. 4");
+    c->cfg.trace_variant = variant;
     return VCT_OK;
 }
 
@@ -1099,6 +1140,7 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     c->gb_current = c->gb_tiled;
     c->last_row0 = row0;
     c->last_row1 = row1;
+    c->last_row_stride = 1;
     c->have_gbuffer = true;
 #if defined(VCT_BIN_STATS) && VCT_BIN_STATS
     if (binned && getenv("VCT_BIN_STATS_DUMP")) {       // instrumented builds only (tools/r04_binstats.sh)
@@ -1461,11 +1503,20 @@ int vct_trace_resident_rows(vct_ctx* c, int32_t row0, int32_t row1) {
     return launch_trace(c, row0, row1);
 }
 
+int vct_trace_resident_strided(vct_ctx* c, int32_t row0, int32_t row1, int32_t stride) {
+    if (!c) return VCT_ERR_INVALID;
+    if (!c->have_gbuffer) return fail(c, VCT_ERR_INVALID, "vct_trace_resident_strided: no G-buffer resident yet");
+    if (row0 < 0 || row1 > tiles_y(c) || row0 > row1 || stride < 1)
+        return fail(c, VCT_ERR_INVALID, "vct_trace_resident_strided: tile-row range outside the frame or stride < 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return launch_trace(c, row0, row1, nullptr, stride, false);
+}
+
 int vct_trace_resident(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     if (!c->have_gbuffer) return fail(c, VCT_ERR_INVALID, "vct_trace_resident: no G-buffer resident yet");
     HIP_TRY(c, hipSetDevice(c->device));
-    return launch_trace(c, c->last_row0, c->last_row1);
+    return launch_trace(c, c->last_row0, c->last_row1, nullptr, c->last_row_stride, false);
 }
 
 int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16], int32_t mode) {
@@ -1477,7 +1528,15 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
     int row0 = 0, row1 = tiles_y(c);
     const bool rank_ctx = vct_comm_rows(c, &row0, &row1);
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->aux_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    if (!c->aux_stream) {
+        if (c->reserved_cus > 0) {
+            hipDeviceProp_t prop;
+            HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+            HIP_TRY(c, vct_create_masked_stream(&c->aux_stream, c->device, 0, prop.multiProcessorCount - c->reserved_cus));
+        } else {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+        }
+    }
     if (!c->ev_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     if (!c->ev_shadow) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_shadow, hipEventDisableTiming));
     if (!c->ev_join) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -1498,7 +1557,7 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
     else HIP_TRY(c, ej);
     if (rc) return rc;
     if (rank_ctx) return vct_frame_step(c);
-    return launch_trace(c, c->last_row0, c->last_row1);
+    return launch_trace(c, c->last_row0, c->last_row1, nullptr, c->last_row_stride, false);
 }
 
 int vct_download_frame(vct_ctx* c, void* out) {
@@ -1551,6 +1610,7 @@ static int row_steps(vct_ctx* c, std::vector<uint64_t>& rows) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(v.data(), c->tile_steps + per_row * (size_t)r0, v.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int r = r0; r < r1; ++r) {
+        if ((r - r0) % c->last_row_stride) continue;          // an interleaved launch: the other rows belong to other ranks
         uint64_t sum = 0;
         const uint32_t* q = v.data() + per_row * (size_t)(r - r0);
         for (size_t i = 0; i < per_row; ++i) sum += q[i];
@@ -1586,6 +1646,7 @@ int vct_get_stage_counts(vct_ctx* c, uint64_t out[8]) {
     out[1] = c->n_frags;
     out[2] = 0;
     out[3] = c->nslots;
+    out[5] = (uint64_t)c->reserved_cus;          // compute units kept for the communication stream (VCT_COMM_RESERVED_CUS)
     if (c->brick_prev) {
         HIP_TRY(c, hipSetDevice(c->device));
         const size_t nbricks = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512;

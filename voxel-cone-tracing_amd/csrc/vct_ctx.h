@@ -9,10 +9,17 @@
 
 struct vct_comm;      // multi-GPU state (vct_multi.hip)
 
+// A stream restricted to a range of the device's compute units (hipExtStreamCreateWithCUMask).  Used when
+// VCT_COMM_RESERVED_CUS = k > 0 keeps the last k CUs away from the context's streams and hands exactly those to the
+// multi-GPU step's communication stream: a running trace leaves another queue's kernels almost no wave slots
+// (k_raster_mid 658 us instead of 60 beside a trace), and RCCL's gather kernel is such a queue.
+hipError_t vct_create_masked_stream(hipStream_t* s, int device, int first_cu, int last_cu);
+
 struct vct_ctx {
     vct_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    int reserved_cus = 0;             // VCT_COMM_RESERVED_CUS at vct_create: CUs kept for the communication stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
 
@@ -38,12 +45,14 @@ struct vct_ctx {
     unsigned long long* step_counter = nullptr;   // [VCT_STEP_COUNTERS] atomic bank of the bounce kernels (memset before each bounce)
     uint32_t* tile_steps = nullptr;               // [tiles] executed steps per 8x8 tile of the screen trace
     unsigned long long* stats = nullptr;      // [8] march statistics of instrumented builds (VCT_STATS)
+    uint32_t* vt_pix = nullptr;       // trace_variant 4: compaction list [tiles][64] + the virtual-tile counter behind it
     VctStep* steps_dev = nullptr;     // [2][VCT_MAX_STEPS]
     uint32_t* spread_lut = nullptr;   // [1024] spread3(i) << 2 (vct_trace.hip: dilated anchor coordinates by scalar load)
     int n_diffuse = 0, n_specular = 0;
     bool steps_dirty = true;
     bool fast_div = false;            // set by refresh_steps: constant divisors admit the FMA division
     int last_row0 = 0, last_row1 = 0;
+    int last_row_stride = 1;          // the last screen trace took every last_row_stride-th tile row of [last_row0, last_row1)
     bool have_trace = false;
     bool last_was_screen_trace = false;   // the step counters hold a screen trace (indexed by tile row), not a bounce
     bool have_gbuffer = false;        // a G-buffer is resident (uploaded by vct_trace or rendered)
@@ -148,7 +157,8 @@ struct vct_ctx {
 // shared helpers (vct_capi.hip)
 int vct_fail(vct_ctx* c, int code, const std::string& msg);
 // trace kernel on the context stream, asynchronous; out_base (full-frame addressing) overrides the frame target when not null
-int vct_launch_trace_rows(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr);
+// row_stride > 1: only every row_stride-th tile row from row0 on; pack_rows: those rows back to back in out_base (interleaved slabs)
+int vct_launch_trace_rows(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr, int row_stride = 1, bool pack_rows = false);
 int vct_tiles_x(const vct_ctx* c);
 int vct_tiles_y(const vct_ctx* c);
 

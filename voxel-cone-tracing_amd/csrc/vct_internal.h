@@ -145,6 +145,22 @@ __device__ __forceinline__ uint32_t vct_depth24_bits(float z) {
 }
 #endif
 
+// PCF short cut.  A tap is a convex combination of four depths of the 6 x 6 window, so it lies between the window's
+// smallest and largest depth -- up to rounding: the four weights are products of (a, 1 - a) x (b, 1 - b), each within
+// 3 ulp of the exact product, and the four-term sum adds at most 4 more (mul + add or fma chain alike), so every tap of
+// the window is within a factor 1 +- 2^-21 of [dmin, dmax].  With margins of 2^-19: when the compared depth is
+// <= dmin * (1 - 2^-19) all 25 taps pass, when it is > dmax * (1 + 2^-19) none does -- and only a window the shadow
+// boundary crosses pays for the 25 bilinear taps (~330 of the shade kernel's ~1200 instructions per pixel, the larger
+// part of the voxelizer's per-fragment work).  Raw words order like their depths (an older epoch or a never-written
+// word is larger than every word of the current pass and decodes to 1.0), so the minimum / maximum are taken on the
+// words.  Returns 25 / 0, or -1: evaluate the taps.
+#if defined(__HIPCC__)
+__device__ __forceinline__ int vct_pcf_window_verdict(uint32_t wmin, uint32_t wmax, uint32_t ebase, float cur) {
+    const float lo = vct_shadow_depth(wmin, ebase) * 0.999998f, hi = vct_shadow_depth(wmax, ebase) * 1.000002f;
+    return cur <= lo ? 25 : (cur > hi ? 0 : -1);
+}
+#endif
+
 // Six consecutive shadow-map words (one row of a PCF window) as ONE dwordx4 + ONE dwordx2 load: the row starts at any
 // 4-byte boundary (gfx950 under HSA runs with unaligned vector access enabled, and hipcc emits the wide loads for this
 // packed type).  The PCF gathers are bound by the number of load instructions the texture-address unit has to spread
@@ -209,6 +225,11 @@ struct VctTraceParams {
     int32_t n_diffuse, n_specular;
     int32_t width, height, tiles_x, tiles_y;
     int32_t tile_row0, tile_row1;       // slab [row0,row1)
+    // Interleaved slabs (vct_multi.hip): of the rows [row0, row1) only every row_stride-th is traced, starting with row0
+    // (0 / 1: all of them); pack_rows = 1 writes traced row j to pixel rows 8j .. 8j+7 of `out` (a rank's packed slab of
+    // an interleaved frame) instead of the row's own place in the frame.  k_trace_tile_split only.
+    int32_t row_stride, pack_rows;
+    int32_t ntiles;                     // tiles of this launch (rows traced x tiles_x)
     int32_t spec_prio;                  // 1: the specular waves raise their issue priority (slab launches, vct_trace.hip)
     const float* gbuf;                  // tiled [tile][23][64]
     uint16_t* out;                      // RGBA16F [h][w][4]
@@ -237,6 +258,11 @@ struct VctTraceParams {
     uint32_t* bounce_list_count;
     uint32_t bounce_list_cap;
     uint32_t* brick_over;               // bricks whose voxels did not fit the list
+    // Live-pixel compaction (config.trace_variant = 4; vct_trace.hip k_compact_tiles): the live pixels (albedo.a >= 0.5)
+    // of every 16x16-pixel super-tile packed into whole waves.  vt_pix[v * 64 + lane] = tile << 6 | pixel of the tile
+    // (all ones: no pixel), vt_count[0] = virtual tiles.  Null: lane = pixel of the launched tile.
+    uint32_t* vt_pix;
+    uint32_t* vt_count;
 };
 
 #define VCT_VOX_CHUNK 4096u       // most fragments one work item (workgroup) of the voxelize pass takes (vct_capi.hip build_voxel_slots)

@@ -74,6 +74,17 @@ Rccl* rccl() {
     return &r;
 }
 
+// gathered[rank][local row j][8 pixel rows][w] -> frame row (j * world + rank) * 8 + ...; one 8-byte pixel per thread step
+__global__ void __launch_bounds__(256)
+k_deinterleave(const uint2* __restrict__ gathered, uint2* __restrict__ frame, int w, int h, int world, size_t slab_pixels) {
+    const size_t n = (size_t)w * h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / (size_t)w), x = (int)(i - (size_t)y * w);
+        const int tr = y >> 3, r = tr % world, j = tr / world;
+        frame[i] = gathered[(size_t)r * slab_pixels + (size_t)(j * 8 + (y & 7)) * w + x];
+    }
+}
+
 }  // namespace
 
 struct vct_comm {
@@ -85,6 +96,15 @@ struct vct_comm {
     // load-aware partition (vct_comm_set_slab_rows): tile-row boundaries of every rank, [world + 1]; empty = the equal
     // partition above.  Uneven slabs travel by grouped ncclSend / ncclRecv straight to their rows of the root's frame.
     std::vector<int> starts;
+    // Interleaved slabs (vct_comm_set_interleaved): tile row r belongs to rank r % world -- every rank samples the whole
+    // frame, so the slabs cost the same BY CONSTRUCTION (no histogram, no feedback rounds).  A rank traces its rows back
+    // to back into its padded slab, the slabs travel with the one equal-count ncclGather, and the root de-interleaves
+    // them into `il_frame` (one 8-byte copy per pixel on the communication stream, behind the gather).
+    // VCT_COMM_STREAM=same: the gather is issued on the context's stream right behind the trace instead of on the
+    // communication stream behind an event (profiles/experiments/README.md "gather beside the next trace")
+    bool same_stream = false;
+    bool interleaved = false;
+    uint16_t* il_frame[2] = {nullptr, nullptr};      // root only
     size_t buf_halves = 0;             // allocation of each gather buffer
     hipStream_t comm_stream = nullptr;
     uint16_t* buf[2] = {nullptr, nullptr};   // root: the frame (world padded slabs); others: this rank's slab
@@ -118,6 +138,7 @@ static void comm_free(vct_comm* m) {
         else if (rccl()->CommDestroy) (void)rccl()->CommDestroy(m->comm);
     }
     for (int k = 0; k < 2; ++k) {
+        if (m->il_frame[k]) (void)hipFree(m->il_frame[k]);
         if (m->buf[k]) (void)hipFree(m->buf[k]);
         if (m->traced[k]) (void)hipEventDestroy(m->traced[k]);
         if (m->gathered[k]) (void)hipEventDestroy(m->gathered[k]);
@@ -137,6 +158,7 @@ bool vct_comm_rows(const vct_ctx* c, int* row0, int* row1) {
     if (!c || !c->comm) return false;
     *row0 = c->comm->row0;
     *row1 = c->comm->row1;
+    if (c->comm->interleaved) { *row0 = 0; *row1 = vct_tiles_y(c); }      // its rows are spread over the whole frame
     return true;
 }
 
@@ -207,7 +229,15 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
     m->slab_halves = (size_t)m->rows_per_rank * VCT_TILE * c->cfg.width * 4;
     m->buf_halves = rank == 0 ? m->slab_halves * world : m->slab_halves;
     if (const char* t = getenv("VCT_COMM_TIMEOUT_MS")) { const int v = atoi(t); if (v > 0) m->timeout_ms = v; }
-    hipError_t e = hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking);
+    if (const char* t = getenv("VCT_COMM_STREAM")) m->same_stream = t[0] == 's';
+    hipError_t e;
+    if (c->reserved_cus > 0) {       // the CUs the context's streams leave alone (VCT_COMM_RESERVED_CUS)
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, c->device);
+        if (e == hipSuccess) e = vct_create_masked_stream(&m->comm_stream, c->device, prop.multiProcessorCount - c->reserved_cus, prop.multiProcessorCount);
+    } else {
+        e = hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking);
+    }
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipMalloc(&m->buf[k], m->buf_halves * 2);
         if (e == hipSuccess) e = hipMemsetAsync(m->buf[k], 0, m->buf_halves * 2, c->stream);
@@ -296,6 +326,33 @@ int vct_comm_set_slab_rows(vct_ctx* c, const int32_t* starts) {
     return VCT_OK;
 }
 
+// Collective (every rank passes the same value): interleaved tile rows instead of contiguous slabs.  Frames in flight
+// are drained first.  The load-aware boundaries are dropped (the two are alternatives).
+int vct_comm_set_interleaved(vct_ctx* c, int32_t on) {
+    if (!c) return VCT_ERR_INVALID;
+    vct_comm* m = c->comm;
+    if (!m || m->broken) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_set_interleaved: no usable communicator (vct_comm_init)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = vct_comm_sync(c);
+    if (rc) return rc;
+    m->starts.clear();
+    vct_slab_partition(c->cfg.height, m->world, m->rank, &m->row0, &m->row1, nullptr);
+    m->interleaved = on != 0;
+    if (m->interleaved) {
+        const int ty = vct_tiles_y(c);
+        m->row0 = m->rank < ty ? m->rank : ty;
+        m->row1 = ty;
+        if (m->rank == 0)
+            for (int k = 0; k < 2; ++k)
+                if (!m->il_frame[k]) {
+                    const hipError_t e = hipMalloc(&m->il_frame[k], (size_t)c->cfg.width * c->cfg.height * 8);
+                    if (e != hipSuccess) { m->interleaved = false; return vct_fail(c, VCT_ERR_NOMEM, std::string("vct_comm_set_interleaved: ") + hipGetErrorString(e)); }
+                }
+    }
+    m->last = -1;
+    return VCT_OK;
+}
+
 // One frame: trace this rank's slab into gather buffer k and start its gather.  Asynchronous.
 int vct_frame_step(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
@@ -313,15 +370,27 @@ int vct_frame_step(vct_ctx* c) {
     HIP_TRY(c, hipStreamWaitEvent(c->stream, m->gathered[k], 0));    // buffer k is free once its last gather is done
     const bool uneven = !m->starts.empty();
     uint16_t* out_base = (m->rank == 0 && uneven) ? m->buf[k] : slab - first_row_halves;
-    const int rc = vct_launch_trace_rows(c, m->row0, m->row1, out_base);     // an empty slab launches nothing
+    // interleaved: every world-th tile row from `rank` on, back to back at the start of the slab
+    const int rc = m->interleaved ? vct_launch_trace_rows(c, m->row0, m->row1, slab, m->world, true)
+                                  : vct_launch_trace_rows(c, m->row0, m->row1, out_base);     // an empty slab launches nothing
     if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(m->traced[k], c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(m->comm_stream, m->traced[k], 0));
+    const hipStream_t cs = m->same_stream ? c->stream : m->comm_stream;
+    if (!m->same_stream) {
+        HIP_TRY(c, hipEventRecord(m->traced[k], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(m->comm_stream, m->traced[k], 0));
+    }
     Rccl* r = rccl();
-    if (!uneven) {
-        // ONE collective per frame.  Root: in place (its slab already sits at offset rank * sendcount = 0).
+    if (m->interleaved) {
         NCCL_TRY(c, m, r->Gather(slab, m->rank == 0 ? m->buf[k] : nullptr, m->slab_halves, ncclFloat16, 0, m->comm,
-                                 m->comm_stream));
+                                 cs));
+        if (m->rank == 0) {
+            hipLaunchKernelGGL(k_deinterleave, dim3(2048), dim3(256), 0, cs, (const uint2*)m->buf[k],
+                               (uint2*)m->il_frame[k], c->cfg.width, c->cfg.height, m->world, m->slab_halves / 4);
+            HIP_TRY(c, hipGetLastError());
+        }
+    } else if (!uneven) {
+        // ONE collective per frame.  Root: in place (its slab already sits at offset rank * sendcount = 0).
+        NCCL_TRY(c, m, r->Gather(slab, m->rank == 0 ? m->buf[k] : nullptr, m->slab_halves, ncclFloat16, 0, m->comm, cs));
     } else {
         // load-aware slabs differ in size: one fused group of point-to-point transfers, each slab straight to its
         // rows of the root's frame (what ncclGather is made of inside RCCL, with per-rank counts)
@@ -331,17 +400,17 @@ int vct_frame_step(vct_ctx* c) {
         if (m->rank == 0) {
             for (int peer = 1; peer < m->world && gr == ncclSuccess; ++peer) {
                 const size_t n = (size_t)(m->starts[peer + 1] - m->starts[peer]) * row_halves;
-                if (n) gr = r->Recv(m->buf[k] + (size_t)m->starts[peer] * row_halves, n, ncclFloat16, peer, m->comm, m->comm_stream);
+                if (n) gr = r->Recv(m->buf[k] + (size_t)m->starts[peer] * row_halves, n, ncclFloat16, peer, m->comm, cs);
             }
         } else {
             const size_t n = (size_t)(m->row1 - m->row0) * row_halves;
-            if (n) gr = r->Send(slab, n, ncclFloat16, 0, m->comm, m->comm_stream);
+            if (n) gr = r->Send(slab, n, ncclFloat16, 0, m->comm, cs);
         }
         const ncclResult_t ge = r->GroupEnd();
         if (gr != ncclSuccess) return comm_fail(c, m, "ncclSend/ncclRecv", gr);
         if (ge != ncclSuccess) return comm_fail(c, m, "ncclGroupEnd", ge);
     }
-    HIP_TRY(c, hipEventRecord(m->gathered[k], m->comm_stream));
+    HIP_TRY(c, hipEventRecord(m->gathered[k], cs));
     m->last = k;
     ++m->frames;
     return VCT_OK;
@@ -390,7 +459,7 @@ int vct_comm_frame(vct_ctx* c, void** dev, size_t* bytes) {
     vct_comm* m = c->comm;
     if (!m || m->last < 0) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_frame: no frame gathered yet");
     if (m->rank != 0) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_frame: only the root (rank 0) holds the frame");
-    *dev = m->buf[m->last];
+    *dev = m->interleaved ? m->il_frame[m->last] : m->buf[m->last];
     if (bytes) *bytes = (size_t)c->cfg.width * c->cfg.height * 8;
     return VCT_OK;
 }
@@ -405,6 +474,43 @@ int vct_comm_download_frame(vct_ctx* c, void* out) {
     if (rc) return rc;
     HIP_TRY(c, hipMemcpy(out, dev, bytes, hipMemcpyDeviceToHost));
     return VCT_OK;
+}
+
+// The interleaved step's data path on ONE GPU, for any world size (no multi-GPU box is needed to check it): the resident
+// G-buffer is traced once per emulated rank -- its rows, strided and packed, into slab `rank` of a stand-in gather
+// buffer, exactly as vct_frame_step does -- the root's de-interleave kernel runs over that buffer, and the result is
+// compared with the frame one launch traces.  *mismatches = pixels that differ (0 expected).
+int vct_selftest_interleaved(vct_ctx* c, int32_t world, uint64_t* mismatches) {
+    if (!c || !mismatches || world < 1) return VCT_ERR_INVALID;
+    if (!c->have_gbuffer) return vct_fail(c, VCT_ERR_INVALID, "vct_selftest_interleaved: no G-buffer resident yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int w = c->cfg.width, h = c->cfg.height, ty = vct_tiles_y(c);
+    const int per = (ty + world - 1) / world;
+    const size_t slab_pixels = (size_t)per * VCT_TILE * w, npix = (size_t)w * h;
+    uint2 *gathered = nullptr, *il = nullptr, *plain = nullptr;
+    auto done = [&](int rc) { if (gathered) (void)hipFree(gathered); if (il) (void)hipFree(il); if (plain) (void)hipFree(plain); return rc; };
+    if (hipMalloc(&gathered, slab_pixels * world * 8) != hipSuccess || hipMalloc(&il, npix * 8) != hipSuccess ||
+        hipMalloc(&plain, npix * 8) != hipSuccess)
+        return done(vct_fail(c, VCT_ERR_NOMEM, "vct_selftest_interleaved: out of memory"));
+    hipError_t e = hipMemsetAsync(gathered, 0, slab_pixels * world * 8, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(plain, 0, npix * 8, c->stream);
+    if (e != hipSuccess) return done(vct_fail(c, VCT_ERR_DEVICE, hipGetErrorString(e)));
+    for (int r = 0; r < world; ++r) {
+        const int rc = vct_launch_trace_rows(c, r < ty ? r : ty, ty, (uint16_t*)(gathered + slab_pixels * r), world, true);
+        if (rc) return done(rc);
+    }
+    hipLaunchKernelGGL(k_deinterleave, dim3(2048), dim3(256), 0, c->stream, gathered, il, w, h, world, slab_pixels);
+    int rc = vct_launch_trace_rows(c, 0, ty, (uint16_t*)plain);
+    if (rc) return done(rc);
+    std::vector<uint2> a(npix), b(npix);
+    e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(a.data(), il, npix * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(b.data(), plain, npix * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(vct_fail(c, VCT_ERR_DEVICE, hipGetErrorString(e)));
+    uint64_t bad = 0;
+    for (size_t i = 0; i < npix; ++i) bad += (a[i].x != b[i].x || a[i].y != b[i].y) ? 1u : 0u;
+    *mismatches = bad;
+    return done(VCT_OK);
 }
 
 }  // extern "C"

@@ -1677,16 +1677,26 @@ k_gbuffer_shade(const ShadeParams p) {
                     VctWords6 w[6];
 #pragma unroll
                     for (int y = 0; y < 6; ++y) w[y] = *reinterpret_cast<const VctWords6*>(p.shadow + (size_t)row[y] * S + col[0]);
-                    float r0[6], r1[6];
+                    uint32_t wmin = 0xffffffffu, wmax = 0u;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) r0[i] = vct_shadow_depth(w[0].v[i], p.shadow_ebase);
+                    for (int y = 0; y < 6; ++y)
 #pragma unroll
-                    for (int y = 0; y < 5; ++y) {
+                        for (int i = 0; i < 6; ++i) { wmin = min(wmin, w[y].v[i]); wmax = max(wmax, w[y].v[i]); }
+                    const int verdict = vct_pcf_window_verdict(wmin, wmax, p.shadow_ebase, cur);      // vct_internal.h "PCF short cut"
+                    if (verdict >= 0) {
+                        cnt = (float)verdict;
+                    } else {
+                        float r0[6], r1[6];
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) r1[i] = vct_shadow_depth(w[y + 1].v[i], p.shadow_ebase);
-                        tap_row(y, r0, r1);
+                        for (int i = 0; i < 6; ++i) r0[i] = vct_shadow_depth(w[0].v[i], p.shadow_ebase);
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) r0[i] = r1[i];
+                        for (int y = 0; y < 5; ++y) {
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) r1[i] = vct_shadow_depth(w[y + 1].v[i], p.shadow_ebase);
+                            tap_row(y, r0, r1);
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) r0[i] = r1[i];
+                        }
                     }
                 } else {       // a window at a clamped border: texel by texel, two rows live at a time
                     float r0[6], r1[6];

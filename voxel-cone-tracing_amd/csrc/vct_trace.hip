@@ -80,9 +80,12 @@ __device__ __forceinline__ F3 reflect3(F3 I, F3 N) {
 //     non-zero trilinear weight is >= 2^-75, a non-zero texel >= 1/255, the level blend factors are
 //     0 or >= 2^-10 and oma >= 2^-5 (both checked on the host: vct_capi.hip refresh_steps).
 #define VCT_DIV_TINY 0x1p-100f
-template <bool FAST>
+// MODE 0: the IEEE division, 1: the verified one-round form, 2: x * r alone -- NOT exact: only the opt-in "loose" trace
+// variant that prices the exactness (config.trace_variant = 3, k_trace_tile_split<.., 2, ..>) uses it
+template <int MODE>
 __device__ __forceinline__ float div_const(float x, float d, float r) {
-    if (!FAST) return x / d;
+    if (MODE == 0) return x / d;
+    if (MODE == 2) return x * r;
     const float q = x * r;
     const float e = fmaf(-d, q, x);
     return fmaf(e, r, q);
@@ -119,11 +122,37 @@ __device__ __forceinline__ uint32_t spread_byte(SpreadLut lut, int a, uint32_t m
     return *(SpreadLut)((const __attribute__((address_space(4))) char*)lut + off);
 }
 
+// EXPERIMENT / option (-DVCT_LUT=1 | 2 | 3; round 4): the exact unorm8 -> float decode through a
+// 256-entry table in LDS (1 KiB per workgroup, entry i = (float)i / 255.0f computed by the same two-term product) --
+// one SDWA byte-select shift + one ds_read_b32 per channel instead of cvt + mul + fma.  Bit 0: the cooperative
+// block's four decodes per lane, bit 1: the per-lane gather's 32.  Same bits either way; measurements in
+// profiles/experiments/README.md.
+#ifndef VCT_LUT
+#define VCT_LUT 0
+#endif
+typedef const __attribute__((address_space(3))) float* UnormLut;
 struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
     SpreadLut lut;              // (wave-uniform) the dilated-coordinate table
     int lane;
     uint32_t sbx, sby, sbz;     // BYTE offsets: 4 * dilated (l&3), ((l>>2)&3)<<1, (l>>4)<<2
+    UnormLut unorm;             // VCT_LUT: the decode table in LDS
 };
+#if VCT_LUT
+#define VCT_LUT_DECL __shared__ float lds_unorm[256];
+// (called by every thread of the workgroup before its first barrier / before any sample)
+#define VCT_LUT_FILL(lb)                                                                                      \
+    for (uint32_t i_ = threadIdx.x; i_ < 256u; i_ += blockDim.x) lds_unorm[i_] = vct_unorm8_to_float(i_);     \
+    (lb).unorm = (UnormLut)lds_unorm;
+#else
+#define VCT_LUT_DECL
+#define VCT_LUT_FILL(lb) (lb).unorm = nullptr;
+#endif
+template <int SHIFT, bool LOOSE = false>
+__device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lut) {
+    if (LOOSE) return (float)((t >> SHIFT) & 0xffu) * 0x1.010102p-8f;     // one multiply: wrong in the last bit for 126 of the 256 bytes
+    if (use_lut) return lut[(t >> SHIFT) & 0xffu];
+    return vct_unorm8_to_float((t >> SHIFT) & 0xffu);
+}
 
 // Instrumented build (-DVCT_STATS=1, tools/trace_stats.py): wave-level counters of the march, kept in
 // SGPRs and flushed once per wave.  The production build compiles all of it away.
@@ -158,7 +187,7 @@ struct MarchStats {
 // [GL] tri(level): trilinear, texel centres, REPEAT (or clamp).  `level` is wave-uniform; must be
 // called in wave-uniform control flow with at least one lane `act`.  Lanes without `act` help
 // fetch the block and return garbage-free zeros / unused values.
-template <bool WRAP, bool COOP>
+template <bool WRAP, bool COOP, bool LOOSE = false>
 __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, const VctLevelRef lv,
                                            float ux, float uy, float uz, bool act, unsigned long long am,
                                            float4* __restrict__ blk, const LaneBlock& lb, MarchStats& ms) {
@@ -257,10 +286,10 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         if (VCT_STATS) { if (any_texel) ++ms.coop_hit; else ++ms.coop_zero; }
         if (any_texel) {     // all 64 texels zero: every footprint sums to exactly +0
             float4 d;
-            d.x = unorm8(t & 0xffu);
-            d.y = unorm8((t >> 8) & 0xffu);
-            d.z = unorm8((t >> 16) & 0xffu);
-            d.w = unorm8(t >> 24);
+            d.x = unorm8_of<0, LOOSE>(lb.unorm, t, (VCT_LUT & 1) != 0);
+            d.y = unorm8_of<8, LOOSE>(lb.unorm, t, (VCT_LUT & 1) != 0);
+            d.z = unorm8_of<16, LOOSE>(lb.unorm, t, (VCT_LUT & 1) != 0);
+            d.w = unorm8_of<24, LOOSE>(lb.unorm, t, (VCT_LUT & 1) != 0);
             blk[lb.lane] = d;
             wave_sync();
 #if VCT_TWO_BLOCKS
@@ -363,16 +392,17 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
         const float wg[8] = {(a0 * b0) * c0, (a * b0) * c0, (a0 * b) * c0, (a * b) * c0,
                              (a0 * b0) * c,  (a * b0) * c,  (a0 * b) * c,  (a * b) * c};
-        r.x = wg[0] * unorm8(t[0] & 0xffu);
-        r.y = wg[0] * unorm8((t[0] >> 8) & 0xffu);
-        r.z = wg[0] * unorm8((t[0] >> 16) & 0xffu);
-        r.w = wg[0] * unorm8(t[0] >> 24);
+        constexpr bool L = (VCT_LUT & 2) != 0;
+        r.x = wg[0] * unorm8_of<0, LOOSE>(lb.unorm, t[0], L);
+        r.y = wg[0] * unorm8_of<8, LOOSE>(lb.unorm, t[0], L);
+        r.z = wg[0] * unorm8_of<16, LOOSE>(lb.unorm, t[0], L);
+        r.w = wg[0] * unorm8_of<24, LOOSE>(lb.unorm, t[0], L);
 #pragma unroll
         for (int i = 1; i < 8; ++i) {
-            r.x = fmaf(wg[i], unorm8(t[i] & 0xffu), r.x);
-            r.y = fmaf(wg[i], unorm8((t[i] >> 8) & 0xffu), r.y);
-            r.z = fmaf(wg[i], unorm8((t[i] >> 16) & 0xffu), r.z);
-            r.w = fmaf(wg[i], unorm8(t[i] >> 24), r.w);
+            r.x = fmaf(wg[i], unorm8_of<0, LOOSE>(lb.unorm, t[i], L), r.x);
+            r.y = fmaf(wg[i], unorm8_of<8, LOOSE>(lb.unorm, t[i], L), r.y);
+            r.z = fmaf(wg[i], unorm8_of<16, LOOSE>(lb.unorm, t[i], L), r.z);
+            r.w = fmaf(wg[i], unorm8_of<24, LOOSE>(lb.unorm, t[i], L), r.w);
         }
       }
     }
@@ -523,10 +553,10 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
         const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f); \
         const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f); \
         F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, live, blk, lb, ac, ms) \
-                                         : sample_level<WRAP, COOP>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms); \
+                                         : sample_level<WRAP, COOP, FASTDIV == 2>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms); \
         if (st.two_levels) { \
             const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, live, blk + 64, lb, ac, ms) \
-                                : sample_level<WRAP, COOP>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms); \
+                                : sample_level<WRAP, COOP, FASTDIV == 2>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms); \
             const float g = st.omf;      /* 1 - frac, from the table */ \
             vc.x = fmaf(st.frac, t2.x, g * vc.x); \
             vc.y = fmaf(st.frac, t2.y, g * vc.y); \
@@ -543,7 +573,7 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
             ++steps; \
         }
 
-template <bool WRAP, bool FASTDIV, bool COOP, bool ANISO = false>
+template <bool WRAP, int FASTDIV, bool COOP, bool ANISO = false>
 __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3 start, F3 dir,
                                          const VctStep* tab_global, int n,
                                          float4* __restrict__ blk, const LaneBlock& lb,
@@ -610,7 +640,7 @@ __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3
 #define VCT_LOCKSTEP 0
 #endif
 struct ConeAcc { float cr, cg, cb, alpha, occ; int steps; };
-template <bool WRAP, bool FASTDIV, bool COOP>
+template <bool WRAP, int FASTDIV, bool COOP>
 __device__ __forceinline__ void cone_march3(const VctTraceParams& p, bool alive, F3 start, const F3 dirs[3],
                                             const VctStep* tab_global, int n, float4* __restrict__ blk,
                                             const LaneBlock& lb, ConeAcc out[3], MarchStats& ms) {
@@ -704,22 +734,27 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
 // adjacent tiles per workgroup.  Workgroups are dealt to XCDs round-robin by the dispatcher (block b -> XCD b % 8), so
 // the tile order is remapped to give every XCD one contiguous run of tiles: neighbouring tiles
 // march through neighbouring voxels and share that XCD's L2.
-template <bool WRAP, bool FASTDIV, bool COOP>
+template <bool WRAP, int FASTDIV, bool COOP>
 __global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_TRACE_MIN_WAVES)
 k_trace_tile(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_WAVES_PER_BLOCK][2][64];
+    VCT_LUT_DECL
     const int lane = threadIdx.x & 63;
     // wave-uniform by construction; readfirstlane tells the compiler, so tile indices, the tile's
     // G-buffer base and the LDS slab base live in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float4* blk = &lds_blk[wave][0][0];
+    LaneBlock lb;
+    VCT_LUT_FILL(lb)
+#if VCT_LUT
+    __syncthreads();
+#endif
 
     const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
     const int vb = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int ti = vb * VCT_WAVES_PER_BLOCK + wave;
     if (ti >= ntiles) return;
 
-    LaneBlock lb;
     lb.lane = lane;
     lb.lut = (SpreadLut)p.spread_lut;
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
@@ -872,7 +907,7 @@ static_assert(VCT_SPLIT == 3 || VCT_SPLIT == 4 || VCT_SPLIT == 7, "VCT_SPLIT mus
 
 // (the anisotropic instantiation carries three samples' worth of state: it gets 128 VGPRs instead of
 // spilling under the 80 of the default kernel)
-template <bool WRAP, bool FASTDIV, bool ANISO>
+template <bool WRAP, int FASTDIV, bool ANISO, bool COMPACT = false>
 __global__ void __launch_bounds__(64 * VCT_SPLIT, ANISO ? VCT_ANISO_MIN_WAVES : VCT_TRACE_MIN_WAVES)
 k_trace_tile_split(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_SPLIT][ANISO ? 4 : 2][64];   // per wave: level-1 slab, level-2 slab (+ their "-axis" slabs)
@@ -882,14 +917,27 @@ k_trace_tile_split(const VctTraceParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float4* blk = &lds_blk[wave][0][0];
+    VCT_LUT_DECL
+    LaneBlock lb;
+    VCT_LUT_FILL(lb)
     if (threadIdx.x == 0) { lds_done = 0; lds_steps = 0; }
     __syncthreads();
 
-    const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
+    const int ntiles = p.ntiles;          // (host-computed: a division here is ~40 instructions per wave -- 1 % of the frame)
     const int ti = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     if (ti >= ntiles) return;
+    // Live-pixel compaction (experiment, trace_variant 4): the wave's 64 pixels come from the compaction list -- the live
+    // pixels of a 16x16 super-tile -- instead of being the launched tile's.  `cpix` = tile << 6 | pixel of the tile.
+    constexpr bool compact = COMPACT;         // (a separate instantiation: the default kernel carries none of this)
+    uint32_t cpix = 0u;
+    if (compact) {
+        if ((uint32_t)ti >= *p.vt_count) {
+            if (threadIdx.x == 0) p.tile_steps[p.tile_row0 * p.tiles_x + ti] = 0u;
+            return;
+        }
+        cpix = p.vt_pix[(size_t)ti * 64 + lane];
+    }
 
-    LaneBlock lb;
     lb.lane = lane;
     lb.lut = (SpreadLut)p.spread_lut;
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
@@ -897,19 +945,29 @@ k_trace_tile_split(const VctTraceParams p) {
     lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
     MarchStats ms = {};
 
-    const int tile = p.tile_row0 * p.tiles_x + ti;
+    // (interleaved slabs: traced row j of the launch is tile row row0 + j * stride; the plain launch pays no second division)
+    int lrow = 0, tile0 = p.tile_row0 * p.tiles_x + ti;           // tile0: where the wave's step count is stored
+    if (p.row_stride > 1) {
+        lrow = ti / p.tiles_x;
+        tile0 = (p.tile_row0 + lrow * p.row_stride) * p.tiles_x + (ti - lrow * p.tiles_x);
+    }
+    const bool cvalid = !compact || cpix != 0xffffffffu;
+    const int tile = compact ? (cvalid ? (int)(cpix >> 6) : 0) : tile0;
     const int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
-    auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    // tile row of the output (a packed slab holds its rows back to back)
+    const int oy = p.pack_rows ? (p.row_stride > 1 ? lrow : ty - p.tile_row0) : ty;
+    const int plane_ = compact ? (int)(cpix & 63u) : lane;        // this lane's pixel inside its tile
+    auto fresh_lane = [&]() { int l = plane_; asm volatile("" : "+v"(l)); return l; };
     auto pixel_index = [&](int l) {
-        return (size_t)(ty * VCT_TILE + (l >> 3)) * p.width + (tx * VCT_TILE + (l & 7));
+        return (size_t)(oy * VCT_TILE + (l >> 3)) * p.width + (tx * VCT_TILE + (l & 7));
     };
     auto gbuf_ptr = [&](int l) {
         return p.gbuf + (size_t)tile * (VCT_GB_NPLANES * VCT_TILE_PIX) + l;
     };
-    const int x = tx * VCT_TILE + (lane & 7), y = ty * VCT_TILE + (lane >> 3);
-    const float* gb = gbuf_ptr(lane);
+    const int x = tx * VCT_TILE + (plane_ & 7), y = ty * VCT_TILE + (plane_ >> 3);
+    const float* gb = gbuf_ptr(plane_);
 #define VCT_GB(k) gb[(k) * VCT_TILE_PIX]
-    const bool in_frame = (x < p.width) && (y < p.height);
+    const bool in_frame = cvalid && (x < p.width) && (y < p.height);
     const bool alive = in_frame && !(VCT_GB(18) < 0.5f);            // trace.fs:171 discard
     int total = 0;
     if (wave < VCT_SPLIT - 1) {
@@ -1002,7 +1060,7 @@ k_trace_tile_split(const VctTraceParams p) {
     arrived = __builtin_amdgcn_readfirstlane(arrived);
     if (arrived != VCT_SPLIT - 1) return;
     __threadfence_block();
-    if (lane == 0) p.tile_steps[tile] = (uint32_t)lds_steps;      // one plain store per tile: no global atomic, nothing to clear
+    if (lane == 0) p.tile_steps[tile0] = (uint32_t)lds_steps;     // one plain store per tile: no global atomic, nothing to clear
 
     // composite by the last wave                                                   trace.fs:179-227
     const float* gb3 = gbuf_ptr(fresh_lane());
@@ -1127,7 +1185,10 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
     const int lane = threadIdx.x & 63;                                       \
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); \
     float4* blk = &lds_blk[wave][0][0];                                      \
+    VCT_LUT_DECL                                                             \
     LaneBlock lb;                                                            \
+    VCT_LUT_FILL(lb)                                                         \
+    if (VCT_LUT) __syncthreads();                                            \
     lb.lane = lane;                                                          \
     lb.lut = (SpreadLut)p.spread_lut;                                        \
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;                          \
@@ -1221,7 +1282,7 @@ k_bounce_list(const VctTraceParams p) {
 #define VCT_BOUNCE_MIN_WAVES 5     // the per-voxel frame + attribute state spills under the trace kernel's budget; A/B at 512^3
                                    // (bounce + mips, ms): 4: 0.495, 5: 0.489, 6: 0.500, 7: 0.504
 #endif
-template <bool WRAP, bool FASTDIV>
+template <bool WRAP, int FASTDIV>
 __global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_BOUNCE_MIN_WAVES)
 k_bounce_march(const VctTraceParams p) {
     VCT_BOUNCE_SETUP
@@ -1243,7 +1304,7 @@ k_bounce_march(const VctTraceParams p) {
         atomicAdd(p.step_counter + ((blockIdx.x * VCT_WAVES_PER_BLOCK + wave) & (VCT_STEP_COUNTERS - 1)), wave_steps);
 }
 
-template <bool WRAP, bool FASTDIV>
+template <bool WRAP, int FASTDIV>
 __global__ void __launch_bounds__(64 * VCT_WAVES_PER_BLOCK, VCT_BOUNCE_MIN_WAVES)
 k_bounce_bricks(const VctTraceParams p) {
     VCT_BOUNCE_SETUP
@@ -1278,14 +1339,64 @@ k_bounce_bricks(const VctTraceParams p) {
         atomicAdd(p.step_counter + ((blockIdx.x * VCT_WAVES_PER_BLOCK + wave) & (VCT_STEP_COUNTERS - 1)), wave_steps);
 }
 
-template <bool WRAP, bool FASTDIV, bool COOP>
+// Live-pixel compaction (experiment, north_star "compact still-active cones"; profiles/experiments/README.md): one wave
+// per 16x16-pixel super-tile of the launched rows gathers the live pixels (albedo.a >= 0.5, trace.fs:169-172) of its up
+// to four 8x8 tiles into whole waves of 64 -- "virtual tiles" -- and gives the discarded pixels their clear colour
+// (VCT.h:156-159) right away.  The trace then runs one workgroup per virtual tile.
+__global__ void __launch_bounds__(256)
+k_compact_tiles(const VctTraceParams p) {
+    const int lane = threadIdx.x & 63;
+    const int rows = p.tile_row1 - p.tile_row0;
+    const int sx_n = (p.tiles_x + 1) >> 1, sy_n = (rows + 1) >> 1;
+    const int st = blockIdx.x * (blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    if (st >= sx_n * sy_n) return;
+    const int sy = st / sx_n, sx = st - sy * sx_n;
+    unsigned long long m[4];
+    int tiles[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int tx = 2 * sx + (k & 1), ty = p.tile_row0 + 2 * sy + (k >> 1);
+        const bool have = tx < p.tiles_x && ty < p.tile_row1;
+        tiles[k] = have ? ty * p.tiles_x + tx : -1;
+        bool live = false;
+        if (have) {
+            const int x = tx * VCT_TILE + (lane & 7), y = ty * VCT_TILE + (lane >> 3);
+            const bool in_frame = x < p.width && y < p.height;
+            const float a = p.gbuf[(size_t)tiles[k] * (VCT_GB_NPLANES * VCT_TILE_PIX) + 18 * VCT_TILE_PIX + lane];
+            live = in_frame && !(a < 0.5f);
+            if (in_frame && !live) {
+                const float cc = p.ambient < 0.5f ? 0.5f : 1.0f;
+                uint2 pk;
+                pk.x = pack_half2(cc, cc);
+                pk.y = pack_half2(cc, 1.0f);
+                *reinterpret_cast<uint2*>(p.out + ((size_t)y * p.width + x) * 4) = pk;
+            }
+        }
+        m[k] = ballot64(live);
+    }
+    const int total = (int)(__popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]));
+    const int nvt = (total + 63) >> 6;
+    uint32_t base = 0u;
+    if (lane == 0 && nvt) base = atomicAdd(p.vt_count, (uint32_t)nvt);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((m[k] >> lane) & 1ull)
+            p.vt_pix[(size_t)base * 64 + n + __popcll(m[k] & ((1ull << lane) - 1ull))] = ((uint32_t)tiles[k] << 6) | (uint32_t)lane;
+        n += (int)__popcll(m[k]);
+    }
+    for (int i = total + lane; i < nvt * 64; i += 64) p.vt_pix[(size_t)base * 64 + i] = 0xffffffffu;
+}
+
+template <bool WRAP, int FASTDIV, bool COOP>
 hipError_t launch(const VctTraceParams& p, int blocks, hipStream_t s) {
     hipLaunchKernelGGL((k_trace_tile<WRAP, FASTDIV, COOP>), dim3(blocks),
                        dim3(64 * VCT_WAVES_PER_BLOCK), 0, s, p);
     return hipGetLastError();
 }
 
-template <bool WRAP, bool FASTDIV>
+template <bool WRAP, int FASTDIV>
 hipError_t launch_v(const VctTraceParams& p, int variant, int ntiles, hipStream_t s) {
     if (!p.aniso && (variant == 1 || variant == 2)) {      // the anisotropic option exists in the default kernel only
         const int nblocks = (ntiles + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
@@ -1293,6 +1404,23 @@ hipError_t launch_v(const VctTraceParams& p, int variant, int ntiles, hipStream_
         return variant == 1 ? launch<WRAP, FASTDIV, false>(p, blocks, s) : launch<WRAP, FASTDIV, true>(p, blocks, s);
     }
     const int blocks = ((ntiles + 7) / 8) * 8;
+    if (p.vt_pix) {         // variant 4: compaction pre-pass (the counter was zeroed by the caller)
+        const int rows = p.tile_row1 - p.tile_row0;
+        const int nst = ((p.tiles_x + 1) >> 1) * ((rows + 1) >> 1);
+        hipLaunchKernelGGL(k_compact_tiles, dim3((nst + 3) / 4), dim3(256), 0, s, p);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    // variant 3: the default kernel with the one-multiply decode and reciprocal-multiply divisions -- never the default,
+    // not bit-exact; it exists to price the exactness (bench.py exactness_tax)
+    if (variant == 3 && !p.aniso) {
+        hipLaunchKernelGGL((k_trace_tile_split<WRAP, 2, false>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+        return hipGetLastError();
+    }
+    if (p.vt_pix) {
+        hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+        return hipGetLastError();
+    }
     if (p.aniso) hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     else hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     return hipGetLastError();
@@ -1325,7 +1453,7 @@ hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, h
     return hipGetLastError();
 }
 
-template <bool WRAP, bool FASTDIV>
+template <bool WRAP, int FASTDIV>
 hipError_t launch_bounce(const VctTraceParams& p, hipStream_t s) {
     uint32_t blocks = (p.nbricks + VCT_WAVES_PER_BLOCK - 1) / VCT_WAVES_PER_BLOCK;
     if (blocks > 256u * 64u) blocks = 256u * 64u;
@@ -1352,8 +1480,10 @@ hipError_t vct_launch_bounce(const VctTraceParams& p, hipStream_t s) {
 // variant 0 (default): cooperative sampler, each tile split over 3 waves; 2: cooperative sampler, one
 // wave per tile; 1: per-lane sampler only, one wave per tile.
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s) {
-    const int ntiles = (p.tile_row1 - p.tile_row0) * p.tiles_x;
+    const int rstride = p.row_stride > 1 ? p.row_stride : 1;
+    const int ntiles = ((p.tile_row1 - p.tile_row0 + rstride - 1) / rstride) * p.tiles_x;
     if (ntiles <= 0) return hipSuccess;
+    if ((rstride > 1 || p.pack_rows) && (variant == 1 || variant == 2 || variant == 4)) return hipErrorInvalidValue;   // the default kernel only
     if (p.wrap_repeat)
         return p.fast_div ? launch_v<true, true>(p, variant, ntiles, s)
                           : launch_v<true, false>(p, variant, ntiles, s);

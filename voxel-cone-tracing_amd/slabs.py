@@ -33,6 +33,11 @@ def slab_pixel_rows(height, world, rank):
     return r0 * TILE, min(r1 * TILE, height)
 
 
+def interleaved_rows(height, world, rank):
+    """Tile rows of rank `rank` under the interleaved assignment (row r -> rank r % world)."""
+    return list(range(rank, tile_rows(height), world))
+
+
 class FrameGather:
     """Owns the padded gather buffers.  `slab` tensors are [rows_per_rank*8, width, 4] float16."""
 
@@ -48,6 +53,25 @@ class FrameGather:
     def my_rows(self):
         """Pixel rows [y0, y1) of the frame this rank produces."""
         return slab_pixel_rows(self.height, self.world, self.rank)
+
+    def pack_interleaved(self, frame_rows):
+        """Interleaved assignment: copy this rank's tile rows out of a full-height [height, width, 4] tensor (what a
+        strided trace wrote at the rows' own places) into self.slab, back to back."""
+        for j, r in enumerate(interleaved_rows(self.height, self.world, self.rank)):
+            y0, y1 = r * TILE, min(r * TILE + TILE, self.height)
+            self.slab[j * TILE: j * TILE + (y1 - y0)].copy_(frame_rows[y0:y1])
+
+    def gather_interleaved(self, force_collective=False):
+        """The same ONE collective as gather(); the root then de-interleaves: tile row j of rank r's slab is tile row
+        j * world + r of the frame.  Root returns the [height, width, 4] frame, the others None."""
+        if self.gather(force_collective) is None:
+            return None
+        out = torch.empty((self.height, self.width, 4), dtype=self.frame.dtype, device=self.frame.device)
+        for r in range(self.world):
+            for j, row in enumerate(interleaved_rows(self.height, self.world, r)):
+                y0, y1 = row * TILE, min(row * TILE + TILE, self.height)
+                out[y0:y1].copy_(self.frame[r * self.rows + j * TILE: r * self.rows + j * TILE + (y1 - y0)])
+        return out
 
     def gather(self, force_collective=False):
         """One collective: every rank contributes self.slab; root returns the [height,width,4] frame
