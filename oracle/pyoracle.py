@@ -393,6 +393,14 @@ def voxelize_conservative(p, scene, want_acc=False):
     return (l0, acc) if want_acc else l0
 
 
+def voxelize_conservative_zslab(p, scene, z0, z1):
+    """z-slices [z0, z1) of voxelize_conservative's level 0: uint8 [z1 - z0, V, V, 4]."""
+    V = p.V
+    l0 = np.zeros((z1 - z0, V, V, 4), np.uint8)
+    lib().vcto_voxelize_conservative_zslab(C.byref(p), C.byref(scene), int(z0), int(z1), _ptr(l0))
+    return l0
+
+
 def voxelize_conservative_attr(p, scene):
     """Returns (l0, attr_albedo, attr_normal), each uint8 [V,V,V,4]."""
     V = p.V

@@ -68,6 +68,10 @@ int main() {
         std::vector<uint32_t> acc(nvox * 4);
         vcto_voxelize_reference(&p, &sc, lref.data());
         vcto_voxelize_conservative_attr(&p, &sc, l0.data(), acc.data(), a_alb.data(), a_nrm.data());
+        {
+            std::vector<uint8_t> slab((size_t)3 * p.V * p.V * 4);
+            vcto_voxelize_conservative_zslab(&p, &sc, 2, 5, slab.data());
+        }
         std::vector<uint8_t> chain(nchain * 4, 0), aniso(6 * (nchain - nvox) * 4, 0);
         memcpy(chain.data(), l0.data(), nvox * 4);
         vcto_build_mips(chain.data(), V);
@@ -106,6 +110,7 @@ int main() {
     vcto_sample(&p, tiny.data(), pos3, 1.5f, out4);
     vcto_sample(&p, tiny.data(), pos3, 99.0f, out4);
     vcto_sample(&p, tiny.data(), pos3, -1.0f, out4);
+    { const float uvw[3] = {0.25f, 1.75f, -0.5f}; vcto_texture_lod(&p, tiny.data(), uvw, 0.7f, out4); }
     if (vcto_f32_to_f16(65520.0f) != 0x7c00 || vcto_f16_to_f32(0x3c00) != 1.0f) return 1;
     printf("sanitize_check ok\n");
     return 0;

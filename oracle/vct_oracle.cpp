@@ -783,11 +783,25 @@ struct ConsFrag {
 // scalar restatement; integer sums make the result independent of the order), sorted by voxel and
 // reduced, so memory scales with the surface (fragments), not with V^3: a 1024^3 grid needs no 16 GiB
 // accumulator on the checker side either.
+namespace {
+void voxelize_conservative_z(const vcto_params* p, const vcto_scene* s, int z0, int z1, uint8_t* l0,
+                             uint32_t* acc_out, uint8_t* attr_albedo, uint8_t* attr_normal);
+}
 void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
                                      uint32_t* acc_out, uint8_t* attr_albedo, uint8_t* attr_normal) {
+    voxelize_conservative_z(p, s, 0, p->V, l0, acc_out, attr_albedo, attr_normal);
+}
+/* z-slices [z0, z1) of the same voxelization: l0_slab is [(z1 - z0)][V][V][4].  A voxel's value depends only on the
+ * triangles that overlap it, so a slab of the full result costs a slab of memory (checks of 1024^3 on small hosts). */
+void vcto_voxelize_conservative_zslab(const vcto_params* p, const vcto_scene* s, int32_t z0, int32_t z1, uint8_t* l0_slab) {
+    voxelize_conservative_z(p, s, z0, z1, l0_slab, nullptr, nullptr, nullptr);
+}
+namespace {
+void voxelize_conservative_z(const vcto_params* p, const vcto_scene* s, int z0, int z1, uint8_t* l0,
+                             uint32_t* acc_out, uint8_t* attr_albedo, uint8_t* attr_normal) {
     const int V = p->V;
     const float fV = (float)V;
-    const size_t nvox = (size_t)V * V * V;
+    const size_t nvox = (size_t)V * V * (size_t)(z1 - z0);
     const bool want_attr = attr_albedo || attr_normal;
     auto work = [&](int t0, int t1, std::vector<ConsFrag>* out) {
       for (int t = t0; t < t1; ++t) {
@@ -813,6 +827,8 @@ void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, 
             lo[a] = std::max((int)floorf(mn), 0);
             hi[a] = std::min((int)floorf(mx), V - 1);
         }
+        lo[2] = std::max(lo[2], z0);          // only the slices asked for
+        hi[2] = std::min(hi[2], z1 - 1);
         // 2-D barycentric set-up in the plane orthogonal to the dominant axis (voxel space)
         const int ua = ts.axis == 1 ? 1 : 0, ub = ts.axis == 3 ? 1 : 2;   // X:(y,z) Y:(x,z) Z:(x,y)
         const float ax0 = comp(g[0], ua), ay0 = comp(g[0], ub);
@@ -856,7 +872,7 @@ void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, 
                     frag_value(s, t, ts, b0, b1, b2, dc, f.rgb, alb, duv);
                     if (want_attr)
                         for (int c = 0; c < 3; ++c) f.attr[c] = to_unorm8(alb[c]);      // the fragment's albedo
-                    f.vox = ((uint64_t)k * V + j) * V + i;
+                    f.vox = ((uint64_t)(k - z0) * V + j) * V + i;
                     out->push_back(f);
                 }
       }
@@ -917,6 +933,7 @@ void vcto_voxelize_conservative_attr(const vcto_params* p, const vcto_scene* s, 
         b = e;
     }
 }
+}  // namespace
 
 uint64_t vcto_bounce(const vcto_params* p, const uint8_t* chain0, const uint8_t* attr_albedo,
                      const uint8_t* attr_normal, uint8_t* out_l0, int nthreads) {

@@ -204,6 +204,9 @@ void vcto_voxelize_reference(const vcto_params* p, const vcto_scene* s, uint8_t*
  * (sum r, sum g, sum b, count). */
 void vcto_voxelize_conservative(const vcto_params* p, const vcto_scene* s, uint8_t* l0,
                                 uint32_t* acc);
+/* z-slices [z0, z1) of vcto_voxelize_conservative's level 0: l0_slab [(z1 - z0)][V][V][4] (a slab of memory for a slab
+ * of the result: the 1024^3 check on hosts that cannot hold the whole volume twice). */
+void vcto_voxelize_conservative_zslab(const vcto_params* p, const vcto_scene* s, int32_t z0, int32_t z1, uint8_t* l0_slab);
 
 /* ---- raster input stages -- the checkers of csrc/vct_raster.hip ---------------
  * GL rules restated once: near-plane clip (z >= -w), window coordinates snapped to 1/256 pixel, edge

@@ -387,3 +387,21 @@ def test_minified_checker_takes_the_level_lambda_selects(oracle):
     assert got[0] == want and abs(float(got[0]) - (0.5 * float(flat) + 0.5 * float(lvl0[0]))) < 1e-6
     # the larger of the two axes' footprints decides (the ideal rho of the GL specification)
     assert np.array_equal(oracle.tex_sample(t, u, v, (3.0 / n, 0, 0, 1.0 / n)), oracle.tex_sample(t, u, v, (0, 3.0 / n, 1.0 / n, 0)))
+
+
+def test_zslab_voxelization_equals_the_slices_of_the_whole_volume():
+    """vcto_voxelize_conservative_zslab (the small-host form of the 1024^3 check in test_gpu_configs.py) returns exactly
+    the z-slices of vcto_voxelize_conservative."""
+    from oracle import pyoracle
+    V = 32
+    rng = np.random.default_rng(5)
+    c = rng.uniform(-1300, 1300, (300, 1, 3))
+    pos = (c + rng.normal(scale=120.0, size=(300, 3, 3))).astype(np.float32).reshape(300, 9)
+    mat = rng.integers(0, 3, 300).astype(np.int32)
+    alb = rng.uniform(0.2, 0.9, (3, 4)).astype(np.float32)
+    sc = pyoracle.make_scene(pos, mat, alb)
+    p = pyoracle.default_params(V)
+    full = pyoracle.voxelize_conservative(p, sc)
+    assert (full[..., 3] > 0).sum() > 500
+    for z0, z1 in ((0, 32), (0, 7), (9, 20), (31, 32)):
+        assert np.array_equal(pyoracle.voxelize_conservative_zslab(p, sc, z0, z1), full[z0:z1])

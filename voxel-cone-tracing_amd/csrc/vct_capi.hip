@@ -669,7 +669,7 @@ void vct_destroy(vct_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->vt_pix, c->steps_dev, c->spread_lut, c->tri_pos,
-                    c->tri_mat, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->vox_items, c->vox_acc2, c->vox_acc2_attr, c->vox_multi_slot, c->stage,
+                    c->tri_mat, c->tri_alpha, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->vox_items, c->vox_acc2, c->vox_acc2_attr, c->vox_multi_slot, c->stage,
                     c->stage_albedo, c->stage_normal, c->plan,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_lists[0], c->raster_lists[1],
@@ -746,6 +746,8 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->tri_pos) { (void)hipFree(c->tri_pos); c->tri_pos = nullptr; }
     if (c->tri_mat) { (void)hipFree(c->tri_mat); c->tri_mat = nullptr; }
+    if (c->tri_alpha) { (void)hipFree(c->tri_alpha); c->tri_alpha = nullptr; }
+    c->tri_alpha_dirty = true;
     if (c->mat_albedo) { (void)hipFree(c->mat_albedo); c->mat_albedo = nullptr; }
     for (int k = 0; k < 2; ++k) {
         if (c->raster_lists[k]) { (void)hipFree(c->raster_lists[k]); c->raster_lists[k] = nullptr; }   // sized by ntri
@@ -953,6 +955,14 @@ static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, bool
         a.item_capacity = c->raster_item_capacity[k];
     }
     a.tex = textures_of(c);
+    if (!depth_only) {          // the main draw's alpha-test class per triangle: once per mesh / texture set
+        if (!c->tri_alpha) { HIP_TRY(c, hipMalloc(&c->tri_alpha, (size_t)c->ntri * sizeof(int32_t))); c->tri_alpha_dirty = true; }
+        if (c->tri_alpha_dirty) {
+            HIP_TRY(c, vct_launch_tri_alpha(a, c->tri_alpha, s));
+            c->tri_alpha_dirty = false;
+        }
+        a.tri_alpha = c->tri_alpha;
+    }
     return VCT_OK;
 }
 
@@ -986,6 +996,7 @@ int vct_upload_mesh_uvs(vct_ctx* c, const float* uv) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->tri_uv) { (void)hipFree(c->tri_uv); c->tri_uv = nullptr; }
     const size_t bytes = (size_t)c->ntri * 6 * sizeof(float);
+    c->tri_alpha_dirty = true;          // textures take effect once the coordinates are there
     HIP_TRY(c, hipMalloc(&c->tri_uv, bytes));
     HIP_TRY(c, hipMemcpyAsync(c->tri_uv, uv, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1001,6 +1012,7 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
     if (c->tex_desc) { (void)hipFree(c->tex_desc); c->tex_desc = nullptr; }
     if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }
     c->ntex = 0;
+    c->tri_alpha_dirty = true;
     c->has_alpha_textures = false;
     c->auto_state = 0; c->auto_choice = -1;
     if (ntex == 0) return VCT_OK;                     // detach: flat colours again

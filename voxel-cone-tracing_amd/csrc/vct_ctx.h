@@ -63,6 +63,8 @@ struct vct_ctx {
     // scene
     float* tri_pos = nullptr;
     int32_t* tri_mat = nullptr;
+    int32_t* tri_alpha = nullptr;     // [ntri] alpha-test class per triangle (main draw), rebuilt when the mesh / textures change
+    bool tri_alpha_dirty = true;
     float* mat_albedo = nullptr;
     int32_t ntri = 0, nmat = 0;
     uint32_t* shadow = nullptr;       // shadow-map words (vct_internal.h vct_shadow_depth), shadow_size^2

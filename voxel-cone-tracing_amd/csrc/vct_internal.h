@@ -318,6 +318,7 @@ struct VctRasterArgs {
     const float* tan;
     const float* bit;
     const int32_t* material;     // [ntri]
+    const int32_t* tri_alpha;    // [ntri] alpha-test class of the triangle (vct_raster.hip k_tri_alpha) or null
     const float* albedo;         // [nmat][4]
     const float* specular;       // [nmat][3]
     int32_t ntri;
@@ -367,6 +368,7 @@ hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_pro
                                     const uint32_t* shadow, uint32_t shadow_ebase, int shadow_size,
                                     const float light_vp[16], float* tiled, hipStream_t s);
 // one level of a texture's mip chain from its parent (pw x ph -> w x h), glGenerateMipmap restated as in the oracle
+hipError_t vct_launch_tri_alpha(const VctRasterArgs& a, int32_t* out, hipStream_t s);
 hipError_t vct_launch_tex_mip(const uint32_t* parent, int pw, int ph, uint32_t* level, int w, int h, hipStream_t s);
 hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s);
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);

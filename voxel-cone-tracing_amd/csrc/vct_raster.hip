@@ -363,6 +363,10 @@ struct RasterParams {
     uint32_t* next_counts;       // [3] the counters the NEXT pass will use: zeroed by this pass (no memset launch)
     SubTriRec* recs;             // [2 * ntri] set-up records of the listed sub-triangles: group entries from the front, wave entries from the back
     // alpha test of the main draw (null material: depth-only pass, S/Shadow.fs has no alpha test)
+    // tri_alpha (optional): per triangle alpha_mode | (diffuse texture + 1) << 2, precomputed once per mesh / texture set
+    // (k_tri_alpha) -- one load that travels with the triangle's positions instead of the chain material -> texture
+    // index -> descriptor flags (three dependent round trips in a kernel that is nothing but dependent round trips)
+    const int32_t* tri_alpha;
     const int32_t* material;
     const float* albedo;
     VctTextures tex;
@@ -391,14 +395,27 @@ __device__ __forceinline__ void load_clip_tri(const RasterParams& p, int t, RVer
 // Decides how fragments of triangle t are alpha-tested and, for the per-fragment case, loads the texture
 // coordinates of the sub-triangle's three vertices (fan == null: the unclipped triangle; otherwise the vertices
 // of the near-clipped polygon's fan sub-triangle, interpolated like every other varying).
-__device__ __forceinline__ void setup_alpha(const RasterParams& p, int t, const FanTri* fan, SubTri& s) {
-    if (!p.material) return;
+// what setup_alpha derives per triangle: alpha_mode | (texture + 1) << 2
+__device__ __forceinline__ int alpha_class(const RasterParams& p, int t) {
     const int m = p.material[t];
     const int td = vct_tex_of(p.tex, m, 0);
-    if (td < 0) { s.alpha_mode = p.albedo[4 * (size_t)m + 3] < 0.5f ? 1 : 0; return; }
-    if (!(p.tex.desc[td].flags & 1u)) return;             // every texel opaque: alpha = 1 wherever it is sampled
+    if (td < 0) return p.albedo[4 * (size_t)m + 3] < 0.5f ? 1 : 0;
+    if (!(p.tex.desc[td].flags & 1u)) return 0;           // every texel opaque: alpha = 1 wherever it is sampled
+    return 2 | ((td + 1) << 2);
+}
+__global__ void __launch_bounds__(256)
+k_tri_alpha(const RasterParams p, int32_t* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < p.ntri) out[t] = alpha_class(p, t);
+}
+
+// `pre`: the triangle's word of tri_alpha when the caller has already loaded it (>= 0), else -1
+__device__ __forceinline__ void setup_alpha(const RasterParams& p, int t, const FanTri* fan, SubTri& s, int pre = -1) {
+    if (!p.material) return;
+    const int cls = pre >= 0 ? pre : (p.tri_alpha ? p.tri_alpha[t] : alpha_class(p, t));
+    if ((cls & 3) != 2) { s.alpha_mode = cls & 3; return; }
     s.alpha_mode = 2;
-    s.tex = td;
+    s.tex = (cls >> 2) - 1;
     const float* uv = p.tex.uv + (size_t)t * 6;
     if (!fan) {
 #pragma unroll
@@ -530,7 +547,9 @@ k_raster_vis(const RasterParams p) {
     ClipPoly poly;
     poly.n = 0;
     bool whole = false;
+    int acls = -1;
     if (valid) {
+        if (p.material && p.tri_alpha) acls = p.tri_alpha[t];      // requested with the positions
         load_clip_tri(p, t, in);
         whole = unclipped(in);
         poly.n = 3;
@@ -553,7 +572,7 @@ k_raster_vis(const RasterParams p) {
             const FanTri fan = fan_tri(poly, f);
             if (whole) setup_subtri(&in[0], &in[1], &in[2], p.W, p.H, p.ys0, p.ys1, s);
             else setup_subtri(&fan.v[0].v, &fan.v[1].v, &fan.v[2].v, p.W, p.H, p.ys0, p.ys1, s);
-            if (s.ok) setup_alpha(p, t, whole ? nullptr : &fan, s);
+            if (s.ok) setup_alpha(p, t, whole ? nullptr : &fan, s, acls);
             if (s.ok && s.alpha_mode != 1) {
                 const long long box = (long long)(s.x1 - s.x0 + 1) * (s.y1 - s.y0 + 1);
                 if (box <= VCT_RASTER_SMALL) {
@@ -774,7 +793,7 @@ struct BinRec {
     float sz[3], iw[3];
     float tu[3], tv[3];
     uint32_t id;                    // triangle * 2 + sub-triangle: the tie-breaker of the visibility word
-    uint32_t pad;
+    uint32_t binmask;               // (at most VCT_BIN_INLINE bins) bit j: the triangle -- not only its box -- reaches bin j of the box's bins, row by row
     // the next four are one aligned 16-byte word: all k_bin_fill reads of a record
     uint32_t flags;                 // 0-1 alpha_mode, 2-26 texture + 1, 27 "has per-bin entries", 28-30 "edge k does not own its boundary", 31 fast form
     uint32_t xx, yy;                // x0 | x1 << 16, y0 | y1 << 16 (clipped to the frame and the scissor)
@@ -806,9 +825,7 @@ struct BinParams {
     int32_t bins_x, bins_y;
 };
 
-__device__ __forceinline__ void pack_binrec(const SubTri& s, int id, bool binned, BinRec& r) {
-    FastEdges fe;
-    make_fast(s, fe);
+__device__ __forceinline__ void pack_binrec(const SubTri& s, const FastEdges& fe, int id, bool binned, uint32_t binmask, BinRec& r) {
     uint32_t nb = 0u;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -821,7 +838,7 @@ __device__ __forceinline__ void pack_binrec(const SubTri& s, int id, bool binned
     r.area = s.area;
     r.rcp = fe.rcp;
     r.id = (uint32_t)id;
-    r.pad = 0u;
+    r.binmask = binmask;
     r.flags = (uint32_t)s.alpha_mode | ((uint32_t)(s.tex + 1) << 2) | nb | (fe.ok ? 0x80000000u : 0u) | (binned ? VCT_BINREC_BINNED : 0u);
     r.xx = (uint32_t)s.x0 | ((uint32_t)s.x1 << 16);
     r.yy = (uint32_t)s.y0 | ((uint32_t)s.y1 << 16);
@@ -830,6 +847,30 @@ __device__ __forceinline__ void pack_binrec(const SubTri& s, int id, bool binned
     const float lo = fminf(fminf(s.sz[0], s.sz[1]), s.sz[2]);
     const float lb = (lo > -2.0f && lo < 2.0f) ? lo - 4e-6f : 0.0f;
     r.zmin_bits = lb > 0.0f ? __float_as_uint(lb) : 0u;
+}
+
+// Which of the (at most VCT_BIN_INLINE) bins of its bounding box does the sub-triangle itself reach?  A bin is dropped
+// when one edge function is negative on every pixel centre of the bin's part of the box -- its largest value over that
+// rectangle is taken at the corner its gradient points to.  Exact on the plane equations (make_fast), so no bin with a
+// covered pixel is ever dropped; the general form keeps every bin.  A quarter of the (sub-triangle, bin) pairs of the
+// Bistro-class street go: fewer counter atomics here and in k_bin_fill, fewer entries for k_bin_raster to walk.
+__device__ __forceinline__ uint32_t bin_reach_mask(const SubTri& s, const FastEdges& fe, int bx0, int by0, int bw, int nb) {
+    if (!fe.ok || nb <= 1) return nb >= 32 ? 0xffffffffu : (1u << nb) - 1u;
+    uint32_t mask = 0u;
+    int bx = 0, by = 0;
+    for (int j = 0; j < nb; ++j) {
+        const int xa = max(s.x0, (bx0 + bx) << VCT_BIN_SHIFT), xb = min(s.x1, ((bx0 + bx) << VCT_BIN_SHIFT) + VCT_BIN - 1);
+        const int ya = max(s.y0, (by0 + by) << VCT_BIN_SHIFT), yb = min(s.y1, ((by0 + by) << VCT_BIN_SHIFT) + VCT_BIN - 1);
+        bool reach = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double cx = (double)(fe.a[k] >= 0.0 ? xb : xa) + 0.5, cy = (double)(fe.b[k] >= 0.0 ? yb : ya) + 0.5;
+            if (fma(fe.a[k], cx, fma(fe.b[k], cy, fe.c[k])) < 0.0) reach = false;
+        }
+        if (reach) mask |= 1u << j;
+        if (++bx == bw) { bx = 0; ++by; }
+    }
+    return mask;
 }
 
 #ifndef VCT_BINSETUP_MIN_BLOCKS
@@ -850,7 +891,9 @@ k_bin_setup(const BinParams p) {
     ClipPoly poly;
     poly.n = 0;
     bool whole = false;
+    int acls = -1;
     if (valid) {
+        if (p.r.material && p.r.tri_alpha) acls = p.r.tri_alpha[t];      // requested with the positions
         load_clip_tri(p.r, t, in);
         whole = unclipped(in);
         poly.n = 3;
@@ -875,7 +918,7 @@ k_bin_setup(const BinParams p) {
             const FanTri fan = fan_tri(poly, f);
             if (whole) setup_subtri(&in[0], &in[1], &in[2], p.r.W, p.r.H, p.r.ys0, p.r.ys1, s);
             else setup_subtri(&fan.v[0].v, &fan.v[1].v, &fan.v[2].v, p.r.W, p.r.H, p.r.ys0, p.r.ys1, s);
-            if (s.ok) setup_alpha(p.r, t, whole ? nullptr : &fan, s);
+            if (s.ok) setup_alpha(p.r, t, whole ? nullptr : &fan, s, acls);
             have = s.ok && s.alpha_mode != 1;
         }
         int bx0 = 0, by0 = 0, bw = 0, nb = 0;
@@ -884,7 +927,18 @@ k_bin_setup(const BinParams p) {
             bw = (s.x1 >> VCT_BIN_SHIFT) - bx0 + 1;
             nb = bw * ((s.y1 >> VCT_BIN_SHIFT) - by0 + 1);
         }
-        const uint32_t np = (have && nb <= VCT_BIN_HUGE) ? (uint32_t)nb : 0u;      // entries this sub-triangle asks for
+        FastEdges fe;
+        fe.ok = false;
+        uint32_t binmask = 0xffffffffu;
+        if (have) {
+            make_fast(s, fe);
+            if (nb <= VCT_BIN_INLINE) {
+                binmask = bin_reach_mask(s, fe, bx0, by0, bw, nb);
+                if (binmask == 0u) have = false;          // the box reaches pixel centres, the triangle none of them
+            }
+        }
+        // entries this sub-triangle asks for
+        const uint32_t np = !have ? 0u : (nb <= VCT_BIN_INLINE ? (uint32_t)__popc(binmask) : (nb <= VCT_BIN_HUGE ? (uint32_t)nb : 0u));
         // Reservation of the record and of room in the entry array.  Returning atomics on one address execute one
         // after the other (~11 ns each): one 64-bit atomic per WORKGROUP (entries low, records high) for the first
         // sub-triangle; the second exists for near-clipped triangles only and keeps a per-wave reservation.
@@ -935,13 +989,13 @@ k_bin_setup(const BinParams p) {
                     const uint32_t h = atomicAdd(&p.ctr[4], 1u);
                     if (h < p.huge_cap) { p.huge[h] = rslot; listed = true; }
                 }
-                pack_binrec(s, id, room, p.recs[rslot]);
+                pack_binrec(s, fe, id, room, binmask, p.recs[rslot]);
                 if (room) {
                     if (nb <= VCT_BIN_INLINE) {
                         int bx = 0, by = 0;
                         for (int j = 0; j < nb; ++j) {
                             const uint32_t bin = (uint32_t)((by0 + by) * p.bins_x + bx0 + bx);
-                            atomicAdd(&p.bin_count[(size_t)bin * VCT_BIN_CSTRIDE], 1u);        // result unused: no round trip
+                            if ((binmask >> j) & 1u) atomicAdd(&p.bin_count[(size_t)bin * VCT_BIN_CSTRIDE], 1u);        // result unused: no round trip
                             if (++bx == bw) { bx = 0; ++by; }
                         }
                     } else {
@@ -1044,17 +1098,22 @@ __global__ void __launch_bounds__(256)
 k_bin_fill(const BinParams p) {
     __shared__ uint32_t s_pre[4][64];
     __shared__ uint4 s_hdr[4][64];
+    __shared__ uint32_t s_msk[4][64];
     const uint32_t nrec = min(p.ctr[1], p.rec_cap);
     const bool depth_only = p.r.vis32 != nullptr;
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
     const uint32_t nround = (nrec + 63u) & ~63u;          // whole waves
     for (uint32_t rec = blockIdx.x * blockDim.x + threadIdx.x; rec < nround; rec += gridDim.x * blockDim.x) {
         uint4 q = make_uint4(0u, 0u, 0u, 0u);
-        if (rec < nrec) q = *reinterpret_cast<const uint4*>(&p.recs[rec].flags);
+        uint32_t msk = 0u;
+        if (rec < nrec) { q = *reinterpret_cast<const uint4*>(&p.recs[rec].flags); msk = p.recs[rec].binmask; }
         const bool binned = (q.x & VCT_BINREC_BINNED) != 0u;
         const int bx0 = (int)(q.y & 0xffffu) >> VCT_BIN_SHIFT, by0 = (int)(q.z & 0xffffu) >> VCT_BIN_SHIFT;
         const int bw = ((int)(q.y >> 16) >> VCT_BIN_SHIFT) - bx0 + 1;
-        const uint32_t nb = binned ? (uint32_t)(bw * (((int)(q.z >> 16) >> VCT_BIN_SHIFT) - by0 + 1)) : 0u;
+        const uint32_t nbox = (uint32_t)(bw * (((int)(q.z >> 16) >> VCT_BIN_SHIFT) - by0 + 1));
+        // a record of at most VCT_BIN_INLINE bins has an entry in the bins of its mask, a larger one in every bin of its box
+        const uint32_t nb = !binned ? 0u : (nbox <= VCT_BIN_INLINE ? (uint32_t)__popc(msk) : nbox);
+        if (nbox > VCT_BIN_INLINE) msk = 0u;           // 0: "every bin"
         uint32_t incl = nb;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t v = __shfl_up(incl, off);
@@ -1063,6 +1122,7 @@ k_bin_fill(const BinParams p) {
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         s_pre[wv][lane] = incl;                        // inclusive: pair k belongs to the first lane with incl > k
         s_hdr[wv][lane] = q;
+        s_msk[wv][lane] = msk;
         // (LDS operations of one wave execute in order: no barrier between these writes and the reads below)
         const uint32_t rec0 = rec - (uint32_t)lane;
         // four pairs per lane in flight: their atomics are issued together, and the stores are unconditional (a pair that
@@ -1081,7 +1141,12 @@ k_bin_fill(const BinParams p) {
                     for (int step = 32; step > 0; step >>= 1)
                         if (s_pre[wv][lo + step - 1] <= k) lo += step;
                     const uint4 h = s_hdr[wv][lo];
-                    const uint32_t j = k - (lo ? s_pre[wv][lo - 1] : 0u);
+                    uint32_t j = k - (lo ? s_pre[wv][lo - 1] : 0u);
+                    uint32_t hm = s_msk[wv][lo];
+                    if (hm != 0u) {                   // the j-th set bit of the mask is the bin
+                        for (uint32_t i = 0; i < j; ++i) hm &= hm - 1u;
+                        j = (uint32_t)__ffs((int)hm) - 1u;
+                    }
                     const int hx0 = (int)(h.y & 0xffffu) >> VCT_BIN_SHIFT, hy0 = (int)(h.z & 0xffffu) >> VCT_BIN_SHIFT;
                     const int hw = ((int)(h.y >> 16) >> VCT_BIN_SHIFT) - hx0 + 1;
                     const int by = hy0 + (int)j / hw, bx = hx0 + (int)j % hw;
@@ -1782,6 +1847,7 @@ RasterParams make_raster(const VctRasterArgs& a, const float vp[16], int W, int 
     r.next_counts = a.next_counts;
     r.recs = (SubTriRec*)a.recs;
     r.material = nullptr;
+    r.tri_alpha = nullptr;
     r.albedo = nullptr;
     memset(&r.tex, 0, sizeof(r.tex));
     return r;
@@ -1855,6 +1921,7 @@ static ShadeParams make_shade(const VctRasterArgs& a, const float view_proj[16],
     ShadeParams p;
     p.r = make_raster(a, view_proj, W, H, row0 * VCT_TILE, row1 * VCT_TILE);
     p.r.material = a.material;        // main draw: alpha test before the depth write (trace.fs:169-172)
+    p.r.tri_alpha = a.tri_alpha;
     p.r.albedo = a.albedo;
     p.r.tex = a.tex;
     return p;
@@ -1882,6 +1949,18 @@ hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_pro
     if (tiles <= 0) return hipSuccess;
     if (a.tex.texels) hipLaunchKernelGGL(k_gbuffer_shade<true>, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(k_gbuffer_shade<false>, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_tri_alpha(const VctRasterArgs& a, int32_t* out, hipStream_t s) {
+    if (a.ntri <= 0) return hipSuccess;
+    RasterParams r;
+    memset(&r, 0, sizeof(r));
+    r.ntri = a.ntri;
+    r.material = a.material;
+    r.albedo = a.albedo;
+    r.tex = a.tex;
+    hipLaunchKernelGGL(k_tri_alpha, dim3((a.ntri + 255) / 256), dim3(256), 0, s, r, out);
     return hipGetLastError();
 }
 
