@@ -614,6 +614,11 @@ def main():
             }
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(args, inp, ctx, vct)
+        elif world > 1:
+            # timed on rank 0 at N = 1 only (the host cores are shared by the N ranks here)
+            result["cpu_baseline"] = {"value": None, "unit": "Mcones/s", "cores": None, "kind": "port",
+                                      "sample": "not timed at N > 1: the figure is the N = 1 line's cpu_baseline "
+                                                "(same workload, same host)"}
         print(json.dumps(result), flush=True)
     ctx.close()
     if world > 1 or force_dist:
@@ -640,21 +645,32 @@ def pmc_profile(args, world):
     tools/summarize_prof.py from separate rocprofv3 --pmc passes of this same command).  Counters cannot be
     read from inside the timed process, so they are REPLAYED from that file -- and only when the file was
     recorded for the default workload with exactly the kernel sources being benchmarked (sha match)."""
-    path = os.path.join(ROOT, "profiles", "trace_traffic.json")
-    default = (world == 1 and args.voxel_dim == 256 and args.width == 1920 and args.height == 1080
-               and args.scene == "atrium" and args.variant == 0 and not args.obj and args.bounces == 1
-               and not args.anisotropic and args.scene_detail == 1.0)
-    if not default:
+    common = (args.variant == 0 and not args.obj and args.bounces == 1 and not args.anisotropic
+              and args.scene_detail == 1.0)
+    default = (common and args.voxel_dim == 256 and args.width == 1920 and args.height == 1080 and args.scene == "atrium")
+    # BASELINE.json configs[4] (the Bistro-class street, 1024^3, 4K) has its own profile
+    c5 = (common and args.voxel_dim == 1024 and args.width == 3840 and args.height == 2160 and args.scene == "bistro")
+    if not (default or c5):
         return {"ok": False, "why": "no PMC profile for this configuration"}
+    path = os.path.join(ROOT, "profiles", "trace_traffic.json" if default else "trace_traffic_c5.json")
     if not os.path.exists(path):
-        return {"ok": False, "why": "profiles/trace_traffic.json missing"}
+        return {"ok": False, "why": f"profiles/{os.path.basename(path)} missing"}
     with open(path) as fh:
         t = json.load(fh)
     sha = kernel_source_sha()
     if t.get("kernel_source_sha16") != sha:
-        return {"ok": False, "why": f"profiles/trace_traffic.json was recorded for kernel sources "
+        return {"ok": False, "why": f"profiles/{os.path.basename(path)} was recorded for kernel sources "
                                     f"{t.get('kernel_source_sha16')}, this build is {sha}: re-run tools/profile_gpu.sh"}
     t["ok"] = True
+    if world != 1:
+        # N > 1: the counters were recorded for the whole frame on one GPU.  The kernel is the same and its instruction
+        # count follows the cone steps (profiles/r04f_*: 267 VALU per 64 steps on the atrium whatever the rows), so
+        # rank 0's slab gets the whole-frame counts scaled by its share of the steps; HBM bytes are not scaled (the
+        # chain's cold misses do not split by rows) and are left out.
+        if not t.get("cone_steps_per_launch"):
+            return {"ok": False, "why": "PMC profile without a step count: cannot be scaled to a slab"}
+        t["scale_by_steps"] = True
+        t["hbm_bytes_per_launch"] = None
     mp = os.path.join(ROOT, "profiles", "valu_model.json")      # tools/valu_model.py: issue-cycle model of the same sources
     if os.path.exists(mp):
         with open(mp) as fh:
@@ -686,7 +702,14 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
     if not prof.get("ok"):
         r["note"] = "VALU instruction count / HBM traffic not reported: " + prof["why"]
         return r
-    wi = prof.get("wave_instructions_per_launch") or {}
+    wi = dict(prof.get("wave_instructions_per_launch") or {})
+    gpu_cyc_scale = None
+    if prof.get("scale_by_steps"):
+        f = cone_steps / float(prof["cone_steps_per_launch"])
+        wi = {k: v * f for k, v in wi.items()}
+        r["scaled"] = (f"whole-frame counters x {f:.4f} = this rank's share of the frame's cone steps "
+                       f"(N > 1: no per-slab PMC pass exists)")
+        gpu_cyc_scale = True
     valu = wi.get("valu")
     if valu:
         rate = valu / (kernel_ms * 1e-3) / 1e9
@@ -699,6 +722,8 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
         # instruction count x mean issue cycles of the march loop's mix / (1024 SIMDs x GPU cycles of a
         # launch, GRBM_GUI_ACTIVE of the PMC pass).
         cyc, gpu_cyc = prof.get("model_issue_cycles_per_valu_instr"), prof.get("gpu_cycles_per_launch")
+        if gpu_cyc_scale:
+            gpu_cyc = None            # the slab's launch is shorter than the profiled one: no cycle count for it
         if cyc and gpu_cyc:
             r["valu_pipe_busy_model"] = round(valu * cyc / 1024.0 / gpu_cyc, 3)
         # the scalar pipe issues one instruction per 4 cycles per SIMD (tools/valu_bench.hip); half as many scalar as

@@ -112,16 +112,22 @@ while time.time() < t_end:
     mips = bool(r.integers(0, 2))          # material textures mip-mapped (the default) or level 0 only
     dref, lvp_row = raster_oracle.shadow_map(sc, scene, lightd, S)
     gref = raster_oracle.gbuffer(sc, scene, cam, w, h, dref, lvp_row, mipmaps=mips)
+    # the form of the visibility stage: direct, tile-binned (both passes), or chosen by the library (round 4)
+    path = [None, "direct", "binned", "binned"][int(r.integers(0, 4))]
+    os.environ.pop("VCT_RASTER_PATH", None)
+    if path: os.environ["VCT_RASTER_PATH"] = path
+    counts["raster_" + str(path)] = counts.get("raster_" + str(path), 0) + 1
     with vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S,
                                         texture_mipmaps=1 if mips else 0)) as ctx:
+        os.environ.pop("VCT_RASTER_PATH", None)
         ctx.upload_scene(scene)
         ctx.render_shadow_map(sc.light_view_proj(lightd))
-        if not np.array_equal(ctx.download_shadow_map().view(np.uint32), dref.view(np.uint32)): fail("shadow raster", seed)
+        if not np.array_equal(ctx.download_shadow_map().view(np.uint32), dref.view(np.uint32)): fail("shadow raster", seed, f"path={path}")
         ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
         got = ctx.download_gbuffer()
         if not np.array_equal(got.view(np.uint32), gref.view(np.uint32)):
             bad = np.nonzero((got.view(np.uint32) != gref.view(np.uint32)).any(0))[0]
-            fail("gbuffer raster", seed, f"{len(bad)} px, first {bad[:5]} kind={kind} {w}x{h}")
+            fail("gbuffer raster", seed, f"{len(bad)} px, first {bad[:5]} kind={kind} {w}x{h} path={path}")
         counts["raster"] += 1
         # the same context again: nothing is cleared between passes (self-cleaning visibility words, alternating
         # counters), a scissored slab pass in between, then another camera

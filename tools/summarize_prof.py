@@ -49,10 +49,13 @@ def main():
     # HBM traffic of the trace kernel per launch, corrected as calibrated on this box
     # (profiles/r01_fetch_write_calibration.txt): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024
     traffic = {}
+    trace_name = None
     for p in sorted(glob.glob(os.path.join(src, "pmc*"))):
         for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for r in csv.DictReader(fh):
+                    if "k_trace_tile" in r["Kernel_Name"]:
+                        trace_name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
                     if "k_trace_tile" in r["Kernel_Name"] and r["Counter_Name"] in (
                             "FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
                             "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"):
@@ -64,7 +67,17 @@ def main():
         with open(sys.argv[3], "w") as fh:
             sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
             import bench
-            json.dump({"kernel": "k_trace_tile_split<true, true, false>", "source": os.path.basename(dst),
+            # cone steps of one launch, from the bench line of the kernel-trace pass of the same command: lets bench.py
+            # scale the instruction counts to a slab of the frame (N > 1 lines)
+            steps = None
+            try:
+                with open(os.path.join(src, "trace.log")) as tl:
+                    for ln in tl:
+                        if ln.startswith("{"):
+                            steps = json.loads(ln).get("cone_steps_per_frame")
+            except (OSError, ValueError):
+                pass
+            json.dump({"kernel": trace_name, "source": os.path.basename(dst), "cone_steps_per_launch": steps,
                        "kernel_source_sha16": bench.kernel_source_sha(),
                        "fetch_size_kib": fetch, "write_size_kib": write,
                        "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
@@ -94,7 +107,8 @@ def main():
                 write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
                 out[name] = {"fetch_bytes": int(2.0 * fetch * 1024), "write_bytes": int(write * 1024),
                              "dispatches_profiled": len(c["FETCH_SIZE"])}
-        with open(os.path.join(os.path.dirname(sys.argv[3]), "stage_traffic.json"), "w") as fh:
+        # (argv[4]: another name for the per-kernel file -- non-default workloads keep their own)
+        with open(os.path.join(os.path.dirname(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "stage_traffic.json"), "w") as fh:
             json.dump({"source": os.path.basename(dst), "source_sha16": bench.all_sources_sha(),
                        "correction": "fetch = 2 * FETCH_SIZE KiB, write = WRITE_SIZE KiB (profiles/r01_fetch_write_calibration.txt)",
                        "kernels": out}, fh, indent=1)

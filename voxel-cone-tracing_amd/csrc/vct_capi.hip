@@ -324,6 +324,9 @@ VctVoxParams vox_params(const vct_ctx* c) {
     p.acc = c->acc;
     p.brick_slot = c->brick_slot;
     p.frag_sorted = c->frag_sorted;
+    p.frag_bary = c->frag_bary;
+    p.frag_duv = c->frag_duv;
+    p.tri_qnrm = c->tri_qnrm;
     p.slot_first = c->slot_first;
     p.slot_brick = c->slot_brick;
     p.items = (const uint4*)c->vox_items;
@@ -364,8 +367,10 @@ void drop_voxel_plan(vct_ctx* c) {
     void** old[] = {(void**)&c->acc, (void**)&c->attr_albedo, (void**)&c->attr_normal, (void**)&c->brick_slot,
                     (void**)&c->frag_sorted, (void**)&c->slot_first, (void**)&c->slot_brick, (void**)&c->stage,
                     (void**)&c->stage_albedo, (void**)&c->stage_normal, (void**)&c->vox_items, (void**)&c->vox_acc2,
-                    (void**)&c->vox_acc2_attr, (void**)&c->vox_multi_slot, (void**)&c->ref_big};
+                    (void**)&c->vox_acc2_attr, (void**)&c->vox_multi_slot, (void**)&c->ref_big, (void**)&c->frag_bary,
+                    (void**)&c->frag_duv, (void**)&c->tri_qnrm};
     for (void** q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    c->frag_duv_dirty = true;
     c->nslots = 0;
     c->n_frags = 0;
     c->n_vox_items = 0;
@@ -387,12 +392,13 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     drop_voxel_plan(c);         // (vct_upload_triangles already did, before its first fallible step)
     uint32_t *mark = nullptr, *slot = nullptr, *count = nullptr, *cnt = nullptr, *cursor = nullptr;
     uint32_t *sorted = nullptr, *first = nullptr, *slot_brick = nullptr, *stage = nullptr, *stage_albedo = nullptr,
-             *stage_normal = nullptr, *attr_albedo = nullptr, *attr_normal = nullptr, *multi_slot = nullptr;
+             *stage_normal = nullptr, *attr_albedo = nullptr, *attr_normal = nullptr, *multi_slot = nullptr, *tri_nrm = nullptr;
+    float2* bary = nullptr;
     void* items = nullptr;
     unsigned long long *acc2 = nullptr, *acc2_attr = nullptr;
     auto cleanup = [&]() {
         void* tmp[] = {mark, slot, count, cnt, cursor, sorted, first, slot_brick, stage, stage_albedo, stage_normal,
-                       attr_albedo, attr_normal, multi_slot, items, acc2, acc2_attr};
+                       attr_albedo, attr_normal, multi_slot, items, acc2, acc2_attr, bary, tri_nrm};
         for (void* q : tmp) if (q) (void)hipFree(q);
     };
 #define POOL_TRY(expr)                                                                                  \
@@ -438,6 +444,17 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     for (size_t i = 0; i < ns; ++i) hfirst[i + 1] = hfirst[i] + hcnt[i];
     POOL_TRY(hipMemcpyAsync(first, hfirst.data(), (ns + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     POOL_TRY(vct_launch_frag_scatter(frags, nfrags, slot, first, cursor, sorted, slot_brick, c->stream));
+    // the barycentrics of every fragment (geometry only): the pass reads them instead of re-deriving the triangle set-up
+    POOL_TRY(hipMalloc(&bary, (size_t)(nfrags ? nfrags : 1u) * sizeof(float2)));
+    {
+        VctVoxParams q = vox_params(c);
+        q.frag_sorted = sorted; q.slot_first = first; q.slot_brick = slot_brick; q.nslots = nslots;
+        POOL_TRY(vct_launch_frag_geom(q, bary, nullptr, c->stream));
+        if (c->cfg.voxel_attributes) {
+            POOL_TRY(hipMalloc(&tri_nrm, (size_t)(c->ntri > 0 ? c->ntri : 1) * 3 * sizeof(uint32_t)));
+            POOL_TRY(vct_launch_tri_nrm(q, tri_nrm, c->stream));
+        }
+    }
     // Work items of the pass, the heaviest slots first, slots above VCT_VOX_CHUNK fragments cut into chunks.  Fragments
     // per slot are uneven (atrium at 256^3: 425 on average, 1,918 at most; the street at 256^3: 4,138 and 23,128): with
     // one workgroup per slot in slot order the pass ended when an unluckily late heavy slot did.  Longest-first alone:
@@ -500,6 +517,7 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     c->brick_slot = slot;
     c->nslots = nslots;
     c->frag_sorted = sorted; c->n_frags = nfrags; c->slot_first = first; c->slot_brick = slot_brick;
+    c->frag_bary = bary; c->tri_qnrm = tri_nrm; c->frag_duv_dirty = true;
     c->stage = stage; c->stage_albedo = stage_albedo; c->stage_normal = stage_normal;
     c->vox_items = items; c->n_vox_items = nitems; c->vox_acc2 = acc2; c->vox_acc2_attr = acc2_attr; c->vox_multi_slot = multi_slot; c->n_vox_multi = nmulti;
     return VCT_OK;
@@ -997,6 +1015,7 @@ int vct_upload_mesh_uvs(vct_ctx* c, const float* uv) {
     if (c->tri_uv) { (void)hipFree(c->tri_uv); c->tri_uv = nullptr; }
     const size_t bytes = (size_t)c->ntri * 6 * sizeof(float);
     c->tri_alpha_dirty = true;          // textures take effect once the coordinates are there
+    c->frag_duv_dirty = true;
     HIP_TRY(c, hipMalloc(&c->tri_uv, bytes));
     HIP_TRY(c, hipMemcpyAsync(c->tri_uv, uv, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1013,6 +1032,7 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
     if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }
     c->ntex = 0;
     c->tri_alpha_dirty = true;
+    c->frag_duv_dirty = true;
     c->has_alpha_textures = false;
     c->auto_state = 0; c->auto_choice = -1;
     if (ntex == 0) return VCT_OK;                     // detach: flat colours again
@@ -1217,6 +1237,15 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         glm_voxel_projections(c, p.proj);
         HIP_TRY(c, vct_launch_voxelize_reference(p, c->ref_big + 1, c->ref_big, c->stream));
     } else {
+        if (p.tex.texels && p.tex.mips && c->n_frags) {
+            // texture-coordinate differences of the mip-mapped fetch: geometry + texture coordinates, once per change of those
+            if (!c->frag_duv) { HIP_TRY(c, hipMalloc(&c->frag_duv, (size_t)c->n_frags * sizeof(float4))); c->frag_duv_dirty = true; }
+            if (c->frag_duv_dirty) {
+                HIP_TRY(c, vct_launch_frag_geom(p, nullptr, c->frag_duv, c->stream));
+                c->frag_duv_dirty = false;
+            }
+            p.frag_duv = c->frag_duv;
+        }
         HIP_TRY(c, vct_launch_voxelize(p, c->stream));      // one workgroup per brick: LDS accumulation + resolve into the staging pool
     }
     c->acc_pending = true;

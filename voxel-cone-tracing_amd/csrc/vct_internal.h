@@ -288,6 +288,11 @@ struct VctVoxParams {
     uint32_t* brick_mark;      // mark_only (reference mode, at upload): bricks a fragment lands in
     int32_t mark_only;
     const uint32_t* frag_sorted;  // [nfrag]
+    // geometry-only per-fragment values, written once per mesh by k_frag_geom: the fragment's clamped barycentrics
+    // (b0, b1) and, for mip-mapped textures, the texture-coordinate differences of its fetch (null: no textures)
+    const float2* frag_bary;      // [nfrag]
+    const float4* frag_duv;       // [nfrag] or null
+    const uint32_t* tri_qnrm;     // [ntri][3] quantised front-face normal (voxel attributes) or null
     const uint32_t* slot_first;   // [nslots + 1]
     const uint32_t* slot_brick;   // [nslots]
     uint32_t nslots;
@@ -393,6 +398,8 @@ hipError_t vct_launch_frag_count(const uint2* frags, uint32_t n, const uint32_t*
 hipError_t vct_launch_frag_scatter(const uint2* frags, uint32_t n, const uint32_t* brick_slot, const uint32_t* first,
                                    uint32_t* cursor, uint32_t* sorted, uint32_t* slot_brick, hipStream_t s);
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s);
+hipError_t vct_launch_frag_geom(const VctVoxParams& p, float2* bary, float4* duv, hipStream_t s);
+hipError_t vct_launch_tri_nrm(const VctVoxParams& p, uint32_t* tri_nrm, hipStream_t s);
 hipError_t vct_launch_resolve(unsigned long long* acc, const uint32_t* brick_slot, uint32_t* level0, uint32_t* flags,
                               uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,
                               uint32_t* attr_albedo, uint32_t* attr_normal, bool reference, const uint32_t* stage,

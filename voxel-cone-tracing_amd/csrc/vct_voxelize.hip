@@ -174,7 +174,6 @@ struct TriSetup {
     float alb[3];
     float uv[3][2];     // TexCoord per vertex (vox.vs:17)
     int tex;            // diffuse texture of the triangle's material or -1 (flat colour)
-    uint32_t attr[6];   // per-fragment voxel attributes: unorm8 albedo rgb, biased quantised face normal xyz
     bool valid;
 };
 
@@ -264,17 +263,6 @@ __device__ __forceinline__ void setup_tri(const VctVoxParams& p, int t, TriSetup
     const float* alb = p.albedo + 4 * (size_t)p.material[t];
     r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
     load_tex_setup(p, t, r);
-    if (p.stage_albedo) {
-        // front-face unit normal n = normalize(cross(v1-v0, v2-v0)), quantised floor(n*127+.5)+128
-        const F3 fn = cross3(sub3(w[1], w[0]), sub3(w[2], w[0]));
-        const float fl = __builtin_sqrtf(dot3(fn, fn));
-        const float fc[3] = {__fdiv_rn(fn.x, fl), __fdiv_rn(fn.y, fl), __fdiv_rn(fn.z, fl)};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            r.attr[k] = to_unorm8(alb[k]);
-            r.attr[3 + k] = (uint32_t)((int)floorf(fc[k] * 127.0f + 0.5f) + 128);
-        }
-    }
 }
 
 __device__ __forceinline__ bool overlap(const TriSetup& c, int i, int j, int k) {
@@ -291,21 +279,84 @@ __device__ __forceinline__ bool overlap(const TriSetup& c, int i, int j, int k) 
     return true;
 }
 
-// One conservative fragment of triangle set-up `r` at voxel (i, j, k), known to overlap: the vox.fs:88 value
-// unorm8(albedo * PCF / 25) and, for the second bounce, the fragment's albedo (unorm8) -- vox.fs:18-56.
-struct FragValue { uint32_t r, g, b, ar, ag, ab; };
-__device__ __forceinline__ FragValue frag_eval(const VctVoxParams& p, const TriSetup& r, int i, int j, int k) {
+// The barycentrics of the conservative fragment of triangle set-up `r` at voxel (i, j, k) (vox.fs has none: the oracle's
+// north-star mode evaluates the triangle at the voxel centre projected along the dominant axis, clamped into the
+// triangle), and -- for mip-mapped textures -- the differences of the texture coordinate one voxel further along each
+// in-plane axis.  Pure geometry (triangle, V, G, texture coordinates): evaluated ONCE per mesh by k_frag_geom and stored
+// per fragment; the voxelize pass reads them back (round 4: the pass used to re-derive the whole triangle set-up --
+// nine IEEE divisions, the dominant axis, the in-plane area -- for every fragment, ~300 of its ~1,200 instructions).
+__device__ __forceinline__ void frag_bary(const TriSetup& r, int i, int j, int k, float& b0, float& b1) {
     const F3 ctr = {(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
     const float cx = comp(ctr, r.ua), cy = comp(ctr, r.ub);
     const float ax0 = comp(r.g[0], r.ua), ay0 = comp(r.g[0], r.ub);
     const float ax1 = comp(r.g[1], r.ua), ay1 = comp(r.g[1], r.ub);
     const float ax2 = comp(r.g[2], r.ua), ay2 = comp(r.g[2], r.ub);
-    float b0 = __fdiv_rn((ax1 - cx) * (ay2 - cy) - (ax2 - cx) * (ay1 - cy), r.area);
-    float b1 = __fdiv_rn((ax2 - cx) * (ay0 - cy) - (ax0 - cx) * (ay2 - cy), r.area);
+    b0 = __fdiv_rn((ax1 - cx) * (ay2 - cy) - (ax2 - cx) * (ay1 - cy), r.area);
+    b1 = __fdiv_rn((ax2 - cx) * (ay0 - cy) - (ax0 - cx) * (ay2 - cy), r.area);
     b0 = fminf(fmaxf(b0, 0.0f), 1.0f);
     b1 = fminf(fmaxf(b1, 0.0f), 1.0f);
     const float sum = b0 + b1;
     if (sum > 1.0f) { b0 = __fdiv_rn(b0, sum); b1 = __fdiv_rn(b1, sum); }
+}
+__device__ __forceinline__ void frag_duv(const TriSetup& r, int i, int j, int k, float duv[4]) {
+    const F3 ctr = {(float)i + 0.5f, (float)j + 0.5f, (float)k + 0.5f};
+    const float cx = comp(ctr, r.ua), cy = comp(ctr, r.ub);
+    const float ax0 = comp(r.g[0], r.ua), ay0 = comp(r.g[0], r.ub);
+    const float ax1 = comp(r.g[1], r.ua), ay1 = comp(r.g[1], r.ub);
+    const float ax2 = comp(r.g[2], r.ua), ay2 = comp(r.g[2], r.ub);
+    // (no reference code for this mode) the UNCLAMPED barycentrics one voxel further along each in-plane axis
+    auto uv_at = [&](float qx, float qy, float& ou, float& ov) {
+        const float c0 = __fdiv_rn((ax1 - qx) * (ay2 - qy) - (ax2 - qx) * (ay1 - qy), r.area);
+        const float c1 = __fdiv_rn((ax2 - qx) * (ay0 - qy) - (ax0 - qx) * (ay2 - qy), r.area);
+        const float c2 = 1.0f - c0 - c1;
+        ou = c0 * r.uv[0][0] + c1 * r.uv[1][0] + c2 * r.uv[2][0];
+        ov = c0 * r.uv[0][1] + c1 * r.uv[1][1] + c2 * r.uv[2][1];
+    };
+    float mu, mv, xu, xv, yu, yv;
+    uv_at(cx, cy, mu, mv);
+    uv_at(cx + 1.0f, cy, xu, xv);
+    uv_at(cx, cy + 1.0f, yu, yv);
+    duv[0] = xu - mu; duv[1] = xv - mv; duv[2] = yu - mu; duv[3] = yv - mv;
+}
+
+// What a voxelize pass still needs of a fragment's triangle: the shadow coordinates of its vertices (they follow the
+// light), the material, the texture coordinates.
+struct PassTri {
+    F3 dc[3];
+    float alb[3];
+    float uv[3][2];
+    int tex;
+    uint32_t attr[6];   // per-fragment voxel attributes: unorm8 albedo rgb, biased quantised face normal xyz
+};
+__device__ __forceinline__ void setup_pass(const VctVoxParams& p, int t, PassTri& r) {
+    if (p.shadow) {
+        const VctTri9 rec = *reinterpret_cast<const VctTri9*>(p.pos + (size_t)t * 9);     // three wide loads, not nine
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* q = rec.v + 3 * k;
+            const F3 w = {q[0] * p.model_scale, q[1] * p.model_scale, q[2] * p.model_scale};   // vox.vs:21
+            const F3 d = xform_point(p.light_vp, w);                                          // vox.vs:18
+            r.dc[k] = {d.x * 0.5f + 0.5f, d.y * 0.5f + 0.5f, d.z * 0.5f + 0.5f};               // vox.vs:19
+        }
+    }
+    const float* alb = p.albedo + 4 * (size_t)p.material[t];
+    r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
+    load_tex_setup(p, t, r);
+    if (p.stage_albedo) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            r.attr[k] = to_unorm8(alb[k]);
+            r.attr[3 + k] = p.tri_qnrm[(size_t)t * 3 + k];
+        }
+    }
+}
+
+// One conservative fragment (entry `at` of the sorted list) of triangle `r`: the vox.fs:88 value
+// unorm8(albedo * PCF / 25) and, for the second bounce, the fragment's albedo (unorm8) -- vox.fs:18-56.
+struct FragValue { uint32_t r, g, b, ar, ag, ab; };
+__device__ __forceinline__ FragValue frag_eval(const VctVoxParams& p, const PassTri& r, uint32_t at) {
+    const float2 bb = p.frag_bary[at];
+    const float b0 = bb.x, b1 = bb.y;
     const float b2 = fmaxf(1.0f - b0 - b1, 0.0f);
     float sh = 1.0f;
     if (p.shadow) {
@@ -317,19 +368,8 @@ __device__ __forceinline__ FragValue frag_eval(const VctVoxParams& p, const TriS
     float alb[3];
     float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (r.tex >= 0 && p.tex.mips) {
-        // (no reference code for this mode) the UNCLAMPED barycentrics one voxel further along each in-plane axis
-        auto uv_at = [&](float qx, float qy, float& ou, float& ov) {
-            const float c0 = __fdiv_rn((ax1 - qx) * (ay2 - qy) - (ax2 - qx) * (ay1 - qy), r.area);
-            const float c1 = __fdiv_rn((ax2 - qx) * (ay0 - qy) - (ax0 - qx) * (ay2 - qy), r.area);
-            const float c2 = 1.0f - c0 - c1;
-            ou = c0 * r.uv[0][0] + c1 * r.uv[1][0] + c2 * r.uv[2][0];
-            ov = c0 * r.uv[0][1] + c1 * r.uv[1][1] + c2 * r.uv[2][1];
-        };
-        float mu, mv, xu, xv, yu, yv;
-        uv_at(cx, cy, mu, mv);
-        uv_at(cx + 1.0f, cy, xu, xv);
-        uv_at(cx, cy + 1.0f, yu, yv);
-        duv[0] = xu - mu; duv[1] = xv - mv; duv[2] = yu - mu; duv[3] = yv - mv;
+        const float4 d = p.frag_duv[at];
+        duv[0] = d.x; duv[1] = d.y; duv[2] = d.z; duv[3] = d.w;
     }
     frag_albedo(p, r, b0, b1, b2, duv, alb);                                         // vox.fs:56
     FragValue f;
@@ -480,6 +520,55 @@ k_frag_scatter(const uint2* __restrict__ frags, uint32_t n, const uint32_t* __re
     }
 }
 
+// Per sorted fragment: its barycentrics (BARY) and / or the texture-coordinate differences of the mip-mapped fetch (DUV),
+// see frag_bary / frag_duv.  One workgroup per slot (the sorted list does not name a fragment's brick); once per mesh
+// resp. once per change of the texture coordinates.
+template <bool BARY, bool DUV>
+__global__ void __launch_bounds__(256)
+k_frag_geom(const VctVoxParams p, float2* __restrict__ bary, float4* __restrict__ duv) {
+    for (uint32_t slot = blockIdx.x; slot < p.nslots; slot += gridDim.x) {
+        const uint32_t first = p.slot_first[slot], n = p.slot_first[slot + 1] - first;
+        const uint32_t bm = p.slot_brick[slot] << 9;
+        for (uint32_t f = threadIdx.x; f < n; f += blockDim.x) {
+            const uint32_t e = p.frag_sorted[first + f];
+            const uint32_t vox = bm | (e & 511u);
+            const int t = (int)(e >> 9);
+            TriSetup r;
+            setup_tri(p, t, r);
+            const int i = (int)vct_compact3(vox), j = (int)vct_compact3(vox >> 1), k = (int)vct_compact3(vox >> 2);
+            if (BARY) {
+                float b0, b1;
+                frag_bary(r, i, j, k, b0, b1);
+                bary[first + f] = make_float2(b0, b1);
+            }
+            if (DUV) {
+                float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (r.tex >= 0) frag_duv(r, i, j, k, d);
+                duv[first + f] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
+}
+
+// front-face unit normal n = normalize(cross(v1-v0, v2-v0)) of every triangle, quantised floor(n*127+.5)+128 (the voxel
+// attribute of the second bounce): geometry only, once per mesh
+__global__ void __launch_bounds__(256)
+k_tri_nrm(const VctVoxParams p, uint32_t* __restrict__ tri_nrm) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.ntri) return;
+    F3 w[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float* q = p.pos + (size_t)t * 9 + 3 * k;
+        w[k] = {q[0] * p.model_scale, q[1] * p.model_scale, q[2] * p.model_scale};
+    }
+    const F3 fn = cross3(sub3(w[1], w[0]), sub3(w[2], w[0]));
+    const float fl = __builtin_sqrtf(dot3(fn, fn));
+    const float fc[3] = {__fdiv_rn(fn.x, fl), __fdiv_rn(fn.y, fl), __fdiv_rn(fn.z, fl)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tri_nrm[(size_t)t * 3 + k] = (uint32_t)((int)floorf(fc[k] * 127.0f + 0.5f) + 128);
+}
+
 // ---- the voxelize pass: one workgroup per work item = up to VCT_VOX_CHUNK fragments of one brick slot ------------
 // acc in LDS: [512][2] u64 (sumR | sumG << 32, sumB | count << 32), + [512][3] for the voxel attributes.
 // A slot of one chunk (most) is resolved from LDS by its workgroup.  The chunks of a heavier slot add their non-empty
@@ -522,14 +611,12 @@ k_voxelize_bricks(const VctVoxParams p) {
         if (ATTR) for (uint32_t v = threadIdx.x; v < 512u * 3u; v += blockDim.x) acc_attr[v] = 0ull;
         __syncthreads();
         const uint32_t brick = p.slot_brick[slot];
-        const uint32_t bm = brick << 9;
         for (uint32_t f = threadIdx.x; f < n; f += blockDim.x) {
             const uint32_t e = p.frag_sorted[first + f];
-            const uint32_t local = e & 511u, vox = bm | local;
-            TriSetup r;
-            setup_tri(p, (int)(e >> 9), r);
-            const int i = (int)vct_compact3(vox), j = (int)vct_compact3(vox >> 1), k = (int)vct_compact3(vox >> 2);
-            const FragValue fv = frag_eval(p, r, i, j, k);
+            const uint32_t local = e & 511u;
+            PassTri r;
+            setup_pass(p, (int)(e >> 9), r);
+            const FragValue fv = frag_eval(p, r, first + f);
             atomicAdd(&acc[2 * local], (unsigned long long)fv.r | ((unsigned long long)fv.g << 32));       // ds_add_u64
             atomicAdd(&acc[2 * local + 1], (unsigned long long)fv.b | (1ull << 32));
             if (ATTR) {
@@ -915,6 +1002,21 @@ hipError_t vct_launch_frag_scatter(const uint2* frags, uint32_t n, const uint32_
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(k_frag_scatter, dim3(frag_blocks(n)), dim3(256), 0, s, frags, n, brick_slot, first, cursor, sorted,
                        slot_brick);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_frag_geom(const VctVoxParams& p, float2* bary, float4* duv, hipStream_t s) {
+    if (p.nslots == 0u || (!bary && !duv)) return hipSuccess;
+    const dim3 grid(p.nslots < 256u * 64u ? p.nslots : 256u * 64u), block(256);
+    if (bary && duv) hipLaunchKernelGGL((k_frag_geom<true, true>), grid, block, 0, s, p, bary, duv);
+    else if (bary) hipLaunchKernelGGL((k_frag_geom<true, false>), grid, block, 0, s, p, bary, duv);
+    else hipLaunchKernelGGL((k_frag_geom<false, true>), grid, block, 0, s, p, bary, duv);
+    return hipGetLastError();
+}
+
+hipError_t vct_launch_tri_nrm(const VctVoxParams& p, uint32_t* tri_nrm, hipStream_t s) {
+    if (p.ntri <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tri_nrm, dim3((p.ntri + 255) / 256), dim3(256), 0, s, p, tri_nrm);
     return hipGetLastError();
 }
 
