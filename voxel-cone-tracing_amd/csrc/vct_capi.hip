@@ -325,7 +325,7 @@ VctVoxParams vox_params(const vct_ctx* c) {
     p.brick_slot = c->brick_slot;
     p.frag_sorted = c->frag_sorted;
     p.frag_bary = c->frag_bary;
-    p.frag_duv = c->frag_duv;
+    p.frag_alb = nullptr;       // vct_voxelize attaches it (scenes with textures)
     p.tri_qnrm = c->tri_qnrm;
     p.slot_first = c->slot_first;
     p.slot_brick = c->slot_brick;
@@ -368,9 +368,9 @@ void drop_voxel_plan(vct_ctx* c) {
                     (void**)&c->frag_sorted, (void**)&c->slot_first, (void**)&c->slot_brick, (void**)&c->stage,
                     (void**)&c->stage_albedo, (void**)&c->stage_normal, (void**)&c->vox_items, (void**)&c->vox_acc2,
                     (void**)&c->vox_acc2_attr, (void**)&c->vox_multi_slot, (void**)&c->ref_big, (void**)&c->frag_bary,
-                    (void**)&c->frag_duv, (void**)&c->tri_qnrm};
+                    (void**)&c->frag_alb, (void**)&c->tri_qnrm};
     for (void** q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
-    c->frag_duv_dirty = true;
+    c->frag_alb_dirty = true;
     c->nslots = 0;
     c->n_frags = 0;
     c->n_vox_items = 0;
@@ -474,7 +474,10 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
             const uint32_t chunks = hcnt[sl] ? (hcnt[sl] + CH - 1u) / CH : 1u;
             const uint32_t mi = chunks > 1u ? nmulti++ : 0xffffffffu;
             if (chunks > 1u) hmulti.push_back(sl);
-            for (uint32_t ch = 0; ch < chunks; ++ch) { hitems.push_back(sl); hitems.push_back(ch); hitems.push_back(chunks); hitems.push_back(mi); }
+            for (uint32_t ch = 0; ch < chunks; ++ch) {      // (slot, first fragment, fragments, multi index or ~0)
+                const uint32_t nfr = hcnt[sl] - ch * CH < CH ? hcnt[sl] - ch * CH : CH;
+                hitems.push_back(sl); hitems.push_back(hfirst[sl] + ch * CH); hitems.push_back(nfr); hitems.push_back(mi);
+            }
         }
     const uint32_t nitems = (uint32_t)(hitems.size() / 4);
     POOL_TRY(hipMalloc(&items, (size_t)(nitems ? nitems : 1u) * 16));
@@ -517,7 +520,7 @@ int build_voxel_slots(vct_ctx* c, const uint2* frags, uint32_t nfrags) {
     c->brick_slot = slot;
     c->nslots = nslots;
     c->frag_sorted = sorted; c->n_frags = nfrags; c->slot_first = first; c->slot_brick = slot_brick;
-    c->frag_bary = bary; c->tri_qnrm = tri_nrm; c->frag_duv_dirty = true;
+    c->frag_bary = bary; c->tri_qnrm = tri_nrm; c->frag_alb_dirty = true;
     c->stage = stage; c->stage_albedo = stage_albedo; c->stage_normal = stage_normal;
     c->vox_items = items; c->n_vox_items = nitems; c->vox_acc2 = acc2; c->vox_acc2_attr = acc2_attr; c->vox_multi_slot = multi_slot; c->n_vox_multi = nmulti;
     return VCT_OK;
@@ -1015,7 +1018,7 @@ int vct_upload_mesh_uvs(vct_ctx* c, const float* uv) {
     if (c->tri_uv) { (void)hipFree(c->tri_uv); c->tri_uv = nullptr; }
     const size_t bytes = (size_t)c->ntri * 6 * sizeof(float);
     c->tri_alpha_dirty = true;          // textures take effect once the coordinates are there
-    c->frag_duv_dirty = true;
+    c->frag_alb_dirty = true;
     HIP_TRY(c, hipMalloc(&c->tri_uv, bytes));
     HIP_TRY(c, hipMemcpyAsync(c->tri_uv, uv, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1032,7 +1035,7 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
     if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }
     c->ntex = 0;
     c->tri_alpha_dirty = true;
-    c->frag_duv_dirty = true;
+    c->frag_alb_dirty = true;
     c->has_alpha_textures = false;
     c->auto_state = 0; c->auto_choice = -1;
     if (ntex == 0) return VCT_OK;                     // detach: flat colours again
@@ -1237,14 +1240,15 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         glm_voxel_projections(c, p.proj);
         HIP_TRY(c, vct_launch_voxelize_reference(p, c->ref_big + 1, c->ref_big, c->stream));
     } else {
-        if (p.tex.texels && p.tex.mips && c->n_frags) {
-            // texture-coordinate differences of the mip-mapped fetch: geometry + texture coordinates, once per change of those
-            if (!c->frag_duv) { HIP_TRY(c, hipMalloc(&c->frag_duv, (size_t)c->n_frags * sizeof(float4))); c->frag_duv_dirty = true; }
-            if (c->frag_duv_dirty) {
-                HIP_TRY(c, vct_launch_frag_geom(p, nullptr, c->frag_duv, c->stream));
-                c->frag_duv_dirty = false;
+        if (p.tex.texels && c->n_frags) {
+            // every fragment's albedo (texture fetch or material colour): independent of the light, so evaluated once per
+            // change of the textures / texture coordinates, not once per pass
+            if (!c->frag_alb) { HIP_TRY(c, hipMalloc(&c->frag_alb, (size_t)c->n_frags * 3 * sizeof(float))); c->frag_alb_dirty = true; }
+            if (c->frag_alb_dirty) {
+                HIP_TRY(c, vct_launch_frag_geom(p, nullptr, c->frag_alb, c->stream));
+                c->frag_alb_dirty = false;
             }
-            p.frag_duv = c->frag_duv;
+            p.frag_alb = c->frag_alb;
         }
         HIP_TRY(c, vct_launch_voxelize(p, c->stream));      // one workgroup per brick: LDS accumulation + resolve into the staging pool
     }

@@ -127,8 +127,8 @@ struct vct_ctx {
     // brick slot, and the staging pool a pass resolves into; sparse-resolve state
     uint32_t* frag_sorted = nullptr;   // [n_frags] triangle << 9 | voxel inside the brick
     float2* frag_bary = nullptr;       // [n_frags] the fragment's barycentrics (geometry only: once per mesh, k_frag_geom)
-    float4* frag_duv = nullptr;        // [n_frags] texture-coordinate differences of the mip-mapped fetch; built by the first
-    bool frag_duv_dirty = true;        //   voxelize pass after the texture coordinates / textures changed
+    float* frag_alb = nullptr;         // [n_frags][3] the fragment's albedo (scenes with textures); built by the first
+    bool frag_alb_dirty = true;        //   voxelize pass after the texture coordinates / textures changed
     uint32_t* tri_qnrm = nullptr;      // [ntri][3] quantised face normals (config.voxel_attributes)
     uint32_t n_frags = 0;
     uint32_t* slot_first = nullptr;    // [nslots + 1]

@@ -288,10 +288,10 @@ struct VctVoxParams {
     uint32_t* brick_mark;      // mark_only (reference mode, at upload): bricks a fragment lands in
     int32_t mark_only;
     const uint32_t* frag_sorted;  // [nfrag]
-    // geometry-only per-fragment values, written once per mesh by k_frag_geom: the fragment's clamped barycentrics
-    // (b0, b1) and, for mip-mapped textures, the texture-coordinate differences of its fetch (null: no textures)
+    // light-independent per-fragment values, written by k_frag_geom: the fragment's clamped barycentrics (b0, b1) -- once
+    // per mesh -- and, in a scene with textures, its albedo (once per change of the textures / texture coordinates)
     const float2* frag_bary;      // [nfrag]
-    const float4* frag_duv;       // [nfrag] or null
+    const float* frag_alb;        // [nfrag][3] or null (no textures: the material's colour is read per fragment)
     const uint32_t* tri_qnrm;     // [ntri][3] quantised front-face normal (voxel attributes) or null
     const uint32_t* slot_first;   // [nslots + 1]
     const uint32_t* slot_brick;   // [nslots]
@@ -300,7 +300,7 @@ struct VctVoxParams {
     // slots first (built on the host once per mesh).  A slot of one chunk is accumulated and resolved in LDS; the chunks of a
     // larger one add their LDS partial sums to the slot's accumulators in HBM (acc2: [multi][512][2], acc2_attr:
     // [multi][512][3]); a second small kernel resolves those slots (multi_slot[multi]) and re-zeroes the accumulators.
-    const uint4* items;        // [nitems] (slot, chunk, chunks of the slot, index among the multi-chunk slots)
+    const uint4* items;        // [nitems] (slot, first fragment, fragments, index among the multi-chunk slots or ~0)
     uint32_t nitems;
     uint32_t chunk;            // fragments per work item
     unsigned long long* acc2;
@@ -398,7 +398,7 @@ hipError_t vct_launch_frag_count(const uint2* frags, uint32_t n, const uint32_t*
 hipError_t vct_launch_frag_scatter(const uint2* frags, uint32_t n, const uint32_t* brick_slot, const uint32_t* first,
                                    uint32_t* cursor, uint32_t* sorted, uint32_t* slot_brick, hipStream_t s);
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s);
-hipError_t vct_launch_frag_geom(const VctVoxParams& p, float2* bary, float4* duv, hipStream_t s);
+hipError_t vct_launch_frag_geom(const VctVoxParams& p, float2* bary, float* frag_alb, hipStream_t s);
 hipError_t vct_launch_tri_nrm(const VctVoxParams& p, uint32_t* tri_nrm, hipStream_t s);
 hipError_t vct_launch_resolve(unsigned long long* acc, const uint32_t* brick_slot, uint32_t* level0, uint32_t* flags,
                               uint32_t* prev, int V, bool dense, unsigned long long* acc_attr,

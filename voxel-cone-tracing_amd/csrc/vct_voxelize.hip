@@ -97,39 +97,36 @@ __device__ __forceinline__ int pcf25(const uint32_t* __restrict__ words, uint32_
     for (int k = 0; k < 4; ++k) regular = regular && X.i1[k] == X.i0[k + 1] && Y.i1[k] == Y.i0[k + 1];
     const float cur = c.z - bias;
     int count = 0;
-    if (regular) {
-        int col[6], row[6];
+    // six consecutive texels per row (no clamped border): two wide loads per row.  A window with a clamped border takes the
+    // tap-by-tap path as well: served from 36 single loads it needed 72 address registers, which set the register peak of
+    // the whole voxelize kernel (158 VGPRs, 3 waves per SIMD) for a case only the rim of the map ever sees.
+    if (regular && X.i1[4] - X.i0[0] == 5) {
+        int row[6];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { col[k] = X.i0[k]; row[k] = Y.i0[k]; }
-        col[5] = X.i1[4]; row[5] = Y.i1[4];
-        const bool wide = col[5] - col[0] == 5;       // six consecutive texels per row (no clamped border): two wide loads per row
-        // the window's smallest / largest word first (vct_internal.h "PCF short cut"); the words are not kept -- a window the
-        // shadow boundary crosses loads them once more, from the cache (keeping all 36 next to the decoded ones cost a
-        // resident wave: 0.049 -> 0.080 ms)
-        uint32_t wmin = 0xffffffffu, wmax = 0u;
-        if (wide) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const VctWords6 w = *reinterpret_cast<const VctWords6*>(words + (size_t)row[j] * S + col[0]);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) { wmin = min(wmin, w.v[i]); wmax = max(wmax, w.v[i]); }
-            }
-            const int verdict = vct_pcf_window_verdict(wmin, wmax, eb, cur);
-            if (verdict >= 0) return verdict;
-        }
+        for (int k = 0; k < 5; ++k) row[k] = Y.i0[k];
+        row[5] = Y.i1[4];
+        const uint32_t col0 = (uint32_t)X.i0[0];
+        // One pass over the window: decode in place and take the smallest / largest decoded word on the way (the decode is
+        // monotonic, so these are the window's depth bounds: vct_internal.h "PCF short cut").  A window the shadow boundary
+        // does not cross ends here; the others evaluate the 25 taps from the same registers.  (The first form of the short
+        // cut took the bounds on the raw words and loaded the window a second time: one more round trip in a kernel that
+        // waits on memory two thirds of its time.)
         float d[6][6];
-        if (wide) {
+        uint32_t wmin = 0xffffffffu, wmax = 0u;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const VctWords6 w = *reinterpret_cast<const VctWords6*>(words + (size_t)row[j] * S + col[0]);
+        for (int j = 0; j < 6; ++j) {
+            const VctWords6 w = *reinterpret_cast<const VctWords6*>(words + ((uint32_t)row[j] * (uint32_t)S + col0));
 #pragma unroll
-                for (int i = 0; i < 6; ++i) d[j][i] = vct_shadow_depth(w.v[i], eb);
+            for (int i = 0; i < 6; ++i) {
+                const uint32_t v = min(w.v[i] - eb, VCT_SHADOW_ONE);      // = vct_shadow_depth()
+                d[j][i] = __uint_as_float(v);
+                wmin = min(wmin, v); wmax = max(wmax, v);
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int i = 0; i < 6; ++i) d[j][i] = vct_shadow_depth(words[(size_t)row[j] * S + col[i]], eb);
+        }
+        {
+            const float lo = __uint_as_float(wmin) * 0.999998f, hi = __uint_as_float(wmax) * 1.000002f;
+            if (cur <= lo) return 25;
+            if (cur > hi) return 0;
         }
 #pragma unroll
         for (int x = 0; x < 5; ++x)
@@ -320,14 +317,14 @@ __device__ __forceinline__ void frag_duv(const TriSetup& r, int i, int j, int k,
 }
 
 // What a voxelize pass still needs of a fragment's triangle: the shadow coordinates of its vertices (they follow the
-// light), the material, the texture coordinates.
+// light) and, in a scene without textures, the material's colour (FALB = false; with textures every fragment's albedo
+// comes from frag_alb).
 struct PassTri {
     F3 dc[3];
     float alb[3];
-    float uv[3][2];
-    int tex;
-    uint32_t attr[6];   // per-fragment voxel attributes: unorm8 albedo rgb, biased quantised face normal xyz
+    uint32_t nrm[3];    // biased quantised face normal (voxel attributes)
 };
+template <bool ATTR, bool FALB>
 __device__ __forceinline__ void setup_pass(const VctVoxParams& p, int t, PassTri& r) {
     if (p.shadow) {
         const VctTri9 rec = *reinterpret_cast<const VctTri9*>(p.pos + (size_t)t * 9);     // three wide loads, not nine
@@ -339,24 +336,20 @@ __device__ __forceinline__ void setup_pass(const VctVoxParams& p, int t, PassTri
             r.dc[k] = {d.x * 0.5f + 0.5f, d.y * 0.5f + 0.5f, d.z * 0.5f + 0.5f};               // vox.vs:19
         }
     }
-    const float* alb = p.albedo + 4 * (size_t)p.material[t];
-    r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
-    load_tex_setup(p, t, r);
-    if (p.stage_albedo) {
+    if (!FALB) {
+        const float* alb = p.albedo + 4 * (size_t)p.material[t];
+        r.alb[0] = alb[0]; r.alb[1] = alb[1]; r.alb[2] = alb[2];
+    }
+    if (ATTR) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            r.attr[k] = to_unorm8(alb[k]);
-            r.attr[3 + k] = p.tri_qnrm[(size_t)t * 3 + k];
-        }
+        for (int k = 0; k < 3; ++k) r.nrm[k] = p.tri_qnrm[(size_t)t * 3 + k];
     }
 }
 
-// One conservative fragment (entry `at` of the sorted list) of triangle `r`: the vox.fs:88 value
+// One conservative fragment of triangle `r` with barycentrics (b0, b1) and albedo alb: the vox.fs:88 value
 // unorm8(albedo * PCF / 25) and, for the second bounce, the fragment's albedo (unorm8) -- vox.fs:18-56.
 struct FragValue { uint32_t r, g, b, ar, ag, ab; };
-__device__ __forceinline__ FragValue frag_eval(const VctVoxParams& p, const PassTri& r, uint32_t at) {
-    const float2 bb = p.frag_bary[at];
-    const float b0 = bb.x, b1 = bb.y;
+__device__ __forceinline__ FragValue frag_eval(const VctVoxParams& p, const PassTri& r, float b0, float b1, const float alb[3]) {
     const float b2 = fmaxf(1.0f - b0 - b1, 0.0f);
     float sh = 1.0f;
     if (p.shadow) {
@@ -365,18 +358,9 @@ __device__ __forceinline__ FragValue frag_eval(const VctVoxParams& p, const Pass
                        b0 * r.dc[0].z + b1 * r.dc[1].z + b2 * r.dc[2].z};
         sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f), 25.0f);   // vox.fs:46
     }
-    float alb[3];
-    float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (r.tex >= 0 && p.tex.mips) {
-        const float4 d = p.frag_duv[at];
-        duv[0] = d.x; duv[1] = d.y; duv[2] = d.z; duv[3] = d.w;
-    }
-    frag_albedo(p, r, b0, b1, b2, duv, alb);                                         // vox.fs:56
     FragValue f;
     f.r = to_unorm8(alb[0] * sh); f.g = to_unorm8(alb[1] * sh); f.b = to_unorm8(alb[2] * sh);   // vox.fs:88
-    f.ar = r.tex >= 0 ? to_unorm8(alb[0]) : r.attr[0];                                // the fragment's albedo
-    f.ag = r.tex >= 0 ? to_unorm8(alb[1]) : r.attr[1];
-    f.ab = r.tex >= 0 ? to_unorm8(alb[2]) : r.attr[2];
+    f.ar = to_unorm8(alb[0]); f.ag = to_unorm8(alb[1]); f.ab = to_unorm8(alb[2]);                // the fragment's albedo
     return f;
 }
 
@@ -520,12 +504,14 @@ k_frag_scatter(const uint2* __restrict__ frags, uint32_t n, const uint32_t* __re
     }
 }
 
-// Per sorted fragment: its barycentrics (BARY) and / or the texture-coordinate differences of the mip-mapped fetch (DUV),
-// see frag_bary / frag_duv.  One workgroup per slot (the sorted list does not name a fragment's brick); once per mesh
-// resp. once per change of the texture coordinates.
-template <bool BARY, bool DUV>
+// Per sorted fragment, the values of the pass that do not depend on the light: its barycentrics (BARY: geometry only,
+// once per mesh) and its albedo (ALB: vox.fs:56 texture(DiffuseTexture, uv) -- mip-mapped -- or the material's colour;
+// once per change of the textures / texture coordinates; only scenes with textures store it).  One workgroup per slot
+// (the sorted list does not name a fragment's brick).
+struct __attribute__((packed, aligned(4))) VctF3 { float v[3]; };
+template <bool BARY, bool ALB>
 __global__ void __launch_bounds__(256)
-k_frag_geom(const VctVoxParams p, float2* __restrict__ bary, float4* __restrict__ duv) {
+k_frag_geom(const VctVoxParams p, float2* __restrict__ bary, VctF3* __restrict__ falb) {
     for (uint32_t slot = blockIdx.x; slot < p.nslots; slot += gridDim.x) {
         const uint32_t first = p.slot_first[slot], n = p.slot_first[slot + 1] - first;
         const uint32_t bm = p.slot_brick[slot] << 9;
@@ -536,15 +522,16 @@ k_frag_geom(const VctVoxParams p, float2* __restrict__ bary, float4* __restrict_
             TriSetup r;
             setup_tri(p, t, r);
             const int i = (int)vct_compact3(vox), j = (int)vct_compact3(vox >> 1), k = (int)vct_compact3(vox >> 2);
-            if (BARY) {
-                float b0, b1;
-                frag_bary(r, i, j, k, b0, b1);
-                bary[first + f] = make_float2(b0, b1);
-            }
-            if (DUV) {
+            float b0, b1;
+            frag_bary(r, i, j, k, b0, b1);
+            if (BARY) bary[first + f] = make_float2(b0, b1);
+            if (ALB) {
+                const float b2 = fmaxf(1.0f - b0 - b1, 0.0f);
                 float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (r.tex >= 0) frag_duv(r, i, j, k, d);
-                duv[first + f] = make_float4(d[0], d[1], d[2], d[3]);
+                if (r.tex >= 0 && p.tex.mips) frag_duv(r, i, j, k, d);
+                VctF3 o;
+                frag_albedo(p, r, b0, b1, b2, d, o.v);
+                falb[first + f] = o;
             }
         }
     }
@@ -588,45 +575,65 @@ __device__ __forceinline__ void resolve_attr(uint32_t c, unsigned long long q0, 
     }
 }
 
-template <bool ATTR>
+template <bool ATTR, bool FALB>
 __global__ void __launch_bounds__(256)
 k_voxelize_bricks(const VctVoxParams p) {
     __shared__ unsigned long long acc[512 * 2];
     __shared__ unsigned long long acc_attr[ATTR ? 512 * 3 : 1];
+    const VctF3* __restrict__ falb = reinterpret_cast<const VctF3*>(p.frag_alb);
     for (uint32_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
+        // (slot, first fragment, fragments, index among the multi-chunk slots or ~0: the slot's only chunk): everything
+        // the workgroup needs to start on its fragments in ONE scalar load
         const uint4 w = p.items[it];
-        const uint32_t slot = w.x, chunks = w.z, mi = w.w;
-        const uint32_t first0 = p.slot_first[slot], ntot = p.slot_first[slot + 1] - first0;
+        const uint32_t slot = w.x, first = w.y, n = w.z, mi = w.w;
         uint32_t* __restrict__ out = p.stage + (size_t)slot * 512;
-        if (ntot == 0u) {                 // a brick only the reference-mode voxelizer can touch: nothing of this mode
+        if (n == 0u) {                    // a brick only the reference-mode voxelizer can touch: nothing of this mode
             for (uint32_t v = threadIdx.x; v < 512u; v += blockDim.x) {
                 out[v] = 0u;
                 if (ATTR) { p.stage_albedo[(size_t)slot * 512 + v] = 0u; p.stage_normal[(size_t)slot * 512 + v] = 0u; }
             }
             continue;
         }
-        const uint32_t first = first0 + w.y * p.chunk;
-        const uint32_t n = min(p.chunk, ntot - w.y * p.chunk);
+        // the first fragment's list entry and light-independent values are requested before the accumulators are zeroed;
+        // inside the loop the next fragment's are requested before the current one is evaluated (the kernel waits on
+        // memory two thirds of its time at 4 waves per SIMD: every dependent round trip taken off a fragment counts)
+        uint32_t f = threadIdx.x;
+        uint32_t e = 0u;
+        float2 bb = make_float2(0.0f, 0.0f);
+        VctF3 fa = {{0.0f, 0.0f, 0.0f}};
+        if (f < n) {
+            e = p.frag_sorted[first + f];
+            bb = p.frag_bary[first + f];
+            if (FALB) fa = falb[first + f];
+        }
         for (uint32_t v = threadIdx.x; v < 512u * 2u; v += blockDim.x) acc[v] = 0ull;
         if (ATTR) for (uint32_t v = threadIdx.x; v < 512u * 3u; v += blockDim.x) acc_attr[v] = 0ull;
         __syncthreads();
-        const uint32_t brick = p.slot_brick[slot];
-        for (uint32_t f = threadIdx.x; f < n; f += blockDim.x) {
-            const uint32_t e = p.frag_sorted[first + f];
+        while (f < n) {
+            const uint32_t fn = f + blockDim.x;
+            uint32_t e_next = 0u;
+            float2 bb_next = bb;
+            VctF3 fa_next = fa;
+            if (fn < n) {
+                e_next = p.frag_sorted[first + fn];
+                bb_next = p.frag_bary[first + fn];
+                if (FALB) fa_next = falb[first + fn];
+            }
             const uint32_t local = e & 511u;
             PassTri r;
-            setup_pass(p, (int)(e >> 9), r);
-            const FragValue fv = frag_eval(p, r, first + f);
+            setup_pass<ATTR, FALB>(p, (int)(e >> 9), r);
+            const FragValue fv = frag_eval(p, r, bb.x, bb.y, FALB ? fa.v : r.alb);
             atomicAdd(&acc[2 * local], (unsigned long long)fv.r | ((unsigned long long)fv.g << 32));       // ds_add_u64
             atomicAdd(&acc[2 * local + 1], (unsigned long long)fv.b | (1ull << 32));
             if (ATTR) {
                 atomicAdd(&acc_attr[3 * local], (unsigned long long)fv.ar | ((unsigned long long)fv.ag << 32));
-                atomicAdd(&acc_attr[3 * local + 1], (unsigned long long)fv.ab | ((unsigned long long)r.attr[3] << 32));
-                atomicAdd(&acc_attr[3 * local + 2], (unsigned long long)r.attr[4] | ((unsigned long long)r.attr[5] << 32));
+                atomicAdd(&acc_attr[3 * local + 1], (unsigned long long)fv.ab | ((unsigned long long)r.nrm[0] << 32));
+                atomicAdd(&acc_attr[3 * local + 2], (unsigned long long)r.nrm[1] | ((unsigned long long)r.nrm[2] << 32));
             }
+            f = fn; e = e_next; bb = bb_next; fa = fa_next;
         }
         __syncthreads();
-        if (chunks == 1u) {
+        if (mi == 0xffffffffu) {
             for (uint32_t v = threadIdx.x; v < 512u; v += blockDim.x) {
                 const ulonglong2 a = make_ulonglong2(acc[2 * v], acc[2 * v + 1]);
                 out[v] = resolve_voxel(a);
@@ -637,7 +644,7 @@ k_voxelize_bricks(const VctVoxParams p) {
                     p.stage_normal[(size_t)slot * 512 + v] = nrm;
                 }
             }
-            if (threadIdx.x == 0) p.brick_flags[brick] = 1u;
+            if (threadIdx.x == 0) p.brick_flags[p.slot_brick[slot]] = 1u;
         } else {
             unsigned long long* __restrict__ g = p.acc2 + (size_t)mi * 1024;
             unsigned long long* __restrict__ ga = ATTR ? p.acc2_attr + (size_t)mi * 1536 : nullptr;
@@ -1005,12 +1012,13 @@ hipError_t vct_launch_frag_scatter(const uint2* frags, uint32_t n, const uint32_
     return hipGetLastError();
 }
 
-hipError_t vct_launch_frag_geom(const VctVoxParams& p, float2* bary, float4* duv, hipStream_t s) {
-    if (p.nslots == 0u || (!bary && !duv)) return hipSuccess;
+hipError_t vct_launch_frag_geom(const VctVoxParams& p, float2* bary, float* falb, hipStream_t s) {
+    if (p.nslots == 0u || (!bary && !falb)) return hipSuccess;
     const dim3 grid(p.nslots < 256u * 64u ? p.nslots : 256u * 64u), block(256);
-    if (bary && duv) hipLaunchKernelGGL((k_frag_geom<true, true>), grid, block, 0, s, p, bary, duv);
-    else if (bary) hipLaunchKernelGGL((k_frag_geom<true, false>), grid, block, 0, s, p, bary, duv);
-    else hipLaunchKernelGGL((k_frag_geom<false, true>), grid, block, 0, s, p, bary, duv);
+    VctF3* fa = reinterpret_cast<VctF3*>(falb);
+    if (bary && falb) hipLaunchKernelGGL((k_frag_geom<true, true>), grid, block, 0, s, p, bary, fa);
+    else if (bary) hipLaunchKernelGGL((k_frag_geom<true, false>), grid, block, 0, s, p, bary, fa);
+    else hipLaunchKernelGGL((k_frag_geom<false, true>), grid, block, 0, s, p, bary, fa);
     return hipGetLastError();
 }
 
@@ -1035,8 +1043,11 @@ hipError_t vct_launch_voxelize_reference(const VctVoxParams& p, int32_t* big_lis
 hipError_t vct_launch_voxelize(const VctVoxParams& p, hipStream_t s) {
     if (p.nslots == 0u || p.nitems == 0u) return hipSuccess;
     const unsigned blocks = p.nitems < 256u * 64u ? p.nitems : 256u * 64u;
-    if (p.stage_albedo) hipLaunchKernelGGL(k_voxelize_bricks<true>, dim3(blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_voxelize_bricks<false>, dim3(blocks), dim3(256), 0, s, p);
+    const bool attr = p.stage_albedo != nullptr, falb = p.frag_alb != nullptr;
+    if (attr && falb) hipLaunchKernelGGL((k_voxelize_bricks<true, true>), dim3(blocks), dim3(256), 0, s, p);
+    else if (attr) hipLaunchKernelGGL((k_voxelize_bricks<true, false>), dim3(blocks), dim3(256), 0, s, p);
+    else if (falb) hipLaunchKernelGGL((k_voxelize_bricks<false, true>), dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_voxelize_bricks<false, false>), dim3(blocks), dim3(256), 0, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.nmulti == 0u) return e;
     const unsigned mblocks = p.nmulti < 256u * 16u ? p.nmulti : 256u * 16u;
