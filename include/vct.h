@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VCT_ABI_VERSION 6
+#define VCT_ABI_VERSION 7
 
 typedef enum vct_status {
     VCT_OK = 0,

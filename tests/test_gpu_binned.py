@@ -95,3 +95,33 @@ def test_automatic_choice_of_the_form_keeps_the_result(vct):
     want = render(vct, "direct", scene, 320, 180, 512, cams[:1])
     for x in a[1:]:
         assert np.array_equal(x.view(np.uint32), want[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("caps", ["40,1000000", "1000000,300", "64,64"])
+def test_binned_capacity_overflow_falls_back_in_place(vct, caps):
+    """Scratch capacities are sizes, not limits: what does not fit is rasterised in place by k_bin_setup (the direct
+    form's code) and k_bin_raster merges with atomicMin.  VCT_BIN_TEST_CAPS reports tiny capacities to the kernels."""
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(3, 0.03, 1234)
+    cams = [sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0),
+            sc.default_camera(position=(-30.0, -15.0, 4.0), yaw=15.0, pitch=20.0)]
+    want = render(vct, "direct", scene, 320, 180, 512, cams)
+    os.environ["VCT_BIN_TEST_CAPS"] = caps
+    try:
+        got = render(vct, "binned", scene, 320, 180, 512, cams)
+    finally:
+        os.environ.pop("VCT_BIN_TEST_CAPS", None)
+    for x, y in zip(want, got):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def test_binned_visibility_at_1080p_on_the_street(vct):
+    """Full-size: the Bistro-class street at 1920 x 1080 and a 2048^2 shadow map, binned == direct bit for bit."""
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(3, 0.25, 1234)
+    cams = [sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0)]
+    a = render(vct, "direct", scene, 1920, 1080, 2048, cams)
+    b = render(vct, "binned", scene, 1920, 1080, 2048, cams)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert (a[1][18] >= 0.5).mean() > 0.2

@@ -25,7 +25,7 @@ GB_PLANES = 23
 GB_LINEAR, GB_TILED = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 VOX_CONSERVATIVE_AVG, VOX_REFERENCE = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/vct.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [

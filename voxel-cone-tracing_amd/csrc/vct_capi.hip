@@ -636,6 +636,12 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
         const char* rp = getenv("VCT_RASTER_PATH");
         c->raster_mode = !rp ? 0 : (rp[0] == 'b' ? 2 : (rp[0] == 'd' ? 1 : 0));
         for (int k = 0; k < 4; ++k) CREATE_TRY(hipEventCreate(&c->ev_auto[k]));
+        // VCT_BIN_TEST_CAPS="records,entries": the binned kernels are told these (smaller) capacities, so that a test can
+        // drive the overflow paths -- sub-triangles rasterised in place, the merge by atomicMin -- on a small scene
+        if (const char* tc = getenv("VCT_BIN_TEST_CAPS")) {
+            unsigned a = 0, b = 0;
+            if (sscanf(tc, "%u,%u", &a, &b) == 2) { c->bin_test_caps[0] = a; c->bin_test_caps[1] = b; }
+        }
     }
     const int V = cfg->voxel_dim;
     c->nlev = vct_ilog2(V) + 1;
@@ -943,6 +949,8 @@ static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, bool
     if (binned) {
         a.bin_recs = c->bin_recs[k]; a.bin_rec_cap = c->bin_rec_cap[k];
         a.bin_entries = c->bin_entries[k]; a.bin_entry_cap = c->bin_entry_cap[k];
+        if (c->bin_test_caps[0] && c->bin_test_caps[0] < a.bin_rec_cap) a.bin_rec_cap = c->bin_test_caps[0];
+        if (c->bin_test_caps[1] && c->bin_test_caps[1] < a.bin_entry_cap) a.bin_entry_cap = c->bin_test_caps[1];
         a.bin_count = c->bin_count[k]; a.bin_cursor = c->bin_count[k] + (size_t)c->bin_bins[k] * VCT_BIN_CSTRIDE;
         a.bin_items = c->bin_items[k]; a.bin_item_cap = c->bin_item_cap[k];
         a.bin_huge = c->bin_huge[k]; a.bin_huge_cap = VCT_BIN_HUGE_CAP;

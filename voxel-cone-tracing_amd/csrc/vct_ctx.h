@@ -102,6 +102,7 @@ struct vct_ctx {
     // whole-frame pass runs direct, the second binned, both between events, and the faster one is kept until the mesh,
     // the textures or the frame size change.  1 / 2 = VCT_RASTER_PATH=direct / binned (both passes), for A/B runs.
     int raster_mode = 0;
+    uint32_t bin_test_caps[2] = {0u, 0u};   // VCT_BIN_TEST_CAPS="records,entries": capacities REPORTED to the binned kernels (tests of the overflow paths)
     int auto_state = 0;                                // 0: sample the direct form next, 1: the binned form, 2: both sampled
     int auto_choice = -1;                              // -1 undecided, 0 direct, 1 binned
     hipEvent_t ev_auto[4] = {nullptr, nullptr, nullptr, nullptr};     // direct begin / end, binned begin / end
