@@ -64,48 +64,47 @@ __device__ __forceinline__ float shadow_tex(const uint32_t* __restrict__ words, 
     return acc;
 }
 
-// One axis of the 5 PCF taps: texel indices and filter fraction of tap offsets -2..2, each computed
-// exactly as shadow_tex() does for that tap.
-struct TapAxis { int i0[5], i1[5]; float a[5]; };
-__device__ __forceinline__ void tap_axis(float coord, float inv, float fS, float top, int S, TapAxis& t) {
+// One axis of the 5 PCF taps (offsets -2..2): floor of the texel coordinate and filter fraction, each computed exactly
+// as shadow_tex() does for that tap.
+struct TapAxis { float f[5], a[5]; };
+__device__ __forceinline__ void tap_axis(float coord, float inv, float fS, TapAxis& t) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const float u = coord + inv * (float)(k - 2);
         const float x = u * fS - 0.5f;
-        const float fx = floorf(x);
-        t.a[k] = x - fx;
-        const float f1 = fx + 1.0f;
-        t.i0[k] = !(fx > 0.0f) ? 0 : (fx >= top ? S - 1 : (int)fx);
-        t.i1[k] = !(f1 > 0.0f) ? 0 : (f1 >= top ? S - 1 : (int)f1);
+        t.f[k] = floorf(x);
+        t.a[k] = x - t.f[k];
     }
+}
+// The window of the five taps of an axis is six CONSECUTIVE, UNCLAMPED texels when the floors step by exactly one
+// (fp rounding at a texel boundary can make them step by 0 or 2) and the first / last lie inside the map: then
+// shadow_tex()'s clamped indices are (int)f[k] and (int)f[k] + 1 for every tap -- without computing the ten clamped
+// conversions of each axis (round 4: ~85 of the PCF's instructions).
+__device__ __forceinline__ bool tap_axis_regular(const TapAxis& t, float top) {
+    bool ok = t.f[0] >= 0.0f && t.f[4] + 1.0f <= top;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ok = ok && t.f[k + 1] == t.f[k] + 1.0f;
+    return ok;
 }
 
 // vox.fs:18-52 (count of passing taps; caller divides by 25).  The 25 bilinear taps sit one texel
-// apart, so they normally share a 6x6 texel window: when every tap's upper index equals the next
-// tap's lower index on both axes (checked per lane) the window is loaded once (36 loads instead of
-// 100) and each tap is evaluated from registers with its own exact weights; lanes whose indices
-// are irregular (fp rounding at a texel boundary, clamped borders) take the tap-by-tap path.  Same
-// bits either way.
+// apart, so they normally share a 6x6 texel window: when that window is six consecutive unclamped texels on both axes
+// (checked per lane) it is loaded once (6 x 2 wide loads instead of 100 single ones) and each tap is evaluated from
+// registers with its own exact weights; lanes whose window is irregular (fp rounding at a texel boundary, the rim of
+// the map) take the tap-by-tap path.  Same bits either way.  (A clamped window used to have a path of its own -- 36
+// single loads, i.e. 72 address registers, which set the register peak of the whole voxelize kernel: 158 VGPRs, 3 waves
+// per SIMD, for a case only the rim of the map ever sees.)
 __device__ __forceinline__ int pcf25(const uint32_t* __restrict__ words, uint32_t eb, int S, F3 c, float bias) {
     const float inv = __fdiv_rn(1.0f, (float)S);
     const float fS = (float)S, top = (float)(S - 1);
     TapAxis X, Y;
-    tap_axis(c.x, inv, fS, top, S, X);
-    tap_axis(c.y, inv, fS, top, S, Y);
-    bool regular = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) regular = regular && X.i1[k] == X.i0[k + 1] && Y.i1[k] == Y.i0[k + 1];
+    tap_axis(c.x, inv, fS, X);
+    tap_axis(c.y, inv, fS, Y);
     const float cur = c.z - bias;
     int count = 0;
-    // six consecutive texels per row (no clamped border): two wide loads per row.  A window with a clamped border takes the
-    // tap-by-tap path as well: served from 36 single loads it needed 72 address registers, which set the register peak of
-    // the whole voxelize kernel (158 VGPRs, 3 waves per SIMD) for a case only the rim of the map ever sees.
-    if (regular && X.i1[4] - X.i0[0] == 5) {
-        int row[6];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) row[k] = Y.i0[k];
-        row[5] = Y.i1[4];
-        const uint32_t col0 = (uint32_t)X.i0[0];
+    if (tap_axis_regular(X, top) && tap_axis_regular(Y, top)) {
+        const uint32_t row0 = (uint32_t)(int)Y.f[0];
+        const uint32_t col0 = (uint32_t)(int)X.f[0];
         // One pass over the window: decode in place and take the smallest / largest decoded word on the way (the decode is
         // monotonic, so these are the window's depth bounds: vct_internal.h "PCF short cut").  A window the shadow boundary
         // does not cross ends here; the others evaluate the 25 taps from the same registers.  (The first form of the short
@@ -115,7 +114,7 @@ __device__ __forceinline__ int pcf25(const uint32_t* __restrict__ words, uint32_
         uint32_t wmin = 0xffffffffu, wmax = 0u;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const VctWords6 w = *reinterpret_cast<const VctWords6*>(words + ((uint32_t)row[j] * (uint32_t)S + col0));
+            const VctWords6 w = *reinterpret_cast<const VctWords6*>(words + ((row0 + (uint32_t)j) * (uint32_t)S + col0));
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const uint32_t v = min(w.v[i] - eb, VCT_SHADOW_ONE);      // = vct_shadow_depth()
@@ -575,8 +574,9 @@ __device__ __forceinline__ void resolve_attr(uint32_t c, unsigned long long q0, 
     }
 }
 
+// (4 waves per SIMD: the kernel waits on memory more than it computes; unbounded, hipcc takes 132-134 VGPRs and loses one)
 template <bool ATTR, bool FALB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_voxelize_bricks(const VctVoxParams p) {
     __shared__ unsigned long long acc[512 * 2];
     __shared__ unsigned long long acc_attr[ATTR ? 512 * 3 : 1];
