@@ -552,6 +552,8 @@ def main():
                        "trace_variant": args.variant,
                        # compute units kept away from the trace for the gather's stream (VCT_COMM_RESERVED_CUS; 0: none)
                        "comm_reserved_cus": ctx.stage_counts().get("comm_reserved_cus", 0),
+                       # visibility form of the G-buffer pass that was timed (chosen per context by timing both)
+                       "raster_form": {0: None, 1: "direct", 2: "tile-binned"}.get(ctx.stage_counts().get("raster_form", 0)),
                        "slab_tile_rows": [b - a for a, b in slab_rows]},
             "cone_steps_per_frame": total_steps,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
@@ -752,15 +754,19 @@ def stage_roofline(args, gi, counts, trace_ms, trace_bytes, npix):
     FETCH_SIZE / WRITE_SIZE per kernel: profiles/stage_traffic.json (tools/summarize_prof.py), replayed when present."""
     S, V = args.shadow_size, args.voxel_dim
     ntri, cand, bricks = counts["triangles"], counts["vox_candidates"], counts["touched_bricks"]
+    textured = args.scene in ("bistro", "atrium-textured") or bool(args.obj)
     upper = sum((V >> l) ** 3 for l in range(3, V.bit_length()))          # levels >= 3: dense (tiny)
     stage_bytes = {
         # triangles in, one depth word per shadow-map texel out
         "shadow_map_raster": (ntri * 36 + S * S * 4, "latency: per-triangle fp64 set-up, then dependent loads and L2 atomics of the coverage loops"),
         # triangles in, per pixel 8 B visibility word + 92 B G-buffer out
         "gbuffer_raster": (ntri * 36 + npix * 100, "L2 atomics (visibility), then ALU + dependent fetches (shade)"),
-        # per fragment a 4 B list entry + its triangle's 36 B (re-read per fragment, cache-served: counted once per
-        # triangle), per touched brick 2 KiB of staged texels out; accumulation happens in LDS
-        "voxelize": (ntri * 36 + cand * 4 + bricks * 2048, "VALU instructions per fragment (triangle set-up, 25-tap PCF, albedo): ~1,200 per 64 fragments; accumulation in LDS"),
+        # per fragment a 4 B list entry + 8 B stored barycentrics (+ 12 B stored albedo in a scene with textures) + its
+        # triangle's 36 B (re-read per fragment, cache-served: counted once per triangle), per touched brick 2 KiB of
+        # staged texels out; accumulation happens in LDS
+        "voxelize": (ntri * 36 + cand * (24 if textured else 12) + bricks * 2048,
+                     "the 25-tap PCF: latency of its 6x6 window fetch at 4 waves per SIMD, and 530 of the ~630-740 VALU per 64 "
+                     "fragments (DESIGN.md 3.2); set-up, barycentrics and albedo are per-mesh precomputations since round 4"),
         # per voxel of a touched brick: staged texel read, level-0 texel written
         "inject_resolve": (bricks * 512 * 8, "hbm"),
         # per touched brick 2 KiB read, 1/8 + 1/64 + 1/512 of it written; dense above level 2

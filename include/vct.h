@@ -313,7 +313,9 @@ int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[16]);
 /* Work-item counts behind the per-stage byte figures of bench.py (`stage_roofline`): [0] triangles uploaded,
  * [1] conservative fragments of the mesh at this grid size (the voxelizer's brick-sorted list), [2] reserved,
  * [3] brick slots = 8^3 bricks a fragment of the mesh can land in, [4] bricks level 0 shows after the last
- * resolve, [5..7] reserved (0).  Synchronises the stream. */
+ * resolve, [5] compute units reserved for the communication stream (VCT_COMM_RESERVED_CUS; 0 = none), [6] form of the
+ * last main-draw visibility pass (0 none yet, 1 direct, 2 tile-binned: chosen per context by timing),
+ * [7] reserved (0).  Synchronises the stream. */
 int vct_get_stage_counts(vct_ctx* ctx, uint64_t out[8]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);

@@ -125,3 +125,15 @@ def test_binned_visibility_at_1080p_on_the_street(vct):
     for x, y in zip(a, b):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     assert (a[1][18] >= 0.5).mean() > 0.2
+
+
+def test_automatic_choice_on_a_slab_of_tile_rows(vct):
+    """A rank of a multi-GPU frame only rasterises its slab: the sample pair (direct, then binned over the same rows) and
+    whatever form wins give the slab the direct form gives."""
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(3, 0.03, 1234)
+    cams = [sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0)] * 4
+    a = render(vct, None, scene, 400, 300, 512, cams, rows=(5, 22))
+    want = render(vct, "direct", scene, 400, 300, 512, cams[:1], rows=(5, 22))
+    for x in a[1:]:
+        assert np.array_equal(x.view(np.uint32), want[1].view(np.uint32))

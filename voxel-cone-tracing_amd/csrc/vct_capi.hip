@@ -1165,9 +1165,14 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
                 hipEventElapsedTime(&tb, c->ev_auto[2], c->ev_auto[3]) == hipSuccess)
                 c->auto_choice = tb < td ? 1 : 0;
         }
-        const bool whole = row0 == 0 && row1 == tiles_y(c);
+        // the two samples must cover the same rows (a rank of a multi-GPU frame only ever rasterises its slab, and the
+        // slab may move while the load-aware boundaries settle: a sample pair over different rows starts again)
+        if (c->auto_choice < 0 && c->auto_state == 1 && (row0 != c->auto_rows[0] || row1 != c->auto_rows[1])) c->auto_state = 0;
         if (c->auto_choice >= 0) binned = c->auto_choice == 1;
-        else if (whole && c->auto_state < 2) { sample = c->auto_state; binned = sample == 1; }
+        else if (row1 > row0 && c->auto_state < 2) {
+            sample = c->auto_state; binned = sample == 1;
+            c->auto_rows[0] = row0; c->auto_rows[1] = row1;
+        }
     }
     VctRasterArgs a;
     int rc = raster_args(c, c->cfg.width, c->cfg.height, false, binned, s, a);
@@ -1181,6 +1186,7 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
                                      c->shadow_size, c->light_vp, c->gb_tiled, s);
     if (e != hipSuccess) { c->raster_dirty[1] = true; HIP_TRY(c, e); }
     c->gb_current = c->gb_tiled;
+    c->last_raster_form = binned ? 2 : 1;
     c->last_row0 = row0;
     c->last_row1 = row1;
     c->last_row_stride = 1;
@@ -1192,10 +1198,9 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
         HIP_TRY(c, hipMemcpy(st, c->bin_huge[1] + VCT_BIN_HUGE_CAP, sizeof(st), hipMemcpyDeviceToHost));
         const uint32_t* cur = st + 8 * (c->bin_set[1] ^ 1);
         fprintf(stderr, "binstats: entries %u records %u items %u huge %u | ", cur[0], cur[1], cur[2], cur[4]);
-        static const char* names[] = {"entries_zrejected", "entries_processed", "steps_hiz_skipped", "steps_run", "frag_inside",
-                                      "frag_cov_open", "frag_queued", "flushes", "frag_fetched", "-", "lanes_inbox", "lanes_open", "steps_with_cov"};
-        for (int k = 0; k < 13; ++k) fprintf(stderr, "%s %u ", names[k], st[16 + k]);
-        fprintf(stderr, "\n");
+        // (the adopted form of k_bin_raster only counts its alpha-queue flushes and the fragments they fetched; the
+        // per-step counters of the earlier forms are in profiles/experiments/README.md)
+        fprintf(stderr, "alpha_queue_flushes %u fragments_fetched %u\n", st[16 + 7], st[16 + 8]);
         HIP_TRY(c, hipMemset(c->bin_huge[1] + VCT_BIN_HUGE_CAP + 16, 0, 32 * sizeof(uint32_t)));
     }
 #endif
@@ -1700,6 +1705,7 @@ int vct_get_stage_counts(vct_ctx* c, uint64_t out[8]) {
     out[2] = 0;
     out[3] = c->nslots;
     out[5] = (uint64_t)c->reserved_cus;          // compute units kept for the communication stream (VCT_COMM_RESERVED_CUS)
+    out[6] = (uint64_t)c->last_raster_form;      // visibility form of the last main-draw pass: 1 direct, 2 tile-binned
     if (c->brick_prev) {
         HIP_TRY(c, hipSetDevice(c->device));
         const size_t nbricks = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512;

@@ -99,9 +99,11 @@ struct vct_ctx {
     // tile-binned visibility (vct_raster.hip): scratch per pass kind ([0] shadow pass, [1] main draw), see VctRasterArgs
     // Which form the MAIN draw's visibility takes (the shadow pass is opaque and sparse: the direct form won every
     // measurement).  raster_mode 0 = auto: scenes without alpha-tested textures keep the direct form; otherwise the first
-    // whole-frame pass runs direct, the second binned, both between events, and the faster one is kept until the mesh,
-    // the textures or the frame size change.  1 / 2 = VCT_RASTER_PATH=direct / binned (both passes), for A/B runs.
+    // pass runs direct, the second -- over the same tile rows -- binned, both between events, and the faster one is kept
+    // until the mesh or the textures change.  1 / 2 = VCT_RASTER_PATH=direct / binned (both passes), for A/B runs.
     int raster_mode = 0;
+    int auto_rows[2] = {0, 0};         // tile rows of the timed sample pair
+    int last_raster_form = 0;          // form of the last main-draw visibility pass: 1 direct, 2 tile-binned (vct_get_stage_counts [6])
     uint32_t bin_test_caps[2] = {0u, 0u};   // VCT_BIN_TEST_CAPS="records,entries": capacities REPORTED to the binned kernels (tests of the overflow paths)
     int auto_state = 0;                                // 0: sample the direct form next, 1: the binned form, 2: both sampled
     int auto_choice = -1;                              // -1 undecided, 0 direct, 1 binned

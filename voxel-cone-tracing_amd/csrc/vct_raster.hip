@@ -762,7 +762,8 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
 //                 list that every bin scans.
 //   k_bin_alloc   one thread per bin: its range of the entry array (wave-aggregated cursor), its work items -- slices of
 //                 at most VCT_BIN_SLICE entries -- and the bin counter back to zero.
-//   k_bin_fill    one thread per record: an 8-byte entry (sort key | quadrants touched | record) into each of its bins.
+//   k_bin_fill    one wave per 64 records, lane = (record, bin) pair: an 8-byte entry (sort key | quadrants touched |
+//                 record) into each bin a record reaches.
 //   k_bin_raster  one workgroup per work item; wave w owns the 8x8-pixel quadrant w of the bin, LANE = PIXEL.  The
 //                 entries ARE the sort keys: opaque first, then alpha-tested front to back by a lower bound of the
 //                 sub-triangle's depth (bitonic in LDS, only when the slice has alpha-tested entries).  Records are
@@ -1217,11 +1218,12 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #else
 #define BIN_STAT(k, v) do { } while (0)
 #endif
-#define VCT_VIS_PITCH 17             // words per row of the bin's visibility words in LDS (a quad's two rows on different banks)
 
-// The bin's visibility words live in LDS and are read / lowered by the four waves at once.  (A `volatile` access through
-// a plain pointer compiles to a FLAT load with system scope and a wait for every outstanding memory operation -- on the
-// critical path of every step; these stay ds_read_b64 / ds_min_u64.)
+// A pixel's visibility word lives in its lane's registers; what goes through LDS is the "mail" of the alpha-test queue:
+// a queued fragment is fetched by whichever lane the flush assigns it to, and a survivor is lowered into the slot of the
+// pixel it belongs to (ds_min_u64), which that pixel's lane reads back (ds_read_b64) before its next depth test.  (A
+// `volatile` access through a plain pointer compiles to a FLAT load with system scope and a wait for every outstanding
+// memory operation -- on the critical path of every step; with the address space spelled out these are LDS operations.)
 __device__ __forceinline__ unsigned long long lds_peek(const unsigned long long* w) {
     return *(const volatile __attribute__((address_space(3))) unsigned long long*)w;      // w points into __shared__ memory
 }
