@@ -1065,6 +1065,9 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
         uint32_t flags = 0;
         for (size_t k = 0; k < n; ++k)
             if (rgba8[i][4 * k + 3] != 255) { flags = 1u; break; }
+        // bit 1: a square power-of-two map -- its level offsets have a closed form (vct_tex_level_offset), which saves the
+        // samplers the dependent load of lvl[k]
+        if (width[i] == height[i] && (width[i] & (width[i] - 1)) == 0) flags |= 2u;
         d.flags = flags;
         d.nlev = 1;
         if (c->cfg.texture_mipmaps)

@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t vct_float_to_unorm8(float f) {
 struct VctTexDesc {
     uint32_t off;        // first texel of level 0 in the packed buffer
     int32_t w, h;
-    uint32_t flags;      // bit 0: some texel has alpha != 255 (fragments need the alpha test of trace.fs:169-172)
+    uint32_t flags;      // bit 0: some texel has alpha != 255 (fragments need the alpha test of trace.fs:169-172); bit 1: square power of two
     int32_t nlev;        // levels stored (1: level 0 only)
     uint32_t lvl[VCT_TEX_MAX_LEVELS];     // texel offset of level k behind `off`
 };
@@ -101,6 +101,17 @@ __device__ __forceinline__ float4 vct_tex_sample_lod(const VctTextures& t, int t
     const VctTexDesc* d = t.desc + ti;
     const int W = d->w, H = d->h, nlev = d->nlev;
     const uint32_t* base = t.texels + d->off;
+    const uint32_t dflags = d->flags;
+    // Texel offset of level k behind level 0.  A square power-of-two map stores W^2 (1 + 1/4 + ... ) texels in front of
+    // level k = 4/3 (W^2 - W^2 / 4^k): the difference is a multiple of 3, so the division is one multiply by the inverse
+    // of 3 modulo 2^32 -- the same integers as the table, without the round trip that depended on k.
+    auto level_offset = [&](int k) -> uint32_t {
+        if (dflags & 2u) {
+            const uint32_t wh = (uint32_t)W * (uint32_t)W;
+            return ((wh - (wh >> (2 * k))) << 2) * 0xaaaaaaabu;
+        }
+        return d->lvl[k];
+    };
     if (!t.mips || nlev <= 1) return vct_tex_bilinear(base, W, H, u, v);
     const float du_dx = ds_dx * (float)W, dv_dx = dt_dx * (float)H;
     const float du_dy = ds_dy * (float)W, dv_dy = dt_dy * (float)H;
@@ -109,11 +120,11 @@ __device__ __forceinline__ float4 vct_tex_sample_lod(const VctTextures& t, int t
     if (!(m > 1.0f)) return vct_tex_bilinear(base, W, H, u, v);                     // magnification (and NaN)
     const float lam = 0.5f * vct_log2_det(m);
     const int q = nlev - 1;
-    if (lam >= (float)q) return vct_tex_bilinear(base + d->lvl[q], max(1, W >> q), max(1, H >> q), u, v);
+    if (lam >= (float)q) return vct_tex_bilinear(base + level_offset(q), max(1, W >> q), max(1, H >> q), u, v);
     const int k = (int)lam;
     const float f = lam - (float)k, g = 1.0f - f;
-    const float4 t1 = vct_tex_bilinear(base + d->lvl[k], max(1, W >> k), max(1, H >> k), u, v);
-    const float4 t2 = vct_tex_bilinear(base + d->lvl[k + 1], max(1, W >> (k + 1)), max(1, H >> (k + 1)), u, v);
+    const float4 t1 = vct_tex_bilinear(base + level_offset(k), max(1, W >> k), max(1, H >> k), u, v);
+    const float4 t2 = vct_tex_bilinear(base + level_offset(k + 1), max(1, W >> (k + 1)), max(1, H >> (k + 1)), u, v);
     float4 o;
     o.x = fmaf(f, t2.x, g * t1.x); o.y = fmaf(f, t2.y, g * t1.y);
     o.z = fmaf(f, t2.z, g * t1.z); o.w = fmaf(f, t2.w, g * t1.w);

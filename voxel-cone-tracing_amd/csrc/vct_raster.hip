@@ -1540,6 +1540,17 @@ k_gbuffer_shade(const ShadeParams p) {
                                     p.albedo[4 * (size_t)m_early + 2], p.albedo[4 * (size_t)m_early + 3]};
         const float sp_early[3] = {p.specular[3 * (size_t)m_early], p.specular[3 * (size_t)m_early + 1],
                                    p.specular[3 * (size_t)m_early + 2]};
+        // ... and, in a scene with textures, the material's three texture indices and the triangle's texture coordinates
+        // (round 4: they used to be asked for after the set-up -- material -> indices -> descriptor -> texels was four
+        // dependent round trips behind it, now two)
+        int tex_early[3] = {-1, -1, -1};
+        float uv_early[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (TEX) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tex_early[k] = vct_tex_of(p.r.tex, m_early, k);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) uv_early[k] = p.r.tex.uv[(size_t)t * 6 + k];
+        }
 #endif
         const bool whole = unclipped(in);
         FanTri fan;
@@ -1591,12 +1602,12 @@ k_gbuffer_shade(const ShadeParams p) {
             }
         }
 #if VCT_SHADE_PREFETCH
-        const int m = m_early;
+        const int td = tex_early[0], tsp = tex_early[1], th = tex_early[2];
 #else
         const int m = p.material[t];
-#endif
         const int td = TEX ? vct_tex_of(p.r.tex, m, 0) : -1, tsp = TEX ? vct_tex_of(p.r.tex, m, 1) : -1,
                   th = TEX ? vct_tex_of(p.r.tex, m, 2) : -1;
+#endif
         float tcu = 0.0f, tcv = 0.0f;                                             // tex (trace.vs:36)
         float dq[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                   // its quad differences (mip-mapped textures)
         if (TEX && (td >= 0 || tsp >= 0 || th >= 0)) {
@@ -1604,7 +1615,11 @@ k_gbuffer_shade(const ShadeParams p) {
             float vu[3], vv[3];
             if (whole) {
 #pragma unroll
+#if VCT_SHADE_PREFETCH
+                for (int k = 0; k < 3; ++k) { vu[k] = uv_early[2 * k]; vv[k] = uv_early[2 * k + 1]; }
+#else
                 for (int k = 0; k < 3; ++k) { vu[k] = uv[2 * k]; vv[k] = uv[2 * k + 1]; }
+#endif
             } else {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
