@@ -592,15 +592,13 @@ def main():
             exact = ctx.trace_current().copy()
             exact_steps = ctx.last_step_count()
             ms_e, ms_l = [], []
-            # interleaved pairs, the first pair untimed (the launch after a change of variant / aperture re-uploads the
-            # step table), so that clock drift hits both alike
-            for i in range(7):
-                ctx.set_trace_variant(0)
-                ctx.trace_resident()
-                if i: ms_e.append(ctx.last_trace_ms())
-                ctx.set_trace_variant(3)
-                ctx.trace_resident()
-                if i: ms_l.append(ctx.last_trace_ms())
+            # blocks exact / loose / exact / loose, each 1 untimed + 4 timed launches (the launch after a change of variant
+            # re-uploads the step table inside the timed window), medians: drift of the clocks hits both alike
+            for variant, acc in ((0, ms_e), (3, ms_l), (0, ms_e), (3, ms_l)):
+                ctx.set_trace_variant(variant)
+                for i in range(5):
+                    ctx.trace_resident()
+                    if i: acc.append(ctx.last_trace_ms())
             loose = ctx.trace_current().copy()
             loose_steps = ctx.last_step_count()
             ctx.set_trace_variant(0)
