@@ -321,7 +321,7 @@ int vct_get_stage_counts(vct_ctx* ctx, uint64_t out[8]);
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);
 /* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the
  * device pointers of the resident tiled G-buffer / RGBA16F frame. */
-/* Self-test of the kernel's constant division (x / d as x*r corrected by one FMA round, r = RN(1/d)):
+/* Self-test of the kernel's constant division (x / d as fma(x, r_hi, x * r_lo), r_hi + r_lo = 1/d to 48 bits):
  * runs it on the GPU over every fp32 x of its domain (x == +0 or 2^-100 <= |x| < inf, normal quotient)
  * next to the IEEE divide and returns the number of x whose quotient differs.  0 is the guarantee the
  * trace kernel relies on (vct_trace.hip shows why the march never leaves that domain in a way that

@@ -292,9 +292,9 @@ def test_stale_mips_are_refused_and_upload_then_sparse_builds_stay_correct(vct, 
 
 
 def test_const_divide_exhaustive(vct):
-    """The trace kernel's x/d (x*r + ONE FMA correction round) equals the IEEE divide for EVERY finite fp32 x,
+    """The trace kernel's x/d (fma(x, r_hi, x * r_lo): two instructions) equals the IEEE divide for EVERY finite fp32 x,
     for every divisor the BASELINE grids and apertures use: half_G = 75 and the per-step occlusion denominators
-    1 + 0.03*diameter (trace.fs:61,101).  One round is not exact for arbitrary divisors -- the library verifies
+    1 + 0.03*diameter (trace.fs:61,101).  The form is not exact for arbitrary divisors -- the library verifies
     the divisors of each step table on the device before using them and otherwise runs the IEEE-divide kernel;
     `vct_selftest_const_divide` is that check."""
     with make_ctx(vct, 16, 8, 8) as ctx:

@@ -126,7 +126,7 @@ int build_steps(const vct_config& cfg, float tan_half, std::vector<VctStep>& out
 }
 
 // The kernel divides by wave-uniform constants (half_G, the per-step occlusion denominators) with
-// q = x*r; e = fma(-d,q,x); q = fma(e,r,q), r = RN(1/d) -- exact only for some divisors, so every divisor of
+// q = fma(x, r_hi, x * r_lo), r_hi + r_lo = 1/d to 48 bits (vct_trace.hip div_const) -- exact only for some divisors, so every divisor of
 // a step table is first verified on the device against the IEEE divide over all fp32 inputs
 // (divisors_verified below); structural preconditions: significand not all ones, d and 1/d normal.
 // Anything else switches the kernel to the IEEE-divide instantiation.
@@ -138,7 +138,7 @@ bool divisor_ok(float d) {
     return m != 0x7fffffu && e >= 4 && e <= 250;   // d and 1/d both far from the subnormal range
 }
 
-// Is the one-round constant division exact for divisor d (vct_trace.hip div_const)?  The divisors of the BASELINE
+// Is the kernel's constant division exact for divisor d (vct_trace.hip div_const<1>)?  The divisors of the BASELINE
 // grids and apertures ship as a table (vct_divisors.h: verified on the device, and every entry re-verified by
 // tests/test_gpu_parity.py::test_const_divide_exhaustive), so a fresh process pays nothing for them; any other
 // divisor is checked exhaustively on the device the first time a step table uses it (k_divide_selftest, 2 ms per
@@ -173,11 +173,6 @@ int refresh_steps(vct_ctx* c) {
     std::vector<VctStep> d, s;
     if (build_steps(c->cfg, c->cfg.tan_diffuse, d) || build_steps(c->cfg, c->cfg.tan_specular, s))
         return fail(c, VCT_ERR_INVALID, "cone aperture needs more than VCT_MAX_STEPS march steps");
-    HIP_TRY(c, hipMemcpyAsync(c->steps_dev, d.data(), d.size() * sizeof(VctStep),
-                              hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->steps_dev + VCT_MAX_STEPS, s.data(), s.size() * sizeof(VctStep),
-                              hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // d, s go out of scope
     c->n_diffuse = (int)d.size();
     c->n_specular = (int)s.size();
     // preconditions of the kernel's FMA division (vct_trace.hip div_const): admissible divisors, and
@@ -190,7 +185,7 @@ int refresh_steps(vct_ctx* c) {
     };
     for (const VctStep& st : d) ok = ok && divisor_ok(st.occ_den) && blend_ok(st);
     for (const VctStep& st : s) ok = ok && divisor_ok(st.occ_den) && blend_ok(st);
-    if (ok) {      // every divisor of the tables passes the device's exhaustive check of the one-round division
+    if (ok) {      // every divisor of the tables passes the device's exhaustive check of the kernel's division
         std::vector<float> divs = {c->cfg.grid_world_size * 0.5f};
         for (const VctStep& st : d) divs.push_back(st.occ_den);
         for (const VctStep& st : s) divs.push_back(st.occ_den);
@@ -202,6 +197,17 @@ int refresh_steps(vct_ctx* c) {
         }
     }
     c->fast_div = ok;
+    // a table for the verified division carries what div_const<1> takes beside the reciprocal (VCT_DIV2: its low word)
+    // in the divisor's place; the IEEE-divide kernels of an unverified table keep the divisor
+    if (ok) {
+        for (VctStep& st : d) st.occ_den = vct_div_aux(st.occ_den, st.occ_rcp);
+        for (VctStep& st : s) st.occ_den = vct_div_aux(st.occ_den, st.occ_rcp);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->steps_dev, d.data(), d.size() * sizeof(VctStep),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->steps_dev + VCT_MAX_STEPS, s.data(), s.size() * sizeof(VctStep),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // d, s go out of scope
     c->steps_dirty = false;
     return VCT_OK;
 }
@@ -223,6 +229,7 @@ void fill_march_params(const vct_ctx* c, VctTraceParams& p, const uint32_t* chai
     p.half_G = c->cfg.grid_world_size * 0.5f;                       // trace.fs:61
     p.vs = c->cfg.grid_world_size / (float)c->cfg.voxel_dim;        // trace.fs:90
     p.half_G_rcp = 1.0f / p.half_G;
+    p.half_G_aux = c->fast_div ? vct_div_aux(p.half_G, p.half_G_rcp) : p.half_G;
     p.fast_div = c->fast_div ? 1 : 0;
     p.max_alpha = c->cfg.max_alpha;
     p.wrap_repeat = c->cfg.wrap_repeat;

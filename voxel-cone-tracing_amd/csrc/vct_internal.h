@@ -207,10 +207,26 @@ struct VctLevelRef {    // one mip level as the sampler needs it (all wave-unifo
     int32_t m;         // N - 1
 };
 
+// The verified constant division of the march (vct_trace.hip div_const<1>): 1 = two-term product
+// fma(x, r_hi, x * r_lo) with r_hi + r_lo = 1/d to ~48 bits (2 VALU), 0 = one FMA correction round of x * RN(1/d)
+// (3 VALU, rounds 1-3).  Either is exact only for divisors the device has checked over every fp32 input.
+#ifndef VCT_DIV2
+#define VCT_DIV2 1
+#endif
+// second argument of div_const<1> for divisor d with r = RN(1 / d): the low word of the reciprocal, or d itself
+static inline float vct_div_aux(float d, float r) {
+#if VCT_DIV2
+    return (float)(1.0 / (double)d - (double)r);
+#else
+    (void)r;
+    return d;
+#endif
+}
 struct VctStep {       // 64 B: one s_load_dwordx16 per march step
     float dist;        // trace.fs:91,103
     float occ_rcp;     // RN(1 / occ_den): reciprocal for the exact constant division (vct_trace.hip)
-    float occ_den;     // 1 + 0.03*diameter            trace.fs:101
+    float occ_den;     // 1 + 0.03*diameter            trace.fs:101 -- or, in a table built for the verified two-term
+                       // division (VCT_DIV2, vct_capi.hip refresh_steps), the low word r_lo of its reciprocal
     float frac;        // fract(lod) after [GL] clamp  trace.fs:97
     int32_t level;     // floor(lod)
     int32_t level2;    // min(level+1, maxLevel)
@@ -225,6 +241,7 @@ struct VctTraceParams {
     int32_t V, nlev;
     float G, half_G, vs;
     float half_G_rcp;                   // RN(1 / half_G)
+    float half_G_aux;                   // what div_const takes beside it: half_G, or (VCT_DIV2 and fast_div) the low word of 1 / half_G
     int32_t fast_div;                   // 1: every constant divisor admits the FMA-corrected division
     float cam[3];
     float light[3];

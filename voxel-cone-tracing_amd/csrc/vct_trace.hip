@@ -63,15 +63,19 @@ __device__ __forceinline__ F3 reflect3(F3 I, F3 N) {
     return {I.x - d * N.x, I.y - d * N.y, I.z - d * N.z};
 }
 
-// x / d for a wave-uniform divisor d with r = RN(1/d):  q = x*r; e = fma(-d, q, x); q = fma(e, r, q) -- three
-// 2-cycle instructions instead of v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup.  One correction round
-// is NOT correctly rounded for every divisor (q = x*r may be 2 ulp off before it), so it is used only for
-// divisors the DEVICE has verified: before a step table is used, vct_capi.hip runs k_divide_selftest for each
-// of its divisors (half_G and the per-step occlusion denominators) over EVERY fp32 x of the domain below and
-// requires the IEEE quotient bit for bit (results cached per divisor; all 250 divisors of the BASELINE grids
-// and apertures pass); a table with a divisor that fails runs the IEEE-divide instantiation.
+// x / d for a wave-uniform divisor d: the IEEE division costs v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup.
+// Rounds 1-3: q = x*r; e = fma(-d, q, x); q = fma(e, r, q) with r = RN(1/d) -- three instructions, one correction
+// round.  Round 4 (VCT_DIV2): t = x * r_lo; q = fma(x, r_hi, t) with r_hi = RN(1/d), r_lo = RN(1/d - r_hi) -- TWO
+// instructions: r_hi + r_lo is 1/d to ~48 bits, the fma adds the two products exactly and rounds once, so q is the
+// correctly rounded quotient unless x/d lies within ~2^-47 of a rounding boundary.  Neither form is correctly rounded
+// for every divisor, so both are used only for divisors the DEVICE has verified: before a step table is used,
+// vct_capi.hip runs k_divide_selftest for each of its divisors (half_G and the per-step occlusion denominators) over
+// EVERY fp32 x of the domain below and requires the IEEE quotient bit for bit (results cached per divisor; all 334
+// divisors of the BASELINE grids and apertures pass, in either form: csrc/vct_divisors.h); a table with a divisor that
+// fails runs the IEEE-divide instantiation.  Atrium 0.6177 -> 0.6107 ms, street at 1024^3 / 4K 2.727 -> 2.711 ms.
 // Domain: x == +0 and every finite |x| >= 2^-100 whose quotient is a normal number (host-side precondition on
-// d: vct_capi.hip divisor_ok; below ~2^-102 the exact remainder e can underflow; -0 returns +0).
+// d: vct_capi.hip divisor_ok; below that the low product x * r_lo -- or the remainder e of the older form -- loses
+// bits to underflow; the sign of a zero quotient is not preserved).
 // The march stays inside the domain by construction:
 //   * coordinates: |x| < 2^-100 or x == -0 gives |q| < 2^-26, and u = fma(q, .5, .5) = 0.5 for any
 //     such q, exactly as with the IEEE quotient;
@@ -80,15 +84,23 @@ __device__ __forceinline__ F3 reflect3(F3 I, F3 N) {
 //     non-zero trilinear weight is >= 2^-75, a non-zero texel >= 1/255, the level blend factors are
 //     0 or >= 2^-10 and oma >= 2^-5 (both checked on the host: vct_capi.hip refresh_steps).
 #define VCT_DIV_TINY 0x1p-100f
-// MODE 0: the IEEE division, 1: the verified one-round form, 2: x * r alone -- NOT exact: only the opt-in "loose" trace
+// MODE 0: the IEEE division, 1: the verified form (two-term product, or one correction round without VCT_DIV2), 2: x * r alone -- NOT exact: only the opt-in "loose" trace
 // variant that prices the exactness (config.trace_variant = 3, k_trace_tile_split<.., 2, ..>) uses it
+// `d`: the divisor -- or, for MODE 1 under VCT_DIV2, the low word r_lo of its reciprocal (the host puts it where the
+// divisor used to be: VctStep::occ_den, VctTraceParams::half_G_aux)
 template <int MODE>
 __device__ __forceinline__ float div_const(float x, float d, float r) {
     if (MODE == 0) return x / d;
     if (MODE == 2) return x * r;
+#if VCT_DIV2
+    // x / d = x * (r_hi + r_lo) (1 + e), |e| < 2^-47: the one rounding of the fma is the rounding of the quotient unless
+    // x / d lies within 2^-47 of a rounding boundary -- which the device rules out per divisor, over every fp32 x
+    return fmaf(x, r, x * d);
+#else
     const float q = x * r;
     const float e = fmaf(-d, q, x);
     return fmaf(e, r, q);
+#endif
 }
 
 // unorm8 -> float, bit-identical to (float)c / 255.0f for every c in [0,255]:
@@ -549,9 +561,9 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
         const float px = start.x + dir.x * st.dist; \
         const float py = start.y + dir.y * st.dist; \
         const float pz = start.z + dir.z * st.dist; \
-        const float ux = fmaf(div_const<FASTDIV>(px, p.half_G, p.half_G_rcp), 0.5f, 0.5f); \
-        const float uy = fmaf(div_const<FASTDIV>(py, p.half_G, p.half_G_rcp), 0.5f, 0.5f); \
-        const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G, p.half_G_rcp), 0.5f, 0.5f); \
+        const float ux = fmaf(div_const<FASTDIV>(px, p.half_G_aux, p.half_G_rcp), 0.5f, 0.5f); \
+        const float uy = fmaf(div_const<FASTDIV>(py, p.half_G_aux, p.half_G_rcp), 0.5f, 0.5f); \
+        const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G_aux, p.half_G_rcp), 0.5f, 0.5f); \
         F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, live, blk, lb, ac, ms) \
                                          : sample_level<WRAP, COOP, FASTDIV == 2>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms); \
         if (st.two_levels) { \
@@ -1428,7 +1440,7 @@ hipError_t launch_v(const VctTraceParams& p, int variant, int ntiles, hipStream_
 
 // every fp32 bit pattern: div_const<true> against the IEEE divide
 __global__ void __launch_bounds__(256)
-k_divide_selftest(float d, float r, unsigned long long* mismatches) {
+k_divide_selftest(float d, float r, float aux, unsigned long long* mismatches) {
     unsigned long long bad = 0;
     const unsigned long long total = 1ull << 32;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -1439,7 +1451,7 @@ k_divide_selftest(float d, float r, unsigned long long* mismatches) {
         const float want = x / d;
         if (want != 0.0f && fabsf(want) < 1.17549435e-38f) continue;   // subnormal quotient
         if (fabsf(want) > 3.0e38f) continue;
-        const float got = div_const<true>(x, d, r);
+        const float got = div_const<1>(x, aux, r);
         if (__float_as_uint(got) != __float_as_uint(want)) { ++bad; mismatches[1] = i; }
     }
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off);
@@ -1449,7 +1461,8 @@ k_divide_selftest(float d, float r, unsigned long long* mismatches) {
 }  // namespace
 
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s) {
-    hipLaunchKernelGGL(k_divide_selftest, dim3(256 * 16), dim3(256), 0, s, d, 1.0f / d, mismatches);
+    const float r = 1.0f / d;
+    hipLaunchKernelGGL(k_divide_selftest, dim3(256 * 16), dim3(256), 0, s, d, r, vct_div_aux(d, r), mismatches);
     return hipGetLastError();
 }
 
