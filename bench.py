@@ -578,8 +578,9 @@ def main():
             for ts in (0.07, 0.105, 0.2):
                 ctx.set_cone_apertures(0.577, ts)
                 ms = []
-                for _ in range(5):
-                    ctx.trace_resident()
+                for _ in range(3):                    # six launches back to back, the last one timed: steady state
+                    for _ in range(6):
+                        ctx.trace_resident()
                     ms.append(ctx.last_trace_ms())
                 sweep.append({"tan_specular": ts, "trace_kernel_ms": round(float(np.mean(ms)), 4),
                               "cone_steps": ctx.last_step_count(),
@@ -592,13 +593,14 @@ def main():
             exact = ctx.trace_current().copy()
             exact_steps = ctx.last_step_count()
             ms_e, ms_l = [], []
-            # blocks exact / loose / exact / loose, each 1 untimed + 4 timed launches (the launch after a change of variant
-            # re-uploads the step table inside the timed window), medians: drift of the clocks hits both alike
-            for variant, acc in ((0, ms_e), (3, ms_l), (0, ms_e), (3, ms_l)):
+            # blocks exact / loose / exact / loose / ..., each six launches issued back to back of which the LAST is timed
+            # (a launch on an idle GPU -- what a timed launch per call would measure -- runs 2-5 % slower than the steady
+            # state `value` is made of, and not by the same factor for both variants); medians over three blocks each
+            for variant, acc in ((0, ms_e), (3, ms_l)) * 3:
                 ctx.set_trace_variant(variant)
-                for i in range(5):
+                for _ in range(6):
                     ctx.trace_resident()
-                    if i: acc.append(ctx.last_trace_ms())
+                acc.append(ctx.last_trace_ms())
             loose = ctx.trace_current().copy()
             loose_steps = ctx.last_step_count()
             ctx.set_trace_variant(0)
