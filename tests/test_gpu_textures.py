@@ -236,3 +236,62 @@ def test_ragged_texture_sizes_through_every_stage(oracle):
     ctx, g, l0, chain = textured_pipeline(vct, oracle, scene, cam, 64, 320, 184, 512, attrs=1, mipmaps=True)
     assert len(np.unique(g[15][g[18] >= 0.5])) > 500
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_cached_fragment_values_follow_new_textures_coordinates_and_meshes(oracle):
+    """Round 4: the voxelizer keeps per-fragment barycentrics and albedo between passes (csrc/vct_voxelize.hip
+    k_frag_geom).  Whatever they were computed from may be replaced on a live context -- the textures, the texture
+    coordinates, the whole mesh, or the textures may be detached -- and the next pass must show the new scene."""
+    import torch
+    assert torch.cuda.is_available()
+    vct = vctpkg.load()
+    from voxel_cone_tracing_amd import scene as sc
+    V, S = 64, 512
+    scene = sc.Scene(sc.ATRIUM_TEXTURED, 0.15, 1234)
+    depth, lvp_row = raster_oracle.shadow_map(sc, scene, LIGHT, S)
+    p = oracle.default_params(V, light_dir=LIGHT)
+
+    def want(s, mipmaps=True):
+        return oracle.voxelize_conservative(p, raster_oracle.oracle_scene(s, depth, lvp_row, mipmaps=mipmaps))
+
+    def got(ctx):
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        return ctx.download_chain()
+
+    with vct.Context(vct.default_config(voxel_dim=V, width=64, height=64, shadow_map_size=S, texture_mipmaps=1)) as ctx:
+        ctx.set_light_direction(LIGHT)
+        ctx.upload_scene(scene)
+        ctx.render_shadow_map(sc.light_view_proj(LIGHT))
+        first = oracle.build_mips(want(scene))
+        assert np.array_equal(got(ctx), first)
+        assert np.array_equal(got(ctx), first)                                   # a second pass reads the cached values
+        # (1) other texels in the same maps
+        s2 = sc.Scene(sc.ATRIUM_TEXTURED, 0.15, 1234)
+        s2.textures = [np.ascontiguousarray(255 - t) if i % 2 == 0 else t for i, t in enumerate(scene.textures)]
+        for a, b in zip(s2.textures, scene.textures):
+            a[..., 3] = b[..., 3]                                                # (alpha untouched: the same shadow map holds)
+        ctx.upload_textures(s2.textures, s2.mat_tex)
+        c2 = oracle.build_mips(want(s2))
+        assert not np.array_equal(c2, first) and np.array_equal(got(ctx), c2)
+        # (2) other texture coordinates
+        s3 = sc.Scene(sc.ATRIUM_TEXTURED, 0.15, 1234)
+        s3.textures = s2.textures
+        s3.uv = np.ascontiguousarray(scene.uv[:, [2, 3, 4, 5, 0, 1]] * np.float32(1.7))
+        ctx.upload_mesh_uvs(s3.uv)
+        c3 = oracle.build_mips(want(s3))
+        assert not np.array_equal(c3, c2) and np.array_equal(got(ctx), c3)
+        # (3) textures detached: flat colours again
+        ctx.upload_textures([], scene.mat_tex)
+        flat = sc.Scene(sc.ATRIUM_TEXTURED, 0.15, 1234)
+        flat.textures = []
+        flat.mat_tex = np.full_like(scene.mat_tex, -1)
+        cf = oracle.build_mips(want(flat))
+        assert not np.array_equal(cf, c3) and np.array_equal(got(ctx), cf)
+        # (4) another mesh on the same context (its shadow map too), textured again
+        s4 = sc.Scene(sc.ATRIUM_TEXTURED, 0.1, 77)
+        ctx.upload_scene(s4)
+        ctx.render_shadow_map(sc.light_view_proj(LIGHT))
+        d4, l4 = raster_oracle.shadow_map(sc, s4, LIGHT, S)
+        w4 = oracle.voxelize_conservative(p, raster_oracle.oracle_scene(s4, d4, l4, mipmaps=True))
+        assert np.array_equal(got(ctx), oracle.build_mips(w4))
