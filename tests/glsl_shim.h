@@ -1,7 +1,7 @@
 // glsl_shim.h -- a minimal GLSL-as-C++ stand-in, TEST INFRASTRUCTURE ONLY (tests/test_shader_crosscheck.py).
 //
 // Just enough of GLSL 4.30's vector / matrix types and built-ins for the text of the reference's cone-trace
-// fragment shader (S/VoxelConeTracing.fs) to compile as C++ after a handful of mechanical rewrites (qualifiers
+// fragment shader (S/VoxelConeTracing.fs) and of its voxelization shaders (S/Voxelization.gs / .fs) to compile as C++ after a handful of mechanical rewrites (qualifiers
 // dropped, array constructors -> braces, multi-component swizzles -> calls).  The shader text itself is read from
 // /root/reference at test time and never stored.  Arithmetic: fp32, one rounding per operation (-ffp-contract=off),
 // built-ins as the GLSL specification defines them (normalize(x) = x / length(x), reflect(I, N) = I - 2 dot(N, I) N,
@@ -44,7 +44,13 @@ struct vec4 {
     vec3 rgb() const { return vec3(x, y, z); }
     vec2 gb() const { return vec2(y, z); }
     vec2 xy() const { return vec2(x, y); }
+    vec3 xyz() const { return vec3(x, y, z); }
     vec4 rrra() const { return vec4(x, x, x, w); }
+};
+struct ivec3 {                          // GLSL int(float): truncation toward zero
+    int x, y, z;
+    ivec3() : x(0), y(0), z(0) {}
+    ivec3(double a, double b, double c) : x((int)a), y((int)b), z((int)c) {}
 };
 
 inline vec2 operator+(vec2 a, vec2 b) { return vec2(a.x + b.x, a.y + b.y); }
@@ -69,6 +75,7 @@ inline vec3 normalize(vec3 a) { return a / length(a); }
 inline vec3 cross(vec3 a, vec3 b) { return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 inline vec3 reflect(vec3 I, vec3 N) { return I - 2.0f * dot(N, I) * N; }
 inline float max(float a, float b) { return a < b ? b : a; }     // GLSL: y if x < y else x
+inline float abs(float a) { return fabsf(a); }
 inline float pow(float a, float b) { return powf(a, b); }
 inline float log2(float a) { return log2f(a); }
 
@@ -94,6 +101,25 @@ inline mat3 inverse(const mat3& m) {                        // adjugate / determ
     return r;
 }
 
+struct mat4 {                           // column-major, m * v = sum of columns scaled (GLSL 5.10)
+    vec4 c[4];
+    mat4() {}
+};
+inline vec4 operator*(const mat4& m, vec4 v) {
+    return vec4(m.c[0].x * v.x + m.c[1].x * v.y + m.c[2].x * v.z + m.c[3].x * v.w,
+                m.c[0].y * v.x + m.c[1].y * v.y + m.c[2].y * v.z + m.c[3].y * v.w,
+                m.c[0].z * v.x + m.c[1].z * v.y + m.c[2].z * v.z + m.c[3].z * v.w,
+                m.c[0].w * v.x + m.c[1].w * v.y + m.c[2].w * v.z + m.c[3].w * v.w);
+}
+// geometry-shader plumbing (S/Voxelization.gs): the three input vertices, the emitted ones
+struct GlInVertex { vec4 gl_Position; };
+struct GlInArray {
+    GlInVertex v[3];
+    GlInVertex& operator[](int i) { return v[i]; }
+    int length() const { return 3; }
+};
+struct image3D { int unused; };
+
 // ---- samplers ------------------------------------------------------------------------------------------------
 struct sampler2D { int which; };       // 0 diffuse, 1 specular, 2 mask, 3 height, 4 shadow map
 struct sampler3D { int unused; };
@@ -108,13 +134,20 @@ struct ShimState {                     // set by the harness per pixel
     bool discarded;
     const void* params;                // vcto_params
     const unsigned char* chain;
+    const float* shadow_depth;         // when set: sampler 4 is this S x S depth map ([GL] bilinear, clamp to edge:
+    int shadow_S;                      //   the oracle's vcto_shadow_tex), not the counting stand-in
+    ivec3 stored_pos;                  // imageStore (S/Voxelization.fs:88)
+    vec4 stored_value;
+    int stores;
 };
 extern ShimState g_shim;
 }  // namespace glsl
 extern "C" void vcto_texture_lod(const void* p, const unsigned char* chain, const float uvw[3], float lod, float out[4]);
+extern "C" float vcto_shadow_tex(const float* depth, int S, float u, float v);
 namespace glsl {
 
-inline vec4 texture(const sampler2D& s, vec2) {
+inline vec4 texture(const sampler2D& s, vec2 uv) {
+    if (s.which == 4 && g_shim.shadow_depth) return vec4(vcto_shadow_tex(g_shim.shadow_depth, g_shim.shadow_S, uv.x, uv.y), 0, 0, 1);
     switch (s.which) {
     case 0: return g_shim.diffuse;
     case 1: return g_shim.specular;
@@ -123,6 +156,7 @@ inline vec4 texture(const sampler2D& s, vec2) {
     default: return vec4(0, 0, 0, 1);
     }
 }
+inline void imageStore(const image3D&, ivec3 p, vec4 v) { g_shim.stored_pos = p; g_shim.stored_value = v; ++g_shim.stores; }
 inline void shim_cone_begin() { ++g_shim.ncones; }
 inline vec4 textureLod(const sampler3D&, vec3 uvw, float lod) {
     if (g_shim.ncones >= 1 && g_shim.ncones <= 8) ++g_shim.cone_steps[g_shim.ncones - 1];
