@@ -1276,7 +1276,11 @@ k_bin_raster(const BinParams p) {
     const int lx = (lane & 1) | ((lane >> 1) & 6), ly = ((lane >> 1) & 1) | ((lane >> 3) & 6);
     const uint4* rec16 = reinterpret_cast<const uint4*>(p.recs);
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+#if defined(VCT_BIN_REVERSE) && VCT_BIN_REVERSE
+        const uint4 it = p.items[nitems - 1u - item];       // order-sensitivity probe (profiles/experiments/README.md)
+#else
         const uint4 it = p.items[item];
+#endif
         const int bin = (int)it.x, n = (int)it.z;
         const uint32_t first = it.y;
         const int by = bin / p.bins_x, bx = bin - by * p.bins_x;
