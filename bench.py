@@ -765,7 +765,7 @@ def stage_roofline(args, gi, counts, trace_ms, trace_bytes, npix):
         # triangle's 36 B (re-read per fragment, cache-served: counted once per triangle), per touched brick 2 KiB of
         # staged texels out; accumulation happens in LDS
         "voxelize": (ntri * 36 + cand * (24 if textured else 12) + bricks * 2048,
-                     "the 25-tap PCF: latency of its 6x6 window fetch at 4 waves per SIMD, and 530 of the ~630-740 VALU per 64 "
+                     "the 25-tap PCF: latency of its 6x6 window fetch at 4 waves per SIMD, and ~420 of the 520-630 VALU per 64 "
                      "fragments (DESIGN.md 3.2); set-up, barycentrics and albedo are per-mesh precomputations since round 4"),
         # per voxel of a touched brick: staged texel read, level-0 texel written
         "inject_resolve": (bricks * 512 * 8, "hbm"),
