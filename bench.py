@@ -781,8 +781,15 @@ def stage_roofline(args, gi, counts, trace_ms, trace_bytes, npix):
         gbs = b / (ms * 1e-3) / 1e9
         out[k] = {"algorithmic_bytes": int(b), "ms": round(ms, 4), "GBps": round(gbs, 1),
                   "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "bound": bound}
-    path = os.path.join(ROOT, "profiles", "stage_traffic.json")
-    if os.path.exists(path):
+    # per-kernel PMC bytes exist for the two profiled workloads only (tools/summarize_prof.py: the default one and configs[4])
+    common = (args.variant == 0 and not args.obj and args.bounces == 1 and not args.anisotropic and args.scene_detail == 1.0)
+    name = None
+    if common and args.voxel_dim == 256 and args.width == 1920 and args.height == 1080 and args.scene == "atrium":
+        name = "stage_traffic.json"
+    elif common and args.voxel_dim == 1024 and args.width == 3840 and args.height == 2160 and args.scene == "bistro":
+        name = "stage_traffic_c5.json"
+    path = os.path.join(ROOT, "profiles", name or "-")
+    if name and os.path.exists(path):
         with open(path) as fh:
             t = json.load(fh)
         if t.get("source_sha16") == all_sources_sha():
