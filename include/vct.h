@@ -177,7 +177,10 @@ int vct_download_gbuffer(vct_ctx* ctx, float* planes);
 int vct_trace_current(vct_ctx* ctx, void* out_rgba16f, int32_t out_location);
 
 /* DrawVoxelTexture (VCT.h:213-245) -> vox.vs / vox.gs / vox.fs: voxelize the uploaded triangles
- * into per-voxel integer accumulators (mode selects coverage + resolve rule). */
+ * into per-voxel integer accumulators (mode selects coverage + resolve rule).  In the north-star mode only the light
+ * is evaluated per pass: the fragment list, every fragment's barycentrics and -- with textures -- its albedo depend on
+ * mesh, grid and textures alone and are kept per context (12-24 B per fragment); the first pass after
+ * vct_upload_mesh_uvs / vct_upload_textures rebuilds the albedo (and may return VCT_ERR_NOMEM for it). */
 int vct_voxelize(vct_ctx* ctx, int32_t mode);
 /* vox.fs:88: resolve the accumulators into radiance level 0 (rgb = albedo * PCF shadow, a = 1). */
 int vct_inject_light(vct_ctx* ctx);

@@ -18,6 +18,9 @@
 // shading pass then re-derives the winning fragment from its triangle; nothing per-fragment is
 // stored besides the 8-byte visibility word (4 bytes of depth in the shadow pass).  A pass is two dependent launches
 // (k_raster_vis, k_raster_mid) and no clear: consumers reset the words they read, the counters alternate.
+// Round 4 adds a second, bit-identical form of the visibility stage -- tile-binned, the word in a lane's registers
+// instead of an L2 atomic (k_bin_setup / _alloc / _fill / _raster, below) -- which the context picks for the main draw
+// of scenes with alpha-tested foliage when it measures faster (vct_ctx.h raster_mode).
 #include <stddef.h>
 #include <string.h>
 

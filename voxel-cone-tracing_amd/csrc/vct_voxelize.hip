@@ -12,16 +12,18 @@
 // Work distribution (north-star mode): BRICK-parallel, no global atomics.  Which voxels a triangle overlaps depends
 // only on geometry, V and G, so the fragment list is built ONCE when the triangles are uploaded (k_vox_plan*: exact
 // conservative overlap, entries (triangle, Morton voxel)) and sorted by 8^3 brick (counting sort: k_frag_count /
-// k_frag_scatter).  A voxelize pass -- e.g. after the light moved -- is then one workgroup per touched brick
-// (k_voxelize_bricks): its threads evaluate the brick's fragments (PCF, albedo / texture) and add them into the brick's
-// 512 accumulators IN LDS (64-bit ds_add: the exact, order-independent "atomic RGBA average"), then the same workgroup
+// k_frag_scatter).  What a fragment contributes apart from the light -- its barycentrics on its triangle and its albedo
+// (the mip-mapped diffuse fetch of vox.fs:56, or the material's colour) -- is evaluated once as well (k_frag_geom, round 4)
+// and stored per sorted fragment.  A voxelize pass -- e.g. after the light moved -- is then one workgroup per touched
+// brick (k_voxelize_bricks): its threads read their fragments' stored values, transform the triangle's vertices by the
+// light matrix, run the 25-tap PCF and add albedo * shadow into the brick's 512 accumulators IN LDS (64-bit ds_add: the exact, order-independent "atomic RGBA average"), then the same workgroup
 // resolves the rounded means and writes the brick's 2 KiB of texels -- coalesced, once.  Rounds 1-2 accumulated with
 // two device-scope 64-bit atomics per fragment into per-brick pools in HBM and resolved in a second kernel: 0.098 +
 // 0.018 ms at configs[1], bound by the atomic unit.  All fragments of a brick lie within 8 voxels of each other, so
 // their 25-tap shadow windows overlap: coherent fetches.
 //
 // The texels of a pass go to a staging pool (one 2 KiB slot per brick the mesh can touch); vct_inject_light's sparse
-// resolve (k_resolve_staged) copies the slots of touched bricks into level 0 and clears bricks that are no longer
+// resolve (k_resolve_sparse) copies the slots of touched bricks into level 0 and clears bricks that are no longer
 // covered -- vct_voxelize evaluates the light, vct_inject_light makes it visible, as before.
 #include "vct_internal.h"
 
