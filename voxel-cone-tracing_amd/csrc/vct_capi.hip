@@ -704,7 +704,7 @@ void vct_destroy(vct_ctx* c) {
     void* bufs[] = {c->chain, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->vt_pix, c->steps_dev, c->spread_lut, c->tri_pos,
                     c->tri_mat, c->tri_alpha, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->vox_items, c->vox_acc2, c->vox_acc2_attr, c->vox_multi_slot, c->stage,
-                    c->stage_albedo, c->stage_normal, c->plan,
+                    c->stage_albedo, c->stage_normal, c->plan, c->frag_bary, c->frag_alb, c->tri_qnrm,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->attr_albedo, c->attr_normal,
                     c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_lists[0], c->raster_lists[1],
                     c->raster_counts[0], c->raster_counts[1], c->raster_items[0], c->raster_items[1], c->raster_recs[0],
