@@ -124,7 +124,8 @@ int vct_set_camera_position(vct_ctx* ctx, const float pos[3]);
 int vct_set_light_direction(vct_ctx* ctx, const float dir[3]);
 int vct_set_ambient_factor(vct_ctx* ctx, float ambient);
 int vct_set_cone_apertures(vct_ctx* ctx, float tan_diffuse, float tan_specular);
-/* config.trace_variant of the following traces (0 .. 4, see vct_config) */
+/* config.trace_variant of the following traces (0 .. 4, see vct_config).  No reference counterpart: the variants are
+ * measurement alternatives of the one cone trace of S/VoxelConeTracing.fs:82-107,165-228; 0 is the exact default. */
 int vct_set_trace_variant(vct_ctx* ctx, int32_t variant);
 
 /* Scene upload -- replaces Model/Mesh VBO setup (R/Mesh.h:49-82) for the two attributes the
@@ -225,7 +226,8 @@ int vct_trace_resident(vct_ctx* ctx);
  * vct_trace_resident calls repeat this slab. */
 int vct_trace_resident_rows(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1);
 /* every `stride`-th tile row of [tile_row0, tile_row1), starting with tile_row0 (the rows rank tile_row0 of `stride`
- * ranks traces under interleaved slabs, vct_comm_set_interleaved); the pixels land at their own place in the frame */
+ * ranks traces under interleaved slabs, vct_comm_set_interleaved); the pixels land at their own place in the frame.
+ * (No reference counterpart: the reference draws one full-screen quad on one GPU, R/main.cpp:77-94.) */
 int vct_trace_resident_strided(vct_ctx* ctx, int32_t tile_row0, int32_t tile_row1, int32_t stride);
 /* One whole GI pass for a light AND a camera that moved -- init_voxel_cone_tracing's DrawDepthTexture +
  * DrawVoxelTexture (VCT.h:138-139) followed by Render (VCT.h:146-190) -- issued as one call:
