@@ -1,6 +1,6 @@
 """ctypes binding of the CPU oracle (oracle/libvct_oracle.so).
 
-TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see oracle/vct_oracle.h).  Only tests/,
+TEST INFRASTRUCTURE ONLY -- pinned against the reference's own GLSL (oracle/vct_oracle.h, tests/test_ref_gl.py).  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
 import ctypes as C
@@ -255,9 +255,11 @@ def tex_level(texture, k):
     return chain[off:off + wk * hk].reshape(hk, wk, 4)
 
 
-def _texture_table(textures, keep, mipmaps=False):
+def _texture_table(textures, keep, mipmaps=False, chains=None):
     """textures: list of uint8 [h, w, 4] arrays -> (ctypes array of Texture, count).  mipmaps: attach the mip chain
-    (mip-mapped sampling with implicit derivatives, the reference's sampler state); else level-0 sampling."""
+    (mip-mapped sampling with implicit derivatives, the reference's sampler state); else level-0 sampling.
+    chains: optional list of ready-made chains (uint8 [texels, 4], level 0 first, the layout of tex_build_mips) used
+    instead of the oracle's own box filter -- tests feed the chain a GL driver generated (tests/test_ref_gl.py)."""
     if not textures:
         return None, 0
     arr = (Texture * len(textures))()
@@ -269,6 +271,9 @@ def _texture_table(textures, keep, mipmaps=False):
         arr[i].mips, arr[i].nlev = None, 1
         if mipmaps:
             chain, nlev = tex_build_mips(t)
+            if chains is not None:
+                assert chains[i].shape == chain.shape
+                chain = np.ascontiguousarray(chains[i], np.uint8)
             keep.append(chain)
             arr[i].mips, arr[i].nlev = _ptr(chain), nlev
     keep.append(arr)
@@ -298,7 +303,7 @@ def log2_det(x):
 
 
 def make_mesh(pos, material, albedo, specular=None, frames=None, uv=None, mat_tex=None, textures=None,
-              model_scale=0.05, mipmaps=False):
+              model_scale=0.05, mipmaps=False, tex_chains=None):
     """Input of the raster oracles (render_shadow_map / render_gbuffer).  frames = (normal, tangent, bitangent)."""
     m = Mesh()
     k = m._keep = []
@@ -317,7 +322,7 @@ def make_mesh(pos, material, albedo, specular=None, frames=None, uv=None, mat_te
         m.nrm, m.tan, m.bit = (arr(f, np.float32, (-1, 9)) for f in frames)
     m.uv = arr(uv, np.float32, (-1, 6)) if uv is not None else None
     m.mat_tex = arr(mat_tex, np.int32, (-1, 3)) if mat_tex is not None else None
-    tab, n = _texture_table(textures, k, mipmaps)
+    tab, n = _texture_table(textures, k, mipmaps, tex_chains)
     m.textures = C.cast(tab, C.c_void_p) if tab is not None else None
     m.ntex = n
     m.model_scale = model_scale
@@ -347,7 +352,7 @@ def render_gbuffer(mesh, view_proj_colmajor, w, h, shadow_depth=None, light_vp_c
 
 
 def make_scene(pos, material, albedo, model_scale=0.05, shadow_depth=None, light_vp=None, uv=None, mat_tex=None,
-               textures=None, mipmaps=False):
+               textures=None, mipmaps=False, tex_chains=None):
     """Keeps references to the numpy arrays alive on the returned struct."""
     s = Scene()
     s._keep = [np.ascontiguousarray(pos, np.float32).reshape(-1, 9),
@@ -373,7 +378,7 @@ def make_scene(pos, material, albedo, model_scale=0.05, shadow_depth=None, light
         b = np.ascontiguousarray(mat_tex, np.int32).reshape(-1, 3)
         s._keep += [a, b]
         s.uv, s.mat_tex = _ptr(a), _ptr(b)
-        tab, n = _texture_table(textures, s._keep, mipmaps)
+        tab, n = _texture_table(textures, s._keep, mipmaps, tex_chains)
         s.textures, s.ntex = C.cast(tab, C.c_void_p), n
     return s
 

@@ -5,12 +5,24 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
  * and only as the checker / the reported CPU baseline.
  *
- * PARITY UNPINNED: the reference (AlerianEmperor/Voxel-Cone-Tracing) holds no tests,
- * golden vectors or fixtures, and its implementation of this path is GLSL that
- * only runs inside an OpenGL 4.3 driver (it cannot be compiled or run here).
- * What pins this oracle instead: the known-answer tests derived from the shader
- * text (tests/test_oracle_kat.py) and an independent numpy
- * restatement (tests/np_restatement.py) of the same rules.
+ * PARITY PINNED against the reference's own shaders: the reference (AlerianEmperor/
+ * Voxel-Cone-Tracing) holds no tests, golden vectors or fixtures, and its C++ host needs
+ * GLFW/GLEW/glm/assimp (unbuildable here) -- but the hot path is its seven GLSL files, and
+ * those run in the build container: oracle/ref_gl.c (oracle/_ref/libvct_refgl.so) hands
+ * them, read unmodified from /root/reference at run time, to Mesa llvmpipe (OpenGL 4.5 core).
+ * tests/golden/make_ref_golden.py turns their outputs into the committed fixtures
+ * tests/golden/ref_*.npz; tests/test_ref_gl.py holds this oracle to them:
+ *   cone trace + composite   <= 1e-5 rel-L2 (measured 1.3e-7 .. 3.5e-7), identical discards
+ *   shadow map               identical coverage; depth equal up to GL choice (c) below
+ *   voxelization             identical occupancy; values equal under Mesa's choices, +-1 under ours
+ *   glGenerateMipmap 2-D/3-D equal except exact .5 ties, which Mesa rounds either way
+ *   Render on a textured scene  9.4e-7 rel-L2 under Mesa's choices, 1.2e-3 under ours
+ * "choices" = what GL leaves to the implementation and Mesa decides differently: (a) log2
+ * precision of the texture level of detail, (b) where in the 2x2 quad implicit derivatives
+ * are taken, (c) interpolation on snapped or unsnapped window positions, (d) tie rounding in
+ * glGenerateMipmap; vcto_set_gl_choices() switches the oracle to Mesa's so that each is
+ * shown to be the ONLY difference.  Besides: the known-answer tests derived from the shader
+ * text (tests/test_oracle_kat.py) and an independent numpy restatement (tests/np_restatement.py).
  *
  * Reference files restated (R = Voxel_Cone_Tracing_Final, S = R/Shader):
  *   S/VoxelConeTracing.fs:43-66   constants, SampleVoxels
@@ -166,6 +178,14 @@ int vcto_tex_num_levels(int width, int height);
 size_t vcto_tex_level_offset(int width, int height, int level);      /* in texels; level == nlev: the chain's size */
 void vcto_tex_build_mips(const uint8_t* rgba, int width, int height, uint8_t* chain);
 float vcto_log2_det(float x);                                        /* x > 0, normal */
+/* The two choices above that GL leaves to the implementation (log2 precision, where in the quad the derivatives are
+ * taken) plus whether varyings are interpolated on the snapped or the unsnapped window positions: 0 = as stated above
+ * (default; what the HIP path implements); bits select Mesa llvmpipe's choice instead -- 1: piecewise-linear log2,
+ * 2: one derivative pair per quad at its even/even pixel, 4: unsnapped interpolation positions (7 = all).  Used only
+ * to show that the default differs from the reference's GLSL as run by oracle/_ref in nothing else
+ * (tests/test_ref_gl.py).  Process-global; tests reset it to 0. */
+void vcto_set_gl_choices(int mode);
+int vcto_get_gl_choices(void);
 void vcto_tex_sample(const vcto_texture* t, float u, float v, float out[4]);
 /* ds_dx .. dt_dy: quad differences of the NORMALISED coordinates (s, t) as defined above */
 void vcto_tex_sample_lod(const vcto_texture* t, float u, float v, float ds_dx, float dt_dx, float ds_dy, float dt_dy,

@@ -59,14 +59,16 @@ void raster_triangle(const RVert in[3], int nvar, bool cull_back, int W, int H, 
     if (np < 3) return;
     for (int t = 1; t + 1 < np; ++t) {
         const RVert* v[3] = {&poly[0], &poly[t], &poly[t + 1]};
-        double sx[3], sy[3];
+        double sx[3], sy[3], ux[3], uy[3];
         float sz[3], iw[3];
         bool bad = false;
         for (int k = 0; k < 3; ++k) {
             if (!(v[k]->c[3] > 1e-20f)) { bad = true; break; }
             iw[k] = 1.0f / v[k]->c[3];
-            sx[k] = floor((double)((v[k]->c[0] * iw[k] * 0.5f + 0.5f) * (float)W) * 256.0 + 0.5) / 256.0;
-            sy[k] = floor((double)((v[k]->c[1] * iw[k] * 0.5f + 0.5f) * (float)H) * 256.0 + 0.5) / 256.0;
+            ux[k] = (double)((v[k]->c[0] * iw[k] * 0.5f + 0.5f) * (float)W);
+            uy[k] = (double)((v[k]->c[1] * iw[k] * 0.5f + 0.5f) * (float)H);
+            sx[k] = floor(ux[k] * 256.0 + 0.5) / 256.0;
+            sy[k] = floor(uy[k] * 256.0 + 0.5) / 256.0;
             sz[k] = v[k]->c[2] * iw[k] * 0.5f + 0.5f;
         }
         if (bad) continue;
@@ -75,6 +77,24 @@ void raster_triangle(const RVert in[3], int nvar, bool cull_back, int W, int H, 
         if (area < 0.0 && cull_back) continue;
         const double sgn = area > 0.0 ? 1.0 : -1.0;
         area *= sgn;
+        // Interpolation positions: the snapped ones coverage is decided on (mode 0), or -- vcto_set_gl_choices(1), what
+        // Mesa llvmpipe does -- the unsnapped window coordinates (its plane equations are set up in float from them).
+        const bool unsnapped = (vcto_get_gl_choices() & 4) != 0;
+        const double* ix = unsnapped ? ux : sx;
+        const double* iy = unsnapped ? uy : sy;
+        const double iarea = unsnapped ? ((ux[1] - ux[0]) * (uy[2] - uy[0]) - (ux[2] - ux[0]) * (uy[1] - uy[0])) * sgn : area;
+        if (!(iarea > 0.0)) continue;
+        // barycentrics of a pixel centre on the interpolation positions (identical to the coverage edge functions in mode 0)
+        auto bary = [&](double cx, double cy, float& b0, float& b1) {
+            double f[2];
+            for (int k = 0; k < 2; ++k) {
+                const int a = (k + 1) % 3, b = (k + 2) % 3;
+                const double dx = (ix[b] - ix[a]) * sgn, dy = (iy[b] - iy[a]) * sgn;
+                f[k] = dx * (cy - iy[a]) - dy * (cx - ix[a]);
+            }
+            b0 = (float)(f[0] / iarea);
+            b1 = (float)(f[1] / iarea);
+        };
         const int x0 = std::max(0, (int)floor(std::min({sx[0], sx[1], sx[2]})));
         const int x1 = std::min(W - 1, (int)floor(std::max({sx[0], sx[1], sx[2]})));
         const int y0 = std::max(0, (int)floor(std::min({sy[0], sy[1], sy[2]})));
@@ -92,7 +112,10 @@ void raster_triangle(const RVert in[3], int nvar, bool cull_back, int W, int H, 
                     if (e[k] < 0.0 || (e[k] == 0.0 && !top_left)) { inside = false; break; }
                 }
                 if (!inside) continue;
-                const float b0 = (float)(e[0] / area), b1 = (float)(e[1] / area), b2 = 1.0f - b0 - b1;
+                float b0, b1;
+                if (unsnapped) bary(cx, cy, b0, b1);
+                else { b0 = (float)(e[0] / area); b1 = (float)(e[1] / area); }
+                const float b2 = 1.0f - b0 - b1;
                 const float z = b0 * sz[0] + b1 * sz[1] + b2 * sz[2];
                 if (!(z >= 0.0f && z <= 1.0f)) continue;               // far-plane clip
                 float& zb = zbuf[(size_t)py * W + px];
@@ -105,24 +128,28 @@ void raster_triangle(const RVert in[3], int nvar, bool cull_back, int W, int H, 
                 float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (nvar == kMaxVar) {
                     auto uv_at = [&](int qx, int qy, float out[2]) {       // the same interpolation at another pixel centre
-                        const double nx = (double)qx + 0.5, ny = (double)qy + 0.5;
-                        double f[2];
-                        for (int k = 0; k < 2; ++k) {
-                            const int a = (k + 1) % 3, b = (k + 2) % 3;
-                            const double dx = (sx[b] - sx[a]) * sgn, dy = (sy[b] - sy[a]) * sgn;
-                            f[k] = dx * (ny - sy[a]) - dy * (nx - sx[a]);
-                        }
-                        const float c0 = (float)(f[0] / area), c1 = (float)(f[1] / area), c2 = 1.0f - c0 - c1;
+                        float c0, c1;
+                        bary((double)qx + 0.5, (double)qy + 0.5, c0, c1);
+                        const float c2 = 1.0f - c0 - c1;
                         const float r0 = c0 * iw[0], r1 = c1 * iw[1], r2 = c2 * iw[2];
                         const float rs = 1.0f / (r0 + r1 + r2);
                         for (int i = 0; i < 2; ++i)
                             out[i] = (r0 * v[0]->var[12 + i] + r1 * v[1]->var[12 + i] + r2 * v[2]->var[12 + i]) * rs;
                     };
                     float nx[2], ny[2];
-                    uv_at(px ^ 1, py, nx);
-                    uv_at(px, py ^ 1, ny);
-                    duv[0] = nx[0] - var[12]; duv[1] = nx[1] - var[13];
-                    duv[2] = ny[0] - var[12]; duv[3] = ny[1] - var[13];
+                    if (vcto_get_gl_choices() & 2) {                    // one pair per quad, at its (even, even) pixel
+                        float tl[2];
+                        uv_at(px & ~1, py & ~1, tl);
+                        uv_at(px | 1, py & ~1, nx);
+                        uv_at(px & ~1, py | 1, ny);
+                        duv[0] = nx[0] - tl[0]; duv[1] = nx[1] - tl[1];
+                        duv[2] = ny[0] - tl[0]; duv[3] = ny[1] - tl[1];
+                    } else {
+                        uv_at(px ^ 1, py, nx);
+                        uv_at(px, py ^ 1, ny);
+                        duv[0] = nx[0] - var[12]; duv[1] = nx[1] - var[13];
+                        duv[2] = ny[0] - var[12]; duv[3] = ny[1] - var[13];
+                    }
                 }
                 if (frag(px, py, z, var, duv)) zb = z;
             }
@@ -186,6 +213,27 @@ void vcto_tex_build_mips(const uint8_t* rgba, int width, int height, uint8_t* ch
     }
 }
 
+// ---- implementation-defined GL choices, switchable for the reference-GLSL cross-check (tests/test_ref_gl.py) -----
+// GL leaves (a) the precision of the level-of-detail lambda and (b) where inside the 2x2 quad the implicit
+// derivatives are taken to the implementation.  Mode 0 (the build's definition, what csrc/vct_raster.hip implements):
+// lambda from vcto_log2_det, per-pixel differences towards the quad neighbour.  Mode 1 = what Mesa llvmpipe does (the
+// GL implementation oracle/_ref runs the reference's shaders on): lambda = 0.5 * ((exponent - 1) + mantissa) of rho^2
+// (Mesa's lp_build_fast_log2: exact at powers of two, piecewise linear between); bit 1 (b) one derivative pair per quad taken
+// at its (even x, even y) pixel: d/dx = f(x | 1, y & ~1) - f(x & ~1, y & ~1), d/dy = f(x & ~1, y | 1) - f(x & ~1, y & ~1);
+// bit 2 (c) varyings and depth interpolated on the UNSNAPPED window positions (coverage stays on the 1/256 grid).
+static int g_gl_choices = 0;
+void vcto_set_gl_choices(int mode) { g_gl_choices = mode; }
+int vcto_get_gl_choices(void) { return g_gl_choices; }
+static float fast_log2_mesa(float x) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    const int e = (int)((b >> 23) & 0xffu) - 127 - 1;
+    const uint32_t mb = (b & 0x7fffffu) | 0x3f800000u;
+    float m;
+    memcpy(&m, &mb, 4);
+    return (float)e + m;
+}
+
 // log2 without a math library (the GPU runs the same sequence, csrc/vct_internal.h vct_log2_det): exponent +
 // 2/ln2 * atanh((f - 1) / (f + 1)) of the mantissa f, centred on [sqrt(1/2), sqrt(2)); series to s^9
 float vcto_log2_det(float x) {
@@ -241,7 +289,7 @@ void vcto_tex_sample_lod(const vcto_texture* t, float u, float v, float ds_dx, f
         tex_bilinear(t->mips + 4 * vcto_tex_level_offset(W, H, k), std::max(1, W >> k), std::max(1, H >> k), u, v, o);
     };
     if (!(m > 1.0f)) { level(0, out); return; }                // magnification (and NaN)
-    const float lam = 0.5f * vcto_log2_det(m);
+    const float lam = (g_gl_choices & 1) ? fast_log2_mesa(m) * 0.5f : 0.5f * vcto_log2_det(m);
     const int q = t->nlev - 1;
     if (lam >= (float)q) { level(q, out); return; }
     const int d = (int)lam;

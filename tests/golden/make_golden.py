@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
 """Generates the committed golden vectors under tests/golden/.
 
-The reference (AlerianEmperor/Voxel-Cone-Tracing) holds no tests, fixtures or golden images, and
-its implementation of this path is GLSL that cannot run here: these vectors are
-therefore produced by the build's own scalar oracle (oracle/vct_oracle.cpp) on seeded inputs.  They
-pin (1) the oracle against regressions / compiler drift and (2) the HIP path against fixed expected
-outputs without the oracle library being present at run time.
+These vectors are produced by the build's own scalar oracle (oracle/vct_oracle.cpp) on seeded inputs.  They pin
+(1) the oracle against regressions / compiler drift and (2) the HIP path against fixed expected outputs without the
+oracle library being present at run time.  The vectors produced by the REFERENCE'S OWN shaders (which pin the oracle
+itself) are the ref_*.npz files made by make_ref_golden.py next to this script.
 
     python tests/golden/make_golden.py        # rewrites the .npz files
 """

@@ -136,6 +136,14 @@ def test_interleaved_rows_data_path_for_emulated_ranks(vct):
     ctx.frame_step()
     ctx.comm_sync()
     assert np.array_equal(ctx.comm_download_frame(), want)
+    # contiguous boundaries after interleaved mode: the last call wins (interleaved off), the frame stays right
+    for starts in (None, [0, ty]):
+        ctx.comm_set_interleaved(True)
+        ctx.comm_set_slab_rows(starts)
+        assert ctx.comm_slab() == (0, ty)
+        ctx.frame_step()
+        ctx.comm_sync()
+        assert np.array_equal(ctx.comm_download_frame(), want)
     ctx.comm_destroy()
     ctx.close()
 

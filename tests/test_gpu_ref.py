@@ -1,0 +1,139 @@
+"""The HIP path against the REFERENCE'S OWN GLSL (tests/golden/ref_*.npz), through the C ABI, no oracle involved.
+
+The ref_* arrays were produced in the build container by the reference's unmodified shaders on Mesa llvmpipe
+(oracle/ref_gl.c, tests/golden/make_ref_golden.py); the fixtures travel to the GPU box as data.  Bars:
+  * cone trace + composite: BASELINE.json north_star's 1e-3 relative L2 (the frame is RGBA16F), identical discards;
+  * shadow map / voxelization / G-buffer + trace of the small textured scene: the bounds tests/test_ref_gl.py
+    establishes for the oracle's own GL choices (the HIP kernels implement exactly those), each stage fed the
+    reference's output of the stage before it.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import synth
+import vctpkg
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRACE = ["ref_trace_v32_random", "ref_trace_v64_coherent", "ref_trace_v256_random", "ref_trace_v32_clamp"]
+CLEAR = np.array([0.5, 0.5, 0.5, 1.0], np.float32)
+REL_L2_TOL = 1e-3
+
+
+def load(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def vct():
+    import torch
+    assert torch.cuda.is_available()
+    return vctpkg.load()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("name", TRACE)
+def test_hip_trace_matches_reference_glsl(vct, name, variant):
+    f = load(name)
+    V, W, H = int(f["V"]), int(f["W"]), int(f["H"])
+    if "level0" in f:
+        l0 = f["level0"]
+    else:
+        a = f["level0_args"]
+        l0 = synth.noise_volume(int(a[0]), seed=int(a[1]), occupancy=float(a[2]))
+        assert np.uint32(zlib.crc32(l0.tobytes())) == f["level0_crc32"]
+    with vct.Context(vct.default_config(voxel_dim=V, width=W, height=H, wrap_repeat=int(not f["clamp"]),
+                                        trace_variant=variant)) as ctx:
+        ctx.set_camera_position(tuple(float(x) for x in f["camera_pos"]))
+        ctx.set_light_direction(tuple(float(x) for x in f["light_dir"]))
+        ctx.upload_volume(l0)
+        ctx.build_mips()
+        out = vct.half_to_float(ctx.trace(f["planes"]).reshape(-1, 4))
+    ref = f["ref_rgba"]
+    disc = f["planes"][18] < 0.5
+    assert disc.sum() > 0 and np.all(out[disc] == CLEAR) and np.all(ref[disc] == CLEAR)
+    rel = synth.rel_l2(out[~disc], ref[~disc])
+    print(f"{name} variant {variant}: HIP vs reference GLSL rel-L2 {rel:.2e}")
+    assert rel <= REL_L2_TOL, rel
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    f = load("ref_pipeline_v32")
+    f["textures"] = [f[f"texture_{i}"] for i in range(9)]
+    return f
+
+
+def make_ctx(vct, f):
+    ctx = vct.Context(vct.default_config(voxel_dim=int(f["V"]), width=int(f["W"]), height=int(f["H"]),
+                                         shadow_map_size=int(f["S"])))
+    ctx.upload_triangles(f["pos"], f["material"], f["albedo"])
+    ctx.upload_mesh_attributes(f["nrm"], f["tan"], f["bit"], f["specular"])
+    ctx.upload_mesh_uvs(f["uv"])
+    ctx.upload_textures(f["textures"], f["mat_tex"])
+    ctx.set_camera_position(tuple(float(x) for x in f["eye"]))
+    ctx.set_light_direction(tuple(float(x) for x in f["light_dir"]))
+    return ctx
+
+
+def test_hip_shadow_map_matches_reference_glsl(vct, pipe):
+    """S/Shadow.vs/.fs as DrawDepthTexture runs them: the same texels covered; depth within the snapped-versus-
+    unsnapped interpolation bound (tests/test_ref_gl.py, choice c)."""
+    with make_ctx(vct, pipe) as ctx:
+        ctx.render_shadow_map(pipe["depth_vp"])
+        got = ctx.download_shadow_map()
+    ref = pipe["ref_shadow"]
+    assert np.array_equal(got < 1.0, ref < 1.0)
+    cov = ref < 1.0
+    d = np.abs(np.rint((got.astype(np.float64) - ref) * 16777215.0))[cov]
+    print(f"HIP shadow map vs reference GLSL: |diff| in 24-bit LSB median {np.median(d):.0f} "
+          f"p99 {np.percentile(d, 99):.0f} max {d.max():.0f}")
+    assert np.median(d) <= 64 and np.percentile(d, 99) <= 1024 and d.max() <= 4096
+
+
+def test_hip_voxelization_matches_reference_glsl(vct, pipe):
+    """S/Voxelization.vs/.gs/.fs as DrawVoxelTexture runs them (VCT_VOX_REFERENCE), on the reference's shadow map:
+    the same voxels written, values within one unorm8 step; then glGenerateMipmap's chain within one step."""
+    V = int(pipe["V"])
+    with make_ctx(vct, pipe) as ctx:
+        ctx.upload_shadow_map(pipe["ref_shadow"], pipe["depth_vp"].reshape(4, 4).T)
+        ctx.voxelize(vct.VOX_REFERENCE)
+        ctx.inject_light()
+        ctx.build_mips()
+        chain = ctx.download_chain()
+    ref = pipe["ref_chain"]
+    got0, ref0 = chain[: V ** 3], ref[: V ** 3]
+    assert np.array_equal(got0[:, 3], ref0[:, 3])
+    occ = ref0[:, 3] > 0
+    d = np.abs(got0[occ].astype(int) - ref0[occ].astype(int)).max(1)
+    print(f"HIP voxelization vs reference GLSL: {(d > 0).sum()} of {occ.sum()} voxels differ, max {d.max()}")
+    assert occ.sum() > 1500 and d.max() <= 1 and (d > 0).mean() <= 0.4
+    dm = np.abs(chain[V ** 3:].astype(int) - ref[V ** 3:].astype(int))
+    assert dm.max() <= 2
+
+
+def test_hip_render_matches_reference_glsl(vct, pipe):
+    """Render (VCT.h:146-190) on the reference's shadow map and the reference's voxel chain: the same pixels shaded,
+    the frame within the bound of the GL implementation choices (texture LOD precision, derivative position,
+    interpolation position; tests/test_ref_gl.py)."""
+    W, H = int(pipe["W"]), int(pipe["H"])
+    view_proj = (pipe["proj"].reshape(4, 4).T @ pipe["view"].reshape(4, 4).T).T.astype(np.float32).reshape(16)
+    with make_ctx(vct, pipe) as ctx:
+        ctx.upload_shadow_map(pipe["ref_shadow"], pipe["depth_vp"].reshape(4, 4).T)
+        ctx.upload_chain(pipe["ref_chain"])
+        ctx.render_gbuffer(view_proj)
+        planes = ctx.download_gbuffer()
+        out = vct.half_to_float(ctx.trace_current().reshape(-1, 4))
+    ref = pipe["ref_frame"].reshape(-1, 4)
+    cov_ref = ~np.all(ref == CLEAR, axis=1)
+    assert np.array_equal(planes[18] >= 0.5, cov_ref)
+    err = np.abs(out - ref).max(1)
+    rel = synth.rel_l2(out, ref)
+    print(f"HIP frame vs reference GLSL: rel-L2 {rel:.2e}, median abs {np.median(err):.2e}, "
+          f"pixels > 1e-3: {(err > 1e-3).sum()} of {err.size}, max {err.max():.2e}")
+    assert rel <= 5e-3 and np.median(err) <= 6e-4 and (err > 2e-2).mean() <= 0.005

@@ -1,0 +1,231 @@
+"""The oracle against the REFERENCE'S OWN GLSL (tests/golden/ref_*.npz).
+
+The ref_* arrays of those fixtures were produced by the reference's seven shader files, unmodified, executed by Mesa
+llvmpipe in the build container (oracle/ref_gl.c, tests/golden/make_ref_golden.py).  These tests pin the oracle to them:
+
+  * cone trace + composite (S/VoxelConeTracing.vs/.fs): <= 1e-5 rel-L2 on fp32 outputs, identical discards, on random
+    and screen-coherent G-buffers, V = 32 / 64 / 256, GL_REPEAT and CLAMP_TO_EDGE, with the PCF running as written;
+  * the whole pipeline on a small textured scene -- S/Shadow.*, S/Voxelization.vs/.gs/.fs + glGenerateMipmap, Render --
+    stage by stage, each stage's oracle fed the previous stage's GL output so that one deviation cannot hide another.
+
+Where GL leaves a choice to the implementation and Mesa chose differently from the oracle, the deviation is ENUMERATED:
+the oracle is switched to Mesa's choice (vcto_set_gl_choices(7), oracle-only) and must then agree to float rounding;
+in its own definition it must stay within the stated bound.  The choices: (a) log2 precision of the texture level of
+detail, (b) where in the 2x2 quad implicit derivatives are taken, (c) varyings interpolated on snapped or unsnapped
+window positions, (d) rounding of exact .5 ties in glGenerateMipmap (2-D and 3-D).
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRACE = ["ref_trace_v32_random", "ref_trace_v64_coherent", "ref_trace_v256_random", "ref_trace_v32_clamp"]
+CLEAR = np.array([0.5, 0.5, 0.5, 1.0], np.float32)       # VCT.h:156-157 (ambient 0.1 < 0.5)
+
+
+def load(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def level0_of(f):
+    if "level0" in f:
+        return f["level0"]
+    V, seed, occ = f["level0_args"]
+    l0 = synth.noise_volume(int(V), seed=int(seed), occupancy=float(occ))
+    assert np.uint32(zlib.crc32(l0.tobytes())) == f["level0_crc32"], "seeded volume generator drifted"
+    return l0
+
+
+@pytest.fixture
+def gl_choices(oracle):
+    """Switches the oracle to Mesa's implementation choices for one test; always restores the default."""
+    L = oracle.lib()
+    yield L.vcto_set_gl_choices
+    L.vcto_set_gl_choices(0)
+
+
+# ---------------------------------------------------------------------------------------------- cone trace ----------
+@pytest.mark.parametrize("name", TRACE)
+def test_oracle_matches_reference_glsl_trace(oracle, name):
+    f = load(name)
+    V = int(f["V"])
+    assert b"llvmpipe" in str(f["gl"][1]).encode() and str(f["gl"][2]).startswith("4.")
+    chain = oracle.build_mips(level0_of(f))
+    planes = f["planes"]
+    # plane 22 was filled at generation time from the stored shadow map: re-derive it (trace.vs:28-29, trace.fs:132-163)
+    M = f["depth_vp"].reshape(4, 4).T
+    clip = planes[0:3].T @ M[:3, :3].T.astype(np.float32) + M[:3, 3]
+    coord = (clip * np.float32(0.5) + np.float32(0.5)).astype(np.float32)
+    shadow = np.array([oracle.pcf25(f["shadow_map"], c) * np.float32(0.111) for c in coord], np.float32)
+    assert np.array_equal(shadow, planes[22])
+    assert 0.0 < (shadow < 2.7).mean() < 1.0           # both lit and (partly) occluded pixels
+    p = oracle.default_params(V, camera_pos=f["camera_pos"], light_dir=f["light_dir"], wrap_repeat=int(not f["clamp"]))
+    got = oracle.trace(p, chain, planes)["rgba32f"]
+    ref = f["ref_rgba"]
+    disc = planes[18] < 0.5
+    assert disc.sum() > 0 and np.all(ref[disc] == CLEAR) and np.all(got[disc] == CLEAR)     # identical discards
+    assert not np.any(np.all(ref[~disc] == CLEAR, axis=1))
+    rel = synth.rel_l2(got[~disc], ref[~disc])
+    worst = np.abs(got[~disc] - ref[~disc]).max()
+    print(f"{name}: oracle vs reference GLSL rel-L2 {rel:.2e}, max abs {worst:.2e}")
+    assert rel <= 1e-5 and worst <= 2e-4
+    # what a GL implementation with 8-bit filter weights (llvmpipe's default) returns for the same draw: the size of
+    # the implementation-precision variance the north star's 1e-3 bar has to sit above
+    rel_default = synth.rel_l2(f["ref_rgba_default_precision"][~disc], ref[~disc])
+    print(f"{name}: llvmpipe default filter precision vs float filter precision rel-L2 {rel_default:.2e}")
+    assert 1e-5 < rel_default < 2e-2
+
+
+# ---------------------------------------------------------------------------------- glGenerateMipmap, 3-D ----------
+@pytest.mark.parametrize("V", [32, 64])
+def test_volume_mip_chain_vs_glGenerateMipmap(oracle, V):
+    """VCT.h:248.  GL does not define the filter; Mesa's is the 2x2x2 box and differs from (sum + 4) >> 3 only in
+    how an exact .5 tie (sum mod 8 == 4) rounds, always by one."""
+    f = load("ref_mips3d")
+    _, seed, occ = f[f"args_v{V}"]
+    l0 = synth.noise_volume(V, seed=int(seed), occupancy=float(occ))
+    ref = f[f"ref_chain_v{V}"]
+    assert np.array_equal(ref[: V ** 3], l0.reshape(-1, 4))
+    ties = diffs = 0
+    for k in range(1, oracle.num_levels(V)):
+        N = V >> k
+        o0, o1 = oracle.level_offset(V, k - 1), oracle.level_offset(V, k)
+        parent = ref[o0:o0 + (2 * N) ** 3].reshape(2 * N, 2 * N, 2 * N, 4)
+        # the oracle's rule applied to GL's own parent level (so one level's deviation does not cascade)
+        mine = oracle.build_mips(parent)[(2 * N) ** 3:(2 * N) ** 3 + N ** 3].reshape(N, N, N, 4).astype(int)
+        got = ref[o1:o1 + N ** 3].reshape(N, N, N, 4).astype(int)
+        s = sum(parent[a::2, b::2, c::2].astype(int) for a in (0, 1) for b in (0, 1) for c in (0, 1))
+        d = got != mine
+        assert np.all((s % 8 == 4)[d]) and np.all(np.abs(got - mine)[d] == 1)
+        ties += int((s % 8 == 4).sum())
+        diffs += int(d.sum())
+    print(f"V={V}: {diffs} texels differ, all among the {ties} exact ties, all by 1")
+    assert ties > 0
+
+
+# --------------------------------------------------------------------------------------------- the pipeline ---------
+@pytest.fixture(scope="module")
+def pipe():
+    f = load("ref_pipeline_v32")
+    f["textures"] = [f[f"texture_{i}"] for i in range(9)]
+    f["tex_chains"] = [f[f"ref_tex_chain_{i}"] for i in range(9)]
+    return f
+
+
+def oracle_mesh(oracle, f, gl_chains):
+    return oracle.make_mesh(f["pos"], f["material"], f["albedo"], f["specular"], (f["nrm"], f["tan"], f["bit"]),
+                            f["uv"], f["mat_tex"], f["textures"], 0.05, mipmaps=True,
+                            tex_chains=f["tex_chains"] if gl_chains else None)
+
+
+def oracle_scene(oracle, f, shadow, gl_chains):
+    return oracle.make_scene(f["pos"], f["material"], f["albedo"], shadow_depth=shadow,
+                             light_vp=f["depth_vp"].reshape(4, 4).T, uv=f["uv"], mat_tex=f["mat_tex"],
+                             textures=f["textures"], mipmaps=True, tex_chains=f["tex_chains"] if gl_chains else None)
+
+
+def test_texture_mip_chain_vs_glGenerateMipmap(oracle, pipe):
+    """Model.h:169.  Same finding in 2-D: only exact ties (sum mod 4 == 2) differ, by one."""
+    total = 0
+    for t, ch in zip(pipe["textures"], pipe["tex_chains"]):
+        h, w = t.shape[:2]
+        nlev = oracle.lib().vcto_tex_num_levels(w, h)
+        assert np.array_equal(ch[: h * w], t.reshape(-1, 4))
+        off = h * w
+        parent = t
+        for k in range(1, nlev):
+            hk, wk = max(1, h >> k), max(1, w >> k)
+            got = ch[off:off + hk * wk].reshape(hk, wk, 4)
+            mine = oracle.tex_level(parent, 1).astype(int)
+            s = sum(parent[a::2, b::2].astype(int) for a in (0, 1) for b in (0, 1))
+            d = got.astype(int) != mine
+            assert np.all((s % 4 == 2)[d]) and np.all(np.abs(got.astype(int) - mine)[d] == 1)
+            total += int(d.sum())
+            off += hk * wk
+            parent = got
+    print(f"2-D chains: {total} texels differ, all exact ties, all by 1")
+
+
+def test_shadow_map_vs_reference_glsl(oracle, pipe, gl_choices):
+    """S/Shadow.vs/.fs through DrawDepthTexture (VCT.h:192-211): the same pixels covered; depth equal up to where the
+    plane is evaluated (choice c)."""
+    S = int(pipe["S"])
+    ref = pipe["ref_shadow"]
+    q = 16777215.0
+    for mode, p50, p99, worst in ((0, 64, 1024, 4096), (7, 2, 8, 64)):
+        gl_choices(mode)
+        got = oracle.render_shadow_map(oracle_mesh(oracle, pipe, True), pipe["depth_vp"], S)
+        assert np.array_equal(got < 1.0, ref < 1.0)
+        cov = ref < 1.0
+        assert 0.2 < cov.mean() < 0.9
+        d = np.abs(np.rint((got.astype(np.float64) - ref) * q))[cov]
+        print(f"shadow map, gl_choices {mode}: |diff| in 24-bit LSB median {np.median(d):.0f} "
+              f"p99 {np.percentile(d, 99):.0f} max {d.max():.0f}")
+        assert np.median(d) <= p50 and np.percentile(d, 99) <= p99 and d.max() <= worst
+
+
+def test_voxelization_vs_reference_glsl(oracle, pipe, gl_choices):
+    """S/Voxelization.vs/.gs/.fs through DrawVoxelTexture (VCT.h:213-245), the oracle fed GL's shadow map: the same
+    voxels written; values equal under Mesa's choices, within one unorm8 step under the oracle's own."""
+    V = int(pipe["V"])
+    ref = pipe["ref_chain"][: V ** 3].reshape(V, V, V, 4)
+    p = oracle.default_params(V)
+    for mode, gl_chains, max_frac in ((7, True, 0.005), (0, True, 0.2), (0, False, 0.4)):
+        gl_choices(mode)
+        got = oracle.voxelize_reference(p, oracle_scene(oracle, pipe, pipe["ref_shadow"], gl_chains))
+        assert np.array_equal(got[..., 3], ref[..., 3])                  # occupancy, bit for bit
+        occ = ref[..., 3] > 0
+        assert occ.sum() > 1500
+        d = np.abs(got[occ].astype(int) - ref[occ].astype(int)).max(1)
+        print(f"voxelize, gl_choices {mode}, {'GL' if gl_chains else 'oracle'} 2-D mip chains: "
+              f"{(d > 0).sum()} of {occ.sum()} voxels differ, max {d.max()}")
+        assert d.max() <= 1 and (d > 0).mean() <= max_frac
+    assert (ref[occ][:, :3].max(1) == 0).sum() > 20 and (ref[occ][:, :3].max(1) > 100).sum() > 20    # shadowed + lit
+
+
+def test_render_vs_reference_glsl(oracle, pipe, gl_choices):
+    """S/VoxelConeTracing.vs/.fs through Render (VCT.h:146-190) on GL's shadow map and GL's voxel chain."""
+    V, W, H = int(pipe["V"]), int(pipe["W"]), int(pipe["H"])
+    ref = pipe["ref_frame"].reshape(-1, 4)
+    view_proj = (pipe["proj"].reshape(4, 4).T @ pipe["view"].reshape(4, 4).T).T.astype(np.float32).reshape(16)
+    p = oracle.default_params(V, camera_pos=pipe["eye"], light_dir=pipe["light_dir"])
+    cov_ref = ~np.all(ref == CLEAR, axis=1)
+    assert cov_ref.mean() > 0.9
+    for mode, gl_chains in ((7, True), (6, True), (5, True), (3, True), (0, True), (0, False)):
+        gl_choices(mode)
+        planes = oracle.render_gbuffer(oracle_mesh(oracle, pipe, gl_chains), view_proj, W, H, pipe["ref_shadow"],
+                                       pipe["depth_vp"])
+        got = oracle.trace(p, pipe["ref_chain"], planes)["rgba32f"]
+        assert np.array_equal(planes[18] >= 0.5, cov_ref)                # the same pixels shaded / discarded / empty
+        err = np.abs(got - ref).max(1)
+        rel = synth.rel_l2(got, ref)
+        print(f"render, gl_choices {mode}, {'GL' if gl_chains else 'oracle'} 2-D mip chains: rel-L2 {rel:.2e}, "
+              f"max abs {err.max():.2e}, pixels > 1e-3: {(err > 1e-3).sum()} of {err.size}")
+        if mode == 7:
+            assert rel <= 1e-5 and err.max() <= 2e-4
+        else:
+            # the oracle's own choices: texture LOD / derivative / interpolation-position differences move texel
+            # blends by ~1e-3 and flip single PCF taps on shadow edges (0.111 * albedo each)
+            assert rel <= 5e-3 and np.median(err) <= 5e-4 and (err > 2e-2).mean() <= 0.005
+    # the alpha cut-out sheet is in view: some of its fragments are discarded (trace.fs:171), seen through to the wall
+    assert (planes[18] >= 0.5).mean() > 0.9
+
+
+# ------------------------------------------------------------------- provenance: regenerate where the reference is ---
+def test_fixtures_regenerate_from_reference_shaders():
+    """In the build container (reference tree + Mesa present) the committed fixtures are re-made from the reference's
+    shader files and must come out bit-identical; elsewhere (the GPU box has no /root/reference) this is skipped."""
+    from oracle import pyrefgl
+    if not pyrefgl.available():
+        pytest.skip("reference shaders / Mesa software driver not present (build container only)")
+    import subprocess
+    import sys
+    gen = os.path.join(GOLDEN, "make_ref_golden.py")
+    r = subprocess.run([sys.executable, gen, "--check", "ref_trace_v32_random", "ref_pipeline_v32", "ref_mips3d"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -287,7 +287,8 @@ int vct_comm_set_timeout_ms(vct_ctx* c, int32_t ms) {
 
 // Collective (every rank passes the same boundaries): slab r = tile rows [starts[r], starts[r+1]).  starts == NULL
 // returns to the equal partition.  Frames in flight are drained first; a rank whose new slab outgrows its gather
-// buffers gets larger ones.
+// buffers gets larger ones.  Contiguous slabs and interleaved tile rows are alternatives: this call switches the
+// interleaved assignment off (the last of vct_comm_set_slab_rows / vct_comm_set_interleaved wins).
 int vct_comm_set_slab_rows(vct_ctx* c, const int32_t* starts) {
     if (!c) return VCT_ERR_INVALID;
     vct_comm* m = c->comm;
@@ -301,6 +302,7 @@ int vct_comm_set_slab_rows(vct_ctx* c, const int32_t* starts) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vct_comm_sync(c);
     if (rc) return rc;
+    m->interleaved = false;
     if (!starts) {
         m->starts.clear();
         vct_slab_partition(c->cfg.height, m->world, m->rank, &m->row0, &m->row1, nullptr);
@@ -335,6 +337,14 @@ int vct_comm_set_interleaved(vct_ctx* c, int32_t on) {
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = vct_comm_sync(c);
     if (rc) return rc;
+    // the root's de-interleave target first: a failed allocation leaves this rank's state untouched.  (The other
+    // ranks cannot see the root's failure: on VCT_ERR_NOMEM the caller must destroy the communicator on every rank.)
+    if (on && m->rank == 0)
+        for (int k = 0; k < 2; ++k)
+            if (!m->il_frame[k]) {
+                const hipError_t e = hipMalloc(&m->il_frame[k], (size_t)c->cfg.width * c->cfg.height * 8);
+                if (e != hipSuccess) return vct_fail(c, VCT_ERR_NOMEM, std::string("vct_comm_set_interleaved: ") + hipGetErrorString(e));
+            }
     m->starts.clear();
     vct_slab_partition(c->cfg.height, m->world, m->rank, &m->row0, &m->row1, nullptr);
     m->interleaved = on != 0;
@@ -342,12 +352,6 @@ int vct_comm_set_interleaved(vct_ctx* c, int32_t on) {
         const int ty = vct_tiles_y(c);
         m->row0 = m->rank < ty ? m->rank : ty;
         m->row1 = ty;
-        if (m->rank == 0)
-            for (int k = 0; k < 2; ++k)
-                if (!m->il_frame[k]) {
-                    const hipError_t e = hipMalloc(&m->il_frame[k], (size_t)c->cfg.width * c->cfg.height * 8);
-                    if (e != hipSuccess) { m->interleaved = false; return vct_fail(c, VCT_ERR_NOMEM, std::string("vct_comm_set_interleaved: ") + hipGetErrorString(e)); }
-                }
     }
     m->last = -1;
     return VCT_OK;
