@@ -183,7 +183,7 @@ def test_config3_512_4k_two_bounces(vct, oracle):
     pl.close()
 
 
-def test_config5_1024_4k_three_apertures(vct, oracle):
+def test_config5_1024_4k_three_apertures(vct, oracle, record_property):
     """configs[4]: the Bistro-exterior-class street (2.8 M triangles, 43 % alpha-tested foliage cards, every surface
     textured and mip-mapped), 1024^3 (4.57 GiB chain), 3840x2160, specular tan 0.07 / 0.105 / 0.2."""
     V, w, h = 1024, 3840, 2160
@@ -209,7 +209,12 @@ def test_config5_1024_4k_three_apertures(vct, oracle):
     # the 1024^3 chain, bit for bit against the oracle (host memory permitting: ~14 GiB of arrays)
     ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
     chain = ctx.download_chain()
-    if mem_available_gib() > 24.0:
+    whole = mem_available_gib() > 24.0
+    # which branch ran is part of the result: shown with -s / -rA, and kept in the junit properties
+    print(f"config5 chain check: {'WHOLE 1024^3 chain vs oracle' if whole else 'FOUR Z-SLABS of level 0 vs oracle + box-filter check of every level'} "
+          f"({mem_available_gib():.1f} GiB host memory available)")
+    record_property("config5_chain_check", "whole_chain" if whole else "z_slabs")
+    if whole:
         l0 = oracle.voxelize_conservative(pl.params, pl.oracle_scene())
         assert int((l0[..., 3] > 0).sum()) > 2_000_000
         want = oracle.build_mips(l0)

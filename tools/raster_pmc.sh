@@ -1,5 +1,5 @@
 #!/bin/bash
-# ON THE GPU BOX: SQ counters of the binned raster kernels, two PMC passes.  Usage: tools/r04_raster_pmc.sh <tag> <scene> <w> <h>
+# ON THE GPU BOX: SQ counters of the binned raster kernels, two PMC passes.  Usage: tools/raster_pmc.sh <tag> <scene> <w> <h>
 export VCT_RASTER_PATH=${RPATH:-binned}
 TAG=${1:-p}; SCENE=${2:-atrium}; W=${3:-1920}; H=${4:-1080}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

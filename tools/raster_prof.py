@@ -1,5 +1,5 @@
 """ON THE GPU BOX: the two raster input stages alone (shadow map, G-buffer), N passes -- meant to run under
-`rocprofv3 --kernel-trace --stats` (tools/r04_raster_prof.sh).  Usage: raster_prof.py atrium|bistro W H [passes]"""
+`rocprofv3 --kernel-trace --stats` (tools/raster_prof.sh).  Usage: raster_prof.py atrium|bistro W H [passes]"""
 import os
 import sys
 

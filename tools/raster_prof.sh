@@ -1,5 +1,5 @@
 #!/bin/bash
-# ON THE GPU BOX: per-kernel times of the raster stages.  Usage: tools/r04_raster_prof.sh <tag> [direct]
+# ON THE GPU BOX: per-kernel times of the raster stages.  Usage: tools/raster_prof.sh <tag> [direct]
 TAG=${1:-a}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 [ "$2" = direct ] && export VCT_RASTER_PATH=direct

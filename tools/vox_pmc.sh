@@ -1,6 +1,6 @@
 #!/bin/bash
 # ON THE GPU BOX: SQ counters of k_voxelize_bricks (tools/vox_bench.py: texture_mipmaps 1 / 0 x shadow on / off, 8 launches each).
-# Usage: tools/r04_vox_pmc.sh <tag> [bench.py scene flags]
+# Usage: tools/vox_pmc.sh <tag> [bench.py scene flags]
 TAG=${1:-v}; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/voxpmc_$TAG

@@ -192,13 +192,20 @@ struct Voxel_Cone_Tracing {
     // moves the direct term, VCT.h:168).  With DynamicLight every Render() is one whole GI pass for the current
     // lightDirection (vct_gi_pass: shadow map, voxelize + inject + mips beside the G-buffer raster, trace).
     bool DynamicLight = false;
+    // The reference's own voxelization semantics (S/Voxelization.vs/.gs/.fs as written: dominant-axis raster at pixel
+    // centres, last writer wins, VCT.h:213-250) instead of the north-star default (conservative + averaged); set
+    // before init or before calling DrawVoxelTexture() again.
+    bool ReferenceVoxelization = false;
     int Bounces = 1;    // 2 = re-inject the lit voxels once (the "2 bounces" of the reference's README.md:16,
                         // which its code does not implement: VCT.h:138-139 injects once); set before init
 
     // what replaces the GL object names (Depth_FBO, Depth_Texture, VoxelTexture)
     vct_ctx* ctx = nullptr;
     int last_status = VCT_OK;
-    std::vector<uint16_t> FrameRGBA16F;      // screen_width * screen_height * 4 halves
+    // Like the reference's Render() (VCT.h:146-190: draw into framebuffer 0, never read back) a frame stays in HBM;
+    // Frame() copies it to the host when -- and only when -- somebody asks for it.
+    mutable std::vector<uint16_t> FrameRGBA16F;      // screen_width * screen_height * 4 halves
+    mutable bool frame_on_host = false;
 
     Voxel_Cone_Tracing() {}
     Voxel_Cone_Tracing(int screen_width_, int screen_height_, GLFWwindow*& window_)
@@ -283,24 +290,27 @@ struct Voxel_Cone_Tracing {
         if (vct_comm_slab(ctx, &row0, &row1) == VCT_OK) {       // multi-GPU: this rank's slab, one gather
             if (!check(vct_render_gbuffer_rows(ctx, vp, row0, row1), "vct_render_gbuffer_rows")) return;
             if (!check(vct_frame_step(ctx), "vct_frame_step")) return;
-            if (Rank == 0) {
-                FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
-                check(vct_comm_download_frame(ctx, FrameRGBA16F.data()), "vct_comm_download_frame");
-            } else {
-                check(vct_comm_sync(ctx), "vct_comm_sync");
-            }
+            frame_on_host = false;
             return;
         }
         if (DynamicLight && Bounces < 2) {
             vcth_light_view_proj(L, DepthViewProjectionMatrix.m);                          // VCT.h:84-86, per frame
-            if (!check(vct_gi_pass(ctx, DepthViewProjectionMatrix.m, vp, VCT_VOX_CONSERVATIVE_AVG), "vct_gi_pass")) return;
-            FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
-            check(vct_download_frame(ctx, FrameRGBA16F.data()), "vct_download_frame");
+            const int32_t mode = ReferenceVoxelization ? VCT_VOX_REFERENCE : VCT_VOX_CONSERVATIVE_AVG;
+            if (!check(vct_gi_pass(ctx, DepthViewProjectionMatrix.m, vp, mode), "vct_gi_pass")) return;
+            frame_on_host = false;
             return;
         }
         if (!check(vct_render_gbuffer(ctx, vp), "vct_render_gbuffer")) return;
-        FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
-        check(vct_trace_current(ctx, FrameRGBA16F.data(), VCT_MEM_HOST), "vct_trace_current");
+        if (!check(vct_trace_resident_rows(ctx, 0, (screen_height + 7) / 8), "vct_trace_resident_rows")) return;
+        frame_on_host = false;
+    }
+
+    // Block until the GPU has finished the frames issued so far (glFinish in GL terms); no copy.
+    void Finish() {
+        if (!ctx) return;
+        int32_t row0 = 0, row1 = 0;
+        if (vct_comm_slab(ctx, &row0, &row1) == VCT_OK) check(vct_comm_sync(ctx), "vct_comm_sync");
+        else check(vct_synchronize(ctx), "vct_synchronize");
     }
 
     void DrawDepthTexture() {
@@ -310,13 +320,31 @@ struct Voxel_Cone_Tracing {
 
     void DrawVoxelTexture() {
         if (!ctx) return;
-        if (!check(vct_voxelize(ctx, VCT_VOX_CONSERVATIVE_AVG), "vct_voxelize")) return;
+        if (!check(vct_voxelize(ctx, ReferenceVoxelization ? VCT_VOX_REFERENCE : VCT_VOX_CONSERVATIVE_AVG), "vct_voxelize")) return;
         if (!check(vct_inject_light(ctx), "vct_inject_light")) return;
         if (!check(vct_build_mips(ctx), "vct_build_mips")) return;          // VCT.h:248
         if (Bounces >= 2) check(vct_bounce(ctx), "vct_bounce");
     }
 
-    const uint16_t* Frame() const { return FrameRGBA16F.data(); }
+    // The last frame as RGBA16F on the host (row 0 = bottom row of the GL window): waits for the GPU and downloads on
+    // the first call after a Render().  On a multi-GPU run rank 0 holds the gathered frame; other ranks get nullptr.
+    const uint16_t* Frame() const {
+        if (!ctx) return nullptr;
+        if (!frame_on_host) {
+            FrameRGBA16F.resize((size_t)screen_width * screen_height * 4);
+            int32_t row0 = 0, row1 = 0;
+            int rc;
+            if (vct_comm_slab(ctx, &row0, &row1) == VCT_OK) {
+                if (Rank != 0) { vct_comm_sync(ctx); return nullptr; }
+                rc = vct_comm_download_frame(ctx, FrameRGBA16F.data());
+            } else {
+                rc = vct_download_frame(ctx, FrameRGBA16F.data());
+            }
+            if (rc != VCT_OK) { printf("ERROR::VCT::Frame: %s\n", vct_last_error(ctx)); return nullptr; }
+            frame_on_host = true;
+        }
+        return FrameRGBA16F.data();
+    }
 
 private:
     bool check(int rc, const char* what) {

@@ -133,17 +133,37 @@ int main(int argc, char** argv) {
     if (voxel_cone_tracing.last_status != VCT_OK) return 2;
 
     float delta_time = 0.05f;
+    voxel_cone_tracing.Render();                            // frame 0 pays first-launch costs
+    voxel_cone_tracing.Finish();
+    if (voxel_cone_tracing.last_status != VCT_OK) return 3;
+    // R/main.cpp:77-94 as written: Render() per frame, nothing read back (the reference swaps buffers instead)
     auto t0 = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames; ++f) {                      // R/main.cpp:77-94
-        if (f == 1) t0 = std::chrono::steady_clock::now();  // frame 0 pays first-launch costs
-        if (f > 0) camera.ProcessKeyBoard(FORWARD, delta_time);
+    for (int f = 1; f < frames; ++f) {
+        camera.ProcessKeyBoard(FORWARD, delta_time);
         voxel_cone_tracing.Render();
         if (voxel_cone_tracing.last_status != VCT_OK) return 3;
     }
+    voxel_cone_tracing.Finish();
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (gpus > 0 && rank != 0) return 0;                    // the frame lives on rank 0
+    // the same number of frames with the RGBA16F frame copied to the host after every Render() (a presenter without
+    // GPU interop): what the per-frame download costs
+    double readback_ms = 0.0;
+    if (frames > 1 && gpus <= 0) {
+        const vec3 keep = camera.position;
+        auto t1 = std::chrono::steady_clock::now();
+        for (int f = 1; f < frames; ++f) {
+            voxel_cone_tracing.Render();
+            if (!voxel_cone_tracing.Frame()) return 3;
+        }
+        readback_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        camera.position = keep;
+    }
+    if (gpus > 0 && rank != 0) { voxel_cone_tracing.Frame(); return 0; }       // the frame lives on rank 0
     if (gpus > 0) printf("gpus=%d (screen-tile slabs + one ncclGather per frame)\n", gpus);
-    if (frames > 1) printf("Render(): %.3f ms per frame (wall, %d frames, frame 0 excluded)\n", wall_ms / (frames - 1), frames - 1);
+    if (frames > 1) {
+        printf("Render(): %.3f ms per frame (wall, %d frames, frame 0 excluded, no read-back)\n", wall_ms / (frames - 1), frames - 1);
+        if (gpus <= 0) printf("Render() + Frame(): %.3f ms per frame (frame copied to the host every frame)\n", readback_ms / (frames - 1));
+    }
     const uint16_t* fr = voxel_cone_tracing.Frame();
     const size_t n = (size_t)w * h * 4;
     uint64_t sum = 1469598103934665603ull;                  // FNV-1a over the RGBA16F halves
