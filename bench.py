@@ -78,6 +78,8 @@ def parse():
                     help="six directional mip chains, direction-weighted sampling (north-star option)")
     ap.add_argument("--no-sweep", action="store_true",
                     help="skip the 3-aperture roughness sweep (profiling runs: keeps every trace launch identical)")
+    ap.add_argument("--no-hbm-stress", action="store_true",
+                    help="skip the HBM-bound stress line (dense random 1024^3 chain, random G-buffer) of the default run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the oracle baseline sample (0 disables)")
     ap.add_argument("--slabs", default="balanced", choices=["balanced", "equal", "interleaved"],
@@ -151,7 +153,10 @@ def build_inputs(args, vct, sc):
     if args.scene == "noise":
         import synth
         if args.noise_dense:
-            vol = np.random.default_rng(7).integers(0, 256, (V, V, V, 4), dtype=np.uint8)
+            # content of period 256 above 256^3 (caches key on addresses: same traffic as fully random bytes, a
+            # fifth of the host time) -- the volume of hbm_stress()
+            B = min(V, 256)
+            vol = np.tile(np.random.default_rng(7).integers(0, 256, (B, B, B, 4), dtype=np.uint8), (V // B,) * 3 + (1,))
         else:
             vol = synth.noise_volume(V)
         planes = synth.coherent_gbuffer(w, h) if args.gbuffer == "coherent" else synth.random_gbuffer(w * h, seed=42)
@@ -616,6 +621,10 @@ def main():
                 "note": "loose = config.trace_variant 3: unorm8 * RN(1/255) (wrong in the last bit for 126 bytes), x * RN(1/d) "
                         "for the constant divisions; opt-in, never `value`",
             }
+        default_workload = (args.scene == "atrium" and (V, w, h) == (256, 1920, 1080) and not args.obj
+                            and args.variant == 0 and not args.anisotropic and args.bounces == 1)
+        if world == 1 and not args.no_sweep and not args.no_hbm_stress and default_workload:
+            result["hbm_stress"] = hbm_stress(vct, local_rank)
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(args, inp, ctx, vct)
         elif world > 1:
@@ -628,6 +637,52 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hbm_stress(vct, device):
+    """BASELINE.json configs[4] is labelled "HBM-bound stress", but a real street touches a thin shell of its 1024^3
+    grid and stays cache-resident.  This is the case that IS HBM-bound, every round, in the driver's
+    own bench line: a dense random 1024^3 chain (4.57 GiB: 18x the Infinity Cache) traced from a random 1080p G-buffer --
+    incoherent cones, every level sample a per-lane gather.  Texel content repeats with period 256 (a 64 MiB random
+    block tiled 4 x 4 x 4: generating 4 GiB of random bytes would take the host 20 s); caches key on addresses, so the
+    traffic is that of a fully random volume.  Reported: kernel time, SURVEY 8d algorithmic GB/s, and the counter
+    traffic of the committed rocprofv3 pass of the same workload (profiles/trace_traffic_noise.json) when present."""
+    import synth
+    V, w, h = 1024, 1920, 1080
+    base = np.random.default_rng(7).integers(0, 256, (256, 256, 256, 4), dtype=np.uint8)
+    vol = np.tile(base, (4, 4, 4, 1))
+    planes = synth.random_gbuffer(w * h, seed=42)
+    with vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, device=device)) as c2:
+        c2.set_camera_position((0.0, 4.0, 0.0))
+        c2.set_light_direction((0.0, 1.0, 0.25))
+        c2.upload_volume(vol)
+        del vol
+        c2.build_mips()
+        c2.trace(planes)
+        ms = []
+        for _ in range(3):
+            for _ in range(4):
+                c2.trace_resident()
+            ms.append(c2.last_trace_ms())
+        steps = c2.last_step_count()
+    k_ms = float(np.median(ms))
+    alg = steps * BYTES_PER_STEP + w * h * BYTES_PER_PIXEL
+    out = {"workload": "dense random RGBA8 chain 1024^3 (4.57 GiB, period-256 content), random G-buffer 1920x1080",
+           "trace_kernel_ms": round(k_ms, 4), "cone_steps": int(steps),
+           "Mcones_per_s": round(w * h * 7 / (k_ms * 1e-3) / 1e6, 1),
+           "algorithmic_bytes": int(alg), "algorithmic_GBps": round(alg / (k_ms * 1e-3) / 1e9, 1),
+           "algorithmic_frac_of_8TBps": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "counter_GBps": None, "counter_over_algorithmic": None}
+    path = os.path.join(ROOT, "profiles", "trace_traffic_noise.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            t = json.load(fh)
+        if t.get("kernel_source_sha16") == kernel_source_sha() and t.get("hbm_bytes_per_launch"):
+            out["counter_GBps"] = round(t["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9, 1)
+            out["counter_frac_of_8TBps"] = round(out["counter_GBps"] / HBM_PEAK_GBS, 4)
+            out["counter_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / alg, 2)
+            out["counter_source"] = t.get("source")
+    return out
 
 
 def kernel_source_sha():

@@ -65,6 +65,10 @@ def main():
             "frac_coop_gather": round(st["coop_hit"] / max(samples, 1), 4),
             "frac_per_lane": round(st["fallback"] / max(samples, 1), 4),
             "per_lane_mean_live_lanes": round(st["fallback_lanes"] / max(st["fallback"], 1), 2),
+            # of the per-lane samples' live 2x2 quads / 4x4 quadrants: how many could share one small block
+            "frac_quads_fit_3x3x3": round(st["quads_fit333"] / max(st["quads_live"], 1), 4),
+            "frac_quads_same_cell": round(st["quads_same"] / max(st["quads_live"], 1), 4),
+            "frac_quadrants_fit_4x4x4": round(st["quadrants_fit444"] / max(st["quadrants_live"], 1), 4),
         })
         out["launches"].append(st)
     print(json.dumps(out, indent=1))

@@ -478,7 +478,8 @@ class Context:
         v = (C.c_uint64 * 16)()
         self._ck(_lib.vct_last_trace_stats(self._h, v), "vct_last_trace_stats")
         keys = ("wave_steps", "lane_steps", "coop_zero", "coop_hit", "fallback", "fallback_lanes", "fallback_fits",
-                "greedy_blocks", "greedy_le2", "greedy_le3", "greedy_le4")
+                "greedy_blocks", "greedy_le2", "greedy_le3", "greedy_le4", "quads_live", "quads_fit333", "quads_same",
+                "quadrants_live", "quadrants_fit444")
         return dict(zip(keys, (int(x) for x in v)))
 
     def stage_counts(self):

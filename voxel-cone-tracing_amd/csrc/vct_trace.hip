@@ -181,6 +181,11 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #ifndef VCT_HALF_GATHER
 #define VCT_HALF_GATHER 1     // gather + interpolate the lower z plane, then the upper one (half the texel registers live)
 #endif
+#ifndef VCT_PAIR_LOAD
+#define VCT_PAIR_LOAD 0       // EXPERIMENT (round 5, review item 8): per-lane gather with the x-adjacent texel pair of an even x in one
+                              // 8-byte load (Morton order keeps (x, x+1) adjacent for even x); odd lanes fetch x + 1 with a masked
+                              // 4-byte load.  Same bits.  Result: profiles/experiments/README.md
+#endif
 #ifndef VCT_TWO_BLOCKS
 #define VCT_TWO_BLOCKS 0      // 1: a second cooperative block before the per-lane gather (profiles/experiments/README.md)
 #endif
@@ -194,6 +199,12 @@ struct MarchStats {
     uint32_t fallback_fits;    // per-lane samples whose live footprints WOULD fit one 4x4x4 block (anchored at their minimum)
     uint32_t greedy_blocks, greedy_le2, greedy_le3, greedy_le4;   // blocks a greedy multi-anchor cover of them would need
     uint32_t two_blocks;       // level samples served by two cooperative blocks (VCT_TWO_BLOCKS)
+    // round 5 (review item 3): would sharing inside smaller lane groups serve the per-lane samples?  Per per-lane sample:
+    uint32_t quads_live;       // 2x2-pixel quads with a live lane
+    uint32_t quads_fit333;     // ... whose live footprints span <= 1 texel per axis (their union fits a 3x3x3 block)
+    uint32_t quads_same;       // ... whose live footprints are one and the same 2x2x2 cell
+    uint32_t quadrants_live;   // 4x4-pixel quadrants with a live lane
+    uint32_t quadrants_fit444; // ... whose live footprints fit a 4x4x4 block of their own
 };
 
 // [GL] tri(level): trilinear, texel centres, REPEAT (or clamp).  `level` is wave-uniform; must be
@@ -372,6 +383,25 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
               pending &= ~ballot64(in);
               ++nb;
           }
+          // the same range test inside 2x2-pixel quads (lanes l, l^1, l^8, l^9) and 4x4-pixel quadrants (+ l^2, l^16, ...)
+          int qlo[3] = {act ? i0 : 0x7fffffff, act ? j0 : 0x7fffffff, act ? k0 : 0x7fffffff};
+          int qhi[3] = {act ? i0 : -0x7fffffff, act ? j0 : -0x7fffffff, act ? k0 : -0x7fffffff};
+          bool qany = act;
+          auto widen = [&](int off) {
+              for (int q = 0; q < 3; ++q) { qlo[q] = min(qlo[q], __shfl_xor(qlo[q], off)); qhi[q] = max(qhi[q], __shfl_xor(qhi[q], off)); }
+              qany = qany || (__shfl_xor((int)qany, off) != 0);
+          };
+          widen(1); widen(8);
+          const int span2 = max(max(qhi[0] - qlo[0], qhi[1] - qlo[1]), qhi[2] - qlo[2]);
+          const bool lead2 = (lb.lane & 9) == 0;                      // one lane per quad
+          ms.quads_live += (uint32_t)__popcll(ballot64(lead2 && qany));
+          ms.quads_fit333 += (uint32_t)__popcll(ballot64(lead2 && qany && span2 <= 1));
+          ms.quads_same += (uint32_t)__popcll(ballot64(lead2 && qany && span2 == 0));
+          widen(2); widen(16);
+          const int span4 = max(max(qhi[0] - qlo[0], qhi[1] - qlo[1]), qhi[2] - qlo[2]);
+          const bool lead4 = (lb.lane & 27) == 0;                     // one lane per quadrant
+          ms.quadrants_live += (uint32_t)__popcll(ballot64(lead4 && qany));
+          ms.quadrants_fit444 += (uint32_t)__popcll(ballot64(lead4 && qany && span4 <= 2));
           ms.greedy_blocks += (uint32_t)nb;
           if (nb <= 2) ++ms.greedy_le2;
           if (nb <= 3) ++ms.greedy_le3;
@@ -396,10 +426,28 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         }
         uint32_t t[8];
 #define VCT_TEXEL(o) (*(const uint32_t*)(base + (o)))
+#if VCT_PAIR_LOAD
+        if (WRAP && (MX & 4u)) {            // (not the one-texel level: its x + 1 wraps onto x)
+            const bool even = (mx0 & 4u) == 0u;
+            const uint32_t mxe = mx0 & ~4u;
+            const uint32_t yz[4] = {my0 | mz0, my1 | mz0, my0 | mz1, my1 | mz1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 pr = *(const uint2*)(base + (mxe | yz[q]));
+                uint32_t hi = pr.y;
+                if (!even) hi = VCT_TEXEL(mx1 | yz[q]);
+                t[2 * q] = even ? pr.x : pr.y;
+                t[2 * q + 1] = hi;
+            }
+        } else {
+#endif
         t[0] = VCT_TEXEL(mx0 | my0 | mz0); t[1] = VCT_TEXEL(mx1 | my0 | mz0);
         t[2] = VCT_TEXEL(mx0 | my1 | mz0); t[3] = VCT_TEXEL(mx1 | my1 | mz0);
         t[4] = VCT_TEXEL(mx0 | my0 | mz1); t[5] = VCT_TEXEL(mx1 | my0 | mz1);
         t[6] = VCT_TEXEL(mx0 | my1 | mz1); t[7] = VCT_TEXEL(mx1 | my1 | mz1);
+#if VCT_PAIR_LOAD
+        }
+#endif
 #undef VCT_TEXEL
         const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
         const float wg[8] = {(a0 * b0) * c0, (a * b0) * c0, (a0 * b) * c0, (a * b) * c0,
@@ -691,10 +739,11 @@ __device__ __forceinline__ uint32_t pack_half2(float a, float b) {
 
 __device__ __forceinline__ void flush_stats(const VctTraceParams& p, const MarchStats& ms, int lane) {
     if (VCT_STATS && p.stats && lane == 0) {
-        const uint32_t v[11] = {ms.wave_steps, ms.lane_steps, ms.coop_zero, ms.coop_hit, ms.fallback,
+        const uint32_t v[16] = {ms.wave_steps, ms.lane_steps, ms.coop_zero, ms.coop_hit, ms.fallback,
                                 ms.fallback_lanes, ms.fallback_fits, ms.greedy_blocks, ms.greedy_le2, ms.greedy_le3,
-                                ms.greedy_le4};
-        for (int i = 0; i < 11; ++i)
+                                ms.greedy_le4, ms.quads_live, ms.quads_fit333, ms.quads_same, ms.quadrants_live,
+                                ms.quadrants_fit444};
+        for (int i = 0; i < 16; ++i)
             if (v[i]) atomicAdd(p.stats + i, (unsigned long long)v[i]);
     }
 }
