@@ -78,6 +78,9 @@ def parse():
                     help="six directional mip chains, direction-weighted sampling (north-star option)")
     ap.add_argument("--no-sweep", action="store_true",
                     help="skip the 3-aperture roughness sweep (profiling runs: keeps every trace launch identical)")
+    ap.add_argument("--footprint-records", action="store_true",
+                    help="vct_set_footprint_records(1): 32-byte footprint records beside the chain (for volumes that do "
+                         "not fit the caches; include/vct.h)")
     ap.add_argument("--no-hbm-stress", action="store_true",
                     help="skip the HBM-bound stress line (dense random 1024^3 chain, random G-buffer) of the default run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -246,6 +249,8 @@ def main():
                              voxel_attributes=1 if args.bounces == 2 else 0,
                              anisotropic_mips=1 if args.anisotropic else 0)
     ctx = vct.Context(cfg)
+    if args.footprint_records:
+        ctx.set_footprint_records(True)
     ctx.set_camera_position(inp["cam"])
     ctx.set_light_direction(inp["light"])
     ext_stream = torch.cuda.ExternalStream(ctx.stream(), device=local_rank)
@@ -312,7 +317,9 @@ def main():
     # ---- slab of this rank ----
     # native (default for N > 1): vct_comm_init allocates two gather buffers per rank; vct_frame_step makes the
     # kernel write this rank's slab straight into one of them (full-frame addressing, no copies) and issues
-    # the ONE gather of the frame on a communication stream while the next frame's trace fills the other.
+    # the ONE gather of the frame on a communication stream; the next frame's trace may fill the other buffer meanwhile
+    # (measured on one GPU: the two do not actually overlap -- profiles/experiments/r04_gather_timeline.txt -- so a
+    # frame costs slab trace + dispatch gap + wire time; the `multi_gpu` block of the line reports the parts).
     use_dist = world > 1 or force_dist
     native_fallback, fallback_group = None, None
     r0, r1, _per = vct.slab_partition(h, world, rank)
@@ -482,6 +489,27 @@ def main():
         kernel_ms.append(ctx.last_trace_ms())
     fence()
 
+    # N > 1 lines explain themselves: what RCCL says the communicator is, every rank's slab kernel time, step count and
+    # exchange-step time (untimed reads, after the timed region)
+    multi = None
+    if use_dist and native:
+        info = ctx.comm_info()
+        ctx.frame_step()
+        mine = {"rank": rank, "rccl": info, "slab_kernel_ms": round(float(np.mean(kernel_ms)), 4),
+                "slab_cone_steps": int(steps_slab), "slab_tile_rows": list(slab_rows[rank]),
+                "exchange_ms": round(ctx.comm_last_gather_ms(), 4)}
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        if rank == 0:
+            multi = {"rccl_nranks": info["nranks"], "rccl_version": info["rccl_version"],
+                     "per_rank": per_rank,
+                     "slowest_slab_kernel_ms": max(p["slab_kernel_ms"] for p in per_rank),
+                     "root_exchange_ms": per_rank[0]["exchange_ms"],
+                     "note": "exchange_ms = device time of the frame's one ncclGather (or send/recv group) on that rank, "
+                             "between two events on the stream it ran on; the root's includes waiting for the slowest peer"}
     red_dev = "cpu"                               # control plane over gloo
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     steps_all = torch.tensor([steps_slab], dtype=torch.float64, device=red_dev)
@@ -554,7 +582,7 @@ def main():
                        ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]") +
                        ("" if not native_fallback else f" [native communicator unavailable: {native_fallback}]"),
                        "slabs": args.slabs if (native and use_dist) else ("equal" if use_dist else None),
-                       "trace_variant": args.variant,
+                       "trace_variant": args.variant, "footprint_records": bool(args.footprint_records),
                        # compute units kept away from the trace for the gather's stream (VCT_COMM_RESERVED_CUS; 0: none)
                        "comm_reserved_cus": ctx.stage_counts().get("comm_reserved_cus", 0),
                        # visibility form of the G-buffer pass that was timed (chosen per context by timing both)
@@ -574,6 +602,8 @@ def main():
             "gi_pass_one_call_ms": None if gi_fused is None else round(gi_fused, 4),
             "roofline": roofline_block(prof, k_ms, steps_slab, alg_bytes, alg_gbs),
         }
+        if multi is not None:
+            result["multi_gpu"] = multi
         if stage_counts is not None:
             result["stage_roofline"] = stage_roofline(args, gi, stage_counts, k_ms, alg_bytes, w * h)
         if world == 1 and not args.no_sweep:
@@ -648,6 +678,7 @@ def hbm_stress(vct, device):
     traffic is that of a fully random volume.  Reported: kernel time, SURVEY 8d algorithmic GB/s, and the counter
     traffic of the committed rocprofv3 pass of the same workload (profiles/trace_traffic_noise.json) when present."""
     import synth
+    import torch
     V, w, h = 1024, 1920, 1080
     base = np.random.default_rng(7).integers(0, 256, (256, 256, 256, 4), dtype=np.uint8)
     vol = np.tile(base, (4, 4, 4, 1))
@@ -659,20 +690,42 @@ def hbm_stress(vct, device):
         del vol
         c2.build_mips()
         c2.trace(planes)
-        ms = []
-        for _ in range(3):
-            for _ in range(4):
-                c2.trace_resident()
-            ms.append(c2.last_trace_ms())
+
+        def timed():
+            ms = []
+            for _ in range(3):
+                for _ in range(4):
+                    c2.trace_resident()
+                ms.append(c2.last_trace_ms())
+            return float(np.median(ms))
+        k_ms = timed()
         steps = c2.last_step_count()
-    k_ms = float(np.median(ms))
+        frame = c2.download_frame()
+        # the same trace through footprint records (vct_set_footprint_records: one 32-byte fetch per per-lane level sample
+        # of the levels >= 1; +4.9 GB beside the 4.57 GiB chain) -- the layout for volumes that do not fit the caches
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c2.set_footprint_records(True)            # (allocates and builds once, untimed)
+        c2.synchronize()
+        st = torch.cuda.ExternalStream(c2.stream(), device=device)
+        e0.record(st); c2.build_mips(); e1.record(st)
+        c2.synchronize()
+        build_ms = e0.elapsed_time(e1)
+        c2.trace_resident()
+        r_ms = timed()
+        same = bool(np.array_equal(c2.download_frame(), frame)) and c2.last_step_count() == steps
     alg = steps * BYTES_PER_STEP + w * h * BYTES_PER_PIXEL
     out = {"workload": "dense random RGBA8 chain 1024^3 (4.57 GiB, period-256 content), random G-buffer 1920x1080",
            "trace_kernel_ms": round(k_ms, 4), "cone_steps": int(steps),
            "Mcones_per_s": round(w * h * 7 / (k_ms * 1e-3) / 1e6, 1),
            "algorithmic_bytes": int(alg), "algorithmic_GBps": round(alg / (k_ms * 1e-3) / 1e9, 1),
            "algorithmic_frac_of_8TBps": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-           "counter_GBps": None, "counter_over_algorithmic": None}
+           "counter_GBps": None, "counter_over_algorithmic": None,
+           "footprint_records": {"trace_kernel_ms": round(r_ms, 4), "Mcones_per_s": round(w * h * 7 / (r_ms * 1e-3) / 1e6, 1),
+                                 "algorithmic_GBps": round(alg / (r_ms * 1e-3) / 1e9, 1),
+                                 "algorithmic_frac_of_8TBps": round(alg / (r_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "speedup": round(k_ms / r_ms, 3), "same_frame_and_steps": same,
+                                 "mip_build_with_records_ms": round(build_ms, 3),
+                                 "extra_bytes": int((vct.chain_texels(V) - V ** 3) * 32)}}
     path = os.path.join(ROOT, "profiles", "trace_traffic_noise.json")
     if os.path.exists(path):
         with open(path) as fh:

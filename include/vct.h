@@ -127,6 +127,16 @@ int vct_set_cone_apertures(vct_ctx* ctx, float tan_diffuse, float tan_specular);
 /* config.trace_variant of the following traces (0 .. 4, see vct_config).  No reference counterpart: the variants are
  * measurement alternatives of the one cone trace of S/VoxelConeTracing.fs:82-107,165-228; 0 is the exact default. */
 int vct_set_trace_variant(vct_ctx* ctx, int32_t variant);
+/* Footprint records (no reference counterpart; a layout option of the 8^3-brick Morton chain for HBM-bound volumes):
+ * on != 0 keeps, beside the chain, one 32-byte record per texel of the levels >= 1 holding the 8 texels of the
+ * trilinear footprint anchored there (GL_REPEAT folded in), so that an incoherent (per-lane) level sample is one
+ * 32-byte fetch instead of eight 4-byte ones from two to four cache lines.  Costs 8 x the bytes of those levels
+ * (1.14 x level 0: 77 MB at 256^3, 4.9 GB at 1024^3) and a dense rebuild after every mip build.  Same frame, bit for
+ * bit.  Pays where the chain does not fit the caches (dense random 1024^3 chain: trace 5.61 -> 2.86 ms); a scene that
+ * touches a thin shell of its grid stays cache-resident and gains nothing (street at 1024^3 / 4K: 2.72 -> 2.70 ms).
+ * Default off (VCT_FOOTPRINT_RECORDS=1 in the environment turns it on at vct_create).  The clamp-to-edge sampler,
+ * the anisotropic chains and the second-bounce chain keep per-texel gathers. */
+int vct_set_footprint_records(vct_ctx* ctx, int32_t on);
 
 /* Scene upload -- replaces Model/Mesh VBO setup (R/Mesh.h:49-82) for the two attributes the
  * voxelizer reads (vox.vs:3-4).  pos: [ntri][3][3] model-space fp32; material: [ntri];
@@ -270,8 +280,9 @@ int vct_comm_init(vct_ctx* ctx, const void* id128, int32_t rank, int32_t world);
 int vct_comm_destroy(vct_ctx* ctx);
 int vct_comm_slab(vct_ctx* ctx, int32_t* tile_row0, int32_t* tile_row1);
 /* One frame, asynchronous: trace this rank's slab of the resident G-buffer straight into gather buffer k
- * (k alternates), then ONE ncclGather on the communication stream; the gather of frame k overlaps the
- * trace of frame k+1.  Collective: every rank calls it once per frame. */
+ * (k alternates), then ONE ncclGather on the communication stream.  Two buffers let frame k+1 be traced while frame
+ * k is gathered; measured on one GPU the two do NOT overlap (the gather's kernels queue behind the trace's waves), so
+ * budget slab trace + ~23 us dependent dispatch + wire time per frame.  Collective: every rank calls it once per frame. */
 int vct_frame_step(vct_ctx* ctx);
 /* Waits for this rank's trace and gather.  A peer that died or hangs would keep every other rank inside the
  * collective forever: after the communicator's timeout (default 60 s; VCT_COMM_TIMEOUT_MS in the environment or
@@ -279,6 +290,11 @@ int vct_frame_step(vct_ctx* ctx);
  * returns VCT_ERR_DEVICE; afterwards only vct_comm_destroy (then a new vct_comm_init) is accepted on it. */
 int vct_comm_sync(vct_ctx* ctx);
 int vct_comm_set_timeout_ms(vct_ctx* ctx, int32_t milliseconds);
+/* Diagnostics (bench lines of N > 1 runs explain themselves with these): what RCCL reports about the communicator --
+ * out[0] ncclCommCount, out[1] ncclCommUserRank, out[2] ncclCommCuDevice, out[3] ncclGetVersion (-1 where the loaded
+ * RCCL lacks the entry point) -- and the device time of the last frame's exchange step alone (waits for it). */
+int vct_comm_info(vct_ctx* ctx, int32_t out[4]);
+int vct_comm_last_gather_ms(vct_ctx* ctx, float* ms);
 /* Load-aware slabs (SURVEY.md 8e offers unequal assignment as an option): equal ROWS are not equal WORK -- rows
  * showing sky or near walls march fewer steps.  vct_last_row_steps returns the executed cone steps per 8-pixel tile
  * row of the last screen trace (rows outside a slab trace are 0; nrows = ceil(height / 8)); after summing the

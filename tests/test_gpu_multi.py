@@ -169,6 +169,10 @@ def test_native_bench_loop_interleaved_with_forced_one_rank_group():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["gathered_frame_equals_single_gpu_frame"] is True and d["config"]["slabs"] == "interleaved"
+    # the line explains itself: RCCL's own rank count, per-rank slab kernel / step / exchange figures
+    mg = d["multi_gpu"]
+    assert mg["rccl_nranks"] == 1 and len(mg["per_rank"]) == 1 and mg["per_rank"][0]["rccl"]["rank"] == 0
+    assert mg["per_rank"][0]["slab_kernel_ms"] > 0 and mg["root_exchange_ms"] >= 0 and mg["per_rank"][0]["slab_cone_steps"] > 0
 
 
 def test_cpp_caller_multi_gpu_launcher(vct):

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "vct_frame_step", "vct_comm_sync", "vct_comm_frame", "vct_comm_download_frame",
     "vct_upload_mesh_uvs", "vct_upload_textures", "vct_gi_pass",
     "vct_comm_set_timeout_ms", "vct_last_row_steps", "vct_slab_partition_weighted", "vct_comm_set_slab_rows",
-    "vct_get_stage_counts",
+    "vct_get_stage_counts", "vct_comm_info", "vct_comm_last_gather_ms", "vct_set_footprint_records",
 ]
 
 
@@ -127,6 +127,9 @@ for _n in ("vct_comm_destroy", "vct_frame_step", "vct_comm_sync"):
 COMM_ID_BYTES = 128
 _lib.vct_get_stage_counts.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_comm_set_timeout_ms.argtypes = [C.c_void_p, C.c_int32]
+_lib.vct_set_footprint_records.argtypes = [C.c_void_p, C.c_int32]
+_lib.vct_comm_info.argtypes = [C.c_void_p, C.c_void_p]
+_lib.vct_comm_last_gather_ms.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_last_row_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 _lib.vct_slab_partition_weighted.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
 _lib.vct_comm_set_slab_rows.argtypes = [C.c_void_p, C.c_void_p]
@@ -233,6 +236,10 @@ class Context:
     def set_cone_apertures(self, td, ts):
         self._ck(_lib.vct_set_cone_apertures(self._h, float(td), float(ts)), "vct_set_cone_apertures")
 
+    def set_footprint_records(self, on=True):
+        """One 32-byte footprint record per texel of the levels >= 1 (include/vct.h): for HBM-bound volumes."""
+        self._ck(_lib.vct_set_footprint_records(self._h, int(bool(on))), "vct_set_footprint_records")
+
     def set_trace_variant(self, variant):
         self._ck(_lib.vct_set_trace_variant(self._h, int(variant)), "vct_set_trace_variant")
 
@@ -327,6 +334,17 @@ class Context:
         r0, r1 = C.c_int32(), C.c_int32()
         self._ck(_lib.vct_comm_slab(self._h, C.byref(r0), C.byref(r1)), "vct_comm_slab")
         return r0.value, r1.value
+
+    def comm_info(self):
+        """What RCCL says about the communicator: dict(nranks, rank, device, rccl_version)."""
+        v = (C.c_int32 * 4)()
+        self._ck(_lib.vct_comm_info(self._h, v), "vct_comm_info")
+        return dict(nranks=v[0], rank=v[1], device=v[2], rccl_version=v[3])
+
+    def comm_last_gather_ms(self):
+        v = C.c_float()
+        self._ck(_lib.vct_comm_last_gather_ms(self._h, C.byref(v)), "vct_comm_last_gather_ms")
+        return v.value
 
     def comm_set_timeout_ms(self, ms):
         self._ck(_lib.vct_comm_set_timeout_ms(self._h, int(ms)), "vct_comm_set_timeout_ms")

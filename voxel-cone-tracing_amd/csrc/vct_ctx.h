@@ -29,6 +29,9 @@ struct vct_ctx {
     uint32_t* attr_albedo = nullptr;  // [V^3] resolved mean albedo, Morton order
     uint32_t* attr_normal = nullptr;  // [V^3] resolved mean normal (biased), Morton order
     bool mips_valid = true;           // levels >= 1 describe level 0 (a fresh chain is all zero)
+    bool want_cells = false;          // vct_set_footprint_records / VCT_FOOTPRINT_RECORDS=1
+    uint4* cells = nullptr;           // footprint records of the levels >= 1 of `chain` (32 B per texel of those levels)
+    bool cells_valid = false;         // ... rebuilt by vct_build_mips / vct_upload_chain_rgba8
     bool attrs_valid = false;         // attr_albedo / attr_normal hold a resolve of the CURRENT mesh's pools (vct_bounce needs it)
     uint32_t* aniso = nullptr;        // [6][chain_texels - V^3] directional chains (cfg.anisotropic_mips)
     size_t chain_texels = 0;

@@ -248,6 +248,9 @@ struct VctTraceParams {
     float ambient, shininess, max_alpha;
     int32_t wrap_repeat;
     const uint32_t* spread_lut;         // [1024] spread3(i) << 2: dilated byte offsets of an x coordinate (scalar loads)
+    // footprint records of the levels >= 1 (vct_volume.hip k_build_cells), biased so that the record of Morton index c of
+    // the level at texel offset `off` sits at cells_biased + (off + c) * 32; null: per-texel gathers everywhere
+    const char* cells_biased;
     const VctStep* steps_diffuse;
     const VctStep* steps_specular;
     int32_t n_diffuse, n_specular;
@@ -413,6 +416,7 @@ hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N
 hipError_t vct_launch_build_mips(uint32_t* chain, int V, const uint32_t* bricks_now, uint32_t* bricks_seen,
                                  hipStream_t s);
 hipError_t vct_launch_build_mips_aniso(const uint32_t* level0, uint32_t* aniso, int V, hipStream_t s);
+hipError_t vct_launch_build_cells(const uint32_t* chain, uint4* cells, int V, hipStream_t s);
 hipError_t vct_launch_tile_gbuffer(const float* planes_linear, float* tiled, int w, int h,
                                    hipStream_t s);
 // fragment list of the conservative voxelizer, built at upload: small triangles (+ the list of the big ones), big

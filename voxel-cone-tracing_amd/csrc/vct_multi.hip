@@ -11,8 +11,10 @@
 //
 // One process per GPU.  Per frame the host issues, natively: wait(buffer k free) -> trace kernel writes
 // the slab straight into gather buffer k (vct_set_frame_target-style full-frame addressing, no copy) ->
-// event -> ncclGather on a communication stream -> event.  Two buffers: the gather of frame k overlaps
-// the trace of frame k+1.
+// event -> ncclGather on a communication stream -> event.  Two buffers, so that frame k+1 may be traced while frame
+// k is still being gathered -- on one GPU that overlap was measured NOT to happen (0 of 103 gather copies ran beside a
+// trace, profiles/experiments/r04_gather_timeline.txt: the gather's kernels wait for the wave slots the trace holds); a
+// frame costs slab trace + dependent dispatch (~23 us) + wire time.  vct_comm_last_gather_ms reports the gather alone.
 //
 // RCCL is loaded lazily (dlopen) so single-GPU users of libvct_amd.so never pay for it and the library
 // carries no link-time dependency on a particular librccl build (a Python process that already loaded
@@ -46,6 +48,10 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -71,6 +77,11 @@ Rccl* rccl() {
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    // optional (diagnostics only: vct_comm_info)
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
+    r.CommCuDevice = (decltype(r.CommCuDevice))dlsym(r.lib, "ncclCommCuDevice");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.lib, "ncclGetVersion");
     return &r;
 }
 
@@ -109,6 +120,7 @@ struct vct_comm {
     hipStream_t comm_stream = nullptr;
     uint16_t* buf[2] = {nullptr, nullptr};   // root: the frame (world padded slabs); others: this rank's slab
     hipEvent_t traced[2] = {nullptr, nullptr}, gathered[2] = {nullptr, nullptr};
+    hipEvent_t g0[2] = {nullptr, nullptr}, g1[2] = {nullptr, nullptr};     // timing: around the frame's exchange step
     unsigned long long frames = 0;     // steps issued
     int last = -1;                     // buffer of the last issued step
     int timeout_ms = 60000;            // vct_comm_sync gives up after this long and aborts the communicator
@@ -142,6 +154,8 @@ static void comm_free(vct_comm* m) {
         if (m->buf[k]) (void)hipFree(m->buf[k]);
         if (m->traced[k]) (void)hipEventDestroy(m->traced[k]);
         if (m->gathered[k]) (void)hipEventDestroy(m->gathered[k]);
+        if (m->g0[k]) (void)hipEventDestroy(m->g0[k]);
+        if (m->g1[k]) (void)hipEventDestroy(m->g1[k]);
     }
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     delete m;
@@ -243,6 +257,8 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
         if (e == hipSuccess) e = hipMemsetAsync(m->buf[k], 0, m->buf_halves * 2, c->stream);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->traced[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->gathered[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreate(&m->g0[k]);
+        if (e == hipSuccess) e = hipEventCreate(&m->g1[k]);
         if (e == hipSuccess) e = hipEventRecord(m->gathered[k], c->stream);      // "previous gather" of the first use
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -384,6 +400,7 @@ int vct_frame_step(vct_ctx* c) {
         HIP_TRY(c, hipStreamWaitEvent(m->comm_stream, m->traced[k], 0));
     }
     Rccl* r = rccl();
+    HIP_TRY(c, hipEventRecord(m->g0[k], cs));
     if (m->interleaved) {
         NCCL_TRY(c, m, r->Gather(slab, m->rank == 0 ? m->buf[k] : nullptr, m->slab_halves, ncclFloat16, 0, m->comm,
                                  cs));
@@ -414,6 +431,7 @@ int vct_frame_step(vct_ctx* c) {
         if (gr != ncclSuccess) return comm_fail(c, m, "ncclSend/ncclRecv", gr);
         if (ge != ncclSuccess) return comm_fail(c, m, "ncclGroupEnd", ge);
     }
+    HIP_TRY(c, hipEventRecord(m->g1[k], cs));
     HIP_TRY(c, hipEventRecord(m->gathered[k], cs));
     m->last = k;
     ++m->frames;
@@ -456,6 +474,34 @@ int vct_comm_sync(vct_ctx* c) {
         if (++spins < 2000) std::this_thread::yield();                         // the common case: done within microseconds
         else std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
+}
+
+// Diagnostics for multi-GPU bench lines: what RCCL itself says about the communicator.
+// out[0] = ncclCommCount, out[1] = ncclCommUserRank, out[2] = ncclCommCuDevice, out[3] = ncclGetVersion (-1: not exported)
+int vct_comm_info(vct_ctx* c, int32_t out[4]) {
+    if (!c || !out) return VCT_ERR_INVALID;
+    vct_comm* m = c->comm;
+    if (!m || !m->comm) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_info: no usable communicator (vct_comm_init)");
+    Rccl* r = rccl();
+    int v[4] = {-1, -1, -1, -1};
+    if (r->CommCount) (void)r->CommCount(m->comm, &v[0]);
+    if (r->CommUserRank) (void)r->CommUserRank(m->comm, &v[1]);
+    if (r->CommCuDevice) (void)r->CommCuDevice(m->comm, &v[2]);
+    if (r->GetVersion) (void)r->GetVersion(&v[3]);
+    for (int i = 0; i < 4; ++i) out[i] = v[i];
+    return VCT_OK;
+}
+
+// Device time of the LAST frame's exchange step on this rank (the ncclGather / the send-recv group, plus the root's
+// de-interleave in interleaved mode), between two events on the stream it ran on.  Waits for that step (vct_comm_sync).
+int vct_comm_last_gather_ms(vct_ctx* c, float* ms) {
+    if (!c || !ms) return VCT_ERR_INVALID;
+    vct_comm* m = c->comm;
+    if (!m || m->last < 0) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_last_gather_ms: no frame stepped yet");
+    const int rc = vct_comm_sync(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventElapsedTime(ms, m->g0[m->last], m->g1[m->last]));
+    return VCT_OK;
 }
 
 int vct_comm_frame(vct_ctx* c, void** dev, size_t* bytes) {

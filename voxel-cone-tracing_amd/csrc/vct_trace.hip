@@ -181,6 +181,13 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #ifndef VCT_HALF_GATHER
 #define VCT_HALF_GATHER 1     // gather + interpolate the lower z plane, then the upper one (half the texel registers live)
 #endif
+#ifndef VCT_CELLS
+#define VCT_CELLS 1           // footprint records (round 5; vct_set_footprint_records): a per-lane sample of a level >= 1 is ONE
+                              // 32-byte fetch of the footprint's 8 texels (vct_volume.hip k_build_cells) instead of eight 4-byte
+                              // ones from 2-4 cache lines.  Same bits.  Dense random 1024^3 chain + random G-buffer (the one
+                              // HBM-bound case): 5.61 -> 2.86 ms; cache-resident scenes: street at 1024^3 / 4K 2.72 -> 2.70 ms,
+                              // atrium 0.611 -> 0.613 (profiles/experiments/README.md).  Off unless the context asks for it.
+#endif
 #ifndef VCT_PAIR_LOAD
 #define VCT_PAIR_LOAD 0       // EXPERIMENT (round 5, review item 8): per-lane gather with the x-adjacent texel pair of an even x in one
                               // 8-byte load (Morton order keeps (x, x+1) adjacent for even x); odd lanes fetch x + 1 with a masked
@@ -210,10 +217,11 @@ struct MarchStats {
 // [GL] tri(level): trilinear, texel centres, REPEAT (or clamp).  `level` is wave-uniform; must be
 // called in wave-uniform control flow with at least one lane `act`.  Lanes without `act` help
 // fetch the block and return garbage-free zeros / unused values.
-template <bool WRAP, bool COOP, bool LOOSE = false>
+template <bool WRAP, bool COOP, bool LOOSE = false, bool CELLS = false>
 __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, const VctLevelRef lv,
                                            float ux, float uy, float uz, bool act, unsigned long long am,
-                                           float4* __restrict__ blk, const LaneBlock& lb, MarchStats& ms) {
+                                           float4* __restrict__ blk, const LaneBlock& lb, MarchStats& ms,
+                                           const char* __restrict__ cells = nullptr) {
     // `am` is ballot64(act), passed in so that compound predicates are ANDed as lane masks on the
     // scalar unit (a ballot of `x && y` costs a v_cndmask + v_cmp_ne pair to materialise the bool).
     const int m = lv.m;
@@ -426,6 +434,16 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         }
         uint32_t t[8];
 #define VCT_TEXEL(o) (*(const uint32_t*)(base + (o)))
+        if (VCT_CELLS && CELLS && WRAP && lv.off != 0u) {     // (CELLS instantiations are launched with records present)
+            // footprint record of the lower corner: the 8 texels as 32 contiguous bytes (levels >= 1; 4 * Morton index * 8
+            // = byte offset of the record, < 2^32 for every level but the first of a 2048^3 grid, which has none)
+            const char* cb = cells + ((size_t)lv.off << 5);
+            const uint32_t ro = (mx0 | my0 | mz0) << 3;
+            const uint4 lo = *(const uint4*)(cb + ro);
+            const uint4 hi = *(const uint4*)(cb + ro + 16u);
+            t[0] = lo.x; t[1] = lo.y; t[2] = lo.z; t[3] = lo.w;
+            t[4] = hi.x; t[5] = hi.y; t[6] = hi.z; t[7] = hi.w;
+        } else {
 #if VCT_PAIR_LOAD
         if (WRAP && (MX & 4u)) {            // (not the one-texel level: its x + 1 wraps onto x)
             const bool even = (mx0 & 4u) == 0u;
@@ -448,6 +466,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
 #if VCT_PAIR_LOAD
         }
 #endif
+        }
 #undef VCT_TEXEL
         const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
         const float wg[8] = {(a0 * b0) * c0, (a * b0) * c0, (a0 * b) * c0, (a * b) * c0,
@@ -613,10 +632,10 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
         const float uy = fmaf(div_const<FASTDIV>(py, p.half_G_aux, p.half_G_rcp), 0.5f, 0.5f); \
         const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G_aux, p.half_G_rcp), 0.5f, 0.5f); \
         F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, live, blk, lb, ac, ms) \
-                                         : sample_level<WRAP, COOP, FASTDIV == 2>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms); \
+                                         : sample_level<WRAP, COOP, FASTDIV == 2, CELLS>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms, p.cells_biased); \
         if (st.two_levels) { \
             const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, live, blk + 64, lb, ac, ms) \
-                                : sample_level<WRAP, COOP, FASTDIV == 2>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms); \
+                                : sample_level<WRAP, COOP, FASTDIV == 2, CELLS>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms, p.cells_biased); \
             const float g = st.omf;      /* 1 - frac, from the table */ \
             vc.x = fmaf(st.frac, t2.x, g * vc.x); \
             vc.y = fmaf(st.frac, t2.y, g * vc.y); \
@@ -633,7 +652,7 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
             ++steps; \
         }
 
-template <bool WRAP, int FASTDIV, bool COOP, bool ANISO = false>
+template <bool WRAP, int FASTDIV, bool COOP, bool ANISO = false, bool CELLS = false>
 __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3 start, F3 dir,
                                          const VctStep* tab_global, int n,
                                          float4* __restrict__ blk, const LaneBlock& lb,
@@ -704,7 +723,7 @@ template <bool WRAP, int FASTDIV, bool COOP>
 __device__ __forceinline__ void cone_march3(const VctTraceParams& p, bool alive, F3 start, const F3 dirs[3],
                                             const VctStep* tab_global, int n, float4* __restrict__ blk,
                                             const LaneBlock& lb, ConeAcc out[3], MarchStats& ms) {
-    constexpr bool ANISO = false;
+    constexpr bool ANISO = false, CELLS = false;
     const StepTable tab = (StepTable)tab_global;
     AnisoCone ac = {0.0f, 0.0f, 0.0f, false, false, false};
     ConeAcc c0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0}, c1 = c0, c2 = c0;
@@ -968,7 +987,9 @@ static_assert(VCT_SPLIT == 3 || VCT_SPLIT == 4 || VCT_SPLIT == 7, "VCT_SPLIT mus
 
 // (the anisotropic instantiation carries three samples' worth of state: it gets 128 VGPRs instead of
 // spilling under the 80 of the default kernel)
-template <bool WRAP, int FASTDIV, bool ANISO, bool COMPACT = false>
+// CELLS: the per-lane sampler reads footprint records (p.cells_biased != null; vct_set_footprint_records) -- an
+// instantiation of its own, because the same code behind a run-time test cost the default kernel 2 % (0.608 -> 0.620 ms)
+template <bool WRAP, int FASTDIV, bool ANISO, bool COMPACT = false, bool CELLS = false>
 __global__ void __launch_bounds__(64 * VCT_SPLIT, ANISO ? VCT_ANISO_MIN_WAVES : VCT_TRACE_MIN_WAVES)
 k_trace_tile_split(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_SPLIT][ANISO ? 4 : 2][64];   // per wave: level-1 slab, level-2 slab (+ their "-axis" slabs)
@@ -1076,7 +1097,7 @@ k_trace_tile_split(const VctTraceParams p) {
                         k0.z * ddx + k1.z * ddy + k2.z * ddz);
             dir = normalize3(dir);
             int st;
-            const F4 c = cone_march<WRAP, FASTDIV, true, ANISO>(p, alive, start, dir, p.steps_diffuse,
+            const F4 c = cone_march<WRAP, FASTDIV, true, ANISO, CELLS>(p, alive, start, dir, p.steps_diffuse,
                                                                 p.n_diffuse, blk, lb, st, ms);
             total += st;
             lds_cone[i][lane] = make_float4(c.x, c.y, c.z, c.w);
@@ -1099,7 +1120,7 @@ k_trace_tile_split(const VctTraceParams p) {
         const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
         const F3 Rd = normalize3(reflect3(f3(E.x * -1.0f, E.y * -1.0f, E.z * -1.0f), N));  // :217
         int st6;
-        const F4 sc = cone_march<WRAP, FASTDIV, true, ANISO>(p, alive, start, Rd, p.steps_specular,
+        const F4 sc = cone_march<WRAP, FASTDIV, true, ANISO, CELLS>(p, alive, start, Rd, p.steps_specular,
                                                              p.n_specular, blk, lb, st6, ms);
         total += st6;
         lds_cone[6][lane] = make_float4(sc.x, sc.y, sc.z, sc.w);
@@ -1483,6 +1504,8 @@ hipError_t launch_v(const VctTraceParams& p, int variant, int ntiles, hipStream_
         return hipGetLastError();
     }
     if (p.aniso) hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+    else if (VCT_CELLS && WRAP && p.cells_biased)
+        hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false, false, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     else hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     return hipGetLastError();
 }
