@@ -210,3 +210,39 @@ def test_shared_reciprocal_division_equals_the_ieee_division(vct):
     ctx = vct.Context(vct.default_config(voxel_dim=16, width=8, height=8))
     for seed in (1, 0x1234567, 2 ** 40 + 17, 2 ** 63 + 5):
         assert ctx.selftest_area_divide(seed, 1 << 30) == 0, seed
+
+
+@pytest.mark.parametrize("kind,detail,S", [(0, 1.0, 256), (1, 0.15, 512), (1, 0.1, 100)])
+def test_shadow_tile_bounds_do_not_change_a_bit(vct, oracle, monkeypatch, kind, detail, S):
+    """Round 5: depth bounds per dilated 8 x 8 tile of the shadow map decide most PCF windows without fetching them
+    (voxelizer, both modes, and the G-buffer shade).  Built only for large meshes by default; VCT_SHADOW_TILES forces
+    them on / off.  Chain and G-buffer must be the same bits either way -- and the oracle's."""
+    V, w, h = 32, 96, 64
+    light = (0.0, 1.0, 0.25)
+    out = {}
+    for tiles in ("1", "0"):
+        monkeypatch.setenv("VCT_SHADOW_TILES", tiles)
+        sc, scene, ctx = setup_scene(vct, kind, detail, V, w, h, S)
+        cam = sc.default_camera(position=(0.0, 0.0, 58.0)) if kind == 0 else \
+            sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
+        ctx.render_shadow_map(sc.light_view_proj(light))
+        chains = []
+        for mode in (vct.VOX_CONSERVATIVE_AVG, vct.VOX_REFERENCE):
+            ctx.voxelize(mode); ctx.inject_light(); ctx.build_mips()
+            chains.append(ctx.download_chain())
+        ctx.render_gbuffer(sc.camera_view_proj(cam, w, h))
+        out[tiles] = (chains, ctx.download_gbuffer(), ctx.download_shadow_map())
+        ctx.close()
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out["1"][1].view(np.uint32), out["0"][1].view(np.uint32))
+    # against the CPU checkers: shadowed voxelization (conservative) and the G-buffer's PCF plane
+    depth, light_vp_row = raster_oracle.shadow_map(sc, scene, light, S)
+    assert np.array_equal(out["1"][2].view(np.uint32), depth.view(np.uint32))
+    p = oracle.default_params(V)
+    want = oracle.build_mips(oracle.voxelize_conservative(p, raster_oracle.oracle_scene(scene, depth, light_vp_row)))
+    assert np.array_equal(out["1"][0][0], want)
+    planes = raster_oracle.gbuffer(sc, scene, cam, w, h, depth, light_vp_row)
+    assert np.array_equal(out["1"][1][22].view(np.uint32), planes[22].view(np.uint32))
+    lit = planes[22][planes[18] >= 0.5]
+    assert (lit > 2.7).any() and (lit < 2.0).any()          # fully lit pixels and pixels in (partial) shadow both present

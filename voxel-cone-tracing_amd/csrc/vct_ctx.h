@@ -73,6 +73,7 @@ struct vct_ctx {
     uint32_t* shadow = nullptr;       // shadow-map words (vct_internal.h vct_shadow_depth), shadow_size^2
     int32_t shadow_size = 0;
     uint32_t shadow_ebase = 0;        // epoch base of the words the map currently shows
+    uint2* shadow_tiles = nullptr;    // decoded (min, max) per dilated 8 x 8 tile of the current map (vct_launch_shadow_minmax)
     uint32_t shadow_passes = 0;       // shadow passes rasterised into this buffer since its last memset
     // raster input stages
     float* tri_nrm = nullptr;

@@ -170,6 +170,16 @@ __device__ __forceinline__ int vct_pcf_window_verdict(uint32_t wmin, uint32_t wm
     const float lo = vct_shadow_depth(wmin, ebase) * 0.999998f, hi = vct_shadow_depth(wmax, ebase) * 1.000002f;
     return cur <= lo ? 25 : (cur > hi ? 0 : -1);
 }
+// The same verdict from the tile table: (col0, row0) = first texel of a regular (unclamped, six consecutive texels per
+// axis) window.  Tile (tx, ty) holds the bounds of texels [8 tx, 8 tx + 13) x [8 ty, 8 ty + 13) -- every window that
+// STARTS in the tile lies inside that region -- so one 8-byte load bounds the window from outside.  -1: undecided.
+#define VCT_SHADOW_TILE_SHIFT 3
+#define VCT_SHADOW_TILE_REACH 5      // a window spans 6 texels: it ends at most 5 texels beyond the tile it starts in
+__device__ __forceinline__ int vct_pcf_tile_verdict(const uint2* __restrict__ tiles, int S, uint32_t col0, uint32_t row0, float cur) {
+    const uint32_t nb = ((uint32_t)S + 7u) >> VCT_SHADOW_TILE_SHIFT;
+    const uint2 t = tiles[(row0 >> VCT_SHADOW_TILE_SHIFT) * nb + (col0 >> VCT_SHADOW_TILE_SHIFT)];
+    return cur <= __uint_as_float(t.x) * 0.999998f ? 25 : (cur > __uint_as_float(t.y) * 1.000002f ? 0 : -1);
+}
 #endif
 
 // Six consecutive shadow-map words (one row of a PCF window) as ONE dwordx4 + ONE dwordx2 load: the row starts at any
@@ -307,6 +317,7 @@ struct VctVoxParams {
     const uint32_t* shadow;    // [S*S] shadow-map words (vct_shadow_depth) or null
     uint32_t shadow_ebase;     // epoch base of the pass that produced them
     int32_t shadow_size;
+    const uint2* shadow_tiles; // [ceil(S/8)]^2 decoded (min, max) per dilated 8 x 8 tile (vct_launch_shadow_minmax) or null
     float light_vp[16];
     // Per brick the uploaded mesh can touch (found once per mesh) there is a SLOT: brick_slot maps brick -> slot
     // (VCT_NO_SLOT: no fragment ever lands there).  A 1024^3 grid costs the surface, not 16 GiB.
@@ -396,12 +407,17 @@ hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp
 // float depths in [0, 1] <-> shadow-map words (uploads of maps made elsewhere, downloads)
 hipError_t vct_launch_shadow_encode(const float* depth, uint32_t* words, size_t n, uint32_t ebase, hipStream_t s);
 hipError_t vct_launch_shadow_decode(const uint32_t* words, float* depth, size_t n, uint32_t ebase, hipStream_t s);
+// Depth bounds of the shadow map per 8 x 8-texel tile, each over the tile DILATED by the reach of a PCF window (13 x 13
+// texels; decoded words: monotonic in depth), rebuilt after a pass / upload: [ceil(S / 8)]^2 (min, max) pairs.  Where the
+// compared depth lies outside the bounds of the tile a window starts in, all 25 taps pass or fail
+// (vct_pcf_window_verdict's margins hold for any superset of the window) and the window is never fetched.
+hipError_t vct_launch_shadow_minmax(const uint32_t* words, uint32_t ebase, int S, uint2* tiles, hipStream_t s);
 // tile rows [row0, row1) only (whole frame: 0 .. ceil(H/8)); visibility (k_raster_vis + k_raster_mid) and shading
 // (k_gbuffer_shade, the only part that reads the shadow map) are separate calls so that a stream wait can sit between
 hipError_t vct_launch_gbuffer_visibility(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
                                          hipStream_t s);
 hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
-                                    const uint32_t* shadow, uint32_t shadow_ebase, int shadow_size,
+                                    const uint32_t* shadow, uint32_t shadow_ebase, int shadow_size, const uint2* shadow_tiles,
                                     const float light_vp[16], float* tiled, hipStream_t s);
 // one level of a texture's mip chain from its parent (pw x ph -> w x h), glGenerateMipmap restated as in the oracle
 hipError_t vct_launch_tri_alpha(const VctRasterArgs& a, int32_t* out, hipStream_t s);

@@ -1476,6 +1476,7 @@ struct ShadeParams {
     const uint32_t* shadow;      // [S*S] shadow-map words or null
     uint32_t shadow_ebase;
     int32_t shadow_size;
+    const uint2* shadow_tiles;   // per-tile depth bounds of the map (vct_launch_shadow_minmax) or null
     float light_vp[16];
     float* tiled;                // [tile][23][64]
     int32_t tiles_x;
@@ -1759,7 +1760,11 @@ k_gbuffer_shade(const ShadeParams p) {
                         if (cur <= tap) cnt += 1.0f;
                     }
                 };
-                if (wide) {
+                int tile_verdict = -1;
+                if (wide && p.shadow_tiles) tile_verdict = vct_pcf_tile_verdict(p.shadow_tiles, S, (uint32_t)col[0], (uint32_t)row[0], cur);
+                if (tile_verdict >= 0) {
+                    cnt = (float)tile_verdict;      // the tiles the window lies in bound it: no window fetch
+                } else if (wide) {
                     // all six rows in flight at once (round 3: the rows used to be fetched one after the other, two
                     // live at a time to save registers -- six dependent round trips per pixel were the price, 36 of
                     // the pass's 188 us); the taps are counted, so their order is free
@@ -1931,6 +1936,52 @@ hipError_t vct_launch_shadow_raster(const VctRasterArgs& a, const float light_vp
     return a.binned ? run_visibility_binned(a, r, s) : run_visibility(r, s);
 }
 
+namespace {
+// A workgroup per 64 x 64-texel block of the map: the block + the 5-texel reach to the right / top is decoded into LDS
+// (69 x 69), then min / max separably: per row over the 13 texels each of the block's 8 tile columns reaches, then per
+// tile over its 13 rows.  Texels beyond the map do not exist (a regular window never touches them): neutral values.
+#define VCT_SMM_BLOCK 64
+#define VCT_SMM_SPAN (VCT_SMM_BLOCK + VCT_SHADOW_TILE_REACH)
+__global__ void __launch_bounds__(256)
+k_shadow_minmax(const uint32_t* __restrict__ words, uint32_t ebase, int S, int nb, uint2* __restrict__ tiles) {
+    __shared__ uint32_t tex[VCT_SMM_SPAN][VCT_SMM_SPAN + 1];
+    __shared__ uint32_t rlo[VCT_SMM_SPAN][8], rhi[VCT_SMM_SPAN][8];
+    const int bx = blockIdx.x * VCT_SMM_BLOCK, by = blockIdx.y * VCT_SMM_BLOCK;
+    for (int i = threadIdx.x; i < VCT_SMM_SPAN * VCT_SMM_SPAN; i += 256) {
+        const int r = i / VCT_SMM_SPAN, c = i - r * VCT_SMM_SPAN;
+        const int x = bx + c, y = by + r;
+        tex[r][c] = (x < S && y < S) ? min(words[(size_t)y * S + x] - ebase, VCT_SHADOW_ONE) : 0xffffffffu;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < VCT_SMM_SPAN * 8; i += 256) {
+        const int r = i >> 3, t = i & 7;
+        uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+        for (int k = 0; k < 8 + VCT_SHADOW_TILE_REACH; ++k) {
+            const uint32_t v = tex[r][t * 8 + k];
+            lo = min(lo, v);
+            hi = v == 0xffffffffu ? hi : max(hi, v);          // (outside the map: neutral for both)
+        }
+        rlo[r][t] = lo; rhi[r][t] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int ty = threadIdx.x >> 3, tx = threadIdx.x & 7;
+        uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+        for (int k = 0; k < 8 + VCT_SHADOW_TILE_REACH; ++k) { lo = min(lo, rlo[ty * 8 + k][tx]); hi = max(hi, rhi[ty * 8 + k][tx]); }
+        const int gx = (bx >> 3) + tx, gy = (by >> 3) + ty;
+        if (gx < nb && gy < nb) tiles[(size_t)gy * nb + gx] = make_uint2(lo, hi);
+    }
+}
+}  // namespace
+
+hipError_t vct_launch_shadow_minmax(const uint32_t* words, uint32_t ebase, int S, uint2* tiles, hipStream_t s) {
+    const int nb = (S + 7) >> 3, g = (S + VCT_SMM_BLOCK - 1) / VCT_SMM_BLOCK;
+    hipLaunchKernelGGL(k_shadow_minmax, dim3(g, g), dim3(256), 0, s, words, ebase, S, nb, tiles);
+    return hipGetLastError();
+}
+
 hipError_t vct_launch_shadow_encode(const float* depth, uint32_t* words, size_t n, uint32_t ebase, hipStream_t s) {
     hipLaunchKernelGGL(k_shadow_encode, dim3(256 * 8), dim3(256), 0, s, depth, words, n, ebase);
     return hipGetLastError();
@@ -1958,9 +2009,10 @@ hipError_t vct_launch_gbuffer_visibility(const VctRasterArgs& a, const float vie
 }
 
 hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_proj[16], int W, int H, int row0, int row1,
-                                    const uint32_t* shadow, uint32_t shadow_ebase, int shadow_size,
+                                    const uint32_t* shadow, uint32_t shadow_ebase, int shadow_size, const uint2* shadow_tiles,
                                     const float light_vp[16], float* tiled, hipStream_t s) {
     ShadeParams p = make_shade(a, view_proj, W, H, row0, row1);
+    p.shadow_tiles = shadow ? shadow_tiles : nullptr;
     p.nrm = a.nrm; p.tan = a.tan; p.bit = a.bit;
     p.material = a.material; p.albedo = a.albedo; p.specular = a.specular;
     p.shadow = shadow; p.shadow_ebase = shadow_ebase; p.shadow_size = shadow_size;

@@ -96,7 +96,8 @@ __device__ __forceinline__ bool tap_axis_regular(const TapAxis& t, float top) {
 // the map) take the tap-by-tap path.  Same bits either way.  (A clamped window used to have a path of its own -- 36
 // single loads, i.e. 72 address registers, which set the register peak of the whole voxelize kernel: 158 VGPRs, 3 waves
 // per SIMD, for a case only the rim of the map ever sees.)
-__device__ __forceinline__ int pcf25(const uint32_t* __restrict__ words, uint32_t eb, int S, F3 c, float bias) {
+__device__ __forceinline__ int pcf25(const uint32_t* __restrict__ words, uint32_t eb, int S, F3 c, float bias,
+                                     const uint2* __restrict__ tiles = nullptr) {
     const float inv = __fdiv_rn(1.0f, (float)S);
     const float fS = (float)S, top = (float)(S - 1);
     TapAxis X, Y;
@@ -107,6 +108,16 @@ __device__ __forceinline__ int pcf25(const uint32_t* __restrict__ words, uint32_
     if (tap_axis_regular(X, top) && tap_axis_regular(Y, top)) {
         const uint32_t row0 = (uint32_t)(int)Y.f[0];
         const uint32_t col0 = (uint32_t)(int)X.f[0];
+        // Round 5: first the depth bounds of the map tile the window starts in (ONE 8-byte load from a table the fragments of
+        // a brick share, instead of twelve wide unaligned ones): a fragment away from every shadow boundary never fetches
+        // a window.
+        if (tiles) {
+            const int v = vct_pcf_tile_verdict(tiles, S, col0, row0, cur);
+#if defined(VCT_PROBE_TILE_ALWAYS)
+            return v >= 0 ? v : 12;          // timing probe only (wrong results): every window decided by the tiles
+#endif
+            if (v >= 0) return v;
+        }
         // One pass over the window: decode in place and take the smallest / largest decoded word on the way (the decode is
         // monotonic, so these are the window's depth bounds: vct_internal.h "PCF short cut").  A window the shadow boundary
         // does not cross ends here; the others evaluate the 25 taps from the same registers.  (The first form of the short
@@ -325,10 +336,13 @@ struct PassTri {
     float alb[3];
     uint32_t nrm[3];    // biased quantised face normal (voxel attributes)
 };
+#ifndef VCT_VOX_PREFETCH
+#define VCT_VOX_PREFETCH 0     // EXPERIMENT (round 5): the next fragment's triangle requested one iteration ahead (list entry two ahead)
+#endif
 template <bool ATTR, bool FALB>
-__device__ __forceinline__ void setup_pass(const VctVoxParams& p, int t, PassTri& r) {
+__device__ __forceinline__ void setup_pass(const VctVoxParams& p, int t, PassTri& r, const VctTri9* pre = nullptr) {
     if (p.shadow) {
-        const VctTri9 rec = *reinterpret_cast<const VctTri9*>(p.pos + (size_t)t * 9);     // three wide loads, not nine
+        const VctTri9 rec = pre ? *pre : *reinterpret_cast<const VctTri9*>(p.pos + (size_t)t * 9);     // three wide loads, not nine
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float* q = rec.v + 3 * k;
@@ -357,7 +371,7 @@ __device__ __forceinline__ FragValue frag_eval(const VctVoxParams& p, const Pass
         const F3 dc = {b0 * r.dc[0].x + b1 * r.dc[1].x + b2 * r.dc[2].x,
                        b0 * r.dc[0].y + b1 * r.dc[1].y + b2 * r.dc[2].y,
                        b0 * r.dc[0].z + b1 * r.dc[1].z + b2 * r.dc[2].z};
-        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f), 25.0f);   // vox.fs:46
+        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f, p.shadow_tiles), 25.0f);   // vox.fs:46
     }
     FragValue f;
     f.r = to_unorm8(alb[0] * sh); f.g = to_unorm8(alb[1] * sh); f.b = to_unorm8(alb[2] * sh);   // vox.fs:88
@@ -577,8 +591,11 @@ __device__ __forceinline__ void resolve_attr(uint32_t c, unsigned long long q0, 
 }
 
 // (4 waves per SIMD: the kernel waits on memory more than it computes; unbounded, hipcc takes 132-134 VGPRs and loses one)
+#ifndef VCT_VOX_MIN_BLOCKS
+#define VCT_VOX_MIN_BLOCKS 4
+#endif
 template <bool ATTR, bool FALB>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, VCT_VOX_MIN_BLOCKS)
 k_voxelize_bricks(const VctVoxParams p) {
     __shared__ unsigned long long acc[512 * 2];
     __shared__ unsigned long long acc_attr[ATTR ? 512 * 3 : 1];
@@ -608,6 +625,14 @@ k_voxelize_bricks(const VctVoxParams p) {
             bb = p.frag_bary[first + f];
             if (FALB) fa = falb[first + f];
         }
+#if VCT_VOX_PREFETCH
+        // two list entries and one triangle ahead: the triangle fetch (dependent on the list entry) leaves the chain of
+        // dependent round trips of an iteration, which is then the PCF window alone
+        uint32_t e1 = 0u;
+        if (f + blockDim.x < n) e1 = p.frag_sorted[first + f + blockDim.x];
+        VctTri9 rec = {};
+        if (p.shadow && f < n) rec = *reinterpret_cast<const VctTri9*>(p.pos + (size_t)(e >> 9) * 9);
+#endif
         for (uint32_t v = threadIdx.x; v < 512u * 2u; v += blockDim.x) acc[v] = 0ull;
         if (ATTR) for (uint32_t v = threadIdx.x; v < 512u * 3u; v += blockDim.x) acc_attr[v] = 0ull;
         __syncthreads();
@@ -616,14 +641,30 @@ k_voxelize_bricks(const VctVoxParams p) {
             uint32_t e_next = 0u;
             float2 bb_next = bb;
             VctF3 fa_next = fa;
+#if VCT_VOX_PREFETCH
+            e_next = e1;
+            uint32_t e2 = 0u;
+            if (fn + blockDim.x < n) e2 = p.frag_sorted[first + fn + blockDim.x];
+            VctTri9 rec_next = rec;
+            if (fn < n) {
+                if (p.shadow) rec_next = *reinterpret_cast<const VctTri9*>(p.pos + (size_t)(e_next >> 9) * 9);
+                bb_next = p.frag_bary[first + fn];
+                if (FALB) fa_next = falb[first + fn];
+            }
+#else
             if (fn < n) {
                 e_next = p.frag_sorted[first + fn];
                 bb_next = p.frag_bary[first + fn];
                 if (FALB) fa_next = falb[first + fn];
             }
+#endif
             const uint32_t local = e & 511u;
             PassTri r;
+#if VCT_VOX_PREFETCH
+            setup_pass<ATTR, FALB>(p, (int)(e >> 9), r, &rec);
+#else
             setup_pass<ATTR, FALB>(p, (int)(e >> 9), r);
+#endif
             const FragValue fv = frag_eval(p, r, bb.x, bb.y, FALB ? fa.v : r.alb);
             atomicAdd(&acc[2 * local], (unsigned long long)fv.r | ((unsigned long long)fv.g << 32));       // ds_add_u64
             atomicAdd(&acc[2 * local + 1], (unsigned long long)fv.b | (1ull << 32));
@@ -633,6 +674,9 @@ k_voxelize_bricks(const VctVoxParams p) {
                 atomicAdd(&acc_attr[3 * local + 2], (unsigned long long)r.nrm[1] | ((unsigned long long)r.nrm[2] << 32));
             }
             f = fn; e = e_next; bb = bb_next; fa = fa_next;
+#if VCT_VOX_PREFETCH
+            e1 = e2; rec = rec_next;
+#endif
         }
         __syncthreads();
         if (mi == 0xffffffffu) {
@@ -776,7 +820,7 @@ __device__ __forceinline__ void ref_fragment(const VctVoxParams& p, const RefSet
         const F3 dc = {l0 * r.dc[0].x + l1 * r.dc[1].x + l2 * r.dc[2].x,
                        l0 * r.dc[0].y + l1 * r.dc[1].y + l2 * r.dc[2].y,
                        l0 * r.dc[0].z + l1 * r.dc[1].z + l2 * r.dc[2].z};
-        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f), 25.0f);    // vox.fs:46
+        sh = __fdiv_rn((float)pcf25(p.shadow, p.shadow_ebase, p.shadow_size, dc, 0.002f, p.shadow_tiles), 25.0f);    // vox.fs:46
     }
     float alb[3];
     float duv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
