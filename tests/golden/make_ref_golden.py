@@ -95,21 +95,28 @@ def gl_trace_points(c):
 
 
 # ---- the pipeline case: DrawDepthTexture -> DrawVoxelTexture (+ glGenerateMipmap) -> Render ---------------------------
-PIPE = dict(V=32, S=256, W=96, H=64, eye=(10.0, -5.0, 52.0), center=(-5.0, -25.0, 0.0), fov_deg=45.0, scene_seed=11)
+PIPES = {
+    "ref_pipeline_v32": dict(V=32, S=256, W=96, H=64, eye=(10.0, -5.0, 52.0), center=(-5.0, -25.0, 0.0), fov_deg=45.0,
+                             scene_seed=11),
+    # a finer grid, a larger map, another camera (from the left, looking down along the cut-out sheet), other textures
+    "ref_pipeline_v64": dict(V=64, S=512, W=128, H=80, eye=(-48.0, 8.0, 30.0), center=(10.0, -35.0, -20.0), fov_deg=45.0,
+                             scene_seed=23),
+}
+PIPE = PIPES["ref_pipeline_v32"]
 
 
-def pipeline_matrices():
+def pipeline_matrices(c=None):
     from oracle import pyrefgl as rg
-    c = PIPE
+    c = c or PIPE
     return dict(model=rg.scale(0.05), depth_vp=rg.depth_view_proj(LIGHT), view=rg.look_at(c["eye"], c["center"], (0, 1, 0)),
                 proj=rg.perspective(np.deg2rad(c["fov_deg"]), c["W"] / c["H"], 0.1, 1000.0))
 
 
-def gl_pipeline():
+def gl_pipeline(c=None):
     from oracle import pyrefgl as rg
-    c = PIPE
+    c = c or PIPE
     sc = refscene.build(c["scene_seed"])
-    m = pipeline_matrices()
+    m = pipeline_matrices(c)
     tex = [rg.texture_create(t) for t in sc["textures"]]
     tex_chains = []
     for h, t in zip(tex, sc["textures"]):                      # the 2-D chains glGenerateMipmap made (Model.h:169)
@@ -165,8 +172,8 @@ def worker(mode, case, out_path):
     rg.lib(precise=(mode == "precise"))
     if case in TRACE_CASES:
         res = dict(rgba=gl_trace_points(TRACE_CASES[case]))
-    elif case == "ref_pipeline_v32":
-        res = gl_pipeline()
+    elif case in PIPES:
+        res = gl_pipeline(PIPES[case])
     elif case == "ref_mips3d":
         res = gl_mips3d()
     else:
@@ -208,11 +215,11 @@ def build_fixture(name):
             f["level0_args"] = np.array([c["V"], c["vol_seed"], c["occ"]], np.float64)
             f["level0_crc32"] = np.uint32(zlib.crc32(l0.tobytes()))
         return f
-    if name == "ref_pipeline_v32":
-        sc = refscene.build(PIPE["scene_seed"])
-        m = pipeline_matrices()
+    if name in PIPES:
+        sc = refscene.build(PIPES[name]["scene_seed"])
+        m = pipeline_matrices(PIPES[name])
         f = run_worker("precise", name)
-        f.update({k: np.asarray(v) for k, v in PIPE.items()})
+        f.update({k: np.asarray(v) for k, v in PIPES[name].items()})
         f.update(light_dir=np.array(LIGHT, np.float32), **m)
         for k in ("pos", "uv", "material", "nrm", "tan", "bit", "albedo", "specular", "mat_tex"):
             f[k] = sc[k]
@@ -224,7 +231,7 @@ def build_fixture(name):
     raise KeyError(name)
 
 
-ALL = list(TRACE_CASES) + ["ref_pipeline_v32", "ref_mips3d"]
+ALL = list(TRACE_CASES) + list(PIPES) + ["ref_mips3d"]
 
 
 def main():
