@@ -726,15 +726,21 @@ def hbm_stress(vct, device):
                                  "speedup": round(k_ms / r_ms, 3), "same_frame_and_steps": same,
                                  "mip_build_with_records_ms": round(build_ms, 3),
                                  "extra_bytes": int((vct.chain_texels(V) - V ** 3) * 32)}}
-    path = os.path.join(ROOT, "profiles", "trace_traffic_noise.json")
-    if os.path.exists(path):
+    # counter traffic of the committed rocprofv3 passes of the same workload (tools/profile_configs.sh: noise / noise_rec),
+    # replayed only for the kernel sources they were recorded on; corrected as profiles/r01_fetch_write_calibration.txt
+    # prescribes (2 x FETCH_SIZE + WRITE_SIZE) -- calibrated on streaming reads, so an UPPER estimate for scattered 32-byte ones
+    for key, fname, ms, tgt in (("", "trace_traffic_noise.json", k_ms, out),
+                                ("", "trace_traffic_noise_records.json", r_ms, out["footprint_records"])):
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
         with open(path) as fh:
             t = json.load(fh)
         if t.get("kernel_source_sha16") == kernel_source_sha() and t.get("hbm_bytes_per_launch"):
-            out["counter_GBps"] = round(t["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9, 1)
-            out["counter_frac_of_8TBps"] = round(out["counter_GBps"] / HBM_PEAK_GBS, 4)
-            out["counter_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / alg, 2)
-            out["counter_source"] = t.get("source")
+            tgt["counter_GBps"] = round(t["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+            tgt["counter_frac_of_8TBps"] = round(tgt["counter_GBps"] / HBM_PEAK_GBS, 4)
+            tgt["counter_over_algorithmic"] = round(t["hbm_bytes_per_launch"] / alg, 2)
+            tgt["counter_source"] = t.get("source")
     return out
 
 

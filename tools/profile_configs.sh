@@ -1,6 +1,6 @@
 #!/bin/bash
 # ON THE GPU BOX: kernel-trace/stats (+ HBM byte counters) of the non-default BASELINE configurations.
-# Usage: tools/profile_configs.sh <tag>   -> gpurun_out/prof_<tag>_{c3,c5,bistro1080,noise,tex}/   (c5 = the Bistro-class street, BASELINE configs[4])
+# Usage: tools/profile_configs.sh <tag>   -> gpurun_out/prof_<tag>_{c3,c5,bistro1080,noise,noise_rec,tex}/   (c5 = the Bistro-class street, BASELINE configs[4])
 set -u
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -26,3 +26,4 @@ run c5 yes --scene bistro --voxel-dim 1024 --width 3840 --height 2160
 run bistro1080 no --scene bistro
 run tex no --scene atrium-textured
 run noise yes --scene noise --noise-dense --gbuffer random --voxel-dim 1024
+run noise_rec yes --scene noise --noise-dense --gbuffer random --voxel-dim 1024 --footprint-records

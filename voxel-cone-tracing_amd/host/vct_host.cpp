@@ -1,5 +1,6 @@
 // vct_host.cpp -- scenes (procedural + OBJ/MTL reader with textures), camera and light matrices (see vct_host.h).
 #include "vct_host.h"
+#include "vct_image.h"
 
 #include <math.h>
 #include <string.h>
@@ -694,58 +695,15 @@ void build_bistro(vcth_scene* s, float detail, uint32_t seed) {
 }
 
 // Image files of an MTL's map_Kd / map_Ks / map_bump (the reference decodes them with stb_image,
-// R/Model.h:141-226): binary PPM (P6, maxval 255) and uncompressed true-colour TGA (type 2, 24 / 32 bpp) --
-// formats that need no entropy decoder.  Rows are stored bottom-up (row 0 at v = 0), which is what the
-// reference's aiProcess_FlipUVs + top-down stb rows amount to.
+// R/Model.h:141-226): PNG, baseline JPEG, BMP, TGA (raw / RLE, colour / grey), PPM / PGM -- host/vct_image.h, decoders
+// written from the format specifications.  Rows are stored bottom-up (row 0 at v = 0), which is what the reference's
+// aiProcess_FlipUVs + top-down stb rows amount to.
 bool load_image(const std::string& path, Texture& t) {
-    FILE* fp = fopen(path.c_str(), "rb");
-    if (!fp) return false;
-    std::vector<uint8_t> buf;
-    uint8_t tmp[65536];
-    size_t n;
-    while ((n = fread(tmp, 1, sizeof(tmp), fp)) > 0) buf.insert(buf.end(), tmp, tmp + n);
-    fclose(fp);
-    if (buf.size() >= 2 && buf[0] == 'P' && buf[1] == '6') {
-        size_t pos = 2;
-        int vals[3], got = 0;
-        while (got < 3 && pos < buf.size()) {
-            while (pos < buf.size() && (buf[pos] == ' ' || buf[pos] == '\n' || buf[pos] == '\r' || buf[pos] == '\t')) ++pos;
-            if (pos < buf.size() && buf[pos] == '#') { while (pos < buf.size() && buf[pos] != '\n') ++pos; continue; }
-            int v = 0, digits = 0;
-            while (pos < buf.size() && buf[pos] >= '0' && buf[pos] <= '9') { v = v * 10 + (buf[pos] - '0'); ++pos; ++digits; }
-            if (!digits) return false;
-            vals[got++] = v;
-        }
-        ++pos;      // the single whitespace after maxval
-        const int w = vals[0], h = vals[1];
-        if (got < 3 || vals[2] != 255 || w <= 0 || h <= 0 || pos + (size_t)w * h * 3 > buf.size()) return false;
-        t.w = w; t.h = h;
-        t.rgba.resize((size_t)w * h * 4);
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < w; ++x) {
-                const uint8_t* src = &buf[pos + ((size_t)(h - 1 - y) * w + x) * 3];
-                uint8_t* dst = &t.rgba[((size_t)y * w + x) * 4];
-                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = 255;
-            }
-        return true;
-    }
-    if (buf.size() >= 18 && buf[2] == 2 && (buf[16] == 24 || buf[16] == 32)) {      // TGA
-        const int w = buf[12] | (buf[13] << 8), h = buf[14] | (buf[15] << 8), bpp = buf[16] / 8;
-        const size_t off = 18 + buf[0];
-        const bool top_down = (buf[17] & 0x20) != 0;
-        if (w <= 0 || h <= 0 || off + (size_t)w * h * bpp > buf.size()) return false;
-        t.w = w; t.h = h;
-        t.rgba.resize((size_t)w * h * 4);
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < w; ++x) {
-                const int sy = top_down ? h - 1 - y : y;
-                const uint8_t* src = &buf[off + ((size_t)sy * w + x) * bpp];
-                uint8_t* dst = &t.rgba[((size_t)y * w + x) * 4];
-                dst[0] = src[2]; dst[1] = src[1]; dst[2] = src[0]; dst[3] = bpp == 4 ? src[3] : 255;   // BGR(A)
-            }
-        return true;
-    }
-    return false;
+    vct_image::Image im;
+    if (!vct_image::load(path, im)) return false;
+    t.w = im.w; t.h = im.h;
+    t.rgba.swap(im.rgba);
+    return true;
 }
 
 }  // namespace
