@@ -1021,6 +1021,16 @@ void vcth_scene_texture_info(const vcth_scene* s, int32_t i, int32_t* w, int32_t
     if (h) *h = ok ? s->textures[(size_t)i].h : 0;
 }
 
+int32_t vcth_image_load(const char* path, int32_t* width, int32_t* height, uint8_t* rgba) {
+    if (!path) return -1;
+    vct_image::Image im;
+    if (!vct_image::load(path, im)) return -1;
+    if (width) *width = im.w;
+    if (height) *height = im.h;
+    if (rgba) memcpy(rgba, im.rgba.data(), im.rgba.size());
+    return 0;
+}
+
 void vcth_scene_get_texture(const vcth_scene* s, int32_t i, uint8_t* rgba) {
     if (!s || !rgba || i < 0 || i >= (int32_t)s->textures.size()) return;
     memcpy(rgba, s->textures[(size_t)i].rgba.data(), s->textures[(size_t)i].rgba.size());

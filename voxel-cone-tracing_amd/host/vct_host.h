@@ -78,6 +78,11 @@ void vcth_scene_texture_info(const vcth_scene* s, int32_t i, int32_t* width, int
 void vcth_scene_get_texture(const vcth_scene* s, int32_t i, uint8_t* rgba);
 void vcth_scene_get_material_textures(const vcth_scene* s, int32_t* mat_tex);
 
+/* The decoder behind map_Kd / map_Ks / map_bump (host/vct_image.h: PNG, baseline JPEG, BMP, TGA raw / RLE, PPM / PGM --
+ * the containers stb_image serves the reference with, R/Model.h:141-226).  Two calls: rgba == NULL returns the size;
+ * then rgba [h][w][4], row 0 = BOTTOM row.  Returns 0, or -1 when the file is unreadable / unsupported / corrupt. */
+int32_t vcth_image_load(const char* path, int32_t* width, int32_t* height, uint8_t* rgba);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,21 @@ _lib.vcth_scene_get_texture.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 _lib.vcth_scene_get_material_textures.argtypes = [C.c_void_p, C.c_void_p]
 
 
+_lib.vcth_image_load.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def load_image(path):
+    """Decode a PNG / JPEG / BMP / TGA / PPM file with the OBJ reader's decoders: uint8 [h, w, 4], row 0 = bottom row.
+    Raises ValueError for an unreadable, unsupported or corrupt file."""
+    w, h = C.c_int32(), C.c_int32()
+    if _lib.vcth_image_load(os.fsencode(path), C.byref(w), C.byref(h), None) != 0:
+        raise ValueError(f"cannot decode {path}")
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    if _lib.vcth_image_load(os.fsencode(path), None, None, out.ctypes.data) != 0:
+        raise ValueError(f"cannot decode {path}")
+    return out
+
+
 def default_camera(position=None, yaw=None, pitch=None, zoom=None):
     cam = Camera()
     _lib.vcth_default_camera(C.byref(cam))
