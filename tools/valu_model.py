@@ -69,7 +69,7 @@ def main():
                         "-fno-slp-vectorize", "-fPIC", "-Wno-unused-function", "-S", "--cuda-device-only", "-o", out, src],
                        check=True, capture_output=True)
         text = open(out).read()
-    m = re.search(r"^_ZN12_GLOBAL__N_118k_trace_tile_splitILb1ELi1ELb0ELb0EEEv14VctTraceParams:.*?\.end_amdhsa_kernel", text, re.S | re.M)
+    m = re.search(r"^_ZN12_GLOBAL__N_118k_trace_tile_splitILb1ELi1ELb0ELb0ELb0EEEv14VctTraceParams:.*?\.end_amdhsa_kernel", text, re.S | re.M)
     body = m.group(0).split("\n")
     # the specular march = the largest depth-1 inner loop (the diffuse march, inside the cone loop, is depth 2 and has the
     # same body; small depth-1 loops, if any, are prologue code)
