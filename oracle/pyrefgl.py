@@ -53,7 +53,11 @@ def lib(precise=True, win=1024):
             os.environ["GALLIVM_PERF"] = PRECISE
         else:
             os.environ.pop("GALLIVM_PERF", None)
-        os.environ.setdefault("LP_NUM_THREADS", "8")
+        # One rasteriser thread: llvmpipe then draws bin by bin in submission order, so the reference's unordered
+        # imageStore (vox.fs:88: overlapping fragments race) comes out the same on every run.  Which of several writers
+        # of a voxel wins is still GL's choice (bins, not triangles, are the outer loop) -- the fixtures record how many
+        # triangles write each voxel and the tests compare such voxels against the set of candidates.
+        os.environ["LP_NUM_THREADS"] = "1"
         L = C.CDLL(build())
         L.refgl_log.restype = C.c_char_p
         L.refgl_string.restype = C.c_char_p

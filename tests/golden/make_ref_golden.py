@@ -101,6 +101,10 @@ PIPES = {
     # a finer grid, a larger map, another camera (from the left, looking down along the cut-out sheet), other textures
     "ref_pipeline_v64": dict(V=64, S=512, W=128, H=80, eye=(-48.0, 8.0, 30.0), center=(10.0, -35.0, -20.0), fov_deg=45.0,
                              scene_seed=23),
+    # the reference's own grid size (VCT.h:16), 16:9 like its 1280 x 720 window, another light, and AmbientFactor >= 0.5:
+    # the white clear colour branch of VCT.h:156-159 and a strong ambient term (trace.fs:225)
+    "ref_pipeline_v128": dict(V=128, S=1024, W=160, H=90, eye=(30.0, 20.0, 55.0), center=(-10.0, -30.0, -10.0), fov_deg=45.0,
+                              scene_seed=37, light=(0.35, 1.0, -0.2), ambient=0.6),
 }
 PIPE = PIPES["ref_pipeline_v32"]
 
@@ -108,7 +112,8 @@ PIPE = PIPES["ref_pipeline_v32"]
 def pipeline_matrices(c=None):
     from oracle import pyrefgl as rg
     c = c or PIPE
-    return dict(model=rg.scale(0.05), depth_vp=rg.depth_view_proj(LIGHT), view=rg.look_at(c["eye"], c["center"], (0, 1, 0)),
+    return dict(model=rg.scale(0.05), depth_vp=rg.depth_view_proj(c.get("light", LIGHT)),
+                view=rg.look_at(c["eye"], c["center"], (0, 1, 0)),
                 proj=rg.perspective(np.deg2rad(c["fov_deg"]), c["W"] / c["H"], 0.1, 1000.0))
 
 
@@ -142,8 +147,8 @@ def gl_pipeline(c=None):
     rg.draw_voxel_texture(G, m["model"], depth_mvp, meshes, generate_mipmap=True)
     nlev = int(np.log2(c["V"])) + 1
     levels = [rg.volume_get_level(c["V"], k) for k in range(nlev)]
-    fp = rg.frame_params(c["V"], G=G, camera_pos=c["eye"], light_dir=LIGHT, model=m["model"], view=m["view"],
-                         projection=m["proj"], depth_vp=m["depth_vp"])
+    fp = rg.frame_params(c["V"], G=G, camera_pos=c["eye"], light_dir=c.get("light", LIGHT), ambient=c.get("ambient", 0.1),
+                         model=m["model"], view=m["view"], projection=m["proj"], depth_vp=m["depth_vp"])
     frame, zbuf = rg.render(c["W"], c["H"], fp, meshes, want_depth=True)
     out = dict(ref_shadow=shadow, ref_frame=frame, ref_zbuf=zbuf,
                ref_chain=np.concatenate([l.reshape(-1, 4) for l in levels]))
@@ -219,8 +224,18 @@ def build_fixture(name):
         sc = refscene.build(PIPES[name]["scene_seed"])
         m = pipeline_matrices(PIPES[name])
         f = run_worker("precise", name)
+        # how many triangles store into each voxel in the reference's voxelization (geometry only; the oracle's raster, one
+        # triangle at a time): where it is > 1 the reference's result depends on an order GL does not define
+        V = PIPES[name]["V"]
+        count = np.zeros((V, V, V), np.uint8)
+        p = pyoracle.default_params(V)
+        for t in range(len(sc["pos"])):
+            one = pyoracle.make_scene(sc["pos"][t:t + 1], np.zeros(1, np.int32), sc["albedo"][:1])
+            count += (pyoracle.voxelize_reference(p, one)[..., 3] > 0).astype(np.uint8)
+        f["writers"] = count
         f.update({k: np.asarray(v) for k, v in PIPES[name].items()})
-        f.update(light_dir=np.array(LIGHT, np.float32), **m)
+        f.update(light_dir=np.array(PIPES[name].get("light", LIGHT), np.float32),
+                 ambient=np.float32(PIPES[name].get("ambient", 0.1)), **m)
         for k in ("pos", "uv", "material", "nrm", "tan", "bit", "albedo", "specular", "mat_tex"):
             f[k] = sc[k]
         for i, t in enumerate(sc["textures"]):
