@@ -266,10 +266,11 @@ def main():
         if inp["scene"] is not None:
             s = inp["scene"]
             ctx.upload_scene(s)         # triangles, frames, and (textured scenes) texture coordinates + maps
-            # 8 passes, every stage bracketed by events; reported = median of the last 5 (the first passes warm
-            # allocations and caches and bring the clocks up after the host-side scene set-up)
+            # 12 passes, every stage bracketed by events; reported = median of the last 5 (the first passes warm
+            # allocations and caches, bring the clocks up after the host-side scene set-up, and -- scenes with alpha-tested
+            # textures -- are the six passes in which the context samples both visibility forms before it keeps one)
             passes = []
-            for _ in range(8):
+            for _ in range(12):
                 ei = [ev() for _ in range(3)]
                 ei[0].record(); ctx.render_shadow_map(inp["light_vp"])        # DrawDepthTexture
                 ei[1].record(); ctx.render_gbuffer(inp["view_proj"])          # raster part of Render

@@ -87,10 +87,11 @@ def test_binned_visibility_on_scissored_rows_and_repeated_passes(vct):
 
 def test_automatic_choice_of_the_form_keeps_the_result(vct):
     """Without VCT_RASTER_PATH a scene with alpha-tested textures renders its first whole frame with the direct form,
-    the second with the binned one (both timed), and the faster from then on: five passes, five identical G-buffers."""
+    then samples both forms (warm-up + two timed passes each, alternating) and keeps the faster: nine passes, nine identical
+    G-buffers."""
     from voxel_cone_tracing_amd import scene as sc
     scene = sc.Scene(3, 0.03, 1234)
-    cams = [sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0)] * 5
+    cams = [sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0)] * 9
     a = render(vct, None, scene, 320, 180, 512, cams)
     want = render(vct, "direct", scene, 320, 180, 512, cams[:1])
     for x in a[1:]:
@@ -128,11 +129,11 @@ def test_binned_visibility_at_1080p_on_the_street(vct):
 
 
 def test_automatic_choice_on_a_slab_of_tile_rows(vct):
-    """A rank of a multi-GPU frame only rasterises its slab: the sample pair (direct, then binned over the same rows) and
+    """A rank of a multi-GPU frame only rasterises its slab: the sampling sequence (both forms over the same rows) and
     whatever form wins give the slab the direct form gives."""
     from voxel_cone_tracing_amd import scene as sc
     scene = sc.Scene(3, 0.03, 1234)
-    cams = [sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0)] * 4
+    cams = [sc.default_camera(position=(-58.0, -19.0, 1.5), yaw=0.0, pitch=12.0)] * 8
     a = render(vct, None, scene, 400, 300, 512, cams, rows=(5, 22))
     want = render(vct, "direct", scene, 400, 300, 512, cams[:1], rows=(5, 22))
     for x in a[1:]:

@@ -171,8 +171,11 @@ def test_compacted_trace_equals_the_tile_trace_on_sparse_frames(vct, oracle):
         assert ctx.last_step_count() == na
         assert np.array_equal(a, b)
         slab = ctx.trace(planes, rows=(2, 5))
+        with pytest.raises(vct.VctError):        # its step counts are per virtual tile: no per-row histogram to hand out
+            ctx.last_row_steps()
         ctx.set_trace_variant(0)
         assert np.array_equal(slab, ctx.trace(planes, rows=(2, 5)))
+        assert int(ctx.last_row_steps().sum()) == ctx.last_step_count()
 
 
 def test_trace_coherent_gbuffer_dense_volume(vct, oracle):

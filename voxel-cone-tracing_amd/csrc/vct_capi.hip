@@ -303,6 +303,7 @@ int launch_trace(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr, i
     c->last_row_stride = row_stride > 1 ? row_stride : 1;
     c->have_trace = true;
     c->last_was_screen_trace = true;
+    c->last_trace_compacted = variant == 4 && !c->cfg.anisotropic_mips;
     return VCT_OK;
 }
 
@@ -646,7 +647,7 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
         // measurement (vct_ctx.h raster_mode).
         const char* rp = getenv("VCT_RASTER_PATH");
         c->raster_mode = !rp ? 0 : (rp[0] == 'b' ? 2 : (rp[0] == 'd' ? 1 : 0));
-        for (int k = 0; k < 4; ++k) CREATE_TRY(hipEventCreate(&c->ev_auto[k]));
+        for (int k = 0; k < 8; ++k) CREATE_TRY(hipEventCreate(&c->ev_auto[k]));
         if (const char* fr = getenv("VCT_FOOTPRINT_RECORDS")) c->want_cells = fr[0] == '1';     // vct_set_footprint_records
         // VCT_BIN_TEST_CAPS="records,entries": the binned kernels are told these (smaller) capacities, so that a test can
         // drive the overflow paths -- sub-triangles rasterised in place, the merge by atomicMin -- on a small scene
@@ -724,7 +725,7 @@ void vct_destroy(vct_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_shadow) (void)hipEventDestroy(c->ev_shadow);
-    for (int k = 0; k < 4; ++k) if (c->ev_auto[k]) (void)hipEventDestroy(c->ev_auto[k]);
+    for (int k = 0; k < 8; ++k) if (c->ev_auto[k]) (void)hipEventDestroy(c->ev_auto[k]);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1196,29 +1197,37 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     HIP_TRY(c, hipSetDevice(c->device));
     // the form of the visibility stage (vct_ctx.h raster_mode)
     bool binned = c->raster_mode == 2;
-    int sample = -1;            // 0 / 1: this pass is the timed sample of the direct / the binned form
+    // Automatic choice: six passes -- direct (warm-up: the first pass after an upload pays for cold caches), direct timed,
+    // binned (warm-up: it also allocates its scratch), binned timed, direct timed, binned timed -- then the form with the
+    // smaller minimum is kept until the mesh or the textures change.  (Rounds 3-4 compared ONE cold direct pass with one
+    // warm binned pass: biased towards the binned form -- advisor, round 4.)  Results are identical either way.
+    static const struct { int form, slot; } kAutoSeq[6] = {{0, -1}, {0, 0}, {1, -1}, {1, 1}, {0, 2}, {1, 3}};
+    int slot = -1;              // >= 0: this pass is timed sample `slot`
     if (c->raster_mode == 0 && c->has_alpha_textures) {
-        if (c->auto_state == 2 && c->auto_choice < 0 && hipEventQuery(c->ev_auto[3]) == hipSuccess) {
-            float td = 0.0f, tb = 0.0f;
-            if (hipEventElapsedTime(&td, c->ev_auto[0], c->ev_auto[1]) == hipSuccess &&
-                hipEventElapsedTime(&tb, c->ev_auto[2], c->ev_auto[3]) == hipSuccess)
-                c->auto_choice = tb < td ? 1 : 0;
+        if (c->auto_state == 6 && c->auto_choice < 0 && hipEventQuery(c->ev_auto[7]) == hipSuccess) {
+            float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            bool ok = true;
+            for (int k = 0; k < 4; ++k) ok = ok && hipEventElapsedTime(&t[k], c->ev_auto[2 * k], c->ev_auto[2 * k + 1]) == hipSuccess;
+            if (ok) c->auto_choice = fminf(t[1], t[3]) < fminf(t[0], t[2]) ? 1 : 0;
         }
-        // the two samples must cover the same rows (a rank of a multi-GPU frame only ever rasterises its slab, and the
-        // slab may move while the load-aware boundaries settle: a sample pair over different rows starts again)
-        if (c->auto_choice < 0 && c->auto_state == 1 && (row0 != c->auto_rows[0] || row1 != c->auto_rows[1])) c->auto_state = 0;
+        // the samples must cover the same rows (a rank of a multi-GPU frame only ever rasterises its slab, and the
+        // slab may move while the load-aware boundaries settle: a sequence over different rows starts again)
+        if (c->auto_choice < 0 && c->auto_state > 0 && c->auto_state < 6 && (row0 != c->auto_rows[0] || row1 != c->auto_rows[1])) c->auto_state = 0;
         if (c->auto_choice >= 0) binned = c->auto_choice == 1;
-        else if (row1 > row0 && c->auto_state < 2) {
-            sample = c->auto_state; binned = sample == 1;
+        else if (row1 > row0 && c->auto_state < 6) {
+            binned = kAutoSeq[c->auto_state].form == 1;
+            slot = kAutoSeq[c->auto_state].slot;
             c->auto_rows[0] = row0; c->auto_rows[1] = row1;
-        }
+        } else if (c->auto_state >= 6) binned = true;        // all sampled, the last event still pending: stay on the last form
     }
+    const bool sampling = c->raster_mode == 0 && c->has_alpha_textures && c->auto_choice < 0 && row1 > row0 && c->auto_state < 6;
     VctRasterArgs a;
     int rc = raster_args(c, c->cfg.width, c->cfg.height, false, binned, s, a);
     if (rc) return rc;
-    if (sample >= 0) HIP_TRY(c, hipEventRecord(c->ev_auto[2 * sample], s));
+    if (slot >= 0) HIP_TRY(c, hipEventRecord(c->ev_auto[2 * slot], s));
     hipError_t e = vct_launch_gbuffer_visibility(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, s);
-    if (sample >= 0 && e == hipSuccess) { e = hipEventRecord(c->ev_auto[2 * sample + 1], s); c->auto_state = sample + 1; }
+    if (slot >= 0 && e == hipSuccess) e = hipEventRecord(c->ev_auto[2 * slot + 1], s);
+    if (sampling && e == hipSuccess) ++c->auto_state;
     if (e == hipSuccess && shadow_ready) e = hipStreamWaitEvent(s, shadow_ready, 0);
     if (e == hipSuccess)
         e = vct_launch_gbuffer_shade(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow, c->shadow_ebase,
@@ -1795,6 +1804,9 @@ int vct_last_row_steps(vct_ctx* c, uint64_t* rows, int32_t nrows) {
     if (!c->have_trace || !c->last_was_screen_trace)
         return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: the last march was not a screen trace");
     if (nrows != tiles_y(c)) return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: nrows must be the frame's tile rows, ceil(height / 8)");
+    // trace_variant 4 stores its step counts per VIRTUAL tile of the compaction list: only their total means anything
+    if (c->last_trace_compacted)
+        return fail(c, VCT_ERR_INVALID, "vct_last_row_steps: the last trace was compacted (config.trace_variant 4): no per-row histogram");
     HIP_TRY(c, hipSetDevice(c->device));
     std::vector<uint64_t> v;
     const int rc = row_steps(c, v);

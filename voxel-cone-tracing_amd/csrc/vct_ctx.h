@@ -57,6 +57,7 @@ struct vct_ctx {
     int last_row0 = 0, last_row1 = 0;
     int last_row_stride = 1;          // the last screen trace took every last_row_stride-th tile row of [last_row0, last_row1)
     bool have_trace = false;
+    bool last_trace_compacted = false;    // ... of trace_variant 4: counts per virtual tile, no per-row histogram
     bool last_was_screen_trace = false;   // the step counters hold a screen trace (indexed by tile row), not a bounce
     bool have_gbuffer = false;        // a G-buffer is resident (uploaded by vct_trace or rendered)
 
@@ -109,9 +110,9 @@ struct vct_ctx {
     int auto_rows[2] = {0, 0};         // tile rows of the timed sample pair
     int last_raster_form = 0;          // form of the last main-draw visibility pass: 1 direct, 2 tile-binned (vct_get_stage_counts [6])
     uint32_t bin_test_caps[2] = {0u, 0u};   // VCT_BIN_TEST_CAPS="records,entries": capacities REPORTED to the binned kernels (tests of the overflow paths)
-    int auto_state = 0;                                // 0: sample the direct form next, 1: the binned form, 2: both sampled
+    int auto_state = 0;                                // position in the sampling sequence (vct_capi.hip kAutoSeq); 6: all sampled
     int auto_choice = -1;                              // -1 undecided, 0 direct, 1 binned
-    hipEvent_t ev_auto[4] = {nullptr, nullptr, nullptr, nullptr};     // direct begin / end, binned begin / end
+    hipEvent_t ev_auto[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin / end of the four timed samples
     bool has_alpha_textures = false;
     void* bin_recs[2] = {nullptr, nullptr};
     uint32_t bin_rec_cap[2] = {0, 0};
