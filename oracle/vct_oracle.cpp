@@ -1,5 +1,5 @@
 // vct_oracle.cpp -- scalar CPU restatement of the voxel-cone-tracing GI path.
-// TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see vct_oracle.h for the full header).
+// TEST INFRASTRUCTURE ONLY; pinned against the reference's own GLSL (tests/test_ref_gl.py; see vct_oracle.h for the full header).
 // Build: g++ -O2 -ffp-contract=off -mfma (oracle/Makefile).  Every fused multiply-add is an
 // explicit fmaf(); everything else is one IEEE fp32 operation per C operator.
 #include "vct_oracle.h"

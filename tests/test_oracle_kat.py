@@ -1,6 +1,7 @@
 """Known-answer tests for the CPU oracle, derived from the reference's shader text
 (SURVEY.md section 4).  The reference has no tests of its own: these and the numpy
-restatement are what pins the oracle ("parity unpinned" otherwise)."""
+restatement pin the oracle from the shader TEXT; since round 5 tests/test_ref_gl.py also pins it against the outputs of the
+reference's own GLSL run on Mesa llvmpipe (oracle/ref_gl.c)."""
 import numpy as np
 import pytest
 

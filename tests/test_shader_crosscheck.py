@@ -9,9 +9,10 @@ oracle/vct_oracle.cpp vcto_shade_pixel on the same inputs.
 What it shows: the oracle's restatement of trace.fs:82-107 (march), :165-228 (frame, 6 + 1 cones, composite, the .rrra
 rule, discard) agrees with the shader as written -- operation by operation but for rounding (the stand-in uses the GLSL
 definitions of normalize / reflect / inverse and no fused multiply-adds; the oracle fixes its own fp32 order).
-What it does NOT show: parity stays UNPINNED -- `textureLod` here is the oracle's own sampler (no GL driver exists in
-this container), the material / height / shadow samplers are per-pixel constants (the G-buffer contract takes those
-fetches as inputs), and nothing in the reference pins a single output value.
+What it does NOT show by itself: `textureLod` here is the oracle's own sampler and the material / height / shadow
+samplers are per-pixel constants, so this test alone pins no output value.  (Round 5: the reference's shaders DO run in
+this container, unmodified, on Mesa llvmpipe -- oracle/ref_gl.c -- and tests/test_ref_gl.py holds the oracle to what
+they produce; this text-level cross-check stays as a second, driver-independent reading of the same shader.)
 Runs in the build container only: the reference tree does not travel to the GPU box."""
 import ctypes as C
 import os
@@ -256,7 +257,7 @@ def test_oracle_agrees_with_the_reference_voxelization_shaders(tmp_path):
     """S/Voxelization.gs main() (dominant axis, projection by ProjX / ProjY / ProjZ) and S/Voxelization.fs main() (voxel
     index from gl_FragCoord, 25-tap PCF / 25, imageStore of albedo * shadow) run as C++ next to the oracle's fragment-level
     restatements.  Same caveats as above: the shadow sampler under the shader is the oracle's bilinear fetch, the diffuse
-    sampler a per-fragment constant; parity stays unpinned."""
+    sampler a per-fragment constant (the executed-shader check of these stages is tests/test_ref_gl.py)."""
     from oracle import pyoracle
     lib = pyoracle._lib if hasattr(pyoracle, "_lib") else C.CDLL(ORACLE)
     rng = np.random.default_rng(5)

@@ -53,7 +53,11 @@ while time.time() < t_end:
                                         trace_variant=int(r.choice([0, 0, 1, 2])),
                                         anisotropic_mips=int(aniso_on), **kw)) as ctx:
         ctx.set_camera_position(cam); ctx.set_light_direction(light)
+        records = r.random() < 0.4                    # round 5: footprint records beside the chain (same bits)
+        if records and r.random() < 0.5: ctx.set_footprint_records(True)
         ctx.upload_volume(l0); ctx.build_mips()
+        if records: ctx.set_footprint_records(True)
+        counts["trace_records"] = counts.get("trace_records", 0) + int(records)
         if not np.array_equal(ctx.download_chain(), chain): fail("mips", seed)
         if aniso_on:
             an = oracle.build_mips_aniso(l0)
@@ -81,7 +85,7 @@ while time.time() < t_end:
     scn = oracle.make_scene(pos, mat, alb, shadow_depth=depth if use_shadow else None, light_vp=vp if use_shadow else None)
     with vct.Context(vct.default_config(voxel_dim=V, width=8, height=8, voxel_attributes=1)) as ctx:
         ctx.upload_triangles(pos, mat, alb)
-        if use_shadow: ctx.upload_shadow_map(depth, vp)
+        if use_shadow: ctx.upload_shadow_map(depth, vp)       # (an uploaded map always carries its tile bounds)
         ctx.voxelize(vct.VOX_REFERENCE); ctx.inject_light(); ctx.build_mips()
         if not np.array_equal(ctx.download_chain(), oracle.build_mips(oracle.voxelize_reference(p, scn))):
             fail("voxelize reference", seed)
@@ -116,6 +120,10 @@ while time.time() < t_end:
     path = [None, "direct", "binned", "binned"][int(r.integers(0, 4))]
     os.environ.pop("VCT_RASTER_PATH", None)
     if path: os.environ["VCT_RASTER_PATH"] = path
+    tiles = [None, "0", "1", "1"][int(r.integers(0, 4))]      # round 5: the rendered shadow map's tile bounds: default / never / always
+    os.environ.pop("VCT_SHADOW_TILES", None)
+    if tiles: os.environ["VCT_SHADOW_TILES"] = tiles
+    counts["tiles_" + str(tiles)] = counts.get("tiles_" + str(tiles), 0) + 1
     counts["raster_" + str(path)] = counts.get("raster_" + str(path), 0) + 1
     with vct.Context(vct.default_config(voxel_dim=16, width=w, height=h, shadow_map_size=S,
                                         texture_mipmaps=1 if mips else 0)) as ctx:
