@@ -275,7 +275,16 @@ int vct_comm_get_unique_id(void* id128);
 /* ncclCommInitRank on the context's device; allocates the two gather buffers (the root's are whole
  * frames), a communication stream and events.  Collective: every rank must call it. */
 /* All or nothing: on any failure (allocation, ncclCommInitRank) nothing stays attached to the context and the call
- * may be repeated. */
+ * may be repeated.
+ * VCT_COMM_MODE=direct in the environment (EXPERIMENTAL, default off; no reference counterpart): "direct slabs" -- no
+ * RCCL.  The root publishes hipIpc handles of its two frame buffers in a POSIX shared-memory block named after the id,
+ * every other rank maps them and its trace kernel stores its slab straight into the root's frame (8 B per pixel over
+ * xGMI); the frame's exchange step is a pair of flags in that block (mapped into every rank's GPU) instead of a
+ * collective: rank: wait "root is past frame f - 2" -> trace -> "slab f done"; root: trace -> wait for every slab.
+ * Every wait has the communicator's deadline.  All other vct_comm_* / vct_frame_step calls work unchanged (equal,
+ * load-aware and interleaved slabs); vct_comm_get_unique_id then returns 128 random bytes and vct_comm_info reports
+ * version 0.  Ranks must be processes of one host.  Tested with several ranks on ONE GPU (tests/test_gpu_multi.py);
+ * never run across GPUs -- no multi-GPU box was available to this build. */
 int vct_comm_init(vct_ctx* ctx, const void* id128, int32_t rank, int32_t world);
 int vct_comm_destroy(vct_ctx* ctx);
 int vct_comm_slab(vct_ctx* ctx, int32_t* tile_row0, int32_t* tile_row1);

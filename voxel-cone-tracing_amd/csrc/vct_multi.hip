@@ -20,7 +20,11 @@
 // carries no link-time dependency on a particular librccl build (a Python process that already loaded
 // torch's bundled RCCL reuses that one).
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <string>
@@ -96,6 +100,51 @@ k_deinterleave(const uint2* __restrict__ gathered, uint2* __restrict__ frame, in
     }
 }
 
+// ---- direct slabs (VCT_COMM_MODE=direct; experimental, default off) ------------------------------------------------
+// Every rank's trace kernel stores its slab straight into the ROOT's frame buffers (mapped through hipIpc handles: 8 B
+// per pixel over xGMI), and the frame's exchange step is two flags instead of a collective: no RCCL at all.
+//   rendezvous   a POSIX shared-memory block named after the communicator id: the root publishes the IPC handles of
+//                its two frame buffers there, the ranks open them; the same block -- page-locked and mapped into every
+//                rank's GPU (coherent host memory) -- carries the flags
+//   step f, buffer k = f & 1, generation g = f / 2 + 1
+//     rank r > 0:  wait release[k] >= g - 1 (the root is past frame f - 2)  ->  trace into the mapped frame  ->  done[k][r] = g
+//     root:        release[k] = g - 1 (ordered behind everything it issued on its stream: the consumer of frame f - 2)
+//                  ->  trace its own slab  ->  wait done[k][r] >= g for every r  ->  (de-interleave)  ->  frame f is there
+//   Every wait is one lane spinning on a system-scope load with a deadline (the communicator's timeout): a dead peer
+//   costs a wrong frame and an error from vct_comm_sync, never a hang.
+// NOT validated across GPUs (one GPU per box here): what is tested is two processes on ONE GPU (IPC mapping, flags,
+// ordering, the failure path).  Whether peer stores are visible to the root's next kernel without more than the
+// end-of-kernel release is what the first run on a multi-GPU node has to show; hence off by default.
+#define VCT_DIRECT_MAX_RANKS 64
+struct DirectShm {
+    uint32_t magic, world;
+    volatile uint32_t handles_ready;                    // root: the two handles below are valid
+    volatile uint32_t attached[VCT_DIRECT_MAX_RANKS];   // rank r: opened them
+    hipIpcMemHandle_t frame[2];
+    // flags (GPU-written, GPU-read; host memory mapped into every rank's device)
+    uint32_t done[2][VCT_DIRECT_MAX_RANKS];
+    uint32_t release[2];
+    uint32_t timed_out;                                 // a wait gave up
+};
+
+// lanes 0 .. n-1 each wait for flags[lane * stride] >= want; deadline in wall-clock ticks (100 MHz)
+__global__ void k_flag_wait(const uint32_t* flags, int n, int stride, uint32_t want, uint32_t* timed_out, long long ticks) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(flags + (size_t)i * stride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        if ((long long)wall_clock64() - t0 > ticks) {
+            __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+__global__ void k_flag_set(uint32_t* flag, uint32_t v) {
+    __threadfence_system();
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 struct vct_comm {
@@ -123,6 +172,12 @@ struct vct_comm {
     hipEvent_t g0[2] = {nullptr, nullptr}, g1[2] = {nullptr, nullptr};     // timing: around the frame's exchange step
     unsigned long long frames = 0;     // steps issued
     int last = -1;                     // buffer of the last issued step
+    // direct slabs (VCT_COMM_MODE=direct): no RCCL communicator; see DirectShm above
+    bool direct = false;
+    char shm_name[48] = {0};
+    DirectShm* shm = nullptr;          // host mapping of the rendezvous block
+    DirectShm* shm_dev = nullptr;      // the same block as this rank's GPU sees it
+    uint16_t* peer_frame[2] = {nullptr, nullptr};      // ranks > 0: the root's frame buffers, mapped
     int timeout_ms = 60000;            // vct_comm_sync gives up after this long and aborts the communicator
     bool broken = false;               // the communicator was aborted (a peer died or hung): only vct_comm_destroy is left
 };
@@ -145,6 +200,11 @@ static int comm_fail(vct_ctx* c, vct_comm* m, const std::string& what, ncclResul
 static void comm_free(vct_comm* m) {
     if (!m) return;
     if (m->comm_stream && !m->broken) (void)hipStreamSynchronize(m->comm_stream);
+    if (m->direct) {
+        for (int k = 0; k < 2; ++k) if (m->peer_frame[k]) (void)hipIpcCloseMemHandle(m->peer_frame[k]);
+        if (m->shm) { (void)hipHostUnregister(m->shm); munmap(m->shm, sizeof(DirectShm)); }
+        if (m->rank == 0 && m->shm_name[0]) shm_unlink(m->shm_name);
+    }
     if (m->comm) {
         if (m->broken && rccl()->CommAbort) (void)rccl()->CommAbort(m->comm);
         else if (rccl()->CommDestroy) (void)rccl()->CommDestroy(m->comm);
@@ -218,11 +278,74 @@ int vct_slab_partition_weighted(const uint64_t* row_cost, int32_t tile_rows, int
 
 int vct_comm_get_unique_id(void* id128) {
     if (!id128) return VCT_ERR_INVALID;
+    const char* mode = getenv("VCT_COMM_MODE");
+    if (mode && mode[0] == 'd') {              // direct slabs never touch RCCL: any 128 unpredictable bytes name the rendezvous
+        FILE* fp = fopen("/dev/urandom", "rb");
+        const bool ok = fp && fread(id128, 1, 128, fp) == 128;
+        if (fp) fclose(fp);
+        return ok ? VCT_OK : vct_fail(nullptr, VCT_ERR_DEVICE, "vct_comm_get_unique_id: /dev/urandom unreadable");
+    }
     Rccl* r = rccl();
     if (!r->err.empty()) return vct_fail(nullptr, VCT_ERR_DEVICE, r->err);
     ncclUniqueId id;
     if (r->GetUniqueId(&id) != ncclSuccess) return vct_fail(nullptr, VCT_ERR_DEVICE, "ncclGetUniqueId failed");
     memcpy(id128, id.internal, 128);
+    return VCT_OK;
+}
+
+// Rendezvous of the direct mode: shared block, the root's IPC handles, every rank's mapping.  Host-side waits are
+// bounded by the communicator's timeout.
+static int direct_attach(vct_ctx* c, vct_comm* m, const void* id128) {
+    if (m->world > VCT_DIRECT_MAX_RANKS) return vct_fail(c, VCT_ERR_INVALID, "direct slabs: at most 64 ranks");
+    const unsigned char* id = (const unsigned char*)id128;
+    snprintf(m->shm_name, sizeof(m->shm_name), "/vct_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", id[0], id[1], id[2], id[3],
+             id[4], id[5], id[6], id[7], id[8], id[9], id[10], id[11]);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto expired = [&]() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > m->timeout_ms; };
+    int fd = -1;
+    if (m->rank == 0) {
+        shm_unlink(m->shm_name);
+        fd = shm_open(m->shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, sizeof(DirectShm)) != 0) { if (fd >= 0) close(fd); return vct_fail(c, VCT_ERR_DEVICE, "direct slabs: cannot create the rendezvous block"); }
+    } else {
+        while ((fd = shm_open(m->shm_name, O_RDWR, 0600)) < 0) {
+            if (expired()) return vct_fail(c, VCT_ERR_DEVICE, "direct slabs: the root's rendezvous block never appeared");
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        struct stat st;
+        while (fstat(fd, &st) == 0 && (size_t)st.st_size < sizeof(DirectShm)) {      // created, not sized yet
+            if (expired()) { close(fd); return vct_fail(c, VCT_ERR_DEVICE, "direct slabs: rendezvous block not sized"); }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+    }
+    void* p = mmap(nullptr, sizeof(DirectShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return vct_fail(c, VCT_ERR_DEVICE, "direct slabs: mmap failed");
+    m->shm = (DirectShm*)p;
+    hipError_t e = hipHostRegister(p, sizeof(DirectShm), hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&m->shm_dev, p, 0);
+    if (e != hipSuccess) { munmap(p, sizeof(DirectShm)); m->shm = nullptr; return vct_fail(c, VCT_ERR_DEVICE, std::string("direct slabs: hipHostRegister: ") + hipGetErrorString(e)); }
+    if (m->rank == 0) {
+        m->shm->world = (uint32_t)m->world;
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipIpcGetMemHandle(&m->shm->frame[k], m->buf[k]);
+        if (e != hipSuccess) return vct_fail(c, VCT_ERR_DEVICE, std::string("direct slabs: hipIpcGetMemHandle: ") + hipGetErrorString(e));
+        m->shm->magic = 0x56435444u;
+        __atomic_store_n(&m->shm->handles_ready, 1u, __ATOMIC_RELEASE);
+        for (int r = 1; r < m->world; ++r)
+            while (!__atomic_load_n(&m->shm->attached[r], __ATOMIC_ACQUIRE)) {
+                if (expired()) return vct_fail(c, VCT_ERR_DEVICE, "direct slabs: rank " + std::to_string(r) + " never attached");
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+    } else {
+        while (!__atomic_load_n(&m->shm->handles_ready, __ATOMIC_ACQUIRE)) {
+            if (expired()) return vct_fail(c, VCT_ERR_DEVICE, "direct slabs: the root never published its frame buffers");
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        for (int k = 0; k < 2 && e == hipSuccess; ++k)
+            e = hipIpcOpenMemHandle((void**)&m->peer_frame[k], m->shm->frame[k], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return vct_fail(c, VCT_ERR_DEVICE, std::string("direct slabs: hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+        __atomic_store_n(&m->shm->attached[m->rank], 1u, __ATOMIC_RELEASE);
+    }
     return VCT_OK;
 }
 
@@ -233,12 +356,15 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
     if (!c) return VCT_ERR_INVALID;
     if (!id128 || world <= 0 || rank < 0 || rank >= world) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: bad rank / world / id");
     if (c->comm) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: already initialised (vct_comm_destroy first)");
-    Rccl* r = rccl();
-    if (!r->err.empty()) return vct_fail(c, VCT_ERR_DEVICE, r->err);
+    const char* mode = getenv("VCT_COMM_MODE");
+    const bool direct = mode && mode[0] == 'd';       // direct slabs: no RCCL (see DirectShm)
+    Rccl* r = direct ? nullptr : rccl();
+    if (r && !r->err.empty()) return vct_fail(c, VCT_ERR_DEVICE, r->err);
     HIP_TRY(c, hipSetDevice(c->device));
     vct_comm* m = new vct_comm();
     m->rank = rank;
     m->world = world;
+    m->direct = direct;
     vct_slab_partition(c->cfg.height, world, rank, &m->row0, &m->row1, &m->rows_per_rank);
     m->slab_halves = (size_t)m->rows_per_rank * VCT_TILE * c->cfg.width * 4;
     m->buf_halves = rank == 0 ? m->slab_halves * world : m->slab_halves;
@@ -253,8 +379,10 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
         e = hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking);
     }
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-        e = hipMalloc(&m->buf[k], m->buf_halves * 2);
-        if (e == hipSuccess) e = hipMemsetAsync(m->buf[k], 0, m->buf_halves * 2, c->stream);
+        if (!(direct && rank != 0)) {        // (a rank of the direct mode owns no slab buffer: it writes the root's)
+            e = hipMalloc(&m->buf[k], m->buf_halves * 2);
+            if (e == hipSuccess) e = hipMemsetAsync(m->buf[k], 0, m->buf_halves * 2, c->stream);
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->traced[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->gathered[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&m->g0[k]);
@@ -266,6 +394,12 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
         comm_free(m);
         return vct_fail(c, e == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE,
                         std::string("vct_comm_init: ") + hipGetErrorString(e));
+    }
+    if (direct) {
+        const int rc = direct_attach(c, m, id128);
+        if (rc) { comm_free(m); return rc; }
+        c->comm = m;
+        return VCT_OK;
     }
     ncclUniqueId id;
     memcpy(id.internal, id128, 128);
@@ -328,7 +462,7 @@ int vct_comm_set_slab_rows(vct_ctx* c, const int32_t* starts) {
         m->row1 = starts[m->rank + 1];
     }
     const size_t need = m->rank == 0 ? m->buf_halves : (size_t)(m->row1 - m->row0) * VCT_TILE * c->cfg.width * 4;
-    if (need > m->buf_halves) {
+    if (need > m->buf_halves && !m->direct) {        // (direct slabs: a rank owns no buffer, it writes the root's frame)
         uint16_t* nb[2] = {nullptr, nullptr};
         for (int k = 0; k < 2; ++k) {
             const hipError_t e = hipMalloc(&nb[k], need * 2);
@@ -378,7 +512,7 @@ int vct_frame_step(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     vct_comm* m = c->comm;
     if (!m) return vct_fail(c, VCT_ERR_INVALID, "vct_frame_step: call vct_comm_init first");
-    if (m->broken || !m->comm) return vct_fail(c, VCT_ERR_DEVICE, "vct_frame_step: the communicator was aborted (vct_comm_destroy, then vct_comm_init again)");
+    if (m->broken || (!m->comm && !m->direct)) return vct_fail(c, VCT_ERR_DEVICE, "vct_frame_step: the communicator was aborted (vct_comm_destroy, then vct_comm_init again)");
     if (!c->have_gbuffer) return vct_fail(c, VCT_ERR_INVALID, "vct_frame_step: no G-buffer resident yet");
     HIP_TRY(c, hipSetDevice(c->device));
     const int k = (int)(m->frames & 1ull);
@@ -389,6 +523,55 @@ int vct_frame_step(vct_ctx* c) {
     const size_t first_row_halves = (size_t)m->row0 * VCT_TILE * c->cfg.width * 4;
     HIP_TRY(c, hipStreamWaitEvent(c->stream, m->gathered[k], 0));    // buffer k is free once its last gather is done
     const bool uneven = !m->starts.empty();
+    if (m->direct) {
+        // direct slabs (see DirectShm): flags instead of a collective, the slab stored straight into the root's frame
+        const uint32_t gen = (uint32_t)(m->frames >> 1) + 1u;
+        const long long ticks = (long long)m->timeout_ms * 100000ll;           // wall_clock64 counts at 100 MHz
+        const size_t row_halves = (size_t)VCT_TILE * c->cfg.width * 4;
+        if (m->rank == 0) {
+            hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, c->stream, &m->shm_dev->release[k], gen - 1u);
+            HIP_TRY(c, hipGetLastError());
+            uint16_t* base = uneven ? m->buf[k] : slab - first_row_halves;
+            const int rc = m->interleaved ? vct_launch_trace_rows(c, m->row0, m->row1, slab, m->world, true)
+                                          : vct_launch_trace_rows(c, m->row0, m->row1, base);
+            if (rc) return rc;
+            const hipStream_t cs = m->same_stream ? c->stream : m->comm_stream;
+            if (!m->same_stream) {
+                HIP_TRY(c, hipEventRecord(m->traced[k], c->stream));
+                HIP_TRY(c, hipStreamWaitEvent(m->comm_stream, m->traced[k], 0));
+            }
+            HIP_TRY(c, hipEventRecord(m->g0[k], cs));
+            if (m->world > 1) {
+                hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, cs, &m->shm_dev->done[k][1], m->world - 1, 1, gen,
+                                   &m->shm_dev->timed_out, ticks);
+                HIP_TRY(c, hipGetLastError());
+            }
+            if (m->interleaved) {
+                hipLaunchKernelGGL(k_deinterleave, dim3(2048), dim3(256), 0, cs, (const uint2*)m->buf[k],
+                                   (uint2*)m->il_frame[k], c->cfg.width, c->cfg.height, m->world, m->slab_halves / 4);
+                HIP_TRY(c, hipGetLastError());
+            }
+            HIP_TRY(c, hipEventRecord(m->g1[k], cs));
+            HIP_TRY(c, hipEventRecord(m->gathered[k], cs));
+        } else {
+            hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, c->stream, &m->shm_dev->release[k], 1, 1, gen - 1u,
+                               &m->shm_dev->timed_out, ticks);
+            HIP_TRY(c, hipGetLastError());
+            // where this rank's slab lives in the root's buffer k: packed slab `rank` (equal / interleaved) or its own rows
+            uint16_t* peer_slab = m->peer_frame[k] + (uneven ? (size_t)m->starts[m->rank] * row_halves : (size_t)m->rank * m->slab_halves);
+            const int rc = m->interleaved ? vct_launch_trace_rows(c, m->row0, m->row1, peer_slab, m->world, true)
+                                          : vct_launch_trace_rows(c, m->row0, m->row1, peer_slab - first_row_halves);
+            if (rc) return rc;
+            HIP_TRY(c, hipEventRecord(m->g0[k], c->stream));
+            hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, c->stream, &m->shm_dev->done[k][m->rank], gen);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventRecord(m->g1[k], c->stream));
+            HIP_TRY(c, hipEventRecord(m->gathered[k], c->stream));
+        }
+        m->last = k;
+        ++m->frames;
+        return VCT_OK;
+    }
     uint16_t* out_base = (m->rank == 0 && uneven) ? m->buf[k] : slab - first_row_halves;
     // interleaved: every world-th tile row from `rank` on, back to back at the start of the slab
     const int rc = m->interleaved ? vct_launch_trace_rows(c, m->row0, m->row1, slab, m->world, true)
@@ -458,7 +641,14 @@ int vct_comm_sync(vct_ctx* c) {
         const hipError_t qc = hipStreamQuery(c->stream);
         if (qc != hipSuccess && qc != hipErrorNotReady) HIP_TRY(c, qc);
         const hipError_t q = hipStreamQuery(m->comm_stream);
-        if (q == hipSuccess && qc == hipSuccess) return VCT_OK;
+        if (q == hipSuccess && qc == hipSuccess) {
+            if (m->direct && __atomic_load_n(&m->shm->timed_out, __ATOMIC_ACQUIRE)) {
+                m->broken = true;
+                return vct_fail(c, VCT_ERR_DEVICE, "vct_comm_sync: a rank's flag wait gave up after " + std::to_string(m->timeout_ms) +
+                                                   " ms (a peer died or hangs); the frame is incomplete, communicator unusable");
+            }
+            return VCT_OK;
+        }
         if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(c, q);
         ncclResult_t async = ncclSuccess;
         if (m->comm && rccl()->CommGetAsyncError && rccl()->CommGetAsyncError(m->comm, &async) == ncclSuccess &&
@@ -481,6 +671,10 @@ int vct_comm_sync(vct_ctx* c) {
 int vct_comm_info(vct_ctx* c, int32_t out[4]) {
     if (!c || !out) return VCT_ERR_INVALID;
     vct_comm* m = c->comm;
+    if (m && m->direct) {        // direct slabs: no RCCL; what the rendezvous block says, version 0
+        out[0] = (int32_t)m->shm->world; out[1] = m->rank; out[2] = c->device; out[3] = 0;
+        return VCT_OK;
+    }
     if (!m || !m->comm) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_info: no usable communicator (vct_comm_init)");
     Rccl* r = rccl();
     int v[4] = {-1, -1, -1, -1};

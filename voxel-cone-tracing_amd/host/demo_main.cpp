@@ -114,7 +114,9 @@ int main(int argc, char** argv) {
     if (gpus > 0) {                                         // a rank of a multi-GPU run
         voxel_cone_tracing.Rank = rank;
         voxel_cone_tracing.World = gpus;
-        voxel_cone_tracing.Device = rank;
+        // (VCT_DEMO_SINGLE_DEVICE=1: every rank on device 0 -- only the direct-slab mode, VCT_COMM_MODE=direct, accepts that;
+        // it is how that mode is tested on a one-GPU box)
+        voxel_cone_tracing.Device = getenv("VCT_DEMO_SINGLE_DEVICE") ? 0 : rank;
         const std::string tmp = std::string(idfile) + ".tmp";
         if (rank == 0) {                                    // create the RCCL id, publish it atomically
             if (vct_comm_get_unique_id(voxel_cone_tracing.CommId) != VCT_OK) { printf("%s\n", vct_last_error(nullptr)); return 6; }
