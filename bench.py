@@ -240,7 +240,11 @@ def main():
             ctypes.CDLL(None).fflush(None)
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    native = (world > 1 or force_dist) and backend == "nccl"
+    # VCT_COMM_MODE=direct (experimental "direct slabs": no RCCL, the ranks' kernels store into the root's frame through
+    # hipIpc mappings, flags instead of a collective) does not mind ranks sharing a device: with it the native step loop
+    # runs under the gloo functional backend too -- the one way to drive N > 1 native ranks on a one-GPU box
+    direct = os.environ.get("VCT_COMM_MODE", "")[:1] == "d"
+    native = (world > 1 or force_dist) and (backend == "nccl" or direct)
 
     w, h, V = args.width, args.height, args.voxel_dim
     inp = build_inputs(args, vct, sc)
@@ -579,11 +583,13 @@ def main():
                        "anisotropic_mips": bool(args.anisotropic),
                        "parallelism": "single GPU" if world == 1 else
                        f"{world} screen-tile slabs ({args.slabs if native else 'equal'}) + 1 RCCL gather " +
-                       ("(native vct_frame_step)" if native else "(Python-paced step, torch.distributed gather)") +
+                       ("(native vct_frame_step" + (", direct slabs: no collective)" if direct else ")") if native
+                        else "(Python-paced step, torch.distributed gather)") +
                        ("" if backend == "nccl" else f" [FUNCTIONAL TEST over {backend}, not a measurement]") +
                        ("" if not native_fallback else f" [native communicator unavailable: {native_fallback}]"),
                        "slabs": args.slabs if (native and use_dist) else ("equal" if use_dist else None),
                        "trace_variant": args.variant, "footprint_records": bool(args.footprint_records),
+                       "comm_mode": None if world == 1 and not force_dist else ("direct slabs (experimental)" if direct and native else "rccl"),
                        # compute units kept away from the trace for the gather's stream (VCT_COMM_RESERVED_CUS; 0: none)
                        "comm_reserved_cus": ctx.stage_counts().get("comm_reserved_cus", 0),
                        # visibility form of the G-buffer pass that was timed (chosen per context by timing both)

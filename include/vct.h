@@ -293,7 +293,8 @@ int vct_comm_slab(vct_ctx* ctx, int32_t* tile_row0, int32_t* tile_row1);
  * k is gathered; measured on one GPU the two do NOT overlap (the gather's kernels queue behind the trace's waves), so
  * budget slab trace + ~23 us dependent dispatch + wire time per frame.  Collective: every rank calls it once per frame. */
 int vct_frame_step(vct_ctx* ctx);
-/* Waits for this rank's trace and gather.  A peer that died or hangs would keep every other rank inside the
+/* Waits for this rank's trace and gather.  Compute still queued in front of the last step's exchange gets the
+ * timeout to itself first (its "slab traced" event); then: a peer that died or hangs would keep every other rank inside the
  * collective forever: after the communicator's timeout (default 60 s; VCT_COMM_TIMEOUT_MS in the environment or
  * vct_comm_set_timeout_ms) or on an asynchronous RCCL error the communicator is ABORTED (ncclCommAbort) and the call
  * returns VCT_ERR_DEVICE; afterwards only vct_comm_destroy (then a new vct_comm_init) is accepted on it. */

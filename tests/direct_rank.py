@@ -29,7 +29,7 @@ ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
 vp = sc.camera_view_proj(cam, w, h)
 ctx.render_gbuffer(vp)
 alone = ctx.trace_current() if rank == 0 else None
-steps_alone = ctx.last_step_count()
+steps_alone = ctx.last_step_count() if rank == 0 else 0
 
 if rank == 0:
     ident = vct.comm_unique_id()

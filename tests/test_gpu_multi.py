@@ -395,3 +395,26 @@ def test_cpp_caller_direct_slabs_two_ranks_on_one_gpu(vct):
     def fnv(txt):
         return [t for t in txt.split() if t.startswith("fnv1a=")][-1]
     assert "gpus=2" in two.stdout and fnv(one.stdout) == fnv(two.stdout)
+
+
+@pytest.mark.parametrize("slabs", ["balanced", "interleaved"])
+def test_bench_native_loop_two_ranks_direct_slabs_on_one_gpu(slabs):
+    """bench.py --gpus 2 through its NATIVE N-rank step loop (vct_frame_step per frame, load-aware slabs with two
+    feedback rounds or interleaved rows, the acceptance check, the self-describing multi_gpu block) with two real ranks:
+    possible on a one-GPU box only in the direct-slab mode (RCCL refuses two ranks on one device).  A functional run,
+    labelled as such in the line."""
+    env = dict(os.environ, VCT_COMM_MODE="direct", VCT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--width", "320",
+           "--height", "180", "--voxel-dim", "64", "--scene-detail", "0.15", "--shadow-size", "512", "--cpu-seconds", "0",
+           "--no-sweep", "--slabs", slabs]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gathered_frame_equals_single_gpu_frame"] is True
+    assert "direct slabs" in d["config"]["comm_mode"] and "FUNCTIONAL TEST" in d["config"]["parallelism"]
+    mg = d["multi_gpu"]
+    assert mg["rccl_nranks"] == 2 and [p["rank"] for p in mg["per_rank"]] == [0, 1]
+    assert all(p["slab_kernel_ms"] > 0 and p["slab_cone_steps"] > 0 for p in mg["per_rank"])
+    assert sum(p["slab_cone_steps"] for p in mg["per_rank"]) == d["cone_steps_per_frame"]

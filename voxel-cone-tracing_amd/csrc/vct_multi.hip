@@ -635,6 +635,19 @@ int vct_comm_sync(vct_ctx* c) {
     // gathered[k] (vct_frame_step), i.e. behind a collective a dead peer never finishes -- a blocking
     // hipStreamSynchronize(c->stream) here would hang before the deadline loop was ever reached.
     // After the abort below the stuck collective's kernel ends, its event completes and both streams drain.
+    // Compute queued on the context's stream in front of the exchange (several 4K / 1024^3 GI passes, a first-use divisor
+    // self-test) is not communication: it gets a deadline of its own -- the last step's "slab traced" event -- and the
+    // communication deadline starts when that has fired (advisor, round 4).  Both are bounded: a trace that waits behind
+    // the gather of a dead peer two frames back never fires the event, and the second loop then aborts as before.
+    if (m->last >= 0 && !m->same_stream && !m->direct && m->traced[m->last]) {
+        const auto tc = std::chrono::steady_clock::now();
+        int sp = 0;
+        while (hipEventQuery(m->traced[m->last]) == hipErrorNotReady) {
+            if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tc).count() > m->timeout_ms) break;
+            if (++sp < 2000) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
     while (true) {
