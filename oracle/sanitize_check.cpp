@@ -8,8 +8,49 @@
 
 #include <vector>
 
+#include <dirent.h>
+
+#include <string>
+
 #include "../voxel-cone-tracing_amd/host/vct_host.h"
+#include "../voxel-cone-tracing_amd/host/vct_image.h"
 #include "vct_oracle.h"
+
+// The image decoders (PNG / inflate, JPEG, BMP, TGA, PNM) on every file of $VCT_SANITIZE_IMAGES and on thousands of
+// corrupted copies of each (flipped bytes, truncations): whatever they return, they must not touch memory outside
+// their buffers or trip UBSan.  tests/test_sanitize.py writes the sample files.
+static int fuzz_images(const char* dir) {
+    DIR* d = opendir(dir);
+    if (!d) return 0;
+    int files = 0, decoded = 0, variants = 0;
+    uint64_t rng = 0x9e3779b97f4a7c15ull;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    while (dirent* e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        const std::string path = std::string(dir) + "/" + e->d_name;
+        FILE* fp = fopen(path.c_str(), "rb");
+        if (!fp) continue;
+        std::vector<uint8_t> buf;
+        uint8_t tmp[4096];
+        size_t n;
+        while ((n = fread(tmp, 1, sizeof(tmp), fp)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+        fclose(fp);
+        ++files;
+        vct_image::Image im;
+        if (vct_image::decode(buf, im)) ++decoded;
+        for (int k = 0; k < 1500 && buf.size() > 16; ++k) {
+            std::vector<uint8_t> b = buf;
+            if (k % 5 == 4) b.resize((size_t)(next() % b.size()));
+            else for (int j = 0, m = 1 + (int)(next() % 4); j < m; ++j) b[(size_t)(next() % b.size())] ^= (uint8_t)(1 + next() % 255);
+            vct_image::Image v;
+            (void)vct_image::decode(b, v);
+            ++variants;
+        }
+    }
+    closedir(d);
+    printf("image decoders: %d files (%d decoded), %d corrupted variants\n", files, decoded, variants);
+    return files > 0 && decoded == 0;      // sample files were given but none decoded: the check itself is broken
+}
 
 int main() {
     const int V = 16, w = 20, h = 12, S = 64;
@@ -112,6 +153,7 @@ int main() {
     vcto_sample(&p, tiny.data(), pos3, -1.0f, out4);
     { const float uvw[3] = {0.25f, 1.75f, -0.5f}; vcto_texture_lod(&p, tiny.data(), uvw, 0.7f, out4); }
     if (vcto_f32_to_f16(65520.0f) != 0x7c00 || vcto_f16_to_f32(0x3c00) != 1.0f) return 1;
+    if (const char* dir = getenv("VCT_SANITIZE_IMAGES")) if (fuzz_images(dir)) return 2;
     printf("sanitize_check ok\n");
     return 0;
 }

@@ -131,6 +131,40 @@ def test_footprint_records_follow_a_voxelized_scene(vct, oracle):
     assert frames[0][1].sum() > 0
 
 
+def test_footprint_records_with_the_second_bounce_and_the_whole_pass(vct, oracle):
+    """Records on through the paths that swap chains: the second bounce (its chain has no records: per-texel gathers),
+    a new voxelization after it, and vct_gi_pass -- frames equal to the same sequence without records."""
+    from voxel_cone_tracing_amd import scene as sc
+    V, w, h, S = 32, 64, 40, 128
+    scene = sc.Scene(sc.CORNELL)
+    cam = sc.default_camera(position=(0.0, 0.0, 58.0))
+    light = (0.0, 1.0, 0.25)
+    planes = synth.random_gbuffer(w * h, seed=8, extent=55.0)
+    outs = []
+    for on in (False, True):
+        with vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=S, voxel_attributes=1,
+                                            debug_outputs=1)) as ctx:
+            ctx.set_footprint_records(on)
+            ctx.set_camera_position(tuple(cam.position)); ctx.set_light_direction(light)
+            ctx.upload_triangles(scene.pos, scene.material, scene.albedo)
+            ctx.upload_mesh_attributes(*scene.frames(), scene.specular)
+            ctx.render_shadow_map(sc.light_view_proj(light))
+            ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+            a = ctx.trace(planes).copy()
+            ctx.bounce()
+            b = ctx.trace(planes).copy()                     # through the bounce chain
+            sb = ctx.steps().copy()
+            ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+            c = ctx.trace(planes).copy()                     # back on the first chain, records rebuilt
+            ctx.gi_pass(sc.light_view_proj(light), sc.camera_view_proj(cam, w, h))
+            ctx.synchronize()
+            d = ctx.download_frame().copy()
+            outs.append((a, b, sb, c, d))
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(outs[0][0], outs[0][3]) and (outs[0][0] != outs[0][1]).any()
+
+
 def test_loose_variant_stays_inside_the_frame_tolerance(vct, oracle):
     """config.trace_variant = 3 (one-multiply unorm8 decode, reciprocal-multiply divisions -- the opt-in kernel that
     prices the exactness, bench.py exactness_tax) is NOT bit-exact: it must stay within the north-star's 1e-3 relative

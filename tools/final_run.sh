@@ -1,4 +1,9 @@
+#!/bin/bash
+# ON THE GPU BOX: what is run on the final sources of a round -- the whole GPU test suite, the round's profile set
+# (tools/profiles.sh), clean bench lines of every configuration, the randomized parity sweep.  Results land in gpurun_out/;
+# summarise locally with tools/summarize_prof.py and copy what is to be judged into profiles/.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+(timeout 3000 python -m pytest tests -m gpu -q -rA 2>&1 | grep -E "passed|failed|error|config5 chain" | tail -6) > gpurun_out/r05_pytest_gpu.txt
 tools/profiles.sh r05 > gpurun_out/r05_profiles.log 2>&1
 ( time python bench.py ) > gpurun_out/r05f_bench.json 2> gpurun_out/r05f_bench.err
 python bench.py --steps 10 --warmup 3 --scene bistro --voxel-dim 1024 --width 3840 --height 2160 --cpu-seconds 0 > gpurun_out/r05f_c5_bench.json 2>/dev/null
