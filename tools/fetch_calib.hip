@@ -34,7 +34,42 @@ __global__ void write_dwordx2(uint2* __restrict__ p, size_t n) {
         p[i] = make_uint2((uint32_t)i, 7u);
 }
 
-int main() {
+// Scattered 32-byte records (round 5: the access pattern of the trace kernel's footprint records): every lane
+// reads one 32-byte-aligned record (two dwordx4) at a pseudo-random place of a buffer far larger than the caches.  Useful
+// bytes = 32 per access; what the memory system fetches per access (a 64-byte or a 128-byte request) is what the counters
+// and the kernel's own time -- accesses x granule / time against the HBM peak -- have to tell.
+__global__ void gather32(const uint4* __restrict__ p, size_t nrec, size_t naccess, uint32_t* out) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < naccess; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t h = (i + 1) * 0x9e3779b97f4a7c15ull;
+        h ^= h >> 29; h *= 0xbf58476d1ce4e5b9ull; h ^= h >> 32;
+        const size_t r = (size_t)(h % nrec);
+        const uint4 a = p[2 * r], b = p[2 * r + 1];
+        acc += a.x + a.w + b.x + b.w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'g') {          // tools/fetch_calib gather: the scattered-record pattern alone
+        const size_t gb = 8ull << 30, nrec = gb / 32, naccess = 1ull << 27;     // 8 GiB buffer, 4 GiB of useful bytes
+        uint32_t *gbuf, *gout;
+        if (hipMalloc(&gbuf, gb) != hipSuccess || hipMalloc(&gout, 64) != hipSuccess) { printf("alloc failed\n"); return 1; }
+        hipMemset(gbuf, 1, gb);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(gather32, dim3(256 * 32), dim3(256), 0, 0, (const uint4*)gbuf, nrec, naccess, gout);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("gather32: %zu accesses of 32 B in %.3f ms = %.1f G accesses/s; useful %.2f TB/s; x64 B %.2f TB/s; x128 B %.2f TB/s\n",
+                   naccess, ms, naccess / ms / 1e6, naccess * 32.0 / ms / 1e9, naccess * 64.0 / ms / 1e9, naccess * 128.0 / ms / 1e9);
+        }
+        return 0;
+    }
     const size_t bytes = 1ull << 30;     // 1 GiB: 4x the Infinity Cache
     uint32_t *buf, *out;
     hipMalloc(&buf, bytes);
