@@ -735,7 +735,8 @@ def hbm_stress(vct, device):
                                  "extra_bytes": int((vct.chain_texels(V) - V ** 3) * 32)}}
     # counter traffic of the committed rocprofv3 passes of the same workload (tools/profile_configs.sh: noise / noise_rec),
     # replayed only for the kernel sources they were recorded on; corrected as profiles/r01_fetch_write_calibration.txt
-    # prescribes (2 x FETCH_SIZE + WRITE_SIZE) -- calibrated on streaming reads, so an UPPER estimate for scattered 32-byte ones
+    # prescribes (2 x FETCH_SIZE + WRITE_SIZE); the x2 was re-calibrated on scattered 32-byte records, the pattern of the
+    # footprint records (profiles/r05_fetch_calibration_scattered.txt: one 128-byte request per access, tallied as 64 B)
     for key, fname, ms, tgt in (("", "trace_traffic_noise.json", k_ms, out),
                                 ("", "trace_traffic_noise_records.json", r_ms, out["footprint_records"])):
         path = os.path.join(ROOT, "profiles", fname)
