@@ -42,7 +42,7 @@ def build():
     return SO
 
 
-def lib(precise=True, win=1024):
+def lib(precise=True, win=1024, threads=1):
     """Loads the harness and creates the context (once per process: `precise` is fixed by the first call, because
     llvmpipe reads GALLIVM_PERF when the driver is loaded)."""
     global _LIB
@@ -57,7 +57,8 @@ def lib(precise=True, win=1024):
         # imageStore (vox.fs:88: overlapping fragments race) comes out the same on every run.  Which of several writers
         # of a voxel wins is still GL's choice (bins, not triangles, are the outer loop) -- the fixtures record how many
         # triangles write each voxel and the tests compare such voxels against the set of candidates.
-        os.environ["LP_NUM_THREADS"] = "1"
+        # (`threads` != 1: timing runs only -- tools/time_ref_gl.py)
+        os.environ["LP_NUM_THREADS"] = str(threads)
         L = C.CDLL(build())
         L.refgl_log.restype = C.c_char_p
         L.refgl_string.restype = C.c_char_p
