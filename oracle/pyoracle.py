@@ -232,6 +232,15 @@ def pcf25(depth, coord, bias=0.002):
     return lib().vcto_pcf25(_ptr(depth), depth.shape[0], _ptr(c), float(bias))
 
 
+def pcf25_batch(depth, coords, bias=0.002):
+    """pcf25 for [n, 3] shadow coordinates -> int32 [n]."""
+    depth = np.ascontiguousarray(depth, np.float32)
+    c = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
+    out = np.zeros(c.shape[0], np.int32)
+    lib().vcto_pcf25_batch(_ptr(depth), depth.shape[0], _ptr(c), C.c_size_t(c.shape[0]), C.c_float(bias), _ptr(out))
+    return out
+
+
 def tex_build_mips(texture):
     """uint8 [h, w, 4] -> (chain uint8 [texels, 4] with level 0 first, number of levels): glGenerateMipmap restated."""
     t = np.ascontiguousarray(texture, np.uint8)

@@ -497,6 +497,10 @@ float vcto_shadow_tex(const float* depth, int S, float u, float v) {
     return acc;
 }
 
+void vcto_pcf25_batch(const float* depth, int S, const float* coords, size_t n, float bias, int32_t* counts) {
+    for (size_t i = 0; i < n; ++i) counts[i] = vcto_pcf25(depth, S, coords + 3 * i, bias);
+}
+
 int vcto_pcf25(const float* depth, int S, const float coord[3], float bias) {
     const float cur = coord[2];   // coord.z / coord.w with w = 1 (orthographic light)
     const float inv = 1.0f / (float)S;

@@ -127,6 +127,8 @@ float vcto_f16_to_f32(uint16_t h);
  * bilinear, clamp-to-edge.  coord = xyz*0.5+0.5 shadow coordinate.  Returns the number of
  * the 25 taps that pass (caller scales by 1/25 (inject) or 0.111 (trace)). */
 int vcto_pcf25(const float* depth, int S, const float coord[3], float bias);
+/* the same for n coordinates ([n][3]) -> counts[n] (fixture generation at frame sizes) */
+void vcto_pcf25_batch(const float* depth, int S, const float* coords, size_t n, float bias, int32_t* counts);
 float vcto_shadow_tex(const float* depth, int S, float u, float v);
 
 /* ---- voxelization ------------------------------------------------------------------- */

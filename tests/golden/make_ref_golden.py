@@ -46,6 +46,13 @@ TRACE_CASES = {
     "ref_trace_v256_random": dict(V=256, W=32, H=32, vol_seed=7, occ=0.05, gb="random", gb_seed=5, clamp=0),
     "ref_trace_v32_clamp": dict(V=32, W=24, H=16, vol_seed=12, occ=0.2, gb="random", gb_seed=7, clamp=1),
 }
+# BASELINE.json configs[1]'s size through the reference's GLSL: 256^3 chain, 1920 x 1080 coherent G-buffer.  The frame is
+# 33 MB of fp32 -- the fixture keeps 65,536 seeded sample pixels exactly and the frame averaged over 8 x 8 blocks; the
+# inputs are regenerated from their seeds (checksums stored).
+FULL_CASES = {
+    "ref_trace_c2_1080p": dict(V=256, W=1920, H=1080, vol_seed=7, occ=0.05, gb="coherent", gb_seed=3, clamp=0,
+                               samples=65536, sample_seed=99),
+}
 SHADOW_S = 64
 
 
@@ -69,6 +76,30 @@ def trace_inputs(c):
     return l0, planes, depth, cam
 
 
+def shadow_plane(planes, depth):
+    """Plane 22 (shadow_value, trace.fs:186) of a shadow map for the G-buffer's positions -- the one oracle-derived input."""
+    from oracle import pyoracle, pyrefgl as rg
+    dvp = rg.depth_view_proj(LIGHT)
+    P = planes[0:3].T
+    M = dvp.reshape(4, 4).T
+    clip = P @ M[:3, :3].T.astype(np.float32) + M[:3, 3]
+    coord = (clip * np.float32(0.5) + np.float32(0.5)).astype(np.float32)
+    return pyoracle.pcf25_batch(depth, coord).astype(np.float32) * np.float32(0.111)
+
+
+def full_inputs(c):
+    """Inputs of a FULL_CASES case, the same arrays on every host (numpy only + the oracle's PCF for plane 22)."""
+    l0, planes, depth, cam = trace_inputs(c)
+    planes[22] = shadow_plane(planes, depth)
+    return l0, planes, depth, cam
+
+
+def block_mean(frame, W, H):
+    """[H*W, 4] fp32 -> [H/8, W/8, 4]: mean over 8 x 8 pixel blocks in float64, stored fp32."""
+    f = frame.reshape(H // 8, 8, W // 8, 8, 4).astype(np.float64)
+    return f.mean(axis=(1, 3)).astype(np.float32)
+
+
 def gb_to_vertices(planes):
     n = planes.shape[1]
     v = np.zeros((n, 14), np.float32)
@@ -79,7 +110,7 @@ def gb_to_vertices(planes):
 def gl_trace_points(c):
     """The reference's VoxelConeTracing.vs + .fs on one GL_POINT per G-buffer pixel (oracle/ref_gl.c)."""
     from oracle import pyoracle, pyrefgl as rg
-    l0, planes, depth, cam = trace_inputs(c)
+    l0, planes, depth, cam = trace_inputs(c)      # (plane 22 does not reach GL: the shader computes it from the shadow map)
     V, W, H = c["V"], c["W"], c["H"]
     chain = pyoracle.build_mips(l0)        # every level uploaded: isolates the sampler from glGenerateMipmap
     rg.volume_upload_chain(V, [pyoracle.level_view(chain, V, k) for k in range(pyoracle.num_levels(V))])
@@ -177,6 +208,8 @@ def worker(mode, case, out_path):
     rg.lib(precise=(mode == "precise"))
     if case in TRACE_CASES:
         res = dict(rgba=gl_trace_points(TRACE_CASES[case]))
+    elif case in FULL_CASES:
+        res = dict(rgba=gl_trace_points(FULL_CASES[case]))
     elif case in PIPES:
         res = gl_pipeline(PIPES[case])
     elif case == "ref_mips3d":
@@ -220,6 +253,20 @@ def build_fixture(name):
             f["level0_args"] = np.array([c["V"], c["vol_seed"], c["occ"]], np.float64)
             f["level0_crc32"] = np.uint32(zlib.crc32(l0.tobytes()))
         return f
+    if name in FULL_CASES:
+        c = FULL_CASES[name]
+        l0, planes, depth, cam = full_inputs(c)
+        from oracle import pyrefgl as rg
+        pw = run_worker("precise", name)
+        precise, default = pw["rgba"], run_worker("default", name)["rgba"]
+        idx = np.sort(np.random.default_rng(c["sample_seed"]).choice(c["W"] * c["H"], c["samples"], replace=False))
+        return dict(V=c["V"], W=c["W"], H=c["H"], clamp=c["clamp"], shadow_map=depth, camera_pos=cam,
+                    light_dir=np.array(LIGHT, np.float32), depth_vp=rg.depth_view_proj(LIGHT),
+                    case=np.array([c["vol_seed"], c["occ"], c["gb_seed"], c["samples"], c["sample_seed"]], np.float64),
+                    level0_crc32=np.uint32(zlib.crc32(l0.tobytes())), planes_crc32=np.uint32(zlib.crc32(planes.tobytes())),
+                    sample_idx=idx.astype(np.int64), ref_sample=precise[idx], ref_sample_default_precision=default[idx],
+                    ref_block_mean=block_mean(precise, c["W"], c["H"]),
+                    discards=np.int64((planes[18] < 0.5).sum()), gl=pw["gl"])
     if name in PIPES:
         sc = refscene.build(PIPES[name]["scene_seed"])
         m = pipeline_matrices(PIPES[name])
@@ -246,7 +293,7 @@ def build_fixture(name):
     raise KeyError(name)
 
 
-ALL = list(TRACE_CASES) + list(PIPES) + ["ref_mips3d"]
+ALL = list(TRACE_CASES) + list(PIPES) + ["ref_mips3d"] + list(FULL_CASES)
 
 
 def main():

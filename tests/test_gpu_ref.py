@@ -62,6 +62,31 @@ def test_hip_trace_matches_reference_glsl(vct, name, variant):
     assert rel <= REL_L2_TOL, rel
 
 
+def test_hip_trace_matches_reference_glsl_at_configs1_size(vct):
+    """BASELINE.json configs[1]'s size -- 256^3 chain, 1920 x 1080 -- against the reference's GLSL run on the same seeded
+    inputs: the 65,536 sample pixels the fixture keeps exactly, and the whole frame averaged over 8 x 8 blocks."""
+    import test_ref_gl
+    f = load("ref_trace_c2_1080p")
+    l0, planes, block_mean = test_ref_gl.full_case_inputs(f)
+    V, W, H = int(f["V"]), int(f["W"]), int(f["H"])
+    with vct.Context(vct.default_config(voxel_dim=V, width=W, height=H, wrap_repeat=1)) as ctx:
+        ctx.set_camera_position(tuple(float(x) for x in f["camera_pos"]))
+        ctx.set_light_direction(tuple(float(x) for x in f["light_dir"]))
+        ctx.upload_volume(l0)
+        ctx.build_mips()
+        out = vct.half_to_float(ctx.trace(planes).reshape(-1, 4))
+    disc = planes[18] < 0.5
+    assert int(disc.sum()) == int(f["discards"]) and np.all(out[disc] == CLEAR)
+    idx = f["sample_idx"]
+    keep = ~disc[idx]
+    rel = synth.rel_l2(out[idx][keep], f["ref_sample"][keep])
+    got_mean, ref_mean = block_mean(out, W, H), f["ref_block_mean"]
+    rel_mean = synth.rel_l2(got_mean.reshape(-1, 4), ref_mean.reshape(-1, 4))
+    print(f"configs[1] size: HIP vs reference GLSL rel-L2 {rel:.2e} on {int(keep.sum())} sample pixels, "
+          f"{rel_mean:.2e} on the {ref_mean.shape[1]} x {ref_mean.shape[0]} block means of the whole frame")
+    assert rel <= REL_L2_TOL and rel_mean <= REL_L2_TOL
+
+
 @pytest.fixture(scope="module", params=["ref_pipeline_v32", "ref_pipeline_v64", "ref_pipeline_v128"])
 def pipe(request):
     f = load(request.param)

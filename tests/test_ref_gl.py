@@ -49,7 +49,46 @@ def gl_choices(oracle):
     L.vcto_set_gl_choices(0)
 
 
+def full_case_inputs(f):
+    """Regenerates the seeded inputs of a full-size case (tests/golden/make_ref_golden.py FULL_CASES) and checks them
+    against the checksums taken when the reference's shaders ran on them."""
+    import sys
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    import make_ref_golden as mg
+    vol_seed, occ, gb_seed, samples, sample_seed = f["case"]
+    c = dict(V=int(f["V"]), W=int(f["W"]), H=int(f["H"]), vol_seed=int(vol_seed), occ=float(occ), gb="coherent",
+             gb_seed=int(gb_seed), clamp=int(f["clamp"]))
+    l0, planes, depth, cam = mg.full_inputs(c)
+    assert np.uint32(zlib.crc32(l0.tobytes())) == f["level0_crc32"], "seeded volume generator drifted"
+    assert np.uint32(zlib.crc32(planes.tobytes())) == f["planes_crc32"], "seeded G-buffer generator drifted"
+    assert np.array_equal(depth, f["shadow_map"]) and np.array_equal(cam, f["camera_pos"])
+    idx = np.sort(np.random.default_rng(int(sample_seed)).choice(c["W"] * c["H"], int(samples), replace=False))
+    assert np.array_equal(idx, f["sample_idx"])
+    return l0, planes, mg.block_mean
+
+
 # ---------------------------------------------------------------------------------------------- cone trace ----------
+def test_oracle_matches_reference_glsl_at_configs1_size(oracle):
+    """BASELINE.json configs[1]'s size (256^3 chain, 1920 x 1080) through the reference's GLSL: the oracle on the 65,536
+    sample pixels the fixture keeps of that frame."""
+    f = load("ref_trace_c2_1080p")
+    l0, planes, _ = full_case_inputs(f)
+    idx = f["sample_idx"]
+    sub = np.ascontiguousarray(planes[:, idx])
+    p = oracle.default_params(int(f["V"]), camera_pos=f["camera_pos"], light_dir=f["light_dir"], wrap_repeat=1)
+    got = oracle.trace(p, oracle.build_mips(l0), sub)["rgba32f"]
+    ref = f["ref_sample"]
+    disc = sub[18] < 0.5
+    assert disc.sum() > 1000 and np.all(ref[disc] == CLEAR) and np.all(got[disc] == CLEAR)
+    assert 0.0 < (sub[22] < 2.7).mean() < 1.0
+    rel = synth.rel_l2(got[~disc], ref[~disc])
+    worst = np.abs(got[~disc] - ref[~disc]).max()
+    print(f"configs[1] size, {idx.size} sample pixels: oracle vs reference GLSL rel-L2 {rel:.2e}, max abs {worst:.2e}; "
+          f"llvmpipe default filter precision vs float rel-L2 {synth.rel_l2(f['ref_sample_default_precision'][~disc], ref[~disc]):.2e}")
+    assert rel <= 1e-5 and worst <= 2e-4
+
+
 @pytest.mark.parametrize("name", TRACE)
 def test_oracle_matches_reference_glsl_trace(oracle, name):
     f = load(name)
