@@ -51,7 +51,10 @@ TRACE_CASES = {
 # inputs are regenerated from their seeds (checksums stored).
 FULL_CASES = {
     "ref_trace_c2_1080p": dict(V=256, W=1920, H=1080, vol_seed=7, occ=0.05, gb="coherent", gb_seed=3, clamp=0,
-                               samples=65536, sample_seed=99),
+                               samples=65536, sample_seed=99, block=8),
+    # configs[2]'s size (the screen trace; its second bounce has no reference code): 512^3 chain (10 levels), 3840 x 2160
+    "ref_trace_c3_4k": dict(V=512, W=3840, H=2160, vol_seed=11, occ=0.05, gb="coherent", gb_seed=5, clamp=0,
+                            samples=65536, sample_seed=101, block=16),
 }
 SHADOW_S = 64
 
@@ -94,9 +97,9 @@ def full_inputs(c):
     return l0, planes, depth, cam
 
 
-def block_mean(frame, W, H):
-    """[H*W, 4] fp32 -> [H/8, W/8, 4]: mean over 8 x 8 pixel blocks in float64, stored fp32."""
-    f = frame.reshape(H // 8, 8, W // 8, 8, 4).astype(np.float64)
+def block_mean(frame, W, H, b=8):
+    """[H*W, 4] fp32 -> [H/b, W/b, 4]: mean over b x b pixel blocks in float64, stored fp32."""
+    f = frame.reshape(H // b, b, W // b, b, 4).astype(np.float64)
     return f.mean(axis=(1, 3)).astype(np.float32)
 
 
@@ -262,10 +265,10 @@ def build_fixture(name):
         idx = np.sort(np.random.default_rng(c["sample_seed"]).choice(c["W"] * c["H"], c["samples"], replace=False))
         return dict(V=c["V"], W=c["W"], H=c["H"], clamp=c["clamp"], shadow_map=depth, camera_pos=cam,
                     light_dir=np.array(LIGHT, np.float32), depth_vp=rg.depth_view_proj(LIGHT),
-                    case=np.array([c["vol_seed"], c["occ"], c["gb_seed"], c["samples"], c["sample_seed"]], np.float64),
+                    case=np.array([c["vol_seed"], c["occ"], c["gb_seed"], c["samples"], c["sample_seed"], c["block"]], np.float64),
                     level0_crc32=np.uint32(zlib.crc32(l0.tobytes())), planes_crc32=np.uint32(zlib.crc32(planes.tobytes())),
                     sample_idx=idx.astype(np.int64), ref_sample=precise[idx], ref_sample_default_precision=default[idx],
-                    ref_block_mean=block_mean(precise, c["W"], c["H"]),
+                    ref_block_mean=block_mean(precise, c["W"], c["H"], c["block"]),
                     discards=np.int64((planes[18] < 0.5).sum()), gl=pw["gl"])
     if name in PIPES:
         sc = refscene.build(PIPES[name]["scene_seed"])

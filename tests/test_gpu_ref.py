@@ -62,11 +62,13 @@ def test_hip_trace_matches_reference_glsl(vct, name, variant):
     assert rel <= REL_L2_TOL, rel
 
 
-def test_hip_trace_matches_reference_glsl_at_configs1_size(vct):
-    """BASELINE.json configs[1]'s size -- 256^3 chain, 1920 x 1080 -- against the reference's GLSL run on the same seeded
-    inputs: the 65,536 sample pixels the fixture keeps exactly, and the whole frame averaged over 8 x 8 blocks."""
+@pytest.mark.parametrize("name", ["ref_trace_c2_1080p", "ref_trace_c3_4k"])
+def test_hip_trace_matches_reference_glsl_at_baseline_sizes(vct, name):
+    """BASELINE.json configs[1]'s and configs[2]'s sizes -- 256^3 / 1920 x 1080, 512^3 / 3840 x 2160 -- against the
+    reference's GLSL run on the same seeded inputs: the 65,536 sample pixels the fixture keeps exactly, and the whole
+    frame averaged over 8 x 8 (16 x 16) blocks."""
     import test_ref_gl
-    f = load("ref_trace_c2_1080p")
+    f = load(name)
     l0, planes, block_mean = test_ref_gl.full_case_inputs(f)
     V, W, H = int(f["V"]), int(f["W"]), int(f["H"])
     with vct.Context(vct.default_config(voxel_dim=V, width=W, height=H, wrap_repeat=1)) as ctx:
@@ -82,7 +84,7 @@ def test_hip_trace_matches_reference_glsl_at_configs1_size(vct):
     rel = synth.rel_l2(out[idx][keep], f["ref_sample"][keep])
     got_mean, ref_mean = block_mean(out, W, H), f["ref_block_mean"]
     rel_mean = synth.rel_l2(got_mean.reshape(-1, 4), ref_mean.reshape(-1, 4))
-    print(f"configs[1] size: HIP vs reference GLSL rel-L2 {rel:.2e} on {int(keep.sum())} sample pixels, "
+    print(f"{name}: HIP vs reference GLSL rel-L2 {rel:.2e} on {int(keep.sum())} sample pixels, "
           f"{rel_mean:.2e} on the {ref_mean.shape[1]} x {ref_mean.shape[0]} block means of the whole frame")
     assert rel <= REL_L2_TOL and rel_mean <= REL_L2_TOL
 

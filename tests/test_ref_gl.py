@@ -56,7 +56,7 @@ def full_case_inputs(f):
     if GOLDEN not in sys.path:
         sys.path.insert(0, GOLDEN)
     import make_ref_golden as mg
-    vol_seed, occ, gb_seed, samples, sample_seed = f["case"]
+    vol_seed, occ, gb_seed, samples, sample_seed, block = f["case"]
     c = dict(V=int(f["V"]), W=int(f["W"]), H=int(f["H"]), vol_seed=int(vol_seed), occ=float(occ), gb="coherent",
              gb_seed=int(gb_seed), clamp=int(f["clamp"]))
     l0, planes, depth, cam = mg.full_inputs(c)
@@ -65,28 +65,57 @@ def full_case_inputs(f):
     assert np.array_equal(depth, f["shadow_map"]) and np.array_equal(cam, f["camera_pos"])
     idx = np.sort(np.random.default_rng(int(sample_seed)).choice(c["W"] * c["H"], int(samples), replace=False))
     assert np.array_equal(idx, f["sample_idx"])
-    return l0, planes, mg.block_mean
+    return l0, planes, lambda frame, W, H: mg.block_mean(frame, W, H, int(block))
 
 
 # ---------------------------------------------------------------------------------------------- cone trace ----------
-def test_oracle_matches_reference_glsl_at_configs1_size(oracle):
-    """BASELINE.json configs[1]'s size (256^3 chain, 1920 x 1080) through the reference's GLSL: the oracle on the 65,536
-    sample pixels the fixture keeps of that frame."""
-    f = load("ref_trace_c2_1080p")
+FULL = ["ref_trace_c2_1080p", "ref_trace_c3_4k"]
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_oracle_matches_reference_glsl_at_baseline_sizes(oracle, name):
+    """BASELINE.json configs[1]'s and configs[2]'s sizes (256^3 / 1920 x 1080, 512^3 / 3840 x 2160) through the
+    reference's GLSL: the oracle on the 65,536 sample pixels the fixture keeps of that frame."""
+    f = load(name)
     l0, planes, _ = full_case_inputs(f)
     idx = f["sample_idx"]
     sub = np.ascontiguousarray(planes[:, idx])
     p = oracle.default_params(int(f["V"]), camera_pos=f["camera_pos"], light_dir=f["light_dir"], wrap_repeat=1)
-    got = oracle.trace(p, oracle.build_mips(l0), sub)["rgba32f"]
+    chain = oracle.build_mips(l0)
+    got = oracle.trace(p, chain, sub)["rgba32f"]
     ref = f["ref_sample"]
     disc = sub[18] < 0.5
     assert disc.sum() > 1000 and np.all(ref[disc] == CLEAR) and np.all(got[disc] == CLEAR)
     assert 0.0 < (sub[22] < 2.7).mean() < 1.0
     rel = synth.rel_l2(got[~disc], ref[~disc])
     worst = np.abs(got[~disc] - ref[~disc]).max()
-    print(f"configs[1] size, {idx.size} sample pixels: oracle vs reference GLSL rel-L2 {rel:.2e}, max abs {worst:.2e}; "
+    print(f"{name}, {idx.size} sample pixels: oracle vs reference GLSL rel-L2 {rel:.2e}, max abs {worst:.2e}; "
           f"llvmpipe default filter precision vs float rel-L2 {synth.rel_l2(f['ref_sample_default_precision'][~disc], ref[~disc]):.2e}")
-    assert rel <= 1e-5 and worst <= 2e-4
+    assert rel <= 1e-5
+    # Pixels beyond float rounding must be EXPLAINED, not tolerated: the march loop ends on `alpha < 0.95` / `dist < 75`
+    # (trace.fs:97), and a cone whose alpha lands within an ulp of 0.95 takes one step more or fewer depending on the last
+    # bit of an intermediate -- llvmpipe's code and the oracle's need not agree there.  Such a pixel is accepted only if a
+    # <= 4 ulp change of ONE of its inputs makes the oracle take the other branch and reproduce the reference's value.
+    # (ref_trace_c3_4k: one pixel of 62,968, specular cone 4 vs 3 steps, 2.2e-3; ref_trace_c2_1080p: none.)
+    far = np.flatnonzero(np.abs(got - ref).max(1) > 2e-4)
+    assert far.size <= 3, far.size
+    for i in far:
+        g0 = np.ascontiguousarray(sub[:, i:i + 1])
+        base_steps = oracle.trace(p, chain, g0)["steps"][0]
+        explained = False
+        for k in range(15):
+            for towards in (-np.inf, np.inf):
+                v = np.float32(g0[k, 0])
+                for _ in range(4):
+                    v = np.nextafter(v, np.float32(towards))
+                    h = g0.copy()
+                    h[k, 0] = v
+                    r = oracle.trace(p, chain, h)
+                    if not np.array_equal(r["steps"][0], base_steps) and np.abs(r["rgba32f"][0] - ref[i]).max() <= 2e-5:
+                        explained = True
+        print(f"{name}: sample pixel {idx[i]} differs by {np.abs(got[i] - ref[i]).max():.1e}: steps {base_steps.tolist()}, "
+              f"termination knife edge {'confirmed' if explained else 'NOT confirmed'}")
+        assert explained
 
 
 @pytest.mark.parametrize("name", TRACE)
