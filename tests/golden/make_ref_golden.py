@@ -141,6 +141,12 @@ PIPES = {
                               scene_seed=37, light=(0.35, 1.0, -0.2), ambient=0.6),
 }
 PIPE = PIPES["ref_pipeline_v32"]
+# The reference's OWN configuration -- 128^3 (VCT.h:16), a 1280 x 720 window (main.cpp) -- through Render(): the scene,
+# light, shadow map and voxel chain of ref_pipeline_v128 (same 16:9 camera), of whose 921,600-pixel frame the fixture
+# keeps the coverage mask, 65,536 sample pixels exactly and the 8 x 8 block means.
+PIPES_HIRES = {
+    "ref_pipeline_v128_720p": dict(base="ref_pipeline_v128", W=1280, H=720, samples=65536, sample_seed=7, block=8),
+}
 
 
 def pipeline_matrices(c=None):
@@ -215,6 +221,10 @@ def worker(mode, case, out_path):
         res = dict(rgba=gl_trace_points(FULL_CASES[case]))
     elif case in PIPES:
         res = gl_pipeline(PIPES[case])
+    elif case in PIPES_HIRES:
+        h = PIPES_HIRES[case]
+        full = gl_pipeline(dict(PIPES[h["base"]], W=h["W"], H=h["H"]))
+        res = dict(ref_frame=full["ref_frame"], ref_shadow=full["ref_shadow"], ref_chain=full["ref_chain"])
     elif case == "ref_mips3d":
         res = gl_mips3d()
     else:
@@ -270,6 +280,19 @@ def build_fixture(name):
                     sample_idx=idx.astype(np.int64), ref_sample=precise[idx], ref_sample_default_precision=default[idx],
                     ref_block_mean=block_mean(precise, c["W"], c["H"], c["block"]),
                     discards=np.int64((planes[18] < 0.5).sum()), gl=pw["gl"])
+    if name in PIPES_HIRES:
+        h = PIPES_HIRES[name]
+        r = run_worker("precise", name)
+        with np.load(os.path.join(HERE, h["base"] + ".npz")) as z:       # the stages in front of Render are the base fixture's
+            assert np.array_equal(z["ref_shadow"], r["ref_shadow"]) and np.array_equal(z["ref_chain"], r["ref_chain"])
+        W, H = h["W"], h["H"]
+        frame = r["ref_frame"].reshape(-1, 4)
+        amb = PIPES[h["base"]].get("ambient", 0.1)
+        clear = np.array([1.0, 1.0, 1.0, 1.0] if amb >= 0.5 else [0.5, 0.5, 0.5, 1.0], np.float32)
+        cov = ~np.all(frame == clear, axis=1)
+        idx = np.sort(np.random.default_rng(h["sample_seed"]).choice(W * H, h["samples"], replace=False))
+        return dict(base=np.array(h["base"]), W=W, H=H, block=h["block"], coverage_bits=np.packbits(cov), sample_idx=idx.astype(np.int64),
+                    ref_sample=frame[idx], ref_block_mean=block_mean(frame, W, H, h["block"]), gl=r["gl"])
     if name in PIPES:
         sc = refscene.build(PIPES[name]["scene_seed"])
         m = pipeline_matrices(PIPES[name])
@@ -296,7 +319,7 @@ def build_fixture(name):
     raise KeyError(name)
 
 
-ALL = list(TRACE_CASES) + list(PIPES) + ["ref_mips3d"] + list(FULL_CASES)
+ALL = list(TRACE_CASES) + list(PIPES) + ["ref_mips3d"] + list(FULL_CASES) + list(PIPES_HIRES)
 
 
 def main():

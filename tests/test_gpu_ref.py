@@ -168,3 +168,35 @@ def test_hip_render_matches_reference_glsl(vct, pipe):
           f"pixels > 1e-3: {(err > 1e-3).sum()} of {err.size}, max {err.max():.2e}")
     keep = err <= np.quantile(err, 0.998)          # (alpha-edge / shadow-edge pixels: tests/test_ref_gl.py)
     assert synth.rel_l2(out[keep], ref[keep]) <= 5e-3 and np.median(err) <= 1e-3 and (err > 2e-2).mean() <= 0.005
+
+
+def test_hip_render_matches_reference_glsl_at_the_reference_window_size(vct):
+    """The reference's own configuration -- 128^3, 1280 x 720 -- through Render() on the reference's shadow map and voxel
+    chain (ref_pipeline_v128): the same 921,600 pixels shaded, the fixture's 65,536 sample pixels and the 8 x 8 block
+    means of the whole frame within the bounds of the small cases."""
+    import sys
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    import make_ref_golden as mg
+    hi = load("ref_pipeline_v128_720p")
+    f = load(str(hi["base"]))
+    f["textures"] = [f[f"texture_{i}"] for i in range(9)]
+    W, H = int(hi["W"]), int(hi["H"])
+    view_proj = (f["proj"].reshape(4, 4).T @ f["view"].reshape(4, 4).T).T.astype(np.float32).reshape(16)
+    g = dict(f, W=W, H=H)
+    with make_ctx(vct, g) as ctx:
+        ctx.upload_shadow_map(f["ref_shadow"], f["depth_vp"].reshape(4, 4).T)
+        ctx.upload_chain(f["ref_chain"])
+        ctx.render_gbuffer(view_proj)
+        planes = ctx.download_gbuffer()
+        out = vct.half_to_float(ctx.trace_current().reshape(-1, 4))
+    cov_ref = np.unpackbits(hi["coverage_bits"])[: W * H].astype(bool)
+    assert np.array_equal(planes[18] >= 0.5, cov_ref)
+    idx, ref = hi["sample_idx"], hi["ref_sample"]
+    err = np.abs(out[idx] - ref).max(1)
+    rel_mean = synth.rel_l2(mg.block_mean(out, W, H, int(hi["block"])).reshape(-1, 4), hi["ref_block_mean"].reshape(-1, 4))
+    print(f"HIP Render 1280x720 vs reference GLSL: samples rel-L2 {synth.rel_l2(out[idx], ref):.2e}, median abs {np.median(err):.1e}, "
+          f"pixels > 1e-3: {(err > 1e-3).sum()} of {err.size}; block means rel-L2 {rel_mean:.2e}")
+    keep = err <= np.quantile(err, 0.998)
+    assert synth.rel_l2(out[idx][keep], ref[keep]) <= 5e-3 and np.median(err) <= 1e-3 and (err > 2e-2).mean() <= 0.005
+    assert rel_mean <= REL_L2_TOL

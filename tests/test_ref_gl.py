@@ -322,6 +322,42 @@ def test_render_vs_reference_glsl(oracle, pipe, gl_choices):
     assert (planes[18] >= 0.5).mean() > 0.8
 
 
+def test_render_vs_reference_glsl_at_the_reference_window_size(oracle, gl_choices):
+    """The reference's own configuration -- 128^3 grid (VCT.h:16), 1280 x 720 window (main.cpp) -- through Render(), on
+    the shadow map and voxel chain of ref_pipeline_v128: coverage of all 921,600 pixels, the 65,536 sample pixels the
+    fixture keeps exactly, the 8 x 8 block means of the whole frame."""
+    import sys
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    import make_ref_golden as mg
+    hi = load("ref_pipeline_v128_720p")
+    f = load(str(hi["base"]))
+    f["textures"] = [f[f"texture_{i}"] for i in range(9)]
+    f["tex_chains"] = [f[f"ref_tex_chain_{i}"] for i in range(9)]
+    V, W, H = int(f["V"]), int(hi["W"]), int(hi["H"])
+    view_proj = (f["proj"].reshape(4, 4).T @ f["view"].reshape(4, 4).T).T.astype(np.float32).reshape(16)
+    p = oracle.default_params(V, camera_pos=f["eye"], light_dir=f["light_dir"], ambient_factor=float(f["ambient"]))
+    cov_ref = np.unpackbits(hi["coverage_bits"])[: W * H].astype(bool)
+    idx, ref = hi["sample_idx"], hi["ref_sample"]
+    for mode in (7, 0):
+        gl_choices(mode)
+        planes = oracle.render_gbuffer(oracle_mesh(oracle, f, True), view_proj, W, H, f["ref_shadow"], f["depth_vp"])
+        got = oracle.trace(p, f["ref_chain"], planes)["rgba32f"]
+        assert np.array_equal(planes[18] >= 0.5, cov_ref)
+        err = np.abs(got[idx] - ref).max(1)
+        rel_mean = synth.rel_l2(mg.block_mean(got, W, H, int(hi["block"])).reshape(-1, 4), hi["ref_block_mean"].reshape(-1, 4))
+        print(f"Render 1280x720, gl_choices {mode}: samples rel-L2 {synth.rel_l2(got[idx], ref):.2e}, pixels > 1e-3: "
+              f"{(err > 1e-3).sum()} of {err.size}, median {np.median(err):.1e}; block means rel-L2 {rel_mean:.2e}")
+        assert rel_mean <= 1e-3
+        if mode == 7:       # float rounding, but for PCF taps exactly on a shadow edge (0.111 * shading each)
+            flipped = err > 1e-3
+            assert flipped.sum() <= 8 and err.max() <= 0.2
+            assert synth.rel_l2(got[idx][~flipped], ref[~flipped]) <= 1e-5 and err[~flipped].max() <= 2e-4
+        else:               # the oracle's own choices (bounds of test_render_vs_reference_glsl)
+            keep = err <= np.quantile(err, 0.998)
+            assert synth.rel_l2(got[idx][keep], ref[keep]) <= 5e-3 and np.median(err) <= 1e-3 and (err > 2e-2).mean() <= 0.005
+
+
 # ------------------------------------------------------------------- provenance: regenerate where the reference is ---
 def test_fixtures_regenerate_from_reference_shaders():
     """In the build container (reference tree + Mesa present) the committed fixtures are re-made from the reference's
@@ -333,6 +369,6 @@ def test_fixtures_regenerate_from_reference_shaders():
     import sys
     gen = os.path.join(GOLDEN, "make_ref_golden.py")
     r = subprocess.run([sys.executable, gen, "--check", "ref_trace_v32_random", "ref_pipeline_v32", "ref_pipeline_v64",
-                        "ref_pipeline_v128", "ref_mips3d"],
+                        "ref_pipeline_v128", "ref_pipeline_v128_720p", "ref_mips3d"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
