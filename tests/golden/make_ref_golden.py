@@ -15,6 +15,12 @@ llvmpipe reads GALLIVM_PERF when the driver is loaded, so each precision setting
   default  llvmpipe's defaults (8-bit fixed-point filter weights ...) -- recorded to show what "real GL" precision
            variance looks like next to the 1e-3 bar of BASELINE.json's north_star
 
+Cases: TRACE_CASES (small point traces, everything stored), PIPES (the whole pipeline on the small textured scene),
+ref_mips3d, FULL_CASES (point traces at BASELINE configs[1]'s / configs[2]'s sizes: inputs regenerate from seeds under
+stored checksums, of the frame 65,536 sample pixels and the block means are kept), PIPES_HIRES (Render() at the
+reference's own 1280 x 720 on the stages of ref_pipeline_v128: coverage mask, samples, block means).  1024^3 does not
+run here (llvmpipe refuses a 4 GiB 3-D texture).
+
 The oracle is used here for ONE thing: the shadow term of the point fixtures' G-buffers (plane 22 = PCF x 0.111 of the
 stored shadow map at the stored light matrix), so that the GPU test can feed vct_trace a complete G-buffer without the
 oracle; tests/test_ref_gl.py re-derives it.  Every `ref_*` array in the fixtures comes from GL.
