@@ -346,7 +346,8 @@ int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[16]);
  * [3] brick slots = 8^3 bricks a fragment of the mesh can land in, [4] bricks level 0 shows after the last
  * resolve, [5] compute units reserved for the communication stream (VCT_COMM_RESERVED_CUS; 0 = none), [6] form of the
  * last main-draw visibility pass (0 none yet, 1 direct, 2 tile-binned: chosen per context by timing),
- * [7] reserved (0).  Synchronises the stream. */
+ * [7] work items of the voxelize pass (brick slots, the heavy ones cut into chunks of 4096 fragments).  Synchronises
+ * the stream. */
 int vct_get_stage_counts(vct_ctx* ctx, uint64_t out[8]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);

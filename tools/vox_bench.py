@@ -40,7 +40,7 @@ for mips in (1, 0):
             best = t if best is None else [min(a, b) for a, b in zip(best, t)]
     c = ctx.stage_counts()
     print(f"V={V} texture_mipmaps={mips} shadow={shadow}: voxelize {best[0]:.4f} ms  inject {best[1]:.4f} ms  mips {best[2]:.4f} ms   "
-          f"fragments {c['vox_candidates']}  bricks {c['touched_bricks']}  triangles {c['triangles']}")
+          f"fragments {c['vox_candidates']}  bricks {c['touched_bricks']}  triangles {c['triangles']}  items {c.get('vox_items')}")
   del ctx
 raise SystemExit(0)
 

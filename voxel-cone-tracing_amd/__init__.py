@@ -504,7 +504,7 @@ class Context:
         v = (C.c_uint64 * 8)()
         self._ck(_lib.vct_get_stage_counts(self._h, v), "vct_get_stage_counts")
         return dict(zip(("triangles", "vox_candidates", "reserved", "accumulator_bricks", "touched_bricks",
-                         "comm_reserved_cus", "raster_form"), (int(x) for x in v)))
+                         "comm_reserved_cus", "raster_form", "vox_items"), (int(x) for x in v)))
 
     def last_trace_ms(self):
         v = C.c_float()

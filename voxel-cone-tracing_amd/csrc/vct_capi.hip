@@ -1786,6 +1786,7 @@ int vct_get_stage_counts(vct_ctx* c, uint64_t out[8]) {
     out[3] = c->nslots;
     out[5] = (uint64_t)c->reserved_cus;          // compute units kept for the communication stream (VCT_COMM_RESERVED_CUS)
     out[6] = (uint64_t)c->last_raster_form;      // visibility form of the last main-draw pass: 1 direct, 2 tile-binned
+    out[7] = (uint64_t)c->n_vox_items;           // work items of the voxelize pass (slots, heavy ones cut into chunks)
     if (c->brick_prev) {
         HIP_TRY(c, hipSetDevice(c->device));
         const size_t nbricks = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim / 512;

@@ -306,7 +306,9 @@ struct VctTraceParams {
     uint32_t* vt_count;
 };
 
+#ifndef VCT_VOX_CHUNK
 #define VCT_VOX_CHUNK 4096u       // most fragments one work item (workgroup) of the voxelize pass takes (vct_capi.hip build_voxel_slots)
+#endif
 struct VctVoxParams {
     int32_t V;
     float G, model_scale;

@@ -1507,6 +1507,9 @@ __device__ __forceinline__ float shadow_fetch(const uint32_t* __restrict__ words
 #ifndef VCT_SHADE_TEX_MIN_BLOCKS
 #define VCT_SHADE_TEX_MIN_BLOCKS 4
 #endif
+#ifndef VCT_SHADE_BLOCK
+#define VCT_SHADE_BLOCK 256        // threads per workgroup = 64 x tiles per workgroup (the kernel has no workgroup-level state)
+#endif
 template <bool TEX>
 __global__ void __launch_bounds__(256, TEX ? VCT_SHADE_TEX_MIN_BLOCKS : VCT_SHADE_MIN_BLOCKS)
 k_gbuffer_shade(const ShadeParams p) {
@@ -2023,8 +2026,9 @@ hipError_t vct_launch_gbuffer_shade(const VctRasterArgs& a, const float view_pro
     p.tile1 = row1 * p.tiles_x;
     const int tiles = p.tile1 - p.tile0;
     if (tiles <= 0) return hipSuccess;
-    if (a.tex.texels) hipLaunchKernelGGL(k_gbuffer_shade<true>, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_gbuffer_shade<false>, dim3((tiles + 3) / 4), dim3(256), 0, s, p);
+    const int per_block = VCT_SHADE_BLOCK / 64;       // tiles (waves) per workgroup
+    if (a.tex.texels) hipLaunchKernelGGL(k_gbuffer_shade<true>, dim3((tiles + per_block - 1) / per_block), dim3(VCT_SHADE_BLOCK), 0, s, p);
+    else hipLaunchKernelGGL(k_gbuffer_shade<false>, dim3((tiles + per_block - 1) / per_block), dim3(VCT_SHADE_BLOCK), 0, s, p);
     return hipGetLastError();
 }
 
