@@ -786,7 +786,9 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
 #define VCT_BIN 16
 #define VCT_BIN_SHIFT 4
 #define VCT_BIN_SLICE 512           // entries per work item of k_bin_raster (LDS: 4 KiB of sort keys)
-#define VCT_BIN_CHUNK 64            // records staged in LDS at a time (10 KiB)
+#ifndef VCT_BIN_CHUNK
+#define VCT_BIN_CHUNK 64            // records staged in LDS at a time (10 KiB); <= 64: one header per lane.  16 / 32 / 96 / 128 measured: all slower
+#endif
 #define VCT_BIN_INLINE 16           // bins a thread counts / fills by itself
 #define VCT_BIN_HUGE 2048           // above: the record goes to the huge list instead of one entry per bin
 // VCT_BIN_CSTRIDE (vct_internal.h): words between two bins' counters -- device-scope atomics on one line queue up
