@@ -10,5 +10,8 @@ python bench.py --steps 10 --warmup 3 --scene bistro --voxel-dim 1024 --width 38
 python bench.py --steps 10 --warmup 3 --voxel-dim 512 --width 3840 --height 2160 --bounces 2 --cpu-seconds 0 --no-sweep > gpurun_out/r05f_c3_bench.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --scene bistro --cpu-seconds 0 --no-sweep > gpurun_out/r05f_bistro1080_bench.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --scene atrium-textured --cpu-seconds 0 --no-sweep > gpurun_out/r05f_tex_bench.json 2>/dev/null
-( FUZZ_SEED0=300000 python tools/fuzz_gpu.py 600 ; FUZZ_SEED0=300000 python tools/fuzz_gpu.py 900 big ) > gpurun_out/r05_fuzz.txt 2>&1
-tail -3 gpurun_out/r05_fuzz.txt; tail -4 gpurun_out/r05f_bench.err
+if [ -z "$SKIP_FUZZ" ]; then
+  ( FUZZ_SEED0=300000 python tools/fuzz_gpu.py 600 ; FUZZ_SEED0=300000 python tools/fuzz_gpu.py 900 big ) > gpurun_out/r05_fuzz.txt 2>&1
+  tail -3 gpurun_out/r05_fuzz.txt
+fi
+tail -4 gpurun_out/r05f_bench.err
