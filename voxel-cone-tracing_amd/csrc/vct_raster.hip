@@ -786,6 +786,18 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
 #define VCT_BIN 16
 #define VCT_BIN_SHIFT 4
 #define VCT_BIN_SLICE 512           // entries per work item of k_bin_raster (LDS: 4 KiB of sort keys)
+#ifndef VCT_BIN_FILL_AGGREGATE
+#define VCT_BIN_FILL_AGGREGATE 1      // k_bin_fill: one returning atomic per distinct bin of a wave's 64 pairs
+#endif
+#ifndef VCT_BIN_COUNT_AGGREGATE
+#define VCT_BIN_COUNT_AGGREGATE 1     // k_bin_setup: the same for the counting atomics
+#endif
+#ifndef VCT_BIN_COUNT_AGG_ROUNDS
+#define VCT_BIN_COUNT_AGG_ROUNDS 8
+#endif
+#ifndef VCT_BIN_FILL_AGG_ROUNDS
+#define VCT_BIN_FILL_AGG_ROUNDS 16
+#endif
 #ifndef VCT_BIN_CHUNK
 #define VCT_BIN_CHUNK 64            // records staged in LDS at a time (10 KiB); <= 64: one header per lane.  16 / 32 / 96 / 128 measured: all slower
 #endif
@@ -1001,7 +1013,24 @@ k_bin_setup(const BinParams p) {
                         int bx = 0, by = 0;
                         for (int j = 0; j < nb; ++j) {
                             const uint32_t bin = (uint32_t)((by0 + by) * p.bins_x + bx0 + bx);
+#if VCT_BIN_COUNT_AGGREGATE
+                            // the lanes still in this loop that count the same bin send ONE atomic (see k_bin_fill)
+                            uint32_t want = ((binmask >> j) & 1u) ? bin : 0xffffffffu, add = 0u;
+                            unsigned long long left = __builtin_amdgcn_ballot_w64(want != 0xffffffffu);
+                            int singles = 0;
+                            for (int round = 0; round < VCT_BIN_COUNT_AGG_ROUNDS && left != 0ull && singles < 2; ++round) {
+                                const int l = (int)__ffsll((long long)left) - 1;
+                                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)want, l);
+                                const unsigned long long m = __builtin_amdgcn_ballot_w64(want == b);
+                                if (lane == l) add = (uint32_t)__popcll(m);
+                                singles = (m & (m - 1ull)) == 0ull ? singles + 1 : 0;
+                                left &= ~m;
+                            }
+                            if ((left >> lane) & 1ull) add = 1u;
+                            if (add != 0u) atomicAdd(&p.bin_count[(size_t)bin * VCT_BIN_CSTRIDE], add);
+#else
                             if ((binmask >> j) & 1u) atomicAdd(&p.bin_count[(size_t)bin * VCT_BIN_CSTRIDE], 1u);        // result unused: no round trip
+#endif
                             if (++bx == bw) { bx = 0; ++by; }
                         }
                     } else {
@@ -1136,11 +1165,17 @@ k_bin_fill(const BinParams p) {
         for (uint32_t k0 = 0u; k0 < total; k0 += 256u) {
             uint32_t at[4];
             uint2 ent[4];
+#if VCT_BIN_FILL_AGGREGATE
+            uint32_t bin_of[4];
+#endif
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
                 at[u] = p.entry_cap;
                 ent[u] = make_uint2(0u, 0u);
+#if VCT_BIN_FILL_AGGREGATE
+                bin_of[u] = 0xffffffffu;
+#endif
                 if (k < total) {
                     int lo = 0;
 #pragma unroll
@@ -1157,9 +1192,54 @@ k_bin_fill(const BinParams p) {
                     const int hw = ((int)(h.y >> 16) >> VCT_BIN_SHIFT) - hx0 + 1;
                     const int by = hy0 + (int)j / hw, bx = hx0 + (int)j % hw;
                     ent[u] = bin_entry(rec0 + (uint32_t)lo, h, bx, by, depth_only);
+#if VCT_BIN_FILL_AGGREGATE
+                    bin_of[u] = (uint32_t)(by * p.bins_x + bx);
+#else
                     at[u] = atomicAdd(&p.bin_cursor[(size_t)(by * p.bins_x + bx) * VCT_BIN_CSTRIDE], 1u);
+#endif
                 }
             }
+#if VCT_BIN_FILL_AGGREGATE
+            // One returning atomic per DISTINCT bin of the wave's 64 pairs instead of one per pair (neighbouring triangles
+            // land in the same bins; atomics on one address execute one after the other in the L2): the lanes of a bin
+            // elect a leader and take consecutive slots behind what it reserved.  The leaders' atomics of the four rounds
+            // are all issued before any result is used.
+            int leader[4];
+            uint32_t rank[4], cnt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                leader[u] = lane; rank[u] = 0u; cnt[u] = 0u;
+                unsigned long long left = __builtin_amdgcn_ballot_w64(bin_of[u] != 0xffffffffu);
+                // (at most VCT_BIN_FILL_AGG_ROUNDS distinct bins are grouped, and the election stops after two groups of one
+                // in a row; pairs left over take their own atomic: where every pair of the wave has a bin of its own --
+                // large triangles at 4K -- the election would cost more than the atomics it saves)
+                int singles = 0;
+                for (int round = 0; round < VCT_BIN_FILL_AGG_ROUNDS && left != 0ull && singles < 2; ++round) {
+                    const int l = (int)__ffsll((long long)left) - 1;
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bin_of[u], l);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(bin_of[u] == b);
+                    if (bin_of[u] == b) {
+                        leader[u] = l;
+                        rank[u] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    }
+                    if (lane == l) cnt[u] = (uint32_t)__popcll(m);
+                    singles = (m & (m - 1ull)) == 0ull ? singles + 1 : 0;     // two groups of one in a row: no crowding here
+                    left &= ~m;
+                }
+                if ((left >> lane) & 1ull) cnt[u] = 1u;       // not grouped: leader of itself
+            }
+            uint32_t got[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                got[u] = 0u;
+                if (cnt[u] != 0u) got[u] = atomicAdd(&p.bin_cursor[(size_t)bin_of[u] * VCT_BIN_CSTRIDE], cnt[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t base = (uint32_t)__shfl((int)got[u], leader[u]);
+                if (bin_of[u] != 0xffffffffu) at[u] = base + rank[u];
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < 4; ++u) p.entries[at[u] < p.entry_cap ? at[u] : p.entry_cap] = ent[u];
         }
