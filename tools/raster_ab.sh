@@ -1,6 +1,6 @@
 #!/bin/bash
 # ON THE GPU BOX: parity of the raster tests on the in-tree library, then interleaved per-kernel times of the raster stages
-# for the libraries named (tree = in-tree, other words = build/ab/<word>.so).  tools/alpha_ab.sh "old tree" [rounds] [kernel regex]
+# for the libraries named (tree = in-tree, other words = build/ab/<word>.so).  tools/raster_ab.sh "old tree" [rounds] [kernel regex]
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 LIBS=${1:-"tree"}; ROUNDS=${2:-2}; PAT=${3:-"k_bin_raster<false>|k_gbuffer"}
 mkdir -p gpurun_out
