@@ -789,6 +789,12 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
 #ifndef VCT_BIN_FILL_AGGREGATE
 #define VCT_BIN_FILL_AGGREGATE 1      // k_bin_fill: one returning atomic per distinct bin of a wave's 64 pairs
 #endif
+#ifndef VCT_BIN_BUCKET_ORDER
+#define VCT_BIN_BUCKET_ORDER 1        // k_bin_raster: slice entries bucketed by depth instead of sorted
+#endif
+#ifndef VCT_BIN_BUCKETS
+#define VCT_BIN_BUCKETS 32            // per class (opaque / alpha-tested); a multiple of 32
+#endif
 #ifndef VCT_BIN_COUNT_AGGREGATE
 #define VCT_BIN_COUNT_AGGREGATE 1     // k_bin_setup: the same for the counting atomics
 #endif
@@ -1293,7 +1299,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 #ifndef VCT_BINRASTER_MIN_BLOCKS
-#define VCT_BINRASTER_MIN_BLOCKS 2
+#define VCT_BINRASTER_MIN_BLOCKS 6   // (waves per SIMD, __launch_bounds__' second argument: the 26 KB of LDS allow six workgroups per CU,
+                                     // so the register allocator is held to 80 -- left alone it drifts between 72 and 91)
 #endif
 #ifndef VCT_BINRASTER_GRID
 #define VCT_BINRASTER_GRID 16384u    // workgroups of k_bin_raster: each strides the work items
@@ -1351,6 +1358,7 @@ k_bin_raster(const BinParams p) {
     __shared__ unsigned long long s_kv[VCT_BIN_SLICE];
     __shared__ uint4 s_rec[VCT_BIN_CHUNK * 10];
     __shared__ unsigned long long s_mail[4][64];          // per wave: what its alpha-queue flushes won, by pixel
+    __shared__ uint32_t s_bk[2 * VCT_BIN_BUCKETS], s_mm[4];                // bucket counters / cursors and depth ranges of the slice order
     __shared__ BinAlphaQueue s_q[DEPTH_ONLY ? 1 : 4];
     const uint32_t nitems = min(p.ctr[2], p.item_cap);
     const bool any_in_place = p.ctr[5] != 0u;
@@ -1384,6 +1392,60 @@ k_bin_raster(const BinParams p) {
         }
         mail[lane] = ~0ull;
         if (__syncthreads_or(alpha_here ? 1 : 0) && n > 1) {     // opaque first, then alpha-tested front to back
+#if VCT_BIN_BUCKET_ORDER
+            // The order only has to be GOOD (what comes first hides what comes later; any order gives the same words):
+            // instead of a bitonic network (28 barrier rounds for 128 keys, 45 for 512: a tenth of this kernel's time) the
+            // keys are dealt into VCT_BIN_BUCKETS + VCT_BIN_BUCKETS buckets of their class' depth range -- five barriers.
+            unsigned long long* tmp = reinterpret_cast<unsigned long long*>(s_rec);      // (free until the first chunk is staged)
+            if (threadIdx.x < 2 * VCT_BIN_BUCKETS) s_bk[threadIdx.x] = 0u;
+            if (threadIdx.x < 4) s_mm[threadIdx.x] = (threadIdx.x & 1) ? 0u : 0xffffffffu;
+            __syncthreads();
+            for (int i = (int)threadIdx.x; i < n; i += 256) {
+                const uint32_t hi = (uint32_t)(s_kv[i] >> 32), c = hi >> 31, d = hi & 0x7fffffffu;
+                atomicMin(&s_mm[2 * c], d);
+                atomicMax(&s_mm[2 * c + 1], d);
+            }
+            __syncthreads();
+            uint32_t bk[2] = {0u, 0u};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = (int)threadIdx.x + 256 * r;
+                if (i < n) {
+                    const uint32_t hi = (uint32_t)(s_kv[i] >> 32), c = hi >> 31, d = hi & 0x7fffffffu;
+                    const uint32_t lo = s_mm[2 * c], span = s_mm[2 * c + 1] - lo;
+                    const uint32_t q = min((uint32_t)VCT_BIN_BUCKETS - 1u, (uint32_t)((float)(d - lo) * __fdividef((float)VCT_BIN_BUCKETS, (float)span + 1.0f)));
+                    bk[r] = c * (uint32_t)VCT_BIN_BUCKETS + q;
+                    atomicAdd(&s_bk[bk[r]], 1u);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {            // exclusive scan of the counters: they become the buckets' cursors
+                uint32_t carry = 0u;
+#pragma unroll
+                for (int h = 0; h < 2 * VCT_BIN_BUCKETS; h += 64) {
+                    const uint32_t v = s_bk[h + lane];
+                    uint32_t incl = v;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t t = __shfl_up(incl, off);
+                        if (lane >= off) incl += t;
+                    }
+                    s_bk[h + lane] = carry + incl - v;
+                    carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = (int)threadIdx.x + 256 * r;
+                if (i < n) tmp[atomicAdd(&s_bk[bk[r]], 1u)] = s_kv[i];
+            }
+            __syncthreads();
+            for (int i = (int)threadIdx.x; i < n; i += 256) s_kv[i] = tmp[i];
+            // (the chunk loop starts with a barrier)
+#else
+#if defined(VCT_PROBE_SORT_TWICE)
+            for (int rep = 0; rep < 2; ++rep)       // timing probe: what the sort costs (sorted input, same network)
+#endif
             for (int k = 2; k <= m; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     for (int i = (int)threadIdx.x; i < m; i += 256) {
@@ -1395,6 +1457,7 @@ k_bin_raster(const BinParams p) {
                     }
                     __syncthreads();
                 }
+#endif
         }
         const int qx0 = (bx << VCT_BIN_SHIFT) + (wave & 1) * 8, qy0 = (by << VCT_BIN_SHIFT) + (wave >> 1) * 8;
         const int px = qx0 + lx, py = qy0 + ly;
