@@ -792,6 +792,10 @@ k_raster_mid(const RasterParams p, const int gblocks, const int wblocks) {
 #ifndef VCT_BIN_BUCKET_ORDER
 #define VCT_BIN_BUCKET_ORDER 1        // k_bin_raster: slice entries bucketed by depth instead of sorted
 #endif
+#ifndef VCT_BIN_ORDER_MIN
+#define VCT_BIN_ORDER_MIN 16          // slices without alpha-tested entries are ordered too from this many entries on (front to back:
+                                      // the hierarchical depth test rejects more; atrium 95 -> 62 us, depth-only street 300 -> 212)
+#endif
 #ifndef VCT_BIN_BUCKETS
 #define VCT_BIN_BUCKETS 32            // per class (opaque / alpha-tested); a multiple of 32
 #endif
@@ -1391,7 +1395,8 @@ k_bin_raster(const BinParams p) {
             s_kv[i] = kv;
         }
         mail[lane] = ~0ull;
-        if (__syncthreads_or(alpha_here ? 1 : 0) && n > 1) {     // opaque first, then alpha-tested front to back
+        const bool any_alpha = __syncthreads_or(alpha_here ? 1 : 0) != 0;
+        if ((any_alpha || n >= VCT_BIN_ORDER_MIN) && n > 1) {     // opaque first, then alpha-tested front to back
 #if VCT_BIN_BUCKET_ORDER
             // The order only has to be GOOD (what comes first hides what comes later; any order gives the same words):
             // instead of a bitonic network (28 barrier rounds for 128 keys, 45 for 512: a tenth of this kernel's time) the
