@@ -1411,6 +1411,7 @@ k_bin_raster(const BinParams p) {
                 atomicMax(&s_mm[2 * c + 1], d);
             }
             __syncthreads();
+            static_assert(VCT_BIN_SLICE <= 512, "the bucket order keeps two keys per thread (256 threads)");
             uint32_t bk[2] = {0u, 0u};
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
