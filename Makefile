@@ -15,7 +15,7 @@ all: lib host oracle demo
 
 host: $(HOSTLIB)
 
-$(HOSTLIB): $(PKG)/host/vct_host.cpp $(PKG)/host/vct_host.h
+$(HOSTLIB): $(PKG)/host/vct_host.cpp $(PKG)/host/vct_host.h $(PKG)/host/vct_image.h
 	g++ -O2 -std=c++17 -ffp-contract=off -fPIC -Wall -Wextra -shared -o $@ $(PKG)/host/vct_host.cpp
 
 lib: $(LIB)

@@ -12,12 +12,13 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 os.environ["VCT_COMM_MODE"] = "direct"
 rank, world, idfile, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
 die = len(sys.argv) > 5 and sys.argv[5] == "kill"      # failure path: the last rank exits before its first frame step
+late = len(sys.argv) > 5 and sys.argv[5] == "late"     # teardown path: the host deadline fires while flag waits are still QUEUED
 
 import vctpkg
 vct = vctpkg.load()
 from voxel_cone_tracing_amd import scene as sc
 
-w, h, V = 200, 123, 64                                   # 16 tile rows, the last one ragged
+w, h, V = (1280, 720, 64) if late else (200, 123, 64)    # 16 tile rows, the last one ragged (late: launches worth queueing)
 scene = sc.Scene(sc.ATRIUM, 0.15, 1234)
 cam = sc.default_camera(position=(-56.0, -9.0, 2.0), yaw=0.0, pitch=8.0)
 ctx = vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=512, device=0))
@@ -48,6 +49,36 @@ info = ctx.comm_info()
 assert info["nranks"] == world and info["rank"] == rank
 if die and rank == world - 1:
     os._exit(0)
+if late:
+    # The root never steps.  Rank 1 queues far more compute than the communicator's deadline, then three frame steps: the
+    # third one's flag wait (release[0] >= 1, which only a stepping root publishes) is still queued behind that compute
+    # when vct_comm_sync's HOST deadline fires.  vct_comm_destroy must then drain the queued wait and the trace kernel
+    # that stores into the root's mapped frame BEFORE it closes the IPC mappings (a GPU fault otherwise), and the context
+    # must stay usable.
+    done_marker = idfile + ".rank1_done"
+    if rank == 0:
+        t0 = time.time()
+        while not os.path.exists(done_marker) and time.time() - t0 < 120:
+            time.sleep(0.05)
+        ctx.comm_destroy(); ctx.close()
+        sys.exit(0)
+    for _ in range(1500):
+        ctx.trace_resident()
+    for _ in range(3):
+        ctx.frame_step()
+    t0 = time.time()
+    try:
+        ctx.comm_sync()
+        err = ""
+    except vct.VctError as e:
+        err = str(e)
+    waited = time.time() - t0
+    ctx.comm_destroy()                        # queued waits + peer stores drained first, then the mappings go
+    again = ctx.trace_current()               # the context survives
+    np.savez(out, err=np.array(err), waited=np.float64(waited), usable=np.array(bool(np.isfinite(vct.half_to_float(again)).all())))
+    open(done_marker, "w").close()
+    ctx.close()
+    sys.exit(3 if err else 0)
 frames = {}
 ty = (h + 7) // 8
 try:

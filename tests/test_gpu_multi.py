@@ -381,6 +381,22 @@ def test_direct_slabs_dead_peer_is_an_error_not_a_hang(tmp_path):
     assert not bool(z["ok"]) and ("gave up" in str(z["error"]) or "did not complete" in str(z["error"]))
 
 
+def test_direct_slabs_teardown_with_waits_still_queued(tmp_path):
+    """The host deadline of vct_comm_sync fires while a rank's flag wait and the trace that stores into the root's mapped
+    frame are still QUEUED behind long compute: vct_comm_destroy raises the abort word, drains both streams and only then
+    closes the IPC mappings (round-5 advisor: a GPU memory fault otherwise); the context stays usable."""
+    idfile, out = str(tmp_path / "id"), str(tmp_path / "out.npz")
+    env = dict(os.environ, VCT_COMM_TIMEOUT_MS="150")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "direct_rank.py"), str(r), "2", idfile, out, "late"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    assert procs[1].returncode == 3, logs[1][-2000:]          # the expected error, not a fault / abort
+    assert procs[0].returncode == 0, logs[0][-2000:]
+    z = np.load(out)
+    assert "did not complete" in str(z["err"]) or "gave up" in str(z["err"])
+    assert float(z["waited"]) < 30.0 and bool(z["usable"])
+
+
 def test_cpp_caller_direct_slabs_two_ranks_on_one_gpu(vct):
     """vct_demo --gpus 2 with VCT_COMM_MODE=direct and both ranks on device 0: the facade's multi-GPU sequence through the
     direct-slab mode; rank 0's frame checksum equals the single-GPU run's."""

@@ -252,6 +252,81 @@ def test_corrupt_files_fail_cleanly(sc, tmp_path):
                 pass
 
 
+def test_headers_that_promise_more_than_the_file_holds_are_refused_at_once(sc, tmp_path):
+    """Round-5 advisor: nothing is sized from header fields before the limits and the file's own length have been checked --
+    a crafted 200-byte texture must fail in milliseconds without reserving gigabytes or decoding millions of blocks."""
+    import time
+    # JPEG: a real greyscale file, truncated after its first scan bytes, SOF dimensions patched to 65535 x 65535 / 32768 x 8192
+    buf = io.BytesIO()
+    PIL.fromarray(picture()[..., 2], "L").save(buf, "JPEG", quality=80)
+    jpg = bytearray(buf.getvalue())
+    sof = jpg.index(b"\xff\xc0")
+    sos = jpg.index(b"\xff\xda")
+    for dims in ((65535, 65535), (8192, 32768)):
+        b = bytearray(jpg[:sos + 40])                       # header + a few bytes of entropy-coded data, no EOI
+        b[sof + 5:sof + 9] = struct.pack(">HH", *dims)
+        (tmp_path / "huge.jpg").write_bytes(bytes(b))
+        t0 = time.time()
+        with pytest.raises(ValueError):
+            sc.load_image(str(tmp_path / "huge.jpg"))
+        assert time.time() - t0 < 2.0
+    # PNG: 32768 x 8192 RGBA16 declared, a few IDAT bytes present
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 32768, 8192, 16, 6, 0, 0, 0)) +
+           chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""))
+    (tmp_path / "huge.png").write_bytes(png)
+    t0 = time.time()
+    with pytest.raises(ValueError):
+        sc.load_image(str(tmp_path / "huge.png"))
+    assert time.time() - t0 < 2.0
+    # TGA / BMP / PGM headers without their pixels
+    tga = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0]) + struct.pack("<HH", 32768, 8192) + bytes([32, 0])
+    bmp = b"BM" + struct.pack("<IHHI", 54, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 30000, 8000, 1, 24, 0, 0, 0, 0, 0, 0)
+    for name, data in (("h.tga", tga), ("h.bmp", bmp), ("h.pgm", b"P5 32768 8192 255\n")):
+        (tmp_path / name).write_bytes(data)
+        t0 = time.time()
+        with pytest.raises(ValueError):
+            sc.load_image(str(tmp_path / name))
+        assert time.time() - t0 < 2.0
+
+
+def test_single_component_jpeg_ignores_its_sampling_factors(sc, tmp_path):
+    """T.81 A.2.2: a scan with one component is not interleaved -- its MCU is one 8 x 8 block whatever H and V say.  The same
+    greyscale file with its SOF factors patched from 1x1 to 2x2 must decode to the same image (libjpeg agrees)."""
+    h, w = 45, 70
+    ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    g = np.clip(128 + 100 * np.sin(xs * 0.13) * np.cos(ys * 0.07), 0, 255).astype(np.uint8)
+    buf = io.BytesIO()
+    PIL.fromarray(g, "L").save(buf, "JPEG", quality=90)
+    jpg = bytearray(buf.getvalue())
+    (tmp_path / "a.jpg").write_bytes(bytes(jpg))
+    sof = jpg.index(b"\xff\xc0")
+    assert jpg[sof + 9] == 1 and jpg[sof + 11] == 0x11        # one component, 1x1
+    jpg[sof + 11] = 0x22
+    (tmp_path / "b.jpg").write_bytes(bytes(jpg))
+    a, b = sc.load_image(str(tmp_path / "a.jpg")), sc.load_image(str(tmp_path / "b.jpg"))
+    assert a.shape == (h, w, 4) and np.array_equal(a, b)
+    ref = np.asarray(PIL.open(str(tmp_path / "b.jpg")).convert("L"))
+    assert np.abs(b[::-1, :, 0].astype(int) - ref.astype(int)).max() <= 4
+
+
+def test_image_load_never_writes_past_the_callers_capacity(sc, tmp_path):
+    """vcth_image_load's second call reports -2 instead of copying an image that outgrew the buffer sized by the first call."""
+    import ctypes as C
+    p = str(tmp_path / "t.png")
+    PIL.fromarray(picture(), "RGBA").save(p)
+    lib = sc._lib
+    w, h = C.c_int32(), C.c_int32()
+    assert lib.vcth_image_load(os.fsencode(p), C.byref(w), C.byref(h), None, 0) == 0
+    n = w.value * h.value * 4
+    guard = np.full(n + 64, 0xAB, np.uint8)
+    assert lib.vcth_image_load(os.fsencode(p), None, None, guard.ctypes.data, n - 4) == -2
+    assert (guard == 0xAB).all()
+    assert lib.vcth_image_load(os.fsencode(p), None, None, guard.ctypes.data, n) == 0
+    assert (guard[n:] == 0xAB).all() and np.array_equal(guard[:n].reshape(h.value, w.value, 4), expect(picture()))
+
+
 def test_mtl_maps_in_png_and_jpeg(sc, tmp_path):
     """The OBJ + MTL reader takes the new containers (by content, whatever the extension says)."""
     img = picture(16, 16)

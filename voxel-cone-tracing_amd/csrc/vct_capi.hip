@@ -1152,22 +1152,31 @@ int vct_render_shadow_map(vct_ctx* c, const float light_vp[16]) {
     if (want_tiles && !c->shadow_tiles) HIP_TRY(c, hipMalloc(&c->shadow_tiles, shadow_tile_count(S) * sizeof(uint2)));
     if (!want_tiles && c->shadow_tiles) { (void)hipFree(c->shadow_tiles); c->shadow_tiles = nullptr; }
     c->shadow_size = S;
+    // A pass that fails from here on leaves a map (the old one, or a partly written one) but NO tile bounds: a stale or
+    // uninitialised table would decide PCF windows wrongly, without one the consumers just fetch every window (advisor, round 5).
+    auto drop_tiles = [&]() { if (c->shadow_tiles) { (void)hipFree(c->shadow_tiles); c->shadow_tiles = nullptr; } };
     VctRasterArgs a;
     int rc = raster_args(c, S, S, true, c->raster_mode == 2, c->stream, a);
-    if (rc) return rc;
+    if (rc) { drop_tiles(); return rc; }
     // The pass's atomicMin words ARE the map (vct_internal.h "shadow map words"): epoch 3, 2, 1, 0, then one memset
     // and 3 again -- a new pass overwrites older epochs by itself, readers see them as depth 1.0.
     const uint32_t epoch = 3u - (c->shadow_passes & 3u);
-    if (epoch == 3u) HIP_TRY(c, hipMemsetAsync(c->shadow, 0xff, (size_t)S * S * sizeof(uint32_t), c->stream));
+    if (epoch == 3u) {
+        const hipError_t em = hipMemsetAsync(c->shadow, 0xff, (size_t)S * S * sizeof(uint32_t), c->stream);
+        if (em != hipSuccess) { drop_tiles(); HIP_TRY(c, em); }
+    }
     a.vis32 = c->shadow;
     a.vis32_ebase = VCT_SHADOW_EPOCH(epoch);
     memcpy(c->light_vp, light_vp, 64);
     const hipError_t e = vct_launch_shadow_raster(a, light_vp, S, c->stream);
-    if (e != hipSuccess) { c->raster_dirty[0] = true; HIP_TRY(c, e); }
+    if (e != hipSuccess) { c->raster_dirty[0] = true; drop_tiles(); HIP_TRY(c, e); }
     c->shadow_ebase = a.vis32_ebase;
     ++c->shadow_passes;
     // depth bounds per (dilated) 8 x 8 tile of the new map: the PCF consumers (voxelizer, G-buffer shade) decide most windows on them
-    if (c->shadow_tiles) HIP_TRY(c, vct_launch_shadow_minmax(c->shadow, c->shadow_ebase, S, c->shadow_tiles, c->stream));
+    if (c->shadow_tiles) {
+        const hipError_t et = vct_launch_shadow_minmax(c->shadow, c->shadow_ebase, S, c->shadow_tiles, c->stream);
+        if (et != hipSuccess) { drop_tiles(); HIP_TRY(c, et); }
+    }
     return VCT_OK;
 }
 

@@ -127,12 +127,17 @@ struct DirectShm {
     uint32_t timed_out;                                 // a wait gave up
 };
 
-// lanes 0 .. n-1 each wait for flags[lane * stride] >= want; deadline in wall-clock ticks (100 MHz)
-__global__ void k_flag_wait(const uint32_t* flags, int n, int stride, uint32_t want, uint32_t* timed_out, long long ticks) {
+// lanes 0 .. n-1 each wait for flags[lane * stride] >= want; deadline in wall-clock ticks (the device's
+// hipDeviceAttributeWallClockRate, vct_comm::wall_khz).  `abort_word` is this process' own page-locked word: its host sets
+// it before tearing the communicator down, so a wait still queued behind long compute gives up at once instead of
+// polling memory that is about to be unmapped (advisor, round 5).
+__global__ void k_flag_wait(const uint32_t* flags, int n, int stride, uint32_t want, uint32_t* timed_out, long long ticks,
+                            const uint32_t* abort_word) {
     const int i = threadIdx.x;
     if (i >= n) return;
     const long long t0 = (long long)wall_clock64();
     while (__hip_atomic_load(flags + (size_t)i * stride, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;   // local teardown: not a peer's fault
         if ((long long)wall_clock64() - t0 > ticks) {
             __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
@@ -178,6 +183,10 @@ struct vct_comm {
     DirectShm* shm = nullptr;          // host mapping of the rendezvous block
     DirectShm* shm_dev = nullptr;      // the same block as this rank's GPU sees it
     uint16_t* peer_frame[2] = {nullptr, nullptr};      // ranks > 0: the root's frame buffers, mapped
+    hipStream_t ctx_stream = nullptr;  // the context's stream (direct mode queues flag kernels and peer stores on it: drained at teardown)
+    uint32_t* abort_host = nullptr;    // this process' abort word (page-locked, mapped): k_flag_wait gives up when it is set
+    uint32_t* abort_dev = nullptr;
+    long long wall_khz = 100000;       // wall_clock64 rate of this device (hipDeviceAttributeWallClockRate)
     int timeout_ms = 60000;            // vct_comm_sync gives up after this long and aborts the communicator
     bool broken = false;               // the communicator was aborted (a peer died or hung): only vct_comm_destroy is left
 };
@@ -199,11 +208,21 @@ static int comm_fail(vct_ctx* c, vct_comm* m, const std::string& what, ncclResul
 
 static void comm_free(vct_comm* m) {
     if (!m) return;
-    if (m->comm_stream && !m->broken) (void)hipStreamSynchronize(m->comm_stream);
     if (m->direct) {
+        // Direct slabs: flag waits and the trace kernels that store into the root's mapped frame may still be QUEUED
+        // (a host-side deadline fires before a wait that sits behind long compute has even started).  They must have
+        // left the GPU before the mappings they use go away -- so: raise the abort word (every wait of this process
+        // returns at its next poll; each is deadline-bounded anyway), drain BOTH streams, and only then close the IPC
+        // handles and unregister the block.  Cannot hang: nothing left in the queues waits on a peer.
+        if (m->abort_host) __atomic_store_n(m->abort_host, 1u, __ATOMIC_RELEASE);
+        if (m->ctx_stream) (void)hipStreamSynchronize(m->ctx_stream);
+        if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
         for (int k = 0; k < 2; ++k) if (m->peer_frame[k]) (void)hipIpcCloseMemHandle(m->peer_frame[k]);
         if (m->shm) { (void)hipHostUnregister(m->shm); munmap(m->shm, sizeof(DirectShm)); }
         if (m->rank == 0 && m->shm_name[0]) shm_unlink(m->shm_name);
+        if (m->abort_host) (void)hipHostFree(m->abort_host);
+    } else if (m->comm_stream && !m->broken) {
+        (void)hipStreamSynchronize(m->comm_stream);
     }
     if (m->comm) {
         if (m->broken && rccl()->CommAbort) (void)rccl()->CommAbort(m->comm);
@@ -378,9 +397,21 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
     } else {
         e = hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking);
     }
+    m->ctx_stream = c->stream;
+    if (direct && e == hipSuccess) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) m->wall_khz = khz;
+        e = hipHostMalloc((void**)&m->abort_host, sizeof(uint32_t), hipHostMallocMapped);
+        if (e == hipSuccess) { *m->abort_host = 0u; e = hipHostGetDevicePointer((void**)&m->abort_dev, m->abort_host, 0); }
+    }
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         if (!(direct && rank != 0)) {        // (a rank of the direct mode owns no slab buffer: it writes the root's)
-            e = hipMalloc(&m->buf[k], m->buf_halves * 2);
+            // Direct mode: peers store into the root's frame over IPC / xGMI and the root's next kernel reads it with only
+            // a kernel-boundary acquire, which need not invalidate lines of LOCAL coarse-grained memory that the root's L2
+            // kept from an earlier frame.  Fine-grained memory is not cached that way, so the frame buffers peers write
+            // are allocated fine-grained (advisor, round 5); no fallback -- a coarse-grained frame could be silently stale.
+            e = direct ? hipExtMallocWithFlags((void**)&m->buf[k], m->buf_halves * 2, hipDeviceMallocFinegrained)
+                       : hipMalloc(&m->buf[k], m->buf_halves * 2);
             if (e == hipSuccess) e = hipMemsetAsync(m->buf[k], 0, m->buf_halves * 2, c->stream);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->traced[k], hipEventDisableTiming);
@@ -526,7 +557,7 @@ int vct_frame_step(vct_ctx* c) {
     if (m->direct) {
         // direct slabs (see DirectShm): flags instead of a collective, the slab stored straight into the root's frame
         const uint32_t gen = (uint32_t)(m->frames >> 1) + 1u;
-        const long long ticks = (long long)m->timeout_ms * 100000ll;           // wall_clock64 counts at 100 MHz
+        const long long ticks = (long long)m->timeout_ms * m->wall_khz;        // wall_clock64 ticks per ms = its rate in kHz
         const size_t row_halves = (size_t)VCT_TILE * c->cfg.width * 4;
         if (m->rank == 0) {
             hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(1), 0, c->stream, &m->shm_dev->release[k], gen - 1u);
@@ -543,7 +574,7 @@ int vct_frame_step(vct_ctx* c) {
             HIP_TRY(c, hipEventRecord(m->g0[k], cs));
             if (m->world > 1) {
                 hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, cs, &m->shm_dev->done[k][1], m->world - 1, 1, gen,
-                                   &m->shm_dev->timed_out, ticks);
+                                   &m->shm_dev->timed_out, ticks, m->abort_dev);
                 HIP_TRY(c, hipGetLastError());
             }
             if (m->interleaved) {
@@ -555,7 +586,7 @@ int vct_frame_step(vct_ctx* c) {
             HIP_TRY(c, hipEventRecord(m->gathered[k], cs));
         } else {
             hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, c->stream, &m->shm_dev->release[k], 1, 1, gen - 1u,
-                               &m->shm_dev->timed_out, ticks);
+                               &m->shm_dev->timed_out, ticks, m->abort_dev);
             HIP_TRY(c, hipGetLastError());
             // where this rank's slab lives in the root's buffer k: packed slab `rank` (equal / interleaved) or its own rows
             uint16_t* peer_slab = m->peer_frame[k] + (uneven ? (size_t)m->starts[m->rank] * row_halves : (size_t)m->rank * m->slab_halves);

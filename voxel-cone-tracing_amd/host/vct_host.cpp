@@ -1021,13 +1021,17 @@ void vcth_scene_texture_info(const vcth_scene* s, int32_t i, int32_t* w, int32_t
     if (h) *h = ok ? s->textures[(size_t)i].h : 0;
 }
 
-int32_t vcth_image_load(const char* path, int32_t* width, int32_t* height, uint8_t* rgba) {
+int32_t vcth_image_load(const char* path, int32_t* width, int32_t* height, uint8_t* rgba, size_t capacity) {
     if (!path) return -1;
     vct_image::Image im;
     if (!vct_image::load(path, im)) return -1;
     if (width) *width = im.w;
     if (height) *height = im.h;
-    if (rgba) memcpy(rgba, im.rgba.data(), im.rgba.size());
+    if (rgba) {
+        // the file may have changed since the caller asked for its size: never write more than the caller has room for
+        if (im.rgba.size() > capacity) return -2;
+        memcpy(rgba, im.rgba.data(), im.rgba.size());
+    }
     return 0;
 }
 

@@ -14,6 +14,7 @@
 #ifndef VCT_HOST_H_
 #define VCT_HOST_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -80,8 +81,10 @@ void vcth_scene_get_material_textures(const vcth_scene* s, int32_t* mat_tex);
 
 /* The decoder behind map_Kd / map_Ks / map_bump (host/vct_image.h: PNG, baseline JPEG, BMP, TGA raw / RLE, PPM / PGM --
  * the containers stb_image serves the reference with, R/Model.h:141-226).  Two calls: rgba == NULL returns the size;
- * then rgba [h][w][4], row 0 = BOTTOM row.  Returns 0, or -1 when the file is unreadable / unsupported / corrupt. */
-int32_t vcth_image_load(const char* path, int32_t* width, int32_t* height, uint8_t* rgba);
+ * then rgba [h][w][4] with `capacity` bytes of room, row 0 = BOTTOM row (width / height are reported again: check them).
+ * Returns 0, -1 when the file is unreadable / unsupported / corrupt, -2 when the image does not fit `capacity` (the
+ * file changed between the two calls). */
+int32_t vcth_image_load(const char* path, int32_t* width, int32_t* height, uint8_t* rgba, size_t capacity);
 
 #ifdef __cplusplus
 }

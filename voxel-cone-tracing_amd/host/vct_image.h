@@ -156,8 +156,10 @@ inline void put(Image& im, int x, int y_top_down, uint8_t r, uint8_t g, uint8_t 
     uint8_t* d = &im.rgba[((size_t)(im.h - 1 - y_top_down) * im.w + x) * 4];
     d[0] = r; d[1] = g; d[2] = b; d[3] = a;
 }
+// the size limits every decoder applies BEFORE it sizes anything from header fields
+inline bool dims_ok(int w, int h) { return w > 0 && h > 0 && w <= 32768 && h <= 32768 && (size_t)w * h <= ((size_t)1 << 28); }
 inline bool alloc(Image& im, int w, int h) {
-    if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || (size_t)w * h > ((size_t)1 << 28)) return false;
+    if (!dims_ok(w, h)) return false;
     im.w = w; im.h = h;
     im.rgba.assign((size_t)w * h * 4, 0);
     return true;
@@ -192,7 +194,7 @@ inline bool decode_png(const std::vector<uint8_t>& f, Image& im) {
     switch (ctype) { case 0: chans = 1; break; case 2: chans = 3; break; case 3: chans = 1; break; case 4: chans = 2; break; case 6: chans = 4; break; default: return false; }
     const bool depth_ok = ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
                                      : (ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) : (depth == 8 || depth == 16));
-    if (!depth_ok || idat.empty() || (ctype == 3 && plte.size() < 3) || !alloc(im, w, h)) return false;
+    if (!depth_ok || idat.empty() || (ctype == 3 && plte.size() < 3) || !dims_ok(w, h)) return false;
     const int bpp_bits = chans * depth, bpp = (bpp_bits + 7) / 8;
     // passes: one for a non-interlaced image, seven for Adam7 (x0, y0, dx, dy)
     static const int adam[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
@@ -202,6 +204,9 @@ inline bool decode_png(const std::vector<uint8_t>& f, Image& im) {
         const int ph = interlace ? (h - adam[p][1] + adam[p][3] - 1) / adam[p][3] : h;
         if (pw > 0 && ph > 0) raw_size += ((size_t)((size_t)pw * bpp_bits + 7) / 8 + 1) * ph;
     }
+    // DEFLATE expands by at most 1032 : 1 (a 258-byte match per 2 bits): a header that promises more than the IDAT bytes
+    // can hold is refused before anything is sized from it (a 100-byte file must not reserve gigabytes)
+    if (raw_size > idat.size() * 1032 + 1024 || !alloc(im, w, h)) return false;
     std::vector<uint8_t> raw;
     raw.reserve(raw_size);
     if (!Inflater(idat.data(), idat.size()).run(raw, raw_size) || raw.size() != raw_size) return false;
@@ -351,13 +356,14 @@ private:
         if (n < 6 || d[0] != 8) return false;
         h_ = d[1] << 8 | d[2]; w_ = d[3] << 8 | d[4];
         const int nc = d[5];
-        if ((nc != 1 && nc != 3) || n < 6 + (size_t)nc * 3 || w_ <= 0 || h_ <= 0) return false;
+        if ((nc != 1 && nc != 3) || n < 6 + (size_t)nc * 3 || !dims_ok(w_, h_)) return false;     // (the planes are sized from these)
         comp_.assign((size_t)nc, Comp());
         hmax_ = vmax_ = 1;
         for (int i = 0; i < nc; ++i) {
             Comp& c = comp_[(size_t)i];
             c.id = d[6 + i * 3]; c.h = d[7 + i * 3] >> 4; c.v = d[7 + i * 3] & 15; c.tq = d[8 + i * 3];
             if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2 || c.tq > 3) return false;
+            if (nc == 1) c.h = c.v = 1;      // T.81 A.2.2: a single-component scan is never interleaved -- one 8 x 8 block per MCU whatever the factors say
             if (c.h > hmax_) hmax_ = c.h;
             if (c.v > vmax_) vmax_ = c.v;
         }
@@ -382,9 +388,9 @@ private:
                 b = f_[pos_];
                 if (b == 0xff) {
                     const int nx = pos_ + 1 < f_.size() ? f_[pos_ + 1] : 0xd9;
-                    if (nx == 0) pos_ += 2; else b = 0;          // at a marker: stay there
+                    if (nx == 0) pos_ += 2; else { b = 0; ++fed_; }          // at a marker: stay there
                 } else ++pos_;
-            }
+            } else ++fed_;
             buf_ = b; cnt_ = 8;
         }
         return (buf_ >> --cnt_) & 1;
@@ -403,6 +409,9 @@ private:
         static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                                        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
         float co[64] = {0};
+        // a truncated file (or a tiny one with huge dimensions) must not decode millions of blocks out of fed zeros: a
+        // few bytes of slack for the last block's tail, then the scan is corrupt
+        if (fed_ > 16) return false;
         const int s = huff(ht_[0][c.td]);
         if (s < 0 || s > 11) return false;
         c.pred += extend(receive(s), s);
@@ -433,7 +442,7 @@ private:
         return true;
     }
     bool scan(size_t start, Image& im) {
-        pos_ = start; cnt_ = 0;
+        pos_ = start; cnt_ = 0; fed_ = 0;
         const int mcuw = 8 * hmax_, mcuh = 8 * vmax_, mx = (w_ + mcuw - 1) / mcuw, my = (h_ + mcuh - 1) / mcuh;
         for (auto& c : comp_) { c.pw = mx * c.h * 8; c.ph = my * c.v * 8; c.plane.assign((size_t)c.pw * c.ph, 0); c.pred = 0; }
         int until_restart = restart_;
@@ -444,6 +453,7 @@ private:
                     while (pos_ + 1 < f_.size() && !(f_[pos_] == 0xff && f_[pos_ + 1] >= 0xd0 && f_[pos_ + 1] <= 0xd7)) ++pos_;
                     if (pos_ + 1 >= f_.size()) return false;
                     pos_ += 2;
+                    fed_ = 0;
                     for (auto& c : comp_) c.pred = 0;
                     until_restart = restart_;
                 }
@@ -479,6 +489,7 @@ private:
     int w_ = 0, h_ = 0, hmax_ = 1, vmax_ = 1, restart_ = 0;
     size_t pos_ = 0;
     int buf_ = 0, cnt_ = 0;
+    int fed_ = 0;        // zero bytes fed since the last restart because the entropy-coded data had ended
 };
 
 // ------------------------------------------------------------------------------------------- BMP / TGA / PNM --------
@@ -492,7 +503,7 @@ inline bool decode_bmp(const std::vector<uint8_t>& f, Image& im) {
     if ((bpp != 24 && bpp != 32) || (comp != 0 && !(comp == 3 && bpp == 32))) return false;
     const int h = hs < 0 ? -hs : hs;
     const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
-    if (!alloc(im, w, h) || (size_t)off + stride * h > f.size()) return false;
+    if (!dims_ok(w, h) || (size_t)off + stride * h > f.size() || !alloc(im, w, h)) return false;
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             const uint8_t* s = &f[off + stride * (size_t)y + (size_t)x * (bpp / 8)];
@@ -508,10 +519,12 @@ inline bool decode_tga(const std::vector<uint8_t>& f, Image& im) {
     const bool rle = type == 10 || type == 11, grey = type == 3 || type == 11;
     if (!(type == 2 || type == 3 || type == 10 || type == 11) || f[1] != 0) return false;
     if (grey ? bits != 8 : (bits != 24 && bits != 32)) return false;
-    if (!alloc(im, w, h)) return false;
     size_t pos = 18 + (size_t)f[0];
     const bool top_down = (f[17] & 0x20) != 0;
     const size_t npx = (size_t)w * h;
+    // the pixels must be able to come out of the file (raw: all of them; RLE: at most 128 per packet of 1 + bpp bytes)
+    if (!dims_ok(w, h) || pos > f.size() || (rle ? npx > (f.size() - pos) * 128 : pos + npx * (size_t)bpp > f.size())) return false;
+    if (!alloc(im, w, h)) return false;
     std::vector<uint8_t> px(npx * (size_t)bpp);
     if (!rle) {
         if (pos + px.size() > f.size()) return false;
@@ -558,7 +571,7 @@ inline bool decode_pnm(const std::vector<uint8_t>& f, Image& im) {
         vals[got++] = v;
     }
     ++pos;      // the single whitespace after maxval
-    if (got < 3 || vals[2] != 255 || !alloc(im, vals[0], vals[1]) || pos + (size_t)im.w * im.h * ch > f.size()) return false;
+    if (got < 3 || vals[2] != 255 || !dims_ok(vals[0], vals[1]) || pos + (size_t)vals[0] * vals[1] * ch > f.size() || !alloc(im, vals[0], vals[1])) return false;
     for (int y = 0; y < im.h; ++y)
         for (int x = 0; x < im.w; ++x) {
             const uint8_t* s = &f[pos + ((size_t)y * im.w + x) * ch];

@@ -40,18 +40,20 @@ _lib.vcth_scene_get_texture.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 _lib.vcth_scene_get_material_textures.argtypes = [C.c_void_p, C.c_void_p]
 
 
-_lib.vcth_image_load.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.vcth_image_load.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
 
 
 def load_image(path):
     """Decode a PNG / JPEG / BMP / TGA / PPM file with the OBJ reader's decoders: uint8 [h, w, 4], row 0 = bottom row.
     Raises ValueError for an unreadable, unsupported or corrupt file."""
     w, h = C.c_int32(), C.c_int32()
-    if _lib.vcth_image_load(os.fsencode(path), C.byref(w), C.byref(h), None) != 0:
+    if _lib.vcth_image_load(os.fsencode(path), C.byref(w), C.byref(h), None, 0) != 0:
         raise ValueError(f"cannot decode {path}")
     out = np.zeros((h.value, w.value, 4), np.uint8)
-    if _lib.vcth_image_load(os.fsencode(path), None, None, out.ctypes.data) != 0:
-        raise ValueError(f"cannot decode {path}")
+    w2, h2 = C.c_int32(), C.c_int32()
+    if _lib.vcth_image_load(os.fsencode(path), C.byref(w2), C.byref(h2), out.ctypes.data, out.nbytes) != 0 or \
+            (w2.value, h2.value) != (w.value, h.value):
+        raise ValueError(f"cannot decode {path} (or it changed while it was being read)")
     return out
 
 
