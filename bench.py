@@ -88,6 +88,10 @@ def parse():
     ap.add_argument("--slabs", default="balanced", choices=["balanced", "equal", "interleaved"],
                     help="N > 1: balanced = slab boundaries of equal cone-step cost from the first frame's per-row step "
                          "histogram (vct_slab_partition_weighted), equal = ceil(tile_rows / N) rows per rank")
+    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("VCT_BENCH_FRAMES_IN_FLIGHT", "2")), choices=[1, 2],
+                    help="N = 1: 2 = consecutive steps alternate between two frame slots (vct_set_frames_in_flight: own stream, "
+                         "G-buffer and frame each), so that step k + 1 starts while step k drains -- what a renderer's frame "
+                         "loop does; 1 = every step on one stream, each launch waiting for the one before")
     ap.add_argument("--timeout", type=float, default=float(os.environ.get("VCT_BENCH_TIMEOUT_S", "900")),
                     help="self-launched N > 1 run: seconds before the parent kills every rank and exits non-zero")
     return ap.parse_args()
@@ -437,6 +441,19 @@ def main():
         slab_rows = [(r, r + len(range(r, ty_all, world))) for r in range(world)]       # (first row, first row + rows)
         slab_px = sum(min(8, h - 8 * r) for r in range(rank, ty_all, world)) * w
 
+    # Two frames in flight (N = 1): a second frame slot with its own resident G-buffer of the same view; the timed steps
+    # alternate between the slots, so a step's ramp overlaps the drain of the step before it.
+    fif = args.frames_in_flight if not use_dist and args.variant != 4 else 1
+    if fif == 2:
+        ctx.set_frames_in_flight(2)
+        ctx.select_frame_slot(1)
+        if inp["scene"] is None:
+            ctx.trace(inp["planes"], rows=(r0, r1))
+        else:
+            ctx.render_gbuffer(inp["view_proj"])
+            ctx.trace_gbuffer_rows(r0, r1)
+        assert ctx.last_step_count() == steps_slab
+        ctx.select_frame_slot(0)
     comm_stream = torch.cuda.Stream(device=local_rank) if (use_dist and not native) else None
     traced = [torch.cuda.Event() for _ in range(len(fgs))]
     gathered = [torch.cuda.Event() for _ in range(len(fgs))]
@@ -444,7 +461,10 @@ def main():
 
     def one_step():
         if not use_dist:
-            ctx.trace_resident()                  # the trace kernel, on the context stream
+            if fif == 2:                          # frame k in slot k & 1: its own stream, G-buffer and frame
+                ctx.select_frame_slot(step_no[0] & 1)
+                step_no[0] += 1
+            ctx.trace_resident()                  # the trace kernel, on the slot's stream
             return
         if native:
             ctx.frame_step()                      # slab trace + ONE ncclGather, issued from C++
@@ -465,6 +485,7 @@ def main():
             ctx.comm_sync()
         if world > 1:
             dist.barrier()
+        ctx.synchronize()                         # every frame slot's stream
         torch.cuda.synchronize()
 
     for ev_ in gathered:                          # "previous gather" of the first use of each buffer
@@ -489,6 +510,16 @@ def main():
     # per-launch device time of the trace kernel: HIP events on the context's stream, collected
     # in a second, untimed loop so the event reads do not serialise the timed region
     fence()
+    # (one launch in flight at a time here, whatever --frames-in-flight: the duration of a launch that has the GPU to
+    # itself -- what rocprofv3 reports for the same launches and what the roofline block prices)
+    dt_one = None
+    if fif == 2:
+        ctx.select_frame_slot(0)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.trace_resident()
+        fence()
+        dt_one = time.perf_counter() - t1     # the same K steps on ONE stream: what frames_in_flight buys, same run
     for _ in range(min(args.steps, 20)):
         ctx.trace_resident()
         kernel_ms.append(ctx.last_trace_ms())
@@ -595,6 +626,11 @@ def main():
                        # visibility form of the G-buffer pass that was timed (chosen per context by timing both)
                        "raster_form": {0: None, 1: "direct", 2: "tile-binned"}.get(ctx.stage_counts().get("raster_form", 0)),
                        "slab_tile_rows": [b - a for a, b in slab_rows]},
+            "frames_in_flight": {"n": fif, "slot_streams_overlap": ctx.frame_slot_streams_overlap() if fif == 2 else None,
+                                 "ms_per_step_one_stream": None if dt_one is None else round(dt_one / args.steps * 1e3, 4),
+                                 "note": "n = 2: consecutive steps alternate between two frame slots (own stream, own resident "
+                                         "G-buffer of the same view, own frame): a step starts while the one before it drains; "
+                                         "`trace_kernel_ms` and the roofline block are launches that have the GPU to themselves"},
             "cone_steps_per_frame": total_steps,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
             "host_issue_us_per_step": round(t_issue / args.steps * 1e6, 2),

@@ -261,6 +261,30 @@ int vct_set_frame_target(vct_ctx* ctx, void* rgba16f_dev);
 int vct_download_frame(vct_ctx* ctx, void* out_rgba16f_host);
 int vct_synchronize(vct_ctx* ctx);
 
+/* ---- two frames in flight (round 6) -----------------------------------------------------------------
+ * The reference's Render() (VCT.h:146-190) issues GL commands; the driver starts frame k + 1 while frame k
+ * drains -- nothing in R/main.cpp:77-94 waits for a frame.  A HIP stream does wait: each whole-frame trace
+ * launch pays ~20 us of ramp + drain and a dispatch gap before the next kernel of its stream (4-5 % of a
+ * 0.61 ms frame).  With n = 2 the context owns two FRAME SLOTS -- stream, G-buffer, RGBA16F frame, step
+ * counts, timing events each (190 MB + 17 MB more at 1080p) -- and vct_select_frame_slot(ctx, k & 1) before
+ * frame k's vct_render_gbuffer / vct_trace_resident puts consecutive frames on alternate streams: frame
+ * k + 1's raster and trace start while frame k's trace drains.  Every entry point works on the selected
+ * slot (its G-buffer, its frame, its vct_last_* values); the chain, shadow map, mesh and raster scratch are
+ * shared and ordered by events inside the library: a G-buffer pass follows the other slot's G-buffer pass;
+ * a stage that writes shared state (uploads, vct_render_shadow_map, vct_inject_light, vct_build_mips,
+ * vct_bounce, vct_gi_pass) first waits for everything the other slot has in flight, and the other slot's
+ * next work waits for it.  Frames are bit-identical to the one-slot frames.  vct_synchronize waits for both
+ * slots.  n = 1 (default) releases the second slot.  Not with vct_comm_init (a rank's frame is already
+ * double-buffered by vct_frame_step), config.debug_outputs or trace_variant 4.
+ * Measured (tools/pipe_probe.py, bench.py `frames_in_flight`): configs[1] trace 0.626 -> 0.598 ms per
+ * frame, Render() 0.773 -> 0.738; configs[4] (4K, 1024^3, a 1.8 ms raster pass) loses -- hence opt-in. */
+int vct_set_frames_in_flight(vct_ctx* ctx, int32_t n);
+/* streams_overlap: 1 when the second slot's stream was seen to run beside the first at set-up (HIP shares a few hardware
+ * queues between a process' streams; the library probes candidates until one overlaps), 0: no such stream was found --
+ * results are the same, there is just nothing gained. */
+int vct_get_frames_in_flight(const vct_ctx* ctx, int32_t* n, int32_t* selected_slot, int32_t* streams_overlap);
+int vct_select_frame_slot(vct_ctx* ctx, int32_t slot);
+
 /* ---- multi-GPU: screen-tile slabs + ONE RCCL gather per frame (BASELINE.json config 4) -------------
  * No reference counterpart (R/main.cpp:77-94 drives one GL context).  One process and one context per
  * GPU; every rank holds the whole scene + chain (voxelize / inject / mips are replicated: cheaper than

@@ -1,0 +1,229 @@
+"""Two frames in flight (vct_set_frames_in_flight / vct_select_frame_slot, include/vct.h): consecutive frames on
+alternate frame slots -- own stream, G-buffer, frame, step counts -- must give exactly the frames the one-slot context
+gives, whatever is in flight: a moving camera (G-buffer passes sharing the raster scratch), a moving light (stages that
+rewrite the shadow map and the chain between frames), the one-call GI pass, slot-local vct_last_* values.
+The reference has no counterpart in code: its frames overlap inside the GL driver (R/main.cpp:77-94 never waits)."""
+import numpy as np
+import pytest
+
+import vctpkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vct():
+    import torch
+    assert torch.cuda.is_available()
+    return vctpkg.load()
+
+
+def make(vct, w=328, h=200, V=64, **cfg):
+    from voxel_cone_tracing_amd import scene as sc
+    scene = sc.Scene(sc.ATRIUM, 0.15, 1234)
+    ctx = vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=512, **cfg))
+    ctx.set_light_direction((0.0, 1.0, 0.25))
+    ctx.upload_triangles(scene.pos, scene.material, scene.albedo)
+    ctx.upload_mesh_attributes(*scene.frames(), scene.specular)
+    return ctx, sc
+
+
+def cameras(sc, w, h, n):
+    out = []
+    for k in range(n):
+        cam = sc.default_camera(position=(-56.0 + 3.0 * k, -9.0 + 0.5 * k, 2.0 - 0.7 * k), yaw=4.0 * k, pitch=8.0 - k)
+        out.append((tuple(cam.position), sc.camera_view_proj(cam, w, h)))
+    return out
+
+
+def lights(n):
+    return [(0.15 * k, 1.0, 0.25 - 0.1 * k) for k in range(n)]
+
+
+def test_moving_camera_two_frames_in_flight_equals_one(vct):
+    w, h, n = 328, 200, 7
+    ctx, sc = make(vct, w, h)
+    ctx.render_shadow_map(sc.light_view_proj((0.0, 1.0, 0.25)))
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    cams = cameras(sc, w, h, n)
+    want, want_steps = [], []
+    for pos, vp in cams:                       # one slot: frame after frame, read back each
+        ctx.set_camera_position(pos)
+        ctx.render_gbuffer(vp)
+        want.append(ctx.trace_current())
+        want_steps.append(ctx.last_step_count())
+    ctx.set_frames_in_flight(2)
+    assert ctx.frames_in_flight() == (2, 0)
+    got = [None] * n
+    # frames k and k + 1 are both issued before frame k is read back: two in flight at every moment
+    for k, (pos, vp) in enumerate(cams):
+        ctx.select_frame_slot(k & 1)
+        ctx.set_camera_position(pos)
+        ctx.render_gbuffer(vp)
+        ctx.trace_resident()
+        if k >= 1:
+            ctx.select_frame_slot((k - 1) & 1)
+            got[k - 1] = ctx.download_frame()
+            assert ctx.last_step_count() == want_steps[k - 1]          # the slot's own step counts
+    ctx.select_frame_slot((n - 1) & 1)
+    got[n - 1] = ctx.download_frame()
+    for k in range(n):
+        assert np.array_equal(got[k], want[k]), f"frame {k}"
+    # many frames without any read-back in between (nothing throttles the host), then both slots' last frames
+    for rep in range(40):
+        k = rep % n
+        ctx.select_frame_slot(rep & 1)
+        ctx.set_camera_position(cams[k][0])
+        ctx.render_gbuffer(cams[k][1])
+        ctx.trace_resident()
+    ctx.synchronize()
+    ctx.select_frame_slot(1)
+    assert np.array_equal(ctx.download_frame(), want[39 % n])
+    ctx.select_frame_slot(0)
+    assert np.array_equal(ctx.download_frame(), want[38 % n])
+    # back to one slot: still the same frames
+    ctx.set_frames_in_flight(1)
+    assert ctx.frames_in_flight() == (1, 0)
+    ctx.set_camera_position(cams[2][0]); ctx.render_gbuffer(cams[2][1])
+    assert np.array_equal(ctx.trace_current(), want[2])
+    ctx.close()
+
+
+def test_moving_light_between_frames_in_flight(vct):
+    """Every frame re-renders the shadow map, re-voxelizes, injects and rebuilds the mips -- stages that rewrite what the
+    other slot's trace is still reading.  The library orders them (pipeline_join + the switch-time wait): same frames."""
+    w, h, n = 328, 200, 6
+    ctx, sc = make(vct, w, h)
+    cams = cameras(sc, w, h, n)
+    Ls = lights(n)
+
+    def frame(k):
+        ctx.set_light_direction(Ls[k])
+        ctx.set_camera_position(cams[k][0])
+        ctx.render_shadow_map(sc.light_view_proj(Ls[k]))
+        ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+        ctx.render_gbuffer(cams[k][1])
+
+    want = []
+    for k in range(n):
+        frame(k)
+        want.append(ctx.trace_current())
+    ctx.set_frames_in_flight(2)
+    got = [None] * n
+    for k in range(n):
+        ctx.select_frame_slot(k & 1)
+        frame(k)
+        ctx.trace_resident()
+        if k >= 1:
+            ctx.select_frame_slot((k - 1) & 1)
+            got[k - 1] = ctx.download_frame()
+    ctx.select_frame_slot((n - 1) & 1)
+    got[n - 1] = ctx.download_frame()
+    for k in range(n):
+        assert np.array_equal(got[k], want[k]), f"frame {k}"
+    # the same through the one-call pass (its G-buffer raster runs on the auxiliary stream)
+    got2 = [None] * n
+    for k in range(n):
+        ctx.select_frame_slot(k & 1)
+        ctx.set_light_direction(Ls[k]); ctx.set_camera_position(cams[k][0])
+        ctx.gi_pass(sc.light_view_proj(Ls[k]), cams[k][1])
+        if k >= 1:
+            ctx.select_frame_slot((k - 1) & 1)
+            got2[k - 1] = ctx.download_frame()
+    ctx.select_frame_slot((n - 1) & 1)
+    got2[n - 1] = ctx.download_frame()
+    for k in range(n):
+        assert np.array_equal(got2[k], want[k]), f"gi_pass frame {k}"
+    ctx.close()
+
+
+def test_cone_apertures_change_between_frames_in_flight(vct):
+    """A new step table is uploaded while the other slot's trace may still read the old one: the upload waits for it."""
+    w, h = 328, 200
+    ctx, sc = make(vct, w, h)
+    ctx.render_shadow_map(sc.light_view_proj((0.0, 1.0, 0.25)))
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    pos, vp = cameras(sc, w, h, 1)[0]
+    ctx.set_camera_position(pos)
+    ctx.render_gbuffer(vp)
+    aps = [(0.577, 0.07), (0.577, 0.2), (0.45, 0.105), (0.577, 0.07)]
+    want = []
+    for td, ts in aps:
+        ctx.set_cone_apertures(td, ts)
+        want.append(ctx.trace_current())
+    ctx.set_frames_in_flight(2)
+    ctx.select_frame_slot(1); ctx.render_gbuffer(vp); ctx.select_frame_slot(0)
+    got = []
+    for k, (td, ts) in enumerate(aps):
+        ctx.select_frame_slot(k & 1)
+        ctx.set_cone_apertures(td, ts)
+        for _ in range(3):
+            ctx.trace_resident()
+    # (frames k = 2, 3 are the last of their slots)
+    ctx.select_frame_slot(0); got.append(ctx.download_frame())
+    ctx.select_frame_slot(1); got.append(ctx.download_frame())
+    assert np.array_equal(got[0], want[2]) and np.array_equal(got[1], want[3])
+    ctx.close()
+
+
+def test_what_two_frames_in_flight_refuses(vct):
+    ctx, sc = make(vct, 64, 48, 32)
+    with pytest.raises(vct.VctError):
+        ctx.set_frames_in_flight(3)
+    with pytest.raises(vct.VctError):
+        ctx.select_frame_slot(1)                     # one slot only
+    ctx.set_frames_in_flight(2)
+    with pytest.raises(vct.VctError):
+        ctx.set_trace_variant(4)
+    with pytest.raises(vct.VctError):
+        ctx.comm_init(bytes(128), 0, 1)
+    ctx.select_frame_slot(1)
+    with pytest.raises(vct.VctError):                # slot 1 has no G-buffer yet
+        ctx.trace_resident()
+    ctx.set_frames_in_flight(1)                      # from slot 1: slot 0's set comes back
+    assert ctx.frames_in_flight() == (1, 0)
+    ctx.close()
+    dbg, _ = make(vct, 64, 48, 32, debug_outputs=1)
+    with pytest.raises(vct.VctError):
+        dbg.set_frames_in_flight(2)
+    dbg.close()
+
+
+def test_second_slot_is_released(vct):
+    """Enabling and disabling the second slot leaves no memory behind (190 MB per 1080p slot would add up)."""
+    import torch
+    ctx, sc = make(vct, 1920, 1080, 32)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        ctx.set_frames_in_flight(2)
+        assert free0 - torch.cuda.mem_get_info()[0] > 150 << 20
+        ctx.set_frames_in_flight(1)
+    assert abs(free0 - torch.cuda.mem_get_info()[0]) < 8 << 20
+    ctx.set_frames_in_flight(2)
+    ctx.close()                                      # destroy with the second slot alive
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)
+
+
+def test_facade_demo_with_two_frames_in_flight_prints_the_same_checksum():
+    """vct_demo (the reference application's call sequence through host/Voxel_Cone_Tracing.h) with FramesInFlight = 2: a moving
+    camera, frames never read back in the loop -- the last frame's checksum and step count equal the one-slot run's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo = os.path.join(root, "voxel-cone-tracing_amd", "vct_demo")
+    args = ["--scene", "procedural:atrium", "--voxels", "64", "--size", "640x360", "--shadow", "1024", "--frames", "14"]
+    one = subprocess.run([demo] + args, capture_output=True, text=True, timeout=600)
+    two = subprocess.run([demo] + args + ["--frames-in-flight", "2"], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0 and two.returncode == 0, one.stdout + one.stderr + two.stdout + two.stderr
+
+    def last(txt):
+        ln = [l for l in txt.splitlines() if l.startswith("frames=")][-1]
+        return [t for t in ln.split() if t.startswith(("fnv1a=", "cone_steps="))]
+    assert "2 frames in flight" in two.stdout and last(one.stdout) == last(two.stdout)
+    # ... and with the whole GI pass per frame (moving light path of the facade)
+    dl1 = subprocess.run([demo] + args + ["--dynamic-light"], capture_output=True, text=True, timeout=600)
+    dl2 = subprocess.run([demo] + args + ["--dynamic-light", "--frames-in-flight", "2"], capture_output=True, text=True, timeout=600)
+    assert dl1.returncode == 0 and dl2.returncode == 0, dl1.stdout + dl2.stdout + dl2.stderr
+    assert last(dl1.stdout) == last(dl2.stdout)

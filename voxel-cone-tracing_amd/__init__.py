@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "vct_upload_mesh_uvs", "vct_upload_textures", "vct_gi_pass",
     "vct_comm_set_timeout_ms", "vct_last_row_steps", "vct_slab_partition_weighted", "vct_comm_set_slab_rows",
     "vct_get_stage_counts", "vct_comm_info", "vct_comm_last_gather_ms", "vct_set_footprint_records",
+    "vct_set_frames_in_flight", "vct_get_frames_in_flight", "vct_select_frame_slot",
 ]
 
 
@@ -134,6 +135,9 @@ _lib.vct_last_row_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 _lib.vct_slab_partition_weighted.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
 _lib.vct_comm_set_slab_rows.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_upload_mesh_uvs.argtypes = [C.c_void_p, C.c_void_p]
+_lib.vct_set_frames_in_flight.argtypes = [C.c_void_p, C.c_int32]
+_lib.vct_get_frames_in_flight.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+_lib.vct_select_frame_slot.argtypes = [C.c_void_p, C.c_int32]
 _lib.vct_upload_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
 
 
@@ -475,6 +479,26 @@ class Context:
 
     def synchronize(self):
         self._ck(_lib.vct_synchronize(self._h), "vct_synchronize")
+
+    def set_frames_in_flight(self, n):
+        """2: a second frame slot (stream, G-buffer, frame) so that frame k + 1 starts while frame k drains; 1: default."""
+        self._ck(_lib.vct_set_frames_in_flight(self._h, n), "vct_set_frames_in_flight")
+
+    def frames_in_flight(self):
+        """(frames in flight, selected slot)"""
+        n, s = C.c_int32(), C.c_int32()
+        self._ck(_lib.vct_get_frames_in_flight(self._h, C.byref(n), C.byref(s), None), "vct_get_frames_in_flight")
+        return n.value, s.value
+
+    def frame_slot_streams_overlap(self):
+        """True when the second slot's stream was seen to run beside the first (include/vct.h)."""
+        v = C.c_int32()
+        self._ck(_lib.vct_get_frames_in_flight(self._h, None, None, C.byref(v)), "vct_get_frames_in_flight")
+        return bool(v.value)
+
+    def select_frame_slot(self, slot):
+        """Every later call works on this slot's G-buffer / frame / stream (call with k & 1 before frame k)."""
+        self._ck(_lib.vct_select_frame_slot(self._h, slot), "vct_select_frame_slot")
 
     def steps(self):
         out = np.zeros((self.cfg.height * self.cfg.width, 7), np.uint8)

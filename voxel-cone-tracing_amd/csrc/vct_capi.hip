@@ -168,8 +168,102 @@ int divisor_verified(vct_ctx* c, float d, bool* ok) {
     return VCT_OK;
 }
 
+// ---- frame slots (vct_ctx.h VctFrameSlot) ----------------------------------------------------------------------------
+// Does a candidate stream run BESIDE the context's stream?  HIP spreads a process' streams over a few hardware queues
+// (four by default) and two streams that share one execute in order -- a second frame slot on such a stream buys nothing
+// (measured: tools/pipe_probe.py with five streams alive, 0.632 ms per step against 0.592).  A spin kernel on the base
+// stream stamps its end, a stamp kernel issued on the candidate right behind it stamps its start: the streams overlap
+// iff the stamp's start precedes the spin's end.
+__global__ void k_spin_stamp(long long ticks, unsigned long long* out) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    out[0] = wall_clock64();
+}
+__global__ void k_stamp(unsigned long long* out) { out[1] = wall_clock64(); }
+
+int streams_overlap(vct_ctx* c, hipStream_t base, hipStream_t cand, bool* overlap) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 2 * sizeof(unsigned long long), base));
+    HIP_TRY(c, hipStreamSynchronize(base));
+    hipLaunchKernelGGL(k_spin_stamp, dim3(1), dim3(1), 0, base, (long long)khz * 3 / 10, c->stats);      // 0.3 ms
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, cand, c->stats);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(base));
+    HIP_TRY(c, hipStreamSynchronize(cand));
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(v, c->stats, sizeof(v), hipMemcpyDeviceToHost));
+    *overlap = v[1] != 0ull && v[1] < v[0];
+    return VCT_OK;
+}
+
+// A new stream that demonstrably runs beside `base`: candidates are created until one overlaps (the rejected ones stay
+// alive during the search so that the runtime hands out other hardware queues), at most 8; if none does, the last
+// candidate is returned with *overlaps = false (correct all the same, nothing gained).  VCT_STREAM_PROBE=0: the first
+// stream the runtime hands out, unprobed (A/B runs).
+int create_overlapping_stream(vct_ctx* c, hipStream_t base, hipStream_t* out, bool* overlaps) {
+    *out = nullptr;
+    *overlaps = false;
+    const char* pr = getenv("VCT_STREAM_PROBE");
+    if (pr && pr[0] == '0') { HIP_TRY(c, hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return VCT_OK; }
+    hipStream_t rejected[8];
+    int nrej = 0, rc = VCT_OK;
+    while (nrej < 8) {
+        hipStream_t cand = nullptr;
+        const hipError_t e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+        if (e != hipSuccess) { rc = fail(c, VCT_ERR_DEVICE, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e)); break; }
+        bool ov = false;
+        rc = streams_overlap(c, base, cand, &ov);
+        if (rc != VCT_OK) { (void)hipStreamDestroy(cand); break; }
+        if (ov) { *out = cand; *overlaps = true; break; }
+        rejected[nrej++] = cand;
+    }
+    if (rc == VCT_OK && !*out && nrej > 0) *out = rejected[--nrej];
+    for (int k = 0; k < nrej; ++k) (void)hipStreamDestroy(rejected[k]);
+    return rc;
+}
+
+void slot_save(const vct_ctx* c, VctFrameSlot& s) {
+    s.stream = c->stream; s.ev0 = c->ev0; s.ev1 = c->ev1;
+    s.gb_tiled = c->gb_tiled; s.gb_current = c->gb_current; s.frame = c->frame; s.frame_target = c->frame_target;
+    s.tile_steps = c->tile_steps;
+    s.last_row0 = c->last_row0; s.last_row1 = c->last_row1; s.last_row_stride = c->last_row_stride;
+    s.have_trace = c->have_trace; s.last_trace_compacted = c->last_trace_compacted;
+    s.last_was_screen_trace = c->last_was_screen_trace; s.have_gbuffer = c->have_gbuffer;
+}
+void slot_load(vct_ctx* c, const VctFrameSlot& s) {
+    c->stream = s.stream; c->ev0 = s.ev0; c->ev1 = s.ev1;
+    c->gb_tiled = s.gb_tiled; c->gb_current = s.gb_current; c->frame = s.frame; c->frame_target = s.frame_target;
+    c->tile_steps = s.tile_steps;
+    c->last_row0 = s.last_row0; c->last_row1 = s.last_row1; c->last_row_stride = s.last_row_stride;
+    c->have_trace = s.have_trace; c->last_trace_compacted = s.last_trace_compacted;
+    c->last_was_screen_trace = s.last_was_screen_trace; c->have_gbuffer = s.have_gbuffer;
+}
+// A stage that WRITES state both slots read (shadow map, chain, accumulators): on the GPU it waits for everything the
+// other slot has in flight, and the next slot switch makes the other stream wait for it (produced_since_switch).
+int pipeline_join(vct_ctx* c) {
+    if (c->frames_in_flight < 2) return VCT_OK;
+    HIP_TRY(c, hipEventRecord(c->ev_xslot, c->slots[1 - c->cur_slot].stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_xslot, 0));
+    c->produced_since_switch = true;
+    return VCT_OK;
+}
+// Uploads free and reallocate buffers the other slot's kernels may still read: the host waits for that slot.
+int pipeline_drain(vct_ctx* c) {
+    if (c->frames_in_flight < 2) return VCT_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->slots[1 - c->cur_slot].stream));
+    c->produced_since_switch = true;
+    return VCT_OK;
+}
+#define PIPE_TRY(call)                    \
+    do {                                  \
+        const int rc_ = (call);           \
+        if (rc_) return rc_;              \
+    } while (0)
+
 int refresh_steps(vct_ctx* c) {
     if (!c->steps_dirty) return VCT_OK;
+    PIPE_TRY(pipeline_drain(c));      // the other slot's trace may still read the table that is rewritten below
     std::vector<VctStep> d, s;
     if (build_steps(c->cfg, c->cfg.tan_diffuse, d) || build_steps(c->cfg, c->cfg.tan_specular, s))
         return fail(c, VCT_ERR_INVALID, "cone aperture needs more than VCT_MAX_STEPS march steps");
@@ -554,6 +648,9 @@ hipError_t vct_create_masked_stream(hipStream_t* s, int device, int first_cu, in
 int vct_launch_trace_rows(vct_ctx* c, int row0, int row1, uint16_t* out_base, int row_stride, bool pack_rows) {
     return launch_trace(c, row0, row1, out_base, row_stride, pack_rows);
 }
+int vct_create_overlapping_stream(vct_ctx* c, hipStream_t base, hipStream_t* out, bool* overlaps) {
+    return create_overlapping_stream(c, base, out, overlaps);
+}
 int vct_tiles_x(const vct_ctx* c) { return tiles_x(c); }
 int vct_tiles_y(const vct_ctx* c) { return tiles_y(c); }
 void vct_comm_release(vct_ctx* c);      // vct_multi.hip
@@ -707,6 +804,17 @@ void vct_destroy(vct_ctx* c) {
     (void)hipSetDevice(c->device);
     vct_comm_release(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->frames_in_flight > 1) {            // the slot that is not selected: its set is not in the context fields freed below
+        VctFrameSlot& o = c->slots[1 - c->cur_slot];
+        if (o.stream) (void)hipStreamSynchronize(o.stream);
+        void* ob[] = {o.gb_tiled, o.frame, o.tile_steps};
+        for (void* b : ob) if (b) (void)hipFree(b);
+        if (o.ev0) (void)hipEventDestroy(o.ev0);
+        if (o.ev1) (void)hipEventDestroy(o.ev1);
+        if (o.stream) (void)hipStreamDestroy(o.stream);
+    }
+    for (int k = 0; k < 2; ++k) if (c->slots[k].raster_done) (void)hipEventDestroy(c->slots[k].raster_done);
+    if (c->ev_xslot) (void)hipEventDestroy(c->ev_xslot);
     void* bufs[] = {c->chain, c->cells, c->shadow_tiles, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->vt_pix, c->steps_dev, c->spread_lut, c->tri_pos,
                     c->tri_mat, c->tri_alpha, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->vox_items, c->vox_acc2, c->vox_acc2_attr, c->vox_multi_slot, c->stage,
@@ -771,6 +879,8 @@ int vct_set_footprint_records(vct_ctx* c, int32_t on);     // (defined next to v
 int vct_set_trace_variant(vct_ctx* c, int32_t variant) {
     if (!c) return VCT_ERR_INVALID;
     if (variant < 0 || variant > 4) return fail(c, VCT_ERR_INVALID, "vct_set_trace_variant: 0 .. 4");
+    if (variant == 4 && c->frames_in_flight > 1)
+        return fail(c, VCT_ERR_INVALID, "vct_set_trace_variant: variant 4 keeps per-context scratch (vct_set_frames_in_flight(ctx, 1) first)");
     c->cfg.trace_variant = variant;
     return VCT_OK;
 }
@@ -786,6 +896,7 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
         if (material[i] < 0 || material[i] >= nmat)
             return fail(c, VCT_ERR_INVALID, "vct_upload_triangles: material index out of range");
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_drain(c));
     if (c->tri_pos) { (void)hipFree(c->tri_pos); c->tri_pos = nullptr; }
     if (c->tri_mat) { (void)hipFree(c->tri_mat); c->tri_mat = nullptr; }
     if (c->tri_alpha) { (void)hipFree(c->tri_alpha); c->tri_alpha = nullptr; }
@@ -866,6 +977,7 @@ static size_t shadow_tile_count(int S) { const size_t nb = ((size_t)S + 7) >> 3;
 int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const float light_vp[16]) {
     if (!c) return VCT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_drain(c));
     if (c->shadow) { (void)hipFree(c->shadow); c->shadow = nullptr; c->shadow_size = 0; }
     if (c->shadow_tiles) { (void)hipFree(c->shadow_tiles); c->shadow_tiles = nullptr; }
     if (!depth) return VCT_OK;
@@ -1026,6 +1138,7 @@ int vct_upload_mesh_attributes(vct_ctx* c, const float* normal, const float* tan
         return fail(c, VCT_ERR_INVALID, "vct_upload_mesh_attributes: null input");
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_upload_mesh_attributes: call vct_upload_triangles first");
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_drain(c));
     float** dst[3] = {&c->tri_nrm, &c->tri_tan, &c->tri_bit};
     const float* src[3] = {normal, tangent, bitangent};
     const size_t bytes = (size_t)c->ntri * 9 * sizeof(float);
@@ -1047,6 +1160,7 @@ int vct_upload_mesh_uvs(vct_ctx* c, const float* uv) {
     if (!uv) return fail(c, VCT_ERR_INVALID, "vct_upload_mesh_uvs: null input");
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_upload_mesh_uvs: call vct_upload_triangles first");
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_drain(c));
     if (c->tri_uv) { (void)hipFree(c->tri_uv); c->tri_uv = nullptr; }
     const size_t bytes = (size_t)c->ntri * 6 * sizeof(float);
     c->tri_alpha_dirty = true;          // textures take effect once the coordinates are there
@@ -1062,6 +1176,7 @@ int vct_upload_textures(vct_ctx* c, const uint8_t* const* rgba8, const int32_t* 
     if (!c) return VCT_ERR_INVALID;
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_upload_textures: call vct_upload_triangles first");
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_drain(c));
     if (c->tex_texels) { (void)hipFree(c->tex_texels); c->tex_texels = nullptr; }
     if (c->tex_desc) { (void)hipFree(c->tex_desc); c->tex_desc = nullptr; }
     if (c->mat_tex) { (void)hipFree(c->mat_tex); c->mat_tex = nullptr; }
@@ -1135,6 +1250,7 @@ int vct_render_shadow_map(vct_ctx* c, const float light_vp[16]) {
     const int S = c->cfg.shadow_map_size;
     if (S <= 0) return fail(c, VCT_ERR_INVALID, "vct_render_shadow_map: config.shadow_map_size <= 0");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->shadow && c->shadow_size == S) PIPE_TRY(pipeline_join(c)); else PIPE_TRY(pipeline_drain(c));   // (re)allocation: host wait
     if (c->shadow && c->shadow_size != S) {
         (void)hipFree(c->shadow); c->shadow = nullptr; c->shadow_size = 0;
         if (c->shadow_tiles) { (void)hipFree(c->shadow_tiles); c->shadow_tiles = nullptr; }
@@ -1204,6 +1320,10 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     if (row0 < 0 || row1 > tiles_y(c) || row0 > row1)
         return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer_rows: tile-row range outside the frame");
     HIP_TRY(c, hipSetDevice(c->device));
+    // two frames in flight: the raster scratch (visibility words, lists, bins) is shared -- this pass follows the other
+    // slot's G-buffer pass (its shade kernel re-arms the words), NOT the other slot's trace
+    if (c->frames_in_flight > 1 && c->slots[1 - c->cur_slot].raster_pending)
+        HIP_TRY(c, hipStreamWaitEvent(s, c->slots[1 - c->cur_slot].raster_done, 0));
     // the form of the visibility stage (vct_ctx.h raster_mode)
     bool binned = c->raster_mode == 2;
     // Automatic choice: six passes -- direct (warm-up: the first pass after an upload pays for cold caches), direct timed,
@@ -1242,6 +1362,10 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
         e = vct_launch_gbuffer_shade(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow, c->shadow_ebase,
                                      c->shadow_size, c->shadow_tiles, c->light_vp, c->gb_tiled, s);
     if (e != hipSuccess) { c->raster_dirty[1] = true; HIP_TRY(c, e); }
+    if (c->frames_in_flight > 1) {
+        HIP_TRY(c, hipEventRecord(c->slots[c->cur_slot].raster_done, s));
+        c->slots[c->cur_slot].raster_pending = true;
+    }
     c->gb_current = c->gb_tiled;
     c->last_raster_form = binned ? 2 : 1;
     c->last_row0 = row0;
@@ -1331,6 +1455,7 @@ int vct_inject_light(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     if (!c->acc_pending) return fail(c, VCT_ERR_INVALID, "vct_inject_light: call vct_voxelize first");
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_join(c));       // level 0 is rewritten: the other slot's trace may still read the chain
     HIP_TRY(c, vct_launch_resolve(c->acc, c->brick_slot, c->chain, c->brick_flags, c->brick_prev, c->cfg.voxel_dim,
                                   c->level0_dirty, nullptr, c->attr_albedo, c->attr_normal,
                                   c->acc_mode == VCT_VOX_REFERENCE, c->stage, c->stage_albedo, c->stage_normal, c->stream));
@@ -1361,6 +1486,7 @@ int vct_set_footprint_records(vct_ctx* c, int32_t on) {
     if (!c) return VCT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     c->want_cells = on != 0;
+    PIPE_TRY(pipeline_drain(c));
     if (!c->want_cells) {
         c->cells_valid = false;
         if (c->cells) {
@@ -1376,6 +1502,7 @@ int vct_set_footprint_records(vct_ctx* c, int32_t on) {
 int vct_build_mips(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_join(c));
     // Sparse form: only bricks that hold something now (brick_prev) or held something when the mips were
     // last built (mip_seen) are reduced.  Valid while level 0 is the output of a resolve (not an upload)
     // and every other brick has all-zero ancestors -- which an upload destroys until ONE dense build has
@@ -1407,6 +1534,7 @@ int vct_bounce(vct_ctx* c) {
     if (c->level0_dirty || c->acc_mode != VCT_VOX_CONSERVATIVE_AVG)
         return fail(c, VCT_ERR_INVALID, "vct_bounce: level 0 must come from a VCT_VOX_CONSERVATIVE_AVG pass (voxel attributes)");
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_drain(c));      // (allocates the second chain on first use)
     int rc = refresh_steps(c);
     if (rc) return rc;
     const size_t nvox = (size_t)c->cfg.voxel_dim * c->cfg.voxel_dim * c->cfg.voxel_dim;
@@ -1493,6 +1621,7 @@ static int ensure_staging(vct_ctx* c) {
 
 static int upload_levels(vct_ctx* c, const uint8_t* lin, int nlevels) {
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_drain(c));
     c->use_chain_b = false;
     c->mips_valid = nlevels > 1;
     c->cells_valid = false;
@@ -1675,13 +1804,15 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
     int row0 = 0, row1 = tiles_y(c);
     const bool rank_ctx = vct_comm_rows(c, &row0, &row1);
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_join(c));
     if (!c->aux_stream) {
         if (c->reserved_cus > 0) {
             hipDeviceProp_t prop;
             HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
             HIP_TRY(c, vct_create_masked_stream(&c->aux_stream, c->device, 0, prop.multiProcessorCount - c->reserved_cus));
         } else {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            bool ov = false;      // a stream that shares the context stream's hardware queue would run the two halves in sequence
+            PIPE_TRY(create_overlapping_stream(c, c->stream, &c->aux_stream, &ov));
         }
     }
     if (!c->ev_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1725,6 +1856,100 @@ int vct_set_frame_target(vct_ctx* c, void* dev) {
 int vct_synchronize(vct_ctx* c) {
     if (!c) return VCT_ERR_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->frames_in_flight > 1) HIP_TRY(c, hipStreamSynchronize(c->slots[1 - c->cur_slot].stream));      // every frame in flight
+    return VCT_OK;
+}
+
+// ---- two frames in flight (vct_ctx.h VctFrameSlot) ---------------------------------------------------------------------
+int vct_set_frames_in_flight(vct_ctx* c, int32_t n) {
+    if (!c) return VCT_ERR_INVALID;
+    if (n != 1 && n != 2) return fail(c, VCT_ERR_INVALID, "vct_set_frames_in_flight: 1 or 2");
+    if (n == c->frames_in_flight) return VCT_OK;
+    if (n == 2) {
+        if (c->comm) return fail(c, VCT_ERR_INVALID, "vct_set_frames_in_flight: a multi-GPU rank context runs one frame at a time (vct_comm_destroy first)");
+        if (c->cfg.debug_outputs || c->cfg.trace_variant == 4)
+            return fail(c, VCT_ERR_INVALID, "vct_set_frames_in_flight: debug_outputs and trace_variant 4 keep per-context scratch: one frame at a time");
+#if defined(VCT_STATS) && VCT_STATS
+        return fail(c, VCT_ERR_INVALID, "vct_set_frames_in_flight: instrumented build (VCT_STATS): one frame at a time");
+#endif
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(vct_synchronize(c));
+    if (n == 1) {
+        // back to one frame: slot 0's set into the context, slot 1's released
+        if (c->cur_slot != 0) { slot_save(c, c->slots[1]); slot_load(c, c->slots[0]); c->cur_slot = 0; }
+        VctFrameSlot& o = c->slots[1];
+        void* ob[] = {o.gb_tiled, o.frame, o.tile_steps};
+        for (void* b : ob) if (b) (void)hipFree(b);
+        if (o.ev0) (void)hipEventDestroy(o.ev0);
+        if (o.ev1) (void)hipEventDestroy(o.ev1);
+        if (o.stream) (void)hipStreamDestroy(o.stream);
+        hipEvent_t rd = o.raster_done;
+        o = VctFrameSlot();
+        o.raster_done = rd;                 // (the two raster events and ev_xslot live until vct_destroy)
+        c->slots[0].raster_pending = false;
+        c->frames_in_flight = 1;
+        c->produced_since_switch = false;
+        return VCT_OK;
+    }
+    // a second slot: its own stream, timing events, G-buffer, frame and per-tile step counts (190 MB + 17 MB at 1080p)
+    VctFrameSlot o;
+    const size_t npix = (size_t)c->cfg.width * c->cfg.height, nt = (size_t)tiles_x(c) * tiles_y(c);
+    // the slot's stream: one that demonstrably runs beside the context's stream (create_overlapping_stream)
+    PIPE_TRY(create_overlapping_stream(c, c->stream, &o.stream, &c->slot_streams_overlap));
+    hipError_t e = hipEventCreate(&o.ev0);
+    if (e == hipSuccess) e = hipEventCreate(&o.ev1);
+    if (e == hipSuccess) e = hipMalloc(&o.gb_tiled, gb_tiled_floats(c) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&o.frame, npix * 8);
+    if (e == hipSuccess) e = hipMalloc(&o.tile_steps, nt * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(o.gb_tiled, 0, gb_tiled_floats(c) * sizeof(float), o.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(o.frame, 0, npix * 8, o.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(o.tile_steps, 0, nt * sizeof(uint32_t), o.stream);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k)
+        if (!c->slots[k].raster_done) e = hipEventCreateWithFlags(&c->slots[k].raster_done, hipEventDisableTiming);
+    if (e == hipSuccess && !c->ev_xslot) e = hipEventCreateWithFlags(&c->ev_xslot, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamSynchronize(o.stream);
+    if (e != hipSuccess) {
+        void* ob[] = {o.gb_tiled, o.frame, o.tile_steps};
+        for (void* b : ob) if (b) (void)hipFree(b);
+        if (o.ev0) (void)hipEventDestroy(o.ev0);
+        if (o.ev1) (void)hipEventDestroy(o.ev1);
+        if (o.stream) (void)hipStreamDestroy(o.stream);
+        return fail(c, e == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE, std::string("vct_set_frames_in_flight: ") + hipGetErrorString(e));
+    }
+    o.gb_current = o.gb_tiled;
+    o.raster_done = c->slots[1].raster_done;
+    c->slots[1] = o;
+    c->slots[0].raster_pending = false;
+    slot_save(c, c->slots[0]);
+    c->cur_slot = 0;
+    c->frames_in_flight = 2;
+    c->produced_since_switch = false;
+    return VCT_OK;
+}
+
+int vct_get_frames_in_flight(const vct_ctx* c, int32_t* n, int32_t* selected, int32_t* streams_overlap_out) {
+    if (!c) return VCT_ERR_INVALID;
+    if (n) *n = c->frames_in_flight;
+    if (selected) *selected = c->cur_slot;
+    if (streams_overlap_out) *streams_overlap_out = (c->frames_in_flight > 1 && c->slot_streams_overlap) ? 1 : 0;
+    return VCT_OK;
+}
+
+int vct_select_frame_slot(vct_ctx* c, int32_t slot) {
+    if (!c) return VCT_ERR_INVALID;
+    if (slot < 0 || slot >= c->frames_in_flight)
+        return fail(c, VCT_ERR_INVALID, "vct_select_frame_slot: slot outside [0, frames in flight)");
+    if (slot == c->cur_slot) return VCT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->produced_since_switch) {      // shared state was written on this slot's stream: the other stream's next work follows it
+        HIP_TRY(c, hipEventRecord(c->ev_xslot, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->slots[slot].stream, c->ev_xslot, 0));
+        c->produced_since_switch = false;
+    }
+    slot_save(c, c->slots[c->cur_slot]);
+    slot_load(c, c->slots[slot]);
+    c->cur_slot = slot;
     return VCT_OK;
 }
 

@@ -15,6 +15,31 @@ struct vct_comm;      // multi-GPU state (vct_multi.hip)
 // (k_raster_mid 658 us instead of 60 beside a trace), and RCCL's gather kernel is such a queue.
 hipError_t vct_create_masked_stream(hipStream_t* s, int device, int first_cu, int last_cu);
 
+// Two frames in flight (vct_set_frames_in_flight, round 6).  A whole-frame trace launch pays ~20 us of ramp and drain
+// (the last generation of workgroups leaves compute units idle, tools/quant_probe.py) plus the dispatch gap to the next
+// kernel of its stream: 4-5 % of a 0.61 ms frame.  A renderer that starts frame k + 1 on a second stream while frame k
+// drains gets that back (tools/pipe_probe.py: trace 0.626 -> 0.598 ms per frame, Render() 0.773 -> 0.738 at
+// configs[1]) -- what the reference's GL driver does with consecutive frames of its command queue.  What a frame owns
+// -- stream, G-buffer, output frame, per-tile step counts, timing events, "last launch" bookkeeping -- exists once per
+// SLOT; vct_select_frame_slot swaps a slot's set into the context fields of the same names, so every entry point works
+// on the selected slot unchanged.  Everything else (chain, shadow map, mesh, raster scratch) is shared, ordered by
+// events: a G-buffer pass waits for the other slot's G-buffer pass (shared raster scratch), a stage that WRITES shared
+// state (uploads, shadow map, voxelize, inject, mips, bounce) waits for everything the other slot has in flight
+// (pipeline_join), and the next slot switch makes the other stream wait for that stage.
+struct VctFrameSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t raster_done = nullptr;     // behind the slot's last G-buffer pass (visibility + shade)
+    bool raster_pending = false;          // ... recorded since the slot was created
+    float* gb_tiled = nullptr;
+    const float* gb_current = nullptr;
+    uint16_t* frame = nullptr;
+    uint16_t* frame_target = nullptr;
+    uint32_t* tile_steps = nullptr;
+    int last_row0 = 0, last_row1 = 0, last_row_stride = 1;
+    bool have_trace = false, last_trace_compacted = false, last_was_screen_trace = false, have_gbuffer = false;
+};
+
 struct vct_ctx {
     vct_config cfg;
     int device = 0;
@@ -166,6 +191,13 @@ struct vct_ctx {
     int32_t* ref_big = nullptr;        // reference mode: triangles left to the workgroup pass (+ counter)
     bool level0_dirty = false;         // level 0 was written by an upload: next resolve is dense
     vct_comm* comm = nullptr;          // multi-GPU slabs + gather (vct_comm_init)
+    // frame slots (see VctFrameSlot): slots[cur_slot] is STALE while selected -- its live values are the context fields
+    int frames_in_flight = 1;          // 1 or 2
+    int cur_slot = 0;
+    VctFrameSlot slots[2];
+    hipEvent_t ev_xslot = nullptr;     // scratch event of the cross-slot waits
+    bool slot_streams_overlap = false; // the second slot's stream was SEEN to run beside the first (vct_capi.hip streams_overlap)
+    bool produced_since_switch = false;   // a stage that writes shared state ran on the selected slot's stream since the last switch
 };
 
 // shared helpers (vct_capi.hip)
@@ -173,6 +205,9 @@ int vct_fail(vct_ctx* c, int code, const std::string& msg);
 // trace kernel on the context stream, asynchronous; out_base (full-frame addressing) overrides the frame target when not null
 // row_stride > 1: only every row_stride-th tile row from row0 on; pack_rows: those rows back to back in out_base (interleaved slabs)
 int vct_launch_trace_rows(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr, int row_stride = 1, bool pack_rows = false);
+// a new stream that was SEEN to run beside `base` (HIP shares a few hardware queues between a process' streams; two
+// streams on one queue execute in order): vct_capi.hip create_overlapping_stream
+int vct_create_overlapping_stream(vct_ctx* c, hipStream_t base, hipStream_t* out, bool* overlaps);
 int vct_tiles_x(const vct_ctx* c);
 int vct_tiles_y(const vct_ctx* c);
 

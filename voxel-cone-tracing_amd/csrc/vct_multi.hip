@@ -168,6 +168,7 @@ struct vct_comm {
     // VCT_COMM_STREAM=same: the gather is issued on the context's stream right behind the trace instead of on the
     // communication stream behind an event (profiles/experiments/README.md "gather beside the next trace")
     bool same_stream = false;
+    bool comm_stream_overlaps = false;     // the communication stream was seen to run beside the context's stream
     bool interleaved = false;
     uint16_t* il_frame[2] = {nullptr, nullptr};      // root only
     size_t buf_halves = 0;             // allocation of each gather buffer
@@ -375,6 +376,7 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
     if (!c) return VCT_ERR_INVALID;
     if (!id128 || world <= 0 || rank < 0 || rank >= world) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: bad rank / world / id");
     if (c->comm) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: already initialised (vct_comm_destroy first)");
+    if (c->frames_in_flight > 1) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: a multi-GPU rank context runs one frame at a time (vct_set_frames_in_flight(ctx, 1) first)");
     const char* mode = getenv("VCT_COMM_MODE");
     const bool direct = mode && mode[0] == 'd';       // direct slabs: no RCCL (see DirectShm)
     Rccl* r = direct ? nullptr : rccl();
@@ -395,7 +397,11 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
         e = hipGetDeviceProperties(&prop, c->device);
         if (e == hipSuccess) e = vct_create_masked_stream(&m->comm_stream, c->device, prop.multiProcessorCount - c->reserved_cus, prop.multiProcessorCount);
     } else {
-        e = hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking);
+        // the exchange step is meant to run beside the next frame's trace: a stream that shares the context stream's hardware
+        // queue would run behind it instead (round 6: HIP hands out four queues; RCCL and torch hold streams of their own)
+        bool ov = false;
+        e = vct_create_overlapping_stream(c, c->stream, &m->comm_stream, &ov) == VCT_OK ? hipSuccess : hipErrorUnknown;
+        m->comm_stream_overlaps = ov;
     }
     m->ctx_stream = c->stream;
     if (direct && e == hipSuccess) {

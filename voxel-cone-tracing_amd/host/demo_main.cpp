@@ -5,8 +5,10 @@
 // optionally writes it as a tonemapped PPM.
 //
 //   vct_demo [--scene procedural:atrium|procedural:atrium-textured|procedural:bistro|procedural:cornell] [--voxels 128] [--size 1280x720]
-//            [--shadow 4096] [--frames 3] [--bounces 1|2] [--ppm out.ppm] [--gpus N] [--dynamic-light]
+//            [--shadow 4096] [--frames 3] [--bounces 1|2] [--ppm out.ppm] [--gpus N] [--dynamic-light] [--frames-in-flight 1|2]
 //
+// --frames-in-flight 2: consecutive Render() calls alternate between two frame slots (Voxel_Cone_Tracing::FramesInFlight):
+//   frame k + 1 starts while frame k drains; same pixels, same checksum.
 // --dynamic-light: every Render() re-runs the whole GI pass (shadow map, voxelize, inject, mips, G-buffer, trace)
 // for the current lightDirection through vct_gi_pass instead of the reference's build-once volume.
 //
@@ -73,7 +75,7 @@ static int launch_ranks(int gpus, int argc, char** argv) {
 
 int main(int argc, char** argv) {
     int w = SCREEN_WIDTH, h = SCREEN_HEIGHT, frames = 3, voxels = 128, shadow = 4096, bounces = 1;
-    int gpus = 0, rank = -1;
+    int gpus = 0, rank = -1, in_flight = 1;
     const char* scene = "procedural:atrium";
     const char* ppm = nullptr;
     bool dynamic_light = false;
@@ -92,6 +94,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--frames")) frames = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--bounces")) bounces = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--ppm")) ppm = argv[i + 1];
+        else if (!strcmp(argv[i], "--frames-in-flight")) in_flight = atoi(argv[i + 1]);
     }
     for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], "--dynamic-light")) dynamic_light = true;
     GLFWwindow* window = nullptr;          // no window system on a compute node
@@ -111,6 +114,7 @@ int main(int argc, char** argv) {
     voxel_cone_tracing.model_path = scene;
     voxel_cone_tracing.Bounces = bounces;
     voxel_cone_tracing.DynamicLight = dynamic_light;       // every Render() = one whole GI pass (vct_gi_pass)
+    voxel_cone_tracing.FramesInFlight = gpus > 0 ? 1 : in_flight;
     if (gpus > 0) {                                         // a rank of a multi-GPU run
         voxel_cone_tracing.Rank = rank;
         voxel_cone_tracing.World = gpus;
@@ -163,7 +167,8 @@ int main(int argc, char** argv) {
     if (gpus > 0 && rank != 0) { voxel_cone_tracing.Frame(); return 0; }       // the frame lives on rank 0
     if (gpus > 0) printf("gpus=%d (screen-tile slabs + one ncclGather per frame)\n", gpus);
     if (frames > 1) {
-        printf("Render(): %.3f ms per frame (wall, %d frames, frame 0 excluded, no read-back)\n", wall_ms / (frames - 1), frames - 1);
+        printf("Render(): %.3f ms per frame (wall, %d frames, frame 0 excluded, no read-back, %d frame%s in flight)\n", wall_ms / (frames - 1), frames - 1,
+               voxel_cone_tracing.FramesInFlight, voxel_cone_tracing.FramesInFlight == 1 ? "" : "s");
         if (gpus <= 0) printf("Render() + Frame(): %.3f ms per frame (frame copied to the host every frame)\n", readback_ms / (frames - 1));
     }
     const uint16_t* fr = voxel_cone_tracing.Frame();
