@@ -443,14 +443,26 @@ def main():
 
     # Two frames in flight (N = 1): a second frame slot with its own resident G-buffer of the same view; the timed steps
     # alternate between the slots, so a step's ramp overlaps the drain of the step before it.
-    fif = args.frames_in_flight if not use_dist and args.variant != 4 else 1
+    # N > 1 (native step): the same per rank -- vct_frame_step traces on the selected slot's stream, so slab k + 1 starts
+    # while slab k drains (a slab launch pays the same ~20 us of ramp + drain as a whole frame: a third of an 8-way slab).
+    fif = args.frames_in_flight if (not use_dist or native) and args.variant != 4 else 1
     if fif == 2:
         ctx.set_frames_in_flight(2)
         ctx.select_frame_slot(1)
-        if inp["scene"] is None:
+        if native and args.slabs == "interleaved":
+            if inp["scene"] is not None:
+                ctx.render_gbuffer(inp["view_proj"])
+            else:
+                ctx.trace(inp["planes"])
+            ty_all = (h + 7) // 8
+            ctx.trace_gbuffer_strided(min(rank, ty_all), ty_all, world)
+        elif inp["scene"] is None:
             ctx.trace(inp["planes"], rows=(r0, r1))
         else:
-            ctx.render_gbuffer(inp["view_proj"])
+            if native and world > 1:
+                ctx.render_gbuffer_rows(inp["view_proj"], r0, r1)       # this rank's slab only, like slot 0
+            else:
+                ctx.render_gbuffer(inp["view_proj"])
             ctx.trace_gbuffer_rows(r0, r1)
         assert ctx.last_step_count() == steps_slab
         ctx.select_frame_slot(0)
@@ -467,6 +479,9 @@ def main():
             ctx.trace_resident()                  # the trace kernel, on the slot's stream
             return
         if native:
+            if fif == 2:
+                ctx.select_frame_slot(step_no[0] & 1)
+                step_no[0] += 1
             ctx.frame_step()                      # slab trace + ONE ncclGather, issued from C++
             return
         k = step_no[0] % len(fgs)
@@ -517,7 +532,10 @@ def main():
         ctx.select_frame_slot(0)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            ctx.trace_resident()
+            if native:
+                ctx.frame_step()
+            else:
+                ctx.trace_resident()
         fence()
         dt_one = time.perf_counter() - t1     # the same K steps on ONE stream: what frames_in_flight buys, same run
     for _ in range(min(args.steps, 20)):
@@ -612,7 +630,7 @@ def main():
                                    f"specular cone/px, trace of a resident (GPU-rasterised) G-buffer",
                        "voxel_dim": V, "width": w, "height": h, "cones_per_pixel": 7, "bounces": args.bounces,
                        "anisotropic_mips": bool(args.anisotropic),
-                       "parallelism": "single GPU" if world == 1 else
+                       "parallelism": ("single GPU" + (", 2 frames in flight (consecutive steps on alternate frame slots)" if fif == 2 else "")) if world == 1 else
                        f"{world} screen-tile slabs ({args.slabs if native else 'equal'}) + 1 RCCL gather " +
                        ("(native vct_frame_step" + (", direct slabs: no collective)" if direct else ")") if native
                         else "(Python-paced step, torch.distributed gather)") +
@@ -645,6 +663,13 @@ def main():
             "gi_pass_one_call_ms": None if gi_fused is None else round(gi_fused, 4),
             "roofline": roofline_block(prof, k_ms, steps_slab, alg_bytes, alg_gbs),
         }
+        if fif == 2 and result["roofline"].get("valu_wave_instructions_per_launch"):
+            # the same instruction count against the STEP time of the timed region (two launches in flight: a launch's own
+            # duration says nothing there) -- what the overlapped drain / ramp adds to the pipes' utilisation
+            rate = result["roofline"]["valu_wave_instructions_per_launch"] / (ms_per_step * 1e-3) / 1e9
+            result["roofline"]["frac_at_step_rate"] = round(rate / VALU_PEAK_GINSTR, 4)
+            result["roofline"]["frac_at_step_rate_note"] = ("VALU wave-instructions per launch / ms_per_step of the timed region "
+                                                            "(2 frames in flight); `frac` = the same count / one launch's own duration")
         if multi is not None:
             result["multi_gpu"] = multi
         if stage_counts is not None:

@@ -274,8 +274,9 @@ int vct_synchronize(vct_ctx* ctx);
  * a stage that writes shared state (uploads, vct_render_shadow_map, vct_inject_light, vct_build_mips,
  * vct_bounce, vct_gi_pass) first waits for everything the other slot has in flight, and the other slot's
  * next work waits for it.  Frames are bit-identical to the one-slot frames.  vct_synchronize waits for both
- * slots.  n = 1 (default) releases the second slot.  Not with vct_comm_init (a rank's frame is already
- * double-buffered by vct_frame_step), config.debug_outputs or trace_variant 4.
+ * slots.  n = 1 (default) releases the second slot.  Not with config.debug_outputs or trace_variant 4.  A rank of a
+ * multi-GPU frame may use it too: vct_frame_step traces on the selected slot's stream, so slab k + 1 starts while slab k
+ * drains (a slab launch pays the same ~20 us as a whole frame: a third of an 8-way slab); vct_comm_sync waits for both.
  * Measured (tools/pipe_probe.py, bench.py `frames_in_flight`): configs[1] trace 0.626 -> 0.598 ms per
  * frame, Render() 0.773 -> 0.738; configs[4] (4K, 1024^3, a 1.8 ms raster pass) loses -- hence opt-in. */
 int vct_set_frames_in_flight(vct_ctx* ctx, int32_t n);

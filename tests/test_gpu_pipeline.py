@@ -175,8 +175,6 @@ def test_what_two_frames_in_flight_refuses(vct):
     ctx.set_frames_in_flight(2)
     with pytest.raises(vct.VctError):
         ctx.set_trace_variant(4)
-    with pytest.raises(vct.VctError):
-        ctx.comm_init(bytes(128), 0, 1)
     ctx.select_frame_slot(1)
     with pytest.raises(vct.VctError):                # slot 1 has no G-buffer yet
         ctx.trace_resident()
@@ -187,6 +185,44 @@ def test_what_two_frames_in_flight_refuses(vct):
     with pytest.raises(vct.VctError):
         dbg.set_frames_in_flight(2)
     dbg.close()
+
+
+def test_rank_context_with_two_frames_in_flight(vct):
+    """A rank of a multi-GPU frame (1-rank RCCL communicator: the native step's whole data path) with two frame slots: slab
+    k + 1 is traced on the other slot's stream while slab k drains; every gathered frame equals the plain frame, with a
+    moving camera, through both gather buffers and both slots; vct_comm_sync waits for both streams."""
+    w, h, n = 328, 200, 6
+    ctx, sc = make(vct, w, h)
+    ctx.render_shadow_map(sc.light_view_proj((0.0, 1.0, 0.25)))
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    cams = cameras(sc, w, h, n)
+    want = []
+    for pos, vp in cams:
+        ctx.set_camera_position(pos); ctx.render_gbuffer(vp)
+        want.append(ctx.trace_current())
+    ctx.comm_init(vct.comm_unique_id(), 0, 1)
+    ctx.set_frames_in_flight(2)                      # (after the communicator exists: both orders are allowed)
+    r0, r1 = ctx.comm_slab()
+    for k, (pos, vp) in enumerate(cams):
+        ctx.select_frame_slot(k & 1)
+        ctx.set_camera_position(pos)
+        ctx.render_gbuffer_rows(vp, r0, r1)
+        ctx.frame_step()
+        if k >= 1 and k % 2 == 1:                    # read frame k back while nothing newer is in flight behind it
+            ctx.comm_sync()
+            assert np.array_equal(ctx.comm_download_frame(), want[k]), f"frame {k}"
+    for rep in range(30):                            # no read-back in between
+        k = rep % n
+        ctx.select_frame_slot(rep & 1)
+        ctx.set_camera_position(cams[k][0]); ctx.render_gbuffer_rows(cams[k][1], r0, r1)
+        ctx.frame_step()
+    ctx.comm_sync()
+    assert np.array_equal(ctx.comm_download_frame(), want[29 % n])
+    ctx.comm_destroy()
+    ctx.select_frame_slot(0)
+    ctx.set_camera_position(cams[1][0]); ctx.render_gbuffer(cams[1][1])
+    assert np.array_equal(ctx.trace_current(), want[1])
+    ctx.close()
 
 
 def test_second_slot_is_released(vct):

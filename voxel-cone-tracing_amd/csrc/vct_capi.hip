@@ -1866,7 +1866,6 @@ int vct_set_frames_in_flight(vct_ctx* c, int32_t n) {
     if (n != 1 && n != 2) return fail(c, VCT_ERR_INVALID, "vct_set_frames_in_flight: 1 or 2");
     if (n == c->frames_in_flight) return VCT_OK;
     if (n == 2) {
-        if (c->comm) return fail(c, VCT_ERR_INVALID, "vct_set_frames_in_flight: a multi-GPU rank context runs one frame at a time (vct_comm_destroy first)");
         if (c->cfg.debug_outputs || c->cfg.trace_variant == 4)
             return fail(c, VCT_ERR_INVALID, "vct_set_frames_in_flight: debug_outputs and trace_variant 4 keep per-context scratch: one frame at a time");
 #if defined(VCT_STATS) && VCT_STATS
@@ -1874,6 +1873,7 @@ int vct_set_frames_in_flight(vct_ctx* c, int32_t n) {
 #endif
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->comm) PIPE_TRY(vct_comm_sync(c));      // (deadline-bounded: a frame step in flight may wait for a peer)
     PIPE_TRY(vct_synchronize(c));
     if (n == 1) {
         // back to one frame: slot 0's set into the context, slot 1's released

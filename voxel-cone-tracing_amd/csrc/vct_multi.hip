@@ -185,6 +185,7 @@ struct vct_comm {
     DirectShm* shm_dev = nullptr;      // the same block as this rank's GPU sees it
     uint16_t* peer_frame[2] = {nullptr, nullptr};      // ranks > 0: the root's frame buffers, mapped
     hipStream_t ctx_stream = nullptr;  // the context's stream (direct mode queues flag kernels and peer stores on it: drained at teardown)
+    hipStream_t ctx_stream2 = nullptr; // ... and the other frame slot's, when the context runs two frames in flight
     uint32_t* abort_host = nullptr;    // this process' abort word (page-locked, mapped): k_flag_wait gives up when it is set
     uint32_t* abort_dev = nullptr;
     long long wall_khz = 100000;       // wall_clock64 rate of this device (hipDeviceAttributeWallClockRate)
@@ -217,6 +218,7 @@ static void comm_free(vct_comm* m) {
         // handles and unregister the block.  Cannot hang: nothing left in the queues waits on a peer.
         if (m->abort_host) __atomic_store_n(m->abort_host, 1u, __ATOMIC_RELEASE);
         if (m->ctx_stream) (void)hipStreamSynchronize(m->ctx_stream);
+        if (m->ctx_stream2) (void)hipStreamSynchronize(m->ctx_stream2);
         if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
         for (int k = 0; k < 2; ++k) if (m->peer_frame[k]) (void)hipIpcCloseMemHandle(m->peer_frame[k]);
         if (m->shm) { (void)hipHostUnregister(m->shm); munmap(m->shm, sizeof(DirectShm)); }
@@ -243,6 +245,9 @@ static void comm_free(vct_comm* m) {
 
 void vct_comm_release(vct_ctx* c) {
     if (!c || !c->comm) return;
+    // (frame slots may have been added or switched since vct_comm_init: the streams that carry this communicator's work NOW)
+    c->comm->ctx_stream = c->stream;
+    c->comm->ctx_stream2 = c->frames_in_flight > 1 ? c->slots[1 - c->cur_slot].stream : nullptr;
     comm_free(c->comm);
     c->comm = nullptr;
 }
@@ -376,7 +381,6 @@ int vct_comm_init(vct_ctx* c, const void* id128, int32_t rank, int32_t world) {
     if (!c) return VCT_ERR_INVALID;
     if (!id128 || world <= 0 || rank < 0 || rank >= world) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: bad rank / world / id");
     if (c->comm) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: already initialised (vct_comm_destroy first)");
-    if (c->frames_in_flight > 1) return vct_fail(c, VCT_ERR_INVALID, "vct_comm_init: a multi-GPU rank context runs one frame at a time (vct_set_frames_in_flight(ctx, 1) first)");
     const char* mode = getenv("VCT_COMM_MODE");
     const bool direct = mode && mode[0] == 'd';       // direct slabs: no RCCL (see DirectShm)
     Rccl* r = direct ? nullptr : rccl();
@@ -688,8 +692,12 @@ int vct_comm_sync(vct_ctx* c) {
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
     while (true) {
-        const hipError_t qc = hipStreamQuery(c->stream);
+        hipError_t qc = hipStreamQuery(c->stream);
         if (qc != hipSuccess && qc != hipErrorNotReady) HIP_TRY(c, qc);
+        if (qc == hipSuccess && c->frames_in_flight > 1) {      // two frames in flight: the other slot's stream carries steps too
+            qc = hipStreamQuery(c->slots[1 - c->cur_slot].stream);
+            if (qc != hipSuccess && qc != hipErrorNotReady) HIP_TRY(c, qc);
+        }
         const hipError_t q = hipStreamQuery(m->comm_stream);
         if (q == hipSuccess && qc == hipSuccess) {
             if (m->direct && __atomic_load_n(&m->shm->timed_out, __ATOMIC_ACQUIRE)) {

@@ -199,7 +199,7 @@ struct Voxel_Cone_Tracing {
     // 2: consecutive Render() calls alternate between two frame slots of the context (vct_set_frames_in_flight: own
     // stream, G-buffer and frame each), so frame k + 1's raster and trace start while frame k's trace drains -- what the
     // GL driver does with the reference's frames (R/main.cpp:77-94 never waits for one).  Frame() returns the frame of
-    // the last Render().  Same pixels; configs[1]: 0.77 -> 0.74 ms per Render().  Single-GPU only; set before init.
+    // the last Render().  Same pixels; configs[1]: 0.77 -> 0.75 ms per Render().  Set before init.
     int FramesInFlight = 1;
     int Bounces = 1;    // 2 = re-inject the lit voxels once (the "2 bounces" of the reference's README.md:16,
                         // which its code does not implement: VCT.h:138-139 injects once); set before init
@@ -233,11 +233,10 @@ struct Voxel_Cone_Tracing {
         cfg.voxel_attributes = Bounces >= 2 ? 1 : 0;
         cfg.device = Device;
         if (!check(vct_create(&cfg, &ctx), "vct_create")) return;
-        if (World > 1 || Rank != 0 || CommId[0] || CommId[1]) {
+        if (World > 1 || Rank != 0 || CommId[0] || CommId[1])
             if (!check(vct_comm_init(ctx, CommId, Rank, World), "vct_comm_init")) return;
-        } else if (FramesInFlight == 2) {
+        if (FramesInFlight == 2)
             if (!check(vct_set_frames_in_flight(ctx, 2), "vct_set_frames_in_flight")) return;
-        }
         if (!model.Load(model_path)) { last_status = VCT_ERR_INVALID; return; }
 
         // VCT.h:84-86 and :128-134 (the projections are kept as public data; the HIP voxelizer maps
@@ -295,6 +294,9 @@ struct Voxel_Cone_Tracing {
         hc.z_near = 0.1f; hc.z_far = 1000.0f;                                              // VCT.h:162
         float vp[16];
         vcth_camera_view_proj(&hc, screen_width, screen_height, vp);                       // VCT.h:161-163
+        int32_t slots = 1;
+        if (vct_get_frames_in_flight(ctx, &slots, nullptr, nullptr) == VCT_OK && slots == 2)        // frame k in slot k & 1
+            if (!check(vct_select_frame_slot(ctx, (int32_t)(frame_no++ & 1u)), "vct_select_frame_slot")) return;
         int32_t row0 = 0, row1 = 0;
         if (vct_comm_slab(ctx, &row0, &row1) == VCT_OK) {       // multi-GPU: this rank's slab, one gather
             if (!check(vct_render_gbuffer_rows(ctx, vp, row0, row1), "vct_render_gbuffer_rows")) return;
@@ -302,9 +304,6 @@ struct Voxel_Cone_Tracing {
             frame_on_host = false;
             return;
         }
-        int32_t slots = 1;
-        if (vct_get_frames_in_flight(ctx, &slots, nullptr, nullptr) == VCT_OK && slots == 2)        // frame k in slot k & 1
-            if (!check(vct_select_frame_slot(ctx, (int32_t)(frame_no++ & 1u)), "vct_select_frame_slot")) return;
         if (DynamicLight && Bounces < 2) {
             vcth_light_view_proj(L, DepthViewProjectionMatrix.m);                          // VCT.h:84-86, per frame
             const int32_t mode = ReferenceVoxelization ? VCT_VOX_REFERENCE : VCT_VOX_CONSERVATIVE_AVG;

@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
     voxel_cone_tracing.model_path = scene;
     voxel_cone_tracing.Bounces = bounces;
     voxel_cone_tracing.DynamicLight = dynamic_light;       // every Render() = one whole GI pass (vct_gi_pass)
-    voxel_cone_tracing.FramesInFlight = gpus > 0 ? 1 : in_flight;
+    voxel_cone_tracing.FramesInFlight = in_flight;
     if (gpus > 0) {                                         // a rank of a multi-GPU run
         voxel_cone_tracing.Rank = rank;
         voxel_cone_tracing.World = gpus;
