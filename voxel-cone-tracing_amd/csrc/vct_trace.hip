@@ -145,6 +145,8 @@ __device__ __forceinline__ uint32_t spread_byte(SpreadLut lut, int a, uint32_t m
 typedef const __attribute__((address_space(3))) float* UnormLut;
 struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
     SpreadLut lut;              // (wave-uniform) the dilated-coordinate table
+    const uint32_t* lut_vec;    // the same table through a plain global pointer (per-lane gather: VCT_LANE_SPREAD_LUT)
+    const __attribute__((address_space(3))) uint32_t* lut_lds = nullptr;   // VCT_LANE_SPREAD_LUT == 2: a copy in LDS (split kernel)
     int lane;
     uint32_t sbx, sby, sbz;     // BYTE offsets: 4 * dilated (l&3), ((l>>2)&3)<<1, (l>>4)<<2
     UnormLut unorm;             // VCT_LUT: the decode table in LDS
@@ -192,6 +194,9 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #define VCT_PAIR_LOAD 0       // EXPERIMENT (round 5, review item 8): per-lane gather with the x-adjacent texel pair of an even x in one
                               // 8-byte load (Morton order keeps (x, x+1) adjacent for even x); odd lanes fetch x + 1 with a masked
                               // 4-byte load.  Same bits.  Result: profiles/experiments/README.md
+#endif
+#ifndef VCT_LANE_SPREAD_LUT
+#define VCT_LANE_SPREAD_LUT 1  // round 6: the per-lane gather's dilated coordinates by table look-up (profiles/experiments/README.md)
 #endif
 #ifndef VCT_TWO_BLOCKS
 #define VCT_TWO_BLOCKS 0      // 1: a second cooperative block before the per-lane gather (profiles/experiments/README.md)
@@ -418,9 +423,26 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
       if (act) {
         uint32_t mx0, mx1, my0, my1, mz0, mz1;
         if (WRAP) {
+#if VCT_LANE_SPREAD_LUT
+            // the dilated coordinates from the table the anchor path reads with scalar loads -- here one 4-byte VECTOR load
+            // per axis (a 4 KiB table, cache resident) instead of ten vector instructions, half of them 4-cycle ones
+            const uint32_t m4 = (uint32_t)m << 2;
+            if (VCT_LANE_SPREAD_LUT == 2 && lb.lut_lds) {        // (A/B form: the table in LDS, filled per workgroup)
+                const __attribute__((address_space(3))) char* ll = (const __attribute__((address_space(3))) char*)lb.lut_lds;
+                mx0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)i0 << 2) & m4));
+                my0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)j0 << 2) & m4)) << 1;
+                mz0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)k0 << 2) & m4)) << 2;
+            } else {
+            const char* lutb = (const char*)lb.lut_vec;
+            mx0 = *(const uint32_t*)(lutb + (((uint32_t)i0 << 2) & m4));
+            my0 = *(const uint32_t*)(lutb + (((uint32_t)j0 << 2) & m4)) << 1;
+            mz0 = *(const uint32_t*)(lutb + (((uint32_t)k0 << 2) & m4)) << 2;
+            }
+#else
             mx0 = vct_spread3((uint32_t)i0 & (uint32_t)m) << 2;
             my0 = vct_spread3((uint32_t)j0 & (uint32_t)m) << 3;
             mz0 = vct_spread3((uint32_t)k0 & (uint32_t)m) << 4;
+#endif
             mx1 = ((mx0 | ~MX) + 4u) & MX;      // dilated increment, wraps at N
             my1 = ((my0 | ~MY) + 8u) & MY;
             mz1 = ((mz0 | ~MZ) + 16u) & MZ;
@@ -836,7 +858,7 @@ k_trace_tile(const VctTraceParams p) {
     if (ti >= ntiles) return;
 
     lb.lane = lane;
-    lb.lut = (SpreadLut)p.spread_lut;
+    lb.lut = (SpreadLut)p.spread_lut; lb.lut_vec = p.spread_lut;
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
     lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;
     lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
@@ -1002,6 +1024,11 @@ k_trace_tile_split(const VctTraceParams p) {
     VCT_LUT_DECL
     LaneBlock lb;
     VCT_LUT_FILL(lb)
+#if VCT_LANE_SPREAD_LUT == 2
+    __shared__ uint32_t lds_spread[1024];
+    for (uint32_t i_ = threadIdx.x; i_ < 1024u; i_ += blockDim.x) lds_spread[i_] = p.spread_lut[i_];
+    lb.lut_lds = (const __attribute__((address_space(3))) uint32_t*)lds_spread;
+#endif
     if (threadIdx.x == 0) { lds_done = 0; lds_steps = 0; }
     __syncthreads();
 
@@ -1021,7 +1048,7 @@ k_trace_tile_split(const VctTraceParams p) {
     }
 
     lb.lane = lane;
-    lb.lut = (SpreadLut)p.spread_lut;
+    lb.lut = (SpreadLut)p.spread_lut; lb.lut_vec = p.spread_lut;
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
     lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;
     lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
@@ -1272,7 +1299,7 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
     VCT_LUT_FILL(lb)                                                         \
     if (VCT_LUT) __syncthreads();                                            \
     lb.lane = lane;                                                          \
-    lb.lut = (SpreadLut)p.spread_lut;                                        \
+    lb.lut = (SpreadLut)p.spread_lut; lb.lut_vec = p.spread_lut;                                        \
     lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;                          \
     lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;                   \
     lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;                          \
