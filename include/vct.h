@@ -269,8 +269,8 @@ int vct_synchronize(vct_ctx* ctx);
  * counts, timing events each (190 MB + 17 MB more at 1080p) -- and vct_select_frame_slot(ctx, k & 1) before
  * frame k's vct_render_gbuffer / vct_trace_resident puts consecutive frames on alternate streams: frame
  * k + 1's raster and trace start while frame k's trace drains.  Every entry point works on the selected
- * slot (its G-buffer, its frame, its vct_last_* values); the chain, shadow map, mesh and raster scratch are
- * shared and ordered by events inside the library: a G-buffer pass follows the other slot's G-buffer pass;
+ * slot (its G-buffer, its frame, its raster scratch, its vct_last_* values); the chain, shadow map and mesh are
+ * shared and ordered by events inside the library:
  * a stage that writes shared state (uploads, vct_render_shadow_map, vct_inject_light, vct_build_mips,
  * vct_bounce, vct_gi_pass) first waits for everything the other slot has in flight, and the other slot's
  * next work waits for it.  Frames are bit-identical to the one-slot frames.  vct_synchronize waits for both

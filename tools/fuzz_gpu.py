@@ -147,7 +147,16 @@ while time.time() < t_end:
         gref2 = raster_oracle.gbuffer(sc, scene, cam2, w, h, dref, lvp_row, mipmaps=mips)
         ctx.render_shadow_map(sc.light_view_proj(lightd))
         if not np.array_equal(ctx.download_shadow_map().view(np.uint32), dref.view(np.uint32)): fail("shadow raster (2nd pass)", seed)
+        slots = r.random() < 0.5           # round 6: the second pose in the context's second frame slot (two frames in flight)
+        if slots:
+            ctx.set_frames_in_flight(2); ctx.select_frame_slot(1)
+            counts["frame_slots"] = counts.get("frame_slots", 0) + 1
         ctx.render_gbuffer(sc.camera_view_proj(cam2, w, h))
+        if slots:                          # ... issued without waiting: slot 0 re-renders the first pose right behind it
+            ctx.select_frame_slot(0); ctx.render_gbuffer(sc.camera_view_proj(cam, w, h)); ctx.select_frame_slot(1)
         if not np.array_equal(ctx.download_gbuffer().view(np.uint32), gref2.view(np.uint32)): fail("gbuffer raster (2nd pose)", seed)
+        if slots:
+            ctx.select_frame_slot(0)
+            if not np.array_equal(ctx.download_gbuffer().view(np.uint32), gref.view(np.uint32)): fail("gbuffer raster (slot 0 behind slot 1)", seed)
         counts["raster"] += 1
 print("fuzz ok:", counts, "seeds", counts["trace"], "last seed", seed)

@@ -2,6 +2,8 @@
 # ON THE GPU BOX: kernel-trace/stats (+ HBM byte counters) of the non-default BASELINE configurations.
 # Usage: tools/profile_configs.sh <tag>   -> gpurun_out/prof_<tag>_{c3,c5,bistro1080,noise,noise_rec,tex}/   (c5 = the Bistro-class street, BASELINE configs[4])
 set -u
+# --frames-in-flight 1: one trace launch in flight at a time, so that a launch's duration in the kernel trace is its own (the
+# default bench line overlaps consecutive steps on two frame slots; the counters per launch are the same either way)
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
@@ -9,7 +11,7 @@ run() {   # name, pmc-passes ("yes"/"no"), bench args...
   local name=$1 pmc=$2; shift 2
   local OUT=$ROOT/gpurun_out/prof_${TAG}_$name
   mkdir -p "$OUT"
-  local BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-sweep $*"
+  local BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-sweep --frames-in-flight 1 $*"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 10 --warmup 2 > "$OUT/trace.log" 2>&1
   if [ "$pmc" = yes ]; then
     i=0

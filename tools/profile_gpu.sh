@@ -4,12 +4,14 @@
 # PMC passes never combine with other trace domains (pool rule) and each carries few counters
 # (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2 -- MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -u
+# --frames-in-flight 1: one trace launch in flight at a time, so that a launch's duration in the kernel trace is its own (the
+# default bench line overlaps consecutive steps on two frame slots; the counters per launch are the same either way)
 TAG=${1:-r01}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-sweep $*"
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-sweep --frames-in-flight 1 $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 20 --warmup 3 > "$OUT/trace.log" 2>&1
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \

@@ -1,8 +1,8 @@
 #!/bin/bash
 # ON THE GPU BOX: one round's profile set into gpurun_out/ (copy what is to be judged into profiles/<tag>_*):
 # the default workload with its PMC passes (profile_gpu.sh), the other configurations (profile_configs.sh), clean bench
-# lines, the raster stages per kernel in both visibility forms, the voxelizer's counters.   Usage: tools/profiles.sh r05
-TAG=${1:-r05}
+# lines, the raster stages per kernel in both visibility forms, the voxelizer's counters.   Usage: tools/profiles.sh r06
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 tools/profile_gpu.sh $TAG

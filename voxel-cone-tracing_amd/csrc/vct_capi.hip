@@ -813,18 +813,17 @@ void vct_destroy(vct_ctx* c) {
         if (o.ev1) (void)hipEventDestroy(o.ev1);
         if (o.stream) (void)hipStreamDestroy(o.stream);
     }
-    for (int k = 0; k < 2; ++k) if (c->slots[k].raster_done) (void)hipEventDestroy(c->slots[k].raster_done);
     if (c->ev_xslot) (void)hipEventDestroy(c->ev_xslot);
     void* bufs[] = {c->chain, c->cells, c->shadow_tiles, c->staging, c->gb_linear, c->gb_tiled, c->frame, c->dbg_steps,
                     c->dbg_cones, c->step_counter, c->tile_steps, c->stats, c->vt_pix, c->steps_dev, c->spread_lut, c->tri_pos,
                     c->tri_mat, c->tri_alpha, c->mat_albedo, c->shadow, c->acc, c->brick_slot, c->frag_sorted, c->slot_first, c->slot_brick, c->vox_items, c->vox_acc2, c->vox_acc2_attr, c->vox_multi_slot, c->stage,
                     c->stage_albedo, c->stage_normal, c->plan, c->frag_bary, c->frag_alb, c->tri_qnrm,
                     c->aniso, c->ref_big, c->brick_flags, c->brick_prev, c->mip_seen, c->mip_seen_b, c->bounce_list, c->brick_over, c->chain_b, c->attr_albedo, c->attr_normal,
-                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis, c->raster_lists[0], c->raster_lists[1],
-                    c->raster_counts[0], c->raster_counts[1], c->raster_items[0], c->raster_items[1], c->raster_recs[0],
-                    c->raster_recs[1]};
+                    c->tri_nrm, c->tri_tan, c->tri_bit, c->mat_specular, c->tri_uv, c->tex_texels, c->tex_desc, c->mat_tex, c->vis[0], c->vis[1], c->raster_lists[0], c->raster_lists[1], c->raster_lists[2],
+                    c->raster_counts[0], c->raster_counts[1], c->raster_counts[2], c->raster_items[0], c->raster_items[1], c->raster_items[2],
+                    c->raster_recs[0], c->raster_recs[1], c->raster_recs[2]};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         void* bb[] = {c->bin_recs[k], c->bin_entries[k], c->bin_count[k], c->bin_items[k], c->bin_huge[k]};
         for (void* b : bb) if (b) (void)hipFree(b);
     }
@@ -902,7 +901,7 @@ int vct_upload_triangles(vct_ctx* c, const float* pos, const int32_t* material, 
     if (c->tri_alpha) { (void)hipFree(c->tri_alpha); c->tri_alpha = nullptr; }
     c->tri_alpha_dirty = true;
     if (c->mat_albedo) { (void)hipFree(c->mat_albedo); c->mat_albedo = nullptr; }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         if (c->raster_lists[k]) { (void)hipFree(c->raster_lists[k]); c->raster_lists[k] = nullptr; }   // sized by ntri
         if (c->raster_recs[k]) { (void)hipFree(c->raster_recs[k]); c->raster_recs[k] = nullptr; }
         void** bb[] = {&c->bin_recs[k], (void**)&c->bin_entries[k], (void**)&c->bin_items[k]};
@@ -1009,14 +1008,18 @@ int vct_upload_shadow_map(vct_ctx* c, const float* depth, int32_t size, const fl
 // ---- raster input stages ------------------------------------------------------------------
 
 // Scratch of one raster pass on stream `s`: `pixels` 64-bit visibility words (main draw) or 32-bit ones (depth_only).
+// scratch set of the main draw: [1], or [2] in the second frame slot (vct_ctx.h)
+static int raster_set_of(const vct_ctx* c) { return c->frames_in_flight > 1 && c->cur_slot == 1 ? 2 : 1; }
+
 static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, bool binned, hipStream_t s, VctRasterArgs& a) {
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "no triangles uploaded");
     const size_t pixels = (size_t)side_w * side_h;
-    const int k = depth_only ? 0 : 1;
-    if (!depth_only && c->vis_words < pixels) {
-        if (c->vis) { (void)hipFree(c->vis); c->vis = nullptr; c->vis_words = 0; }
-        HIP_TRY(c, hipMalloc(&c->vis, pixels * sizeof(unsigned long long)));
-        c->vis_words = pixels;
+    const int k = depth_only ? 0 : raster_set_of(c);
+    const int vs = k == 2 ? 1 : 0;                 // visibility words of this frame slot
+    if (!depth_only && c->vis_words[vs] < pixels) {
+        if (c->vis[vs]) { (void)hipFree(c->vis[vs]); c->vis[vs] = nullptr; c->vis_words[vs] = 0; }
+        HIP_TRY(c, hipMalloc(&c->vis[vs], pixels * sizeof(unsigned long long)));
+        c->vis_words[vs] = pixels;
         c->raster_dirty[k] = true;
     }
     const uint32_t bins = (uint32_t)(((size_t)side_w + 15) / 16 * (((size_t)side_h + 15) / 16));
@@ -1071,7 +1074,7 @@ static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, bool
     }
     if (c->raster_dirty[k]) {   // first pass, resized buffers, or a pass that failed half way: clear this kind's state once
         if (depth_only) c->shadow_passes = 0u;      // the shadow words restart their epoch cycle with a memset (below)
-        else HIP_TRY(c, hipMemsetAsync(c->vis, 0xff, c->vis_words * sizeof(unsigned long long), s));
+        else HIP_TRY(c, hipMemsetAsync(c->vis[vs], 0xff, c->vis_words[vs] * sizeof(unsigned long long), s));
         if (binned) {
             HIP_TRY(c, hipMemsetAsync(c->bin_count[k], 0, (size_t)c->bin_bins[k] * 2 * VCT_BIN_CSTRIDE * sizeof(uint32_t), s));
             HIP_TRY(c, hipMemsetAsync(c->bin_huge[k] + VCT_BIN_HUGE_CAP, 0, (16 + 32) * sizeof(uint32_t), s));
@@ -1101,7 +1104,7 @@ static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, bool
     a.specular = c->mat_specular;
     a.ntri = c->ntri;
     a.model_scale = c->cfg.model_scale;
-    a.vis = c->vis;
+    a.vis = c->vis[vs];
     a.vis32 = nullptr;          // vct_render_shadow_map points it at the shadow-map words
     a.vis32_ebase = 0u;
     if (!binned) {
@@ -1125,6 +1128,7 @@ static int raster_args(vct_ctx* c, int side_w, int side_h, bool depth_only, bool
         if (c->tri_alpha_dirty) {
             HIP_TRY(c, vct_launch_tri_alpha(a, c->tri_alpha, s));
             c->tri_alpha_dirty = false;
+            c->produced_since_switch = true;      // (shared by both frame slots: the other slot's next pass follows this one)
         }
         a.tri_alpha = c->tri_alpha;
     }
@@ -1320,10 +1324,8 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     if (row0 < 0 || row1 > tiles_y(c) || row0 > row1)
         return fail(c, VCT_ERR_INVALID, "vct_render_gbuffer_rows: tile-row range outside the frame");
     HIP_TRY(c, hipSetDevice(c->device));
-    // two frames in flight: the raster scratch (visibility words, lists, bins) is shared -- this pass follows the other
-    // slot's G-buffer pass (its shade kernel re-arms the words), NOT the other slot's trace
-    if (c->frames_in_flight > 1 && c->slots[1 - c->cur_slot].raster_pending)
-        HIP_TRY(c, hipStreamWaitEvent(s, c->slots[1 - c->cur_slot].raster_done, 0));
+    // (two frames in flight: each frame slot has raster scratch of its own -- raster_set_of -- so this pass waits for
+    // nothing of the other slot's frame)
     // the form of the visibility stage (vct_ctx.h raster_mode)
     bool binned = c->raster_mode == 2;
     // Automatic choice: six passes -- direct (warm-up: the first pass after an upload pays for cold caches), direct timed,
@@ -1361,11 +1363,7 @@ static int render_gbuffer_rows_on(vct_ctx* c, const float view_proj[16], int32_t
     if (e == hipSuccess)
         e = vct_launch_gbuffer_shade(a, view_proj, c->cfg.width, c->cfg.height, row0, row1, c->shadow, c->shadow_ebase,
                                      c->shadow_size, c->shadow_tiles, c->light_vp, c->gb_tiled, s);
-    if (e != hipSuccess) { c->raster_dirty[1] = true; HIP_TRY(c, e); }
-    if (c->frames_in_flight > 1) {
-        HIP_TRY(c, hipEventRecord(c->slots[c->cur_slot].raster_done, s));
-        c->slots[c->cur_slot].raster_pending = true;
-    }
+    if (e != hipSuccess) { c->raster_dirty[raster_set_of(c)] = true; HIP_TRY(c, e); }
     c->gb_current = c->gb_tiled;
     c->last_raster_form = binned ? 2 : 1;
     c->last_row0 = row0;
@@ -1884,10 +1882,16 @@ int vct_set_frames_in_flight(vct_ctx* c, int32_t n) {
         if (o.ev0) (void)hipEventDestroy(o.ev0);
         if (o.ev1) (void)hipEventDestroy(o.ev1);
         if (o.stream) (void)hipStreamDestroy(o.stream);
-        hipEvent_t rd = o.raster_done;
         o = VctFrameSlot();
-        o.raster_done = rd;                 // (the two raster events and ev_xslot live until vct_destroy)
-        c->slots[0].raster_pending = false;
+        // ... and its raster scratch set (vct_ctx.h: set [2], visibility words [1])
+        void** sc[] = {(void**)&c->raster_lists[2], &c->raster_recs[2], (void**)&c->raster_counts[2], (void**)&c->raster_items[2],
+                       &c->bin_recs[2], (void**)&c->bin_entries[2], (void**)&c->bin_count[2], (void**)&c->bin_items[2],
+                       (void**)&c->bin_huge[2], (void**)&c->vis[1]};
+        for (void** q : sc) if (*q) { (void)hipFree(*q); *q = nullptr; }
+        c->raster_item_capacity[2] = c->bin_rec_cap[2] = c->bin_entry_cap[2] = c->bin_bins[2] = c->bin_item_cap[2] = 0u;
+        c->vis_words[1] = 0;
+        c->raster_dirty[2] = true;
+        c->raster_set[2] = c->bin_set[2] = 0;
         c->frames_in_flight = 1;
         c->produced_since_switch = false;
         return VCT_OK;
@@ -1905,8 +1909,6 @@ int vct_set_frames_in_flight(vct_ctx* c, int32_t n) {
     if (e == hipSuccess) e = hipMemsetAsync(o.gb_tiled, 0, gb_tiled_floats(c) * sizeof(float), o.stream);
     if (e == hipSuccess) e = hipMemsetAsync(o.frame, 0, npix * 8, o.stream);
     if (e == hipSuccess) e = hipMemsetAsync(o.tile_steps, 0, nt * sizeof(uint32_t), o.stream);
-    for (int k = 0; k < 2 && e == hipSuccess; ++k)
-        if (!c->slots[k].raster_done) e = hipEventCreateWithFlags(&c->slots[k].raster_done, hipEventDisableTiming);
     if (e == hipSuccess && !c->ev_xslot) e = hipEventCreateWithFlags(&c->ev_xslot, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamSynchronize(o.stream);
     if (e != hipSuccess) {
@@ -1918,9 +1920,7 @@ int vct_set_frames_in_flight(vct_ctx* c, int32_t n) {
         return fail(c, e == hipErrorOutOfMemory ? VCT_ERR_NOMEM : VCT_ERR_DEVICE, std::string("vct_set_frames_in_flight: ") + hipGetErrorString(e));
     }
     o.gb_current = o.gb_tiled;
-    o.raster_done = c->slots[1].raster_done;
     c->slots[1] = o;
-    c->slots[0].raster_pending = false;
     slot_save(c, c->slots[0]);
     c->cur_slot = 0;
     c->frames_in_flight = 2;

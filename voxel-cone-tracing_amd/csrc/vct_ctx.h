@@ -22,15 +22,13 @@ hipError_t vct_create_masked_stream(hipStream_t* s, int device, int first_cu, in
 // configs[1]) -- what the reference's GL driver does with consecutive frames of its command queue.  What a frame owns
 // -- stream, G-buffer, output frame, per-tile step counts, timing events, "last launch" bookkeeping -- exists once per
 // SLOT; vct_select_frame_slot swaps a slot's set into the context fields of the same names, so every entry point works
-// on the selected slot unchanged.  Everything else (chain, shadow map, mesh, raster scratch) is shared, ordered by
-// events: a G-buffer pass waits for the other slot's G-buffer pass (shared raster scratch), a stage that WRITES shared
-// state (uploads, shadow map, voxelize, inject, mips, bounce) waits for everything the other slot has in flight
-// (pipeline_join), and the next slot switch makes the other stream wait for that stage.
+// on the selected slot unchanged; the main draw's raster scratch exists per slot too (set [2] below), so a frame's
+// G-buffer pass needs nothing of the other frame's.  Everything else (chain, shadow map, mesh) is shared, ordered by
+// events: a stage that WRITES shared state (uploads, shadow map, inject, mips, bounce) waits for everything the other
+// slot has in flight (pipeline_join), and the next slot switch makes the other stream wait for that stage.
 struct VctFrameSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t raster_done = nullptr;     // behind the slot's last G-buffer pass (visibility + shade)
-    bool raster_pending = false;          // ... recorded since the slot was created
     float* gb_tiled = nullptr;
     const float* gb_current = nullptr;
     uint16_t* frame = nullptr;
@@ -115,17 +113,19 @@ struct vct_ctx {
     // raster scratch.  Between passes every visibility word is all-ones and the counter set of the next pass is
     // zero: the kernels re-establish both themselves (vct_raster.hip run_visibility), so a pass launches no memset.
     // `raster_dirty` (a launch failed, or nothing is initialised yet) makes the next pass clear everything once.
-    unsigned long long* vis = nullptr;        // 64-bit words of the main draw
-    size_t vis_words = 0;
+    // Scratch SETS: [0] the shadow pass, [1] the main draw, [2] the main draw of the second frame slot (two frames in flight:
+    // frame k + 1's G-buffer pass then needs nothing of frame k's and the two overlap, vct_capi.hip raster_set_of)
+    unsigned long long* vis[2] = {nullptr, nullptr};   // 64-bit words of the main draw, per frame slot
+    size_t vis_words[2] = {0, 0};
     // lists / counters / tile items exist twice, [0] for the shadow pass and [1] for the main draw, so that the main
     // draw's visibility raster can run on the second stream WHILE the shadow map is rasterised (vct_gi_pass)
-    int32_t* raster_lists[2] = {nullptr, nullptr};     // [2*ntri] wave list, [2*ntri] group list
-    void* raster_recs[2] = {nullptr, nullptr};         // [2*ntri] 96-byte set-up records handed from k_raster_vis to k_raster_mid
-    uint32_t* raster_counts[2] = {nullptr, nullptr};   // two sets of [tile work items, wave list, group list, pad]
-    int raster_set[2] = {0, 0};                        // the counter set the next pass of that kind uses
-    bool raster_dirty[2] = {true, true};
-    uint2* raster_items[2] = {nullptr, nullptr};
-    uint32_t raster_item_capacity[2] = {0, 0};
+    int32_t* raster_lists[3] = {nullptr, nullptr, nullptr};     // [2*ntri] wave list, [2*ntri] group list
+    void* raster_recs[3] = {nullptr, nullptr, nullptr};         // [2*ntri] 96-byte set-up records handed from k_raster_vis to k_raster_mid
+    uint32_t* raster_counts[3] = {nullptr, nullptr, nullptr};   // two sets of [tile work items, wave list, group list, pad]
+    int raster_set[3] = {0, 0, 0};                        // the counter set the next pass of that kind uses
+    bool raster_dirty[3] = {true, true, true};
+    uint2* raster_items[3] = {nullptr, nullptr, nullptr};
+    uint32_t raster_item_capacity[3] = {0, 0, 0};
     // tile-binned visibility (vct_raster.hip): scratch per pass kind ([0] shadow pass, [1] main draw), see VctRasterArgs
     // Which form the MAIN draw's visibility takes (the shadow pass is opaque and sparse: the direct form won every
     // measurement).  raster_mode 0 = auto: scenes without alpha-tested textures keep the direct form; otherwise the first
@@ -139,16 +139,16 @@ struct vct_ctx {
     int auto_choice = -1;                              // -1 undecided, 0 direct, 1 binned
     hipEvent_t ev_auto[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // begin / end of the four timed samples
     bool has_alpha_textures = false;
-    void* bin_recs[2] = {nullptr, nullptr};
-    uint32_t bin_rec_cap[2] = {0, 0};
-    uint2* bin_entries[2] = {nullptr, nullptr};
-    uint32_t bin_entry_cap[2] = {0, 0};
-    uint32_t* bin_count[2] = {nullptr, nullptr};       // count + cursor, [2 * bins * VCT_BIN_CSTRIDE]
-    uint32_t bin_bins[2] = {0, 0};
-    uint4* bin_items[2] = {nullptr, nullptr};
-    uint32_t bin_item_cap[2] = {0, 0};
-    uint32_t* bin_huge[2] = {nullptr, nullptr};        // huge list [VCT_BIN_HUGE_CAP] + two counter sets [16] behind it
-    int bin_set[2] = {0, 0};
+    void* bin_recs[3] = {nullptr, nullptr, nullptr};
+    uint32_t bin_rec_cap[3] = {0, 0, 0};
+    uint2* bin_entries[3] = {nullptr, nullptr, nullptr};
+    uint32_t bin_entry_cap[3] = {0, 0, 0};
+    uint32_t* bin_count[3] = {nullptr, nullptr, nullptr};       // count + cursor, [2 * bins * VCT_BIN_CSTRIDE]
+    uint32_t bin_bins[3] = {0, 0, 0};
+    uint4* bin_items[3] = {nullptr, nullptr, nullptr};
+    uint32_t bin_item_cap[3] = {0, 0, 0};
+    uint32_t* bin_huge[3] = {nullptr, nullptr, nullptr};        // huge list [VCT_BIN_HUGE_CAP] + two counter sets [16] behind it
+    int bin_set[3] = {0, 0, 0};
     // second stream: vct_gi_pass runs the G-buffer raster beside the voxel stages
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_shadow = nullptr, ev_join = nullptr;
