@@ -1803,6 +1803,20 @@ int vct_gi_pass(vct_ctx* c, const float light_vp[16], const float view_proj[16],
     const bool rank_ctx = vct_comm_rows(c, &row0, &row1);
     HIP_TRY(c, hipSetDevice(c->device));
     PIPE_TRY(pipeline_join(c));
+    {
+        // VCT_GI_ONE_STREAM=1 (A/B): the six stages in sequence on the context's stream, no fork / join events
+        static const bool one_stream = [] { const char* e = getenv("VCT_GI_ONE_STREAM"); return e && e[0] == '1'; }();
+        if (one_stream) {
+            int rc1 = vct_render_shadow_map(c, light_vp);
+            if (rc1 == VCT_OK) rc1 = vct_voxelize(c, mode);
+            if (rc1 == VCT_OK) rc1 = vct_inject_light(c);
+            if (rc1 == VCT_OK) rc1 = vct_build_mips(c);
+            if (rc1 == VCT_OK) rc1 = render_gbuffer_rows_on(c, view_proj, row0, row1, c->stream);
+            if (rc1) return rc1;
+            if (rank_ctx) return vct_frame_step(c);
+            return launch_trace(c, c->last_row0, c->last_row1, nullptr, c->last_row_stride, false);
+        }
+    }
     if (!c->aux_stream) {
         if (c->reserved_cus > 0) {
             hipDeviceProp_t prop;
