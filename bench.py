@@ -447,7 +447,12 @@ def main():
     # while slab k drains (a slab launch pays the same ~20 us of ramp + drain as a whole frame: a third of an 8-way slab).
     fif = args.frames_in_flight if (not use_dist or native) and args.variant != 4 else 1
     if fif == 2:
-        ctx.set_frames_in_flight(2)
+        try:
+            ctx.set_frames_in_flight(2)
+        except vct.VctError as e:                 # (a second G-buffer did not fit, ...): one frame at a time, and the line says so
+            print(f"[bench] two frames in flight unavailable ({e}); one frame at a time", file=sys.stderr)
+            fif = 1
+    if fif == 2:
         ctx.select_frame_slot(1)
         if native and args.slabs == "interleaved":
             if inp["scene"] is not None:

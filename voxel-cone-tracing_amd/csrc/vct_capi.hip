@@ -1413,6 +1413,7 @@ int vct_voxelize(vct_ctx* c, int32_t mode) {
         return fail(c, VCT_ERR_INVALID, "vct_voxelize: unknown mode");
     if (!c->tri_pos) return fail(c, VCT_ERR_INVALID, "vct_voxelize: no triangles uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
+    PIPE_TRY(pipeline_join(c));       // the staging pool is shared: the other slot's resolve may still read the previous pass
     if (!c->brick_slot || !c->stage || (mode == VCT_VOX_REFERENCE && !c->ref_big))
         return fail(c, VCT_ERR_NOMEM, "vct_voxelize: the voxelization plan of this mesh could not be allocated "
                                       "(vct_upload_triangles reported it)");

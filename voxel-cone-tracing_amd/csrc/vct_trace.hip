@@ -198,6 +198,9 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #ifndef VCT_LANE_SPREAD_LUT
 #define VCT_LANE_SPREAD_LUT 1  // round 6: the per-lane gather's dilated coordinates by table look-up (profiles/experiments/README.md)
 #endif
+#ifndef VCT_CELLS_ARITH
+#define VCT_CELLS_ARITH 1      // the footprint-record instantiation keeps the arithmetic (it is memory bound: see sample_level)
+#endif
 #ifndef VCT_TWO_BLOCKS
 #define VCT_TWO_BLOCKS 0      // 1: a second cooperative block before the per-lane gather (profiles/experiments/README.md)
 #endif
@@ -423,7 +426,10 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
       if (act) {
         uint32_t mx0, mx1, my0, my1, mz0, mz1;
         if (WRAP) {
-#if VCT_LANE_SPREAD_LUT
+            // (the instantiation with footprint records serves volumes that do NOT fit the caches: every sample is a per-lane
+            // one and the memory pipe is what binds -- three more loads per sample cost it 1-3 %, VCT_CELLS_ARITH)
+            constexpr bool use_lut = VCT_LANE_SPREAD_LUT != 0 && !(CELLS && VCT_CELLS_ARITH);
+            if (use_lut) {
             // the dilated coordinates from the table the anchor path reads with scalar loads -- here one 4-byte VECTOR load
             // per axis (a 4 KiB table, cache resident) instead of ten vector instructions, half of them 4-cycle ones
             const uint32_t m4 = (uint32_t)m << 2;
@@ -438,11 +444,11 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             my0 = *(const uint32_t*)(lutb + (((uint32_t)j0 << 2) & m4)) << 1;
             mz0 = *(const uint32_t*)(lutb + (((uint32_t)k0 << 2) & m4)) << 2;
             }
-#else
+            } else {
             mx0 = vct_spread3((uint32_t)i0 & (uint32_t)m) << 2;
             my0 = vct_spread3((uint32_t)j0 & (uint32_t)m) << 3;
             mz0 = vct_spread3((uint32_t)k0 & (uint32_t)m) << 4;
-#endif
+            }
             mx1 = ((mx0 | ~MX) + 4u) & MX;      // dilated increment, wraps at N
             my1 = ((my0 | ~MY) + 8u) & MY;
             mz1 = ((mz0 | ~MZ) + 16u) & MZ;
