@@ -198,6 +198,9 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #ifndef VCT_LANE_SPREAD_LUT
 #define VCT_LANE_SPREAD_LUT 1  // round 6: the per-lane gather's dilated coordinates by table look-up (profiles/experiments/README.md)
 #endif
+#ifndef VCT_QUARTER_GATHER
+#define VCT_QUARTER_GATHER 0
+#endif
 #ifndef VCT_CELLS_ARITH
 #define VCT_CELLS_ARITH 1      // the footprint-record instantiation keeps the arithmetic (it is memory bound: see sample_level)
 #endif
@@ -338,7 +341,38 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             const float4* q = blk + slot;
             const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
             const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
-#if VCT_HALF_GATHER
+#if VCT_QUARTER_GATHER
+            {   // EXPERIMENT (round 6): two texels at a time -- 8 texel registers live instead of 16 (for 64 VGPRs / 8 waves per SIMD)
+                const float w0 = ab00 * c0, w1 = ab10 * c0;
+                { const float4 t0 = q[0], t1 = q[1];
+#define VCT_ACC(ch) r.ch = w0 * t0.ch; r.ch = fmaf(w1, t1.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float w2 = ab01 * c0, w3 = ab11 * c0;
+                { const float4 t2 = q[4], t3 = q[5];
+#define VCT_ACC(ch) r.ch = fmaf(w2, t2.ch, r.ch); r.ch = fmaf(w3, t3.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float w4 = ab00 * c, w5 = ab10 * c;
+                { const float4 t4 = q[16], t5 = q[17];
+#define VCT_ACC(ch) r.ch = fmaf(w4, t4.ch, r.ch); r.ch = fmaf(w5, t5.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float w6 = ab01 * c, w7 = ab11 * c;
+                { const float4 t6 = q[20], t7 = q[21];
+                wave_sync();
+#define VCT_ACC(ch) r.ch = fmaf(w6, t6.ch, r.ch); r.ch = fmaf(w7, t7.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+                }
+            }
+#elif VCT_HALF_GATHER
             {   // lower z plane first, then the upper one: half the texel registers live at a time
                 const float4 t0 = q[0], t1 = q[1], t2 = q[4], t3 = q[5];
                 const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
