@@ -87,10 +87,14 @@ def main():
         cur.append(ln)
     blocks.append(cur)
     sized = [(price(b), b) for b in blocks]
-    big = sorted(((n, c), i) for i, ((n, c), b) in enumerate(sized) if n >= 60)
-    # by construction: two per-lane blocks (~190 VALU) and two cooperative blocks (~70 VALU), one pair per level
-    fb = sorted((x for x in big if x[0][0] > 150), key=lambda x: x[1])
-    coop = sorted((x for x in big if 60 <= x[0][0] <= 150), key=lambda x: x[1])
+    # by construction: two per-lane blocks (eight texel loads each) and two cooperative blocks (eight ds_read_b128 each), one
+    # pair per level.  (Round 6: texels arrive decoded through typed-buffer loads -- ~76 and ~52 VALU; before: ~190 and ~70
+    # with global_load_dword + cvt / mul / fma.)
+    def texel_loads(b):
+        return sum(1 for ln in b if "buffer_load_format_xyzw" in ln or re.match(r"\s+global_load_dword\s", ln))
+    fb = sorted((((n, c), i) for i, ((n, c), b) in enumerate(sized) if texel_loads(b) >= 6 and n >= 40), key=lambda x: x[1])
+    coop = sorted((((n, c), i) for i, ((n, c), b) in enumerate(sized) if sum("ds_read_b128" in ln for ln in b) >= 8), key=lambda x: x[1])
+    big = sorted(fb + coop)
     # the march is unrolled by two (VCT_UNROLL2): two identical steps per loop body -- model the first
     assert len(fb) in (2, 4) and len(coop) == len(fb), [x[0] for x in big]
     unrolled = len(fb) == 4

@@ -40,6 +40,11 @@
 
 #include "vct_internal.h"
 
+typedef int vct_v4i32 __attribute__((ext_vector_type(4)));
+typedef float vct_v4f32 __attribute__((ext_vector_type(4)));
+__device__ vct_v4f32 vct_struct_buffer_load_format_v4f32(vct_v4i32 rsrc, int vindex, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.struct.buffer.load.format.v4f32");
+
 namespace {
 
 struct F3 { float x, y, z; };
@@ -108,6 +113,25 @@ __device__ __forceinline__ float div_const(float x, float d, float r) {
 // (checked exhaustively in tests/test_abi.py::test_unorm8_decode_exact).
 __device__ __forceinline__ float unorm8(uint32_t c) { return vct_unorm8_to_float(c); }
 
+// A level of the chain as a TEXEL BUFFER: buffer resource with stride 4 and format 8_8_8_8 UNORM; the structured load takes
+// the texel's Morton INDEX (a 4 GiB level -- 1024^3 level 0 -- is addressed in full; the raw byte-offset form fails its
+// range check on that level's last texel) and returns the four channels converted by the texture path.  Declared like
+// composable_kernel declares its buffer loads, so that the compiler tracks the load's completion itself.
+// (vct_v4i32 / vct_v4f32 / vct_struct_buffer_load_format_v4f32: declared in front of this namespace)
+__device__ __forceinline__ vct_v4i32 level_texel_buffer(const uint32_t* level_base) {
+    const uint64_t a = (uint64_t)level_base;
+    vct_v4i32 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) | (4u << 16)));     // base[47:32] | stride 4
+    r.z = 0x40000000;                   // records: no level has more than 2^30 texels
+    r.w = 0x50fac;                      // DST_SEL x,y,z,w = R,G,B,A | NUM_FORMAT_UNORM << 12 | DATA_FORMAT_8_8_8_8 << 15
+    return r;
+}
+__device__ __forceinline__ float4 texel_f32(vct_v4i32 rsrc, uint32_t index) {
+    const vct_v4f32 v = vct_struct_buffer_load_format_v4f32(rsrc, (int)index, 0, 0, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // LDS operations of one wave execute in order, so a slab written and then read by the lanes of
 // the same wave needs no s_barrier -- only the compiler must not reorder across this point.
 __device__ __forceinline__ void wave_sync() {
@@ -148,7 +172,7 @@ struct LaneBlock {      // this lane's texel inside the cooperative 4x4x4 block
     const uint32_t* lut_vec;    // the same table through a plain global pointer (per-lane gather: VCT_LANE_SPREAD_LUT)
     const __attribute__((address_space(3))) uint32_t* lut_lds = nullptr;   // VCT_LANE_SPREAD_LUT == 2: a copy in LDS (split kernel)
     int lane;
-    uint32_t sbx, sby, sbz;     // BYTE offsets: 4 * dilated (l&3), ((l>>2)&3)<<1, (l>>4)<<2
+    uint32_t sbx, sby, sbz;     // texel-INDEX offsets: dilated (l&3), ((l>>2)&3)<<1, (l>>4)<<2
     UnormLut unorm;             // VCT_LUT: the decode table in LDS
 };
 #if VCT_LUT
@@ -197,6 +221,20 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #endif
 #ifndef VCT_LANE_SPREAD_LUT
 #define VCT_LANE_SPREAD_LUT 1  // round 6: the per-lane gather's dilated coordinates by table look-up (profiles/experiments/README.md)
+#endif
+#ifndef VCT_HW_UNORM
+#define VCT_HW_UNORM 1         // round 6: texels are fetched through the texture path's typed-buffer load (RGBA8 UNORM, stride 4),
+                               // which returns a texel as four floats -- bit for bit (float)c / 255.0f for every byte
+                               // (tools/unorm_probe.hip) -- so the exact decode (cvt + mul + fma per channel) is not issued at all
+#endif
+#ifndef VCT_LANE_PAIRS
+#define VCT_LANE_PAIRS 0
+#endif
+#ifndef VCT_LANE_224
+#define VCT_LANE_224 0
+#endif
+#ifndef VCT_LANE_RECOMPUTE_XY
+#define VCT_LANE_RECOMPUTE_XY 0
 #endif
 #ifndef VCT_QUARTER_GATHER
 #define VCT_QUARTER_GATHER 0
@@ -261,11 +299,11 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         a = u - fu; b = v - fv; c = w - fw;
         i0 = (int)fu; j0 = (int)fv; k0 = (int)fw;
     }
-    // Texels are addressed by 32-bit BYTE offsets from the level's first texel (4 * Morton index <= 2^32 - 4 at
-    // 1024^3): the dilated-integer arithmetic runs on pre-shifted masks, so no shift and no 64-bit address add
-    // is left per load (global_load_dword v, voffset, s[base]).
-    const char* __restrict__ base = (const char*)(chain + lv.off);
-    const uint32_t MX = lv.mask_x << 2, MY = MX << 1, MZ = MX << 2;
+    // Texels are addressed by their Morton INDEX inside the level (< 2^30): the dilated-integer arithmetic yields it
+    // directly, and the level is a texel buffer whose structured load takes the index (no shift, no 64-bit address add).
+    const uint32_t* __restrict__ base = chain + lv.off;
+    const uint32_t MX = lv.mask_x, MY = MX << 1, MZ = MX << 2;
+    const vct_v4i32 tb = level_texel_buffer(base);
 
     F4 r = {0.0f, 0.0f, 0.0f, 0.0f};
     bool coop = false;
@@ -312,26 +350,35 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         if (WRAP) {
             // scalar unit: dilate the anchor; vector unit: one dilated add per axis
             const uint32_t m4 = (uint32_t)m << 2;
-            const uint32_t sax = spread_byte(lb.lut, ax, m4);
-            const uint32_t say = spread_byte(lb.lut, ay, m4) << 1;
-            const uint32_t saz = spread_byte(lb.lut, az, m4) << 2;
+            // (the table holds spread3(i) << 2: the scalar unit shifts it into place -- one shift for two of the axes, as before)
+            const uint32_t sax = spread_byte(lb.lut, ax, m4) >> 2;
+            const uint32_t say = spread_byte(lb.lut, ay, m4) >> 1;
+            const uint32_t saz = spread_byte(lb.lut, az, m4);
             idx = (((sax | ~MX) + lb.sbx) & MX) | (((say | ~MY) + lb.sby) & MY) |
                   (((saz | ~MZ) + lb.sbz) & MZ);
         } else {
             const int x = min(max(ax + (lb.lane & 3), 0), m);
             const int y = min(max(ay + ((lb.lane >> 2) & 3), 0), m);
             const int z = min(max(az + (lb.lane >> 4), 0), m);
-            idx = vct_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z) << 2;
+            idx = vct_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
         }
-        const uint32_t t = *(const uint32_t*)(base + idx);
+#if VCT_HW_UNORM && !VCT_LUT
+        const float4 d = texel_f32(tb, idx);
+        // (channels are >= +0: the block is empty iff no channel has a bit set)
+        const bool any_texel = ballot64((__float_as_uint(d.x) | __float_as_uint(d.y) | __float_as_uint(d.z) | __float_as_uint(d.w)) != 0u) != 0ull;
+#else
+        const uint32_t t = base[idx];
         const bool any_texel = ballot64(t != 0u) != 0ull;
+#endif
         if (VCT_STATS) { if (any_texel) ++ms.coop_hit; else ++ms.coop_zero; }
         if (any_texel) {     // all 64 texels zero: every footprint sums to exactly +0
+#if !(VCT_HW_UNORM && !VCT_LUT)
             float4 d;
             d.x = unorm8_of<0, LOOSE>(lb.unorm, t, (VCT_LUT & 1) != 0);
             d.y = unorm8_of<8, LOOSE>(lb.unorm, t, (VCT_LUT & 1) != 0);
             d.z = unorm8_of<16, LOOSE>(lb.unorm, t, (VCT_LUT & 1) != 0);
             d.w = unorm8_of<24, LOOSE>(lb.unorm, t, (VCT_LUT & 1) != 0);
+#endif
             blk[lb.lane] = d;
             wave_sync();
 #if VCT_TWO_BLOCKS
@@ -469,51 +516,164 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             const uint32_t m4 = (uint32_t)m << 2;
             if (VCT_LANE_SPREAD_LUT == 2 && lb.lut_lds) {        // (A/B form: the table in LDS, filled per workgroup)
                 const __attribute__((address_space(3))) char* ll = (const __attribute__((address_space(3))) char*)lb.lut_lds;
-                mx0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)i0 << 2) & m4));
-                my0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)j0 << 2) & m4)) << 1;
-                mz0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)k0 << 2) & m4)) << 2;
+                mx0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)i0 << 2) & m4)) >> 2;
+                my0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)j0 << 2) & m4)) >> 1;
+                mz0 = *(const __attribute__((address_space(3))) uint32_t*)(ll + (((uint32_t)k0 << 2) & m4));
             } else {
-            const char* lutb = (const char*)lb.lut_vec;
-            mx0 = *(const uint32_t*)(lutb + (((uint32_t)i0 << 2) & m4));
-            my0 = *(const uint32_t*)(lutb + (((uint32_t)j0 << 2) & m4)) << 1;
-            mz0 = *(const uint32_t*)(lutb + (((uint32_t)k0 << 2) & m4)) << 2;
+            const char* lutb = (const char*)lb.lut_vec;      // (entries are spread3(i) << 2)
+            mx0 = *(const uint32_t*)(lutb + (((uint32_t)i0 << 2) & m4)) >> 2;
+            my0 = *(const uint32_t*)(lutb + (((uint32_t)j0 << 2) & m4)) >> 1;
+            mz0 = *(const uint32_t*)(lutb + (((uint32_t)k0 << 2) & m4));
             }
             } else {
-            mx0 = vct_spread3((uint32_t)i0 & (uint32_t)m) << 2;
-            my0 = vct_spread3((uint32_t)j0 & (uint32_t)m) << 3;
-            mz0 = vct_spread3((uint32_t)k0 & (uint32_t)m) << 4;
+            mx0 = vct_spread3((uint32_t)i0 & (uint32_t)m);
+            my0 = vct_spread3((uint32_t)j0 & (uint32_t)m) << 1;
+            mz0 = vct_spread3((uint32_t)k0 & (uint32_t)m) << 2;
             }
-            mx1 = ((mx0 | ~MX) + 4u) & MX;      // dilated increment, wraps at N
-            my1 = ((my0 | ~MY) + 8u) & MY;
-            mz1 = ((mz0 | ~MZ) + 16u) & MZ;
+            mx1 = ((mx0 | ~MX) + 1u) & MX;      // dilated increment, wraps at N
+            my1 = ((my0 | ~MY) + 2u) & MY;
+            mz1 = ((mz0 | ~MZ) + 4u) & MZ;
         } else {
             const int ci0 = min(max(i0, 0), m), ci1 = min(max(i0 + 1, 0), m);
             const int cj0 = min(max(j0, 0), m), cj1 = min(max(j0 + 1, 0), m);
             const int ck0 = min(max(k0, 0), m), ck1 = min(max(k0 + 1, 0), m);
-            mx0 = vct_spread3((uint32_t)ci0) << 2; mx1 = vct_spread3((uint32_t)ci1) << 2;
-            my0 = vct_spread3((uint32_t)cj0) << 3; my1 = vct_spread3((uint32_t)cj1) << 3;
-            mz0 = vct_spread3((uint32_t)ck0) << 4; mz1 = vct_spread3((uint32_t)ck1) << 4;
+            mx0 = vct_spread3((uint32_t)ci0); mx1 = vct_spread3((uint32_t)ci1);
+            my0 = vct_spread3((uint32_t)cj0) << 1; my1 = vct_spread3((uint32_t)cj1) << 1;
+            mz0 = vct_spread3((uint32_t)ck0) << 2; mz1 = vct_spread3((uint32_t)ck1) << 2;
         }
+        constexpr bool hw_texels = VCT_HW_UNORM && !VCT_LUT && !VCT_PAIR_LOAD && !(VCT_CELLS && CELLS);
+        if (hw_texels) {
+            // eight typed-buffer loads: every texel arrives as four floats; one z plane at a time
+            const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
+            const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
+#if VCT_LANE_PAIRS
+            // two texels at a time (8 texel registers live): four dependent round trips, but no spill at 72 VGPRs
+            {
+                const uint32_t xy00 = mx0 | my0, xy10 = mx1 | my0;
+                const float4 f0 = texel_f32(tb, xy00 | mz0), f1 = texel_f32(tb, xy10 | mz0);
+                const float w0 = ab00 * c0, w1 = ab10 * c0;
+#define VCT_ACC(ch) r.ch = w0 * f0.ch; r.ch = fmaf(w1, f1.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const uint32_t xy01 = mx0 | my1, xy11 = mx1 | my1;
+                const float4 f2 = texel_f32(tb, xy01 | mz0), f3 = texel_f32(tb, xy11 | mz0);
+                const float w2 = ab01 * c0, w3 = ab11 * c0;
+#define VCT_ACC(ch) r.ch = fmaf(w2, f2.ch, r.ch); r.ch = fmaf(w3, f3.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const uint32_t xy00 = mx0 | my0, xy10 = mx1 | my0;
+                const float4 f4 = texel_f32(tb, xy00 | mz1), f5 = texel_f32(tb, xy10 | mz1);
+                const float w4 = ab00 * c, w5 = ab10 * c;
+#define VCT_ACC(ch) r.ch = fmaf(w4, f4.ch, r.ch); r.ch = fmaf(w5, f5.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const uint32_t xy01 = mx0 | my1, xy11 = mx1 | my1;
+                const float4 f6 = texel_f32(tb, xy01 | mz1), f7 = texel_f32(tb, xy11 | mz1);
+                const float w6 = ab01 * c, w7 = ab11 * c;
+#define VCT_ACC(ch) r.ch = fmaf(w6, f6.ch, r.ch); r.ch = fmaf(w7, f7.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+#else
+#if VCT_LANE_224
+            // phases of 2 + 2 + 4 texels: the first phase is where most else is still live (both planes' addresses, all weight
+            // inputs), the last one where least is
+            {
+                const float4 f0 = texel_f32(tb, mx0 | my0 | mz0), f1 = texel_f32(tb, mx1 | my0 | mz0);
+                const float w0 = ab00 * c0, w1 = ab10 * c0;
+#define VCT_ACC(ch) r.ch = w0 * f0.ch; r.ch = fmaf(w1, f1.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float4 f2 = texel_f32(tb, mx0 | my1 | mz0), f3 = texel_f32(tb, mx1 | my1 | mz0);
+                const float w2 = ab01 * c0, w3 = ab11 * c0;
+#define VCT_ACC(ch) r.ch = fmaf(w2, f2.ch, r.ch); r.ch = fmaf(w3, f3.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float4 f4 = texel_f32(tb, mx0 | my0 | mz1), f5 = texel_f32(tb, mx1 | my0 | mz1);
+                const float4 f6 = texel_f32(tb, mx0 | my1 | mz1), f7 = texel_f32(tb, mx1 | my1 | mz1);
+                const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
+#define VCT_ACC(ch) r.ch = fmaf(w4, f4.ch, r.ch); r.ch = fmaf(w5, f5.ch, r.ch); r.ch = fmaf(w6, f6.ch, r.ch); r.ch = fmaf(w7, f7.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+#elif VCT_LANE_RECOMPUTE_XY
+            // (the x|y parts are formed again for the upper plane instead of being kept across the lower one)
+            {
+                const float4 f0 = texel_f32(tb, mx0 | my0 | mz0), f1 = texel_f32(tb, mx1 | my0 | mz0);
+                const float4 f2 = texel_f32(tb, mx0 | my1 | mz0), f3 = texel_f32(tb, mx1 | my1 | mz0);
+                const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
+#define VCT_ACC(ch) r.ch = w0 * f0.ch; r.ch = fmaf(w1, f1.ch, r.ch); r.ch = fmaf(w2, f2.ch, r.ch); r.ch = fmaf(w3, f3.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                uint32_t x0 = mx0, x1 = mx1, y0 = my0, y1 = my1;
+                asm volatile("" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));      // (no common subexpression with the lower plane)
+                const float4 f4 = texel_f32(tb, x0 | y0 | mz1), f5 = texel_f32(tb, x1 | y0 | mz1);
+                const float4 f6 = texel_f32(tb, x0 | y1 | mz1), f7 = texel_f32(tb, x1 | y1 | mz1);
+                const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
+#define VCT_ACC(ch) r.ch = fmaf(w4, f4.ch, r.ch); r.ch = fmaf(w5, f5.ch, r.ch); r.ch = fmaf(w6, f6.ch, r.ch); r.ch = fmaf(w7, f7.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+#else
+            const uint32_t xy00 = mx0 | my0, xy10 = mx1 | my0, xy01 = mx0 | my1, xy11 = mx1 | my1;
+            {
+                const float4 f0 = texel_f32(tb, xy00 | mz0), f1 = texel_f32(tb, xy10 | mz0);
+                const float4 f2 = texel_f32(tb, xy01 | mz0), f3 = texel_f32(tb, xy11 | mz0);
+                const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
+#define VCT_ACC(ch) r.ch = w0 * f0.ch; r.ch = fmaf(w1, f1.ch, r.ch); r.ch = fmaf(w2, f2.ch, r.ch); r.ch = fmaf(w3, f3.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (the upper plane's loads are issued after the lower plane is folded: 16 texel registers)
+            {
+                const float4 f4 = texel_f32(tb, xy00 | mz1), f5 = texel_f32(tb, xy10 | mz1);
+                const float4 f6 = texel_f32(tb, xy01 | mz1), f7 = texel_f32(tb, xy11 | mz1);
+                const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
+#define VCT_ACC(ch) r.ch = fmaf(w4, f4.ch, r.ch); r.ch = fmaf(w5, f5.ch, r.ch); r.ch = fmaf(w6, f6.ch, r.ch); r.ch = fmaf(w7, f7.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+#endif
+#endif
+        } else {
         uint32_t t[8];
-#define VCT_TEXEL(o) (*(const uint32_t*)(base + (o)))
+#define VCT_TEXEL(o) (base[(o)])
         if (VCT_CELLS && CELLS && WRAP && lv.off != 0u) {     // (CELLS instantiations are launched with records present)
-            // footprint record of the lower corner: the 8 texels as 32 contiguous bytes (levels >= 1; 4 * Morton index * 8
+            // footprint record of the lower corner: the 8 texels as 32 contiguous bytes (levels >= 1; Morton index * 32
             // = byte offset of the record, < 2^32 for every level but the first of a 2048^3 grid, which has none)
             const char* cb = cells + ((size_t)lv.off << 5);
-            const uint32_t ro = (mx0 | my0 | mz0) << 3;
+            const uint32_t ro = (mx0 | my0 | mz0) << 5;
             const uint4 lo = *(const uint4*)(cb + ro);
             const uint4 hi = *(const uint4*)(cb + ro + 16u);
             t[0] = lo.x; t[1] = lo.y; t[2] = lo.z; t[3] = lo.w;
             t[4] = hi.x; t[5] = hi.y; t[6] = hi.z; t[7] = hi.w;
         } else {
 #if VCT_PAIR_LOAD
-        if (WRAP && (MX & 4u)) {            // (not the one-texel level: its x + 1 wraps onto x)
-            const bool even = (mx0 & 4u) == 0u;
-            const uint32_t mxe = mx0 & ~4u;
+        if (WRAP && (MX & 1u)) {            // (not the one-texel level: its x + 1 wraps onto x)
+            const bool even = (mx0 & 1u) == 0u;
+            const uint32_t mxe = mx0 & ~1u;
             const uint32_t yz[4] = {my0 | mz0, my1 | mz0, my0 | mz1, my1 | mz1};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint2 pr = *(const uint2*)(base + (mxe | yz[q]));
+                const uint2 pr = *(const uint2*)(base + (mxe | yz[q]));       // (base: uint32_t*, index arithmetic)
                 uint32_t hi = pr.y;
                 if (!even) hi = VCT_TEXEL(mx1 | yz[q]);
                 t[2 * q] = even ? pr.x : pr.y;
@@ -544,6 +704,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             r.y = fmaf(wg[i], unorm8_of<8, LOOSE>(lb.unorm, t[i], L), r.y);
             r.z = fmaf(wg[i], unorm8_of<16, LOOSE>(lb.unorm, t[i], L), r.z);
             r.w = fmaf(wg[i], unorm8_of<24, LOOSE>(lb.unorm, t[i], L), r.w);
+        }
         }
       }
     }
@@ -591,12 +752,12 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
         const uint32_t far = max(max((uint32_t)dx, (uint32_t)dy), (uint32_t)dz);
         if ((ballot64(far > 2u) & m) == 0ull) {
             done = true;
-            const uint32_t MX = lv.mask_x << 2, MY = MX << 1, MZ = MX << 2;      // byte offsets, as in sample_level
+            const uint32_t MX = lv.mask_x, MY = MX << 1, MZ = MX << 2;      // texel indices, as in sample_level
             const uint32_t m4 = (uint32_t)mm << 2;
             const SpreadLut lut = (SpreadLut)p.spread_lut;
-            const uint32_t sax = spread_byte(lut, ax, m4);
-            const uint32_t say = spread_byte(lut, ay, m4) << 1;
-            const uint32_t saz = spread_byte(lut, az, m4) << 2;
+            const uint32_t sax = spread_byte(lut, ax, m4) >> 2;
+            const uint32_t say = spread_byte(lut, ay, m4) >> 1;
+            const uint32_t saz = spread_byte(lut, az, m4);
             const uint32_t idx = (((sax | ~MX) + lb.sbx) & MX) | (((say | ~MY) + lb.sby) & MY) |
                                  (((saz | ~MZ) + lb.sbz) & MZ);
             const unsigned long long mneg[3] = {mx, my, mz};
@@ -604,8 +765,8 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
             uint32_t tpos[3], tneg[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {          // all block loads first (up to 6 in flight)
-                tpos[k] = mneg[k] != m ? *(const uint32_t*)((const char*)(chain_of(2 * k) + lv.off) + idx) : 0u;          // some lane is >= 0
-                tneg[k] = mneg[k] != 0ull ? *(const uint32_t*)((const char*)(chain_of(2 * k + 1) + lv.off) + idx) : 0u;   // some lane is < 0
+                tpos[k] = mneg[k] != m ? (chain_of(2 * k) + lv.off)[idx] : 0u;          // some lane is >= 0
+                tneg[k] = mneg[k] != 0ull ? (chain_of(2 * k + 1) + lv.off)[idx] : 0u;   // some lane is < 0
             }
             const int slot = act ? (dz * 4 + dy) * 4 + dx : 0;
             const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
@@ -899,9 +1060,9 @@ k_trace_tile(const VctTraceParams p) {
 
     lb.lane = lane;
     lb.lut = (SpreadLut)p.spread_lut; lb.lut_vec = p.spread_lut;
-    lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
-    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;
-    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
+    lb.sbx = vct_spread3((uint32_t)lane & 3u);     
+    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;
     MarchStats ms = {};
 
     const int tile = p.tile_row0 * p.tiles_x + ti;
@@ -1089,9 +1250,9 @@ k_trace_tile_split(const VctTraceParams p) {
 
     lb.lane = lane;
     lb.lut = (SpreadLut)p.spread_lut; lb.lut_vec = p.spread_lut;
-    lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;
-    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;
-    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;
+    lb.sbx = vct_spread3((uint32_t)lane & 3u);     
+    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;
     MarchStats ms = {};
 
     // (interleaved slabs: traced row j of the launch is tile row row0 + j * stride; the plain launch pays no second division)
@@ -1340,9 +1501,9 @@ __device__ __forceinline__ void bounce_voxels(const VctTraceParams& p, bool aliv
     if (VCT_LUT) __syncthreads();                                            \
     lb.lane = lane;                                                          \
     lb.lut = (SpreadLut)p.spread_lut; lb.lut_vec = p.spread_lut;                                        \
-    lb.sbx = vct_spread3((uint32_t)lane & 3u) << 2;                          \
-    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 3;                   \
-    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 4;                          \
+    lb.sbx = vct_spread3((uint32_t)lane & 3u);                               \
+    lb.sby = vct_spread3(((uint32_t)lane >> 2) & 3u) << 1;                   \
+    lb.sbz = vct_spread3((uint32_t)lane >> 4) << 2;                          \
     MarchStats ms = {};
 
 // compaction of one brick into `list` (LDS); returns the number of occupied voxels
