@@ -231,7 +231,7 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #define VCT_LANE_PAIRS 0
 #endif
 #ifndef VCT_LANE_224
-#define VCT_LANE_224 0
+#define VCT_LANE_224 1         // (A/B: 4 + 4 spills five registers at 72 VGPRs and runs 1-2.5 % slower; pairs only: slower on the street)
 #endif
 #ifndef VCT_LANE_RECOMPUTE_XY
 #define VCT_LANE_RECOMPUTE_XY 0
