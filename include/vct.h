@@ -389,6 +389,12 @@ int vct_last_trace_ms(vct_ctx* ctx, float* ms);
  * trace kernel relies on (vct_trace.hip shows why the march never leaves that domain in a way that
  * could change a result). */
 int vct_selftest_const_divide(vct_ctx* ctx, float d, uint64_t* mismatches);
+/* Round 6: the trace kernels fetch texels through typed-buffer loads (the level as an RGBA8 UNORM texel buffer) and take
+ * the four floats the texture path returns instead of decoding the bytes themselves -- valid because that conversion
+ * is bit for bit (float)c / 255.0f on gfx950.  This runs every byte value in every channel position through the same
+ * load against the library's exact decode: *mismatches = channel values that differ (0 expected).  vct_create runs it
+ * once per process and device and fails (VCT_ERR_DEVICE) on a device where the conversion is not exact. */
+int vct_selftest_texel_buffer(vct_ctx* ctx, uint64_t* mismatches);
 /* Self-test of the rasteriser's shared-reciprocal division (csrc/vct_raster.hip div_area: the barycentrics' x / area
  * as two FMA corrections of x * RN(1/area), correctly rounded by Markstein's theorem): `count` pseudo-random pairs of
  * the operands' form (integers of 1..53 bits scaled by 2^-16) next to the IEEE division; returns the number of pairs

@@ -378,6 +378,14 @@ def test_stale_mips_are_refused_and_upload_then_sparse_builds_stay_correct(vct, 
         assert ctx.last_step_count() == steps       # the self-test does not disturb the step counters
 
 
+def test_texel_buffer_conversion_is_the_exact_decode(vct):
+    """Round 6: the trace kernels take the four floats the texture path returns for an RGBA8 UNORM texel (typed-buffer
+    load) instead of decoding the bytes -- [GL] value = byte / 255.  Every byte value in every channel
+    position through that load equals the exact decode bit for bit; vct_create refuses a device where it does not."""
+    with make_ctx(vct, 16, 8, 8) as ctx:
+        assert ctx.selftest_texel_buffer() == 0
+
+
 def test_const_divide_exhaustive(vct):
     """The trace kernel's x/d (fma(x, r_hi, x * r_lo): two instructions) equals the IEEE divide for EVERY finite fp32 x,
     for every divisor the BASELINE grids and apertures use: half_G = 75 and the per-step occlusion denominators

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "vct_upload_mesh_uvs", "vct_upload_textures", "vct_gi_pass",
     "vct_comm_set_timeout_ms", "vct_last_row_steps", "vct_slab_partition_weighted", "vct_comm_set_slab_rows",
     "vct_get_stage_counts", "vct_comm_info", "vct_comm_last_gather_ms", "vct_set_footprint_records",
-    "vct_set_frames_in_flight", "vct_get_frames_in_flight", "vct_select_frame_slot",
+    "vct_set_frames_in_flight", "vct_get_frames_in_flight", "vct_select_frame_slot", "vct_selftest_texel_buffer",
 ]
 
 
@@ -138,6 +138,7 @@ _lib.vct_upload_mesh_uvs.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_set_frames_in_flight.argtypes = [C.c_void_p, C.c_int32]
 _lib.vct_get_frames_in_flight.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.vct_select_frame_slot.argtypes = [C.c_void_p, C.c_int32]
+_lib.vct_selftest_texel_buffer.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_upload_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
 
 
@@ -479,6 +480,12 @@ class Context:
 
     def synchronize(self):
         self._ck(_lib.vct_synchronize(self._h), "vct_synchronize")
+
+    def selftest_texel_buffer(self):
+        """Channel values (of 4096) that the typed-buffer texel load converts differently from (float)c / 255.0f: 0 expected."""
+        v = C.c_uint64()
+        self._ck(_lib.vct_selftest_texel_buffer(self._h, C.byref(v)), "vct_selftest_texel_buffer")
+        return v.value
 
     def set_frames_in_flight(self, n):
         """2: a second frame slot (stream, G-buffer, frame) so that frame k + 1 starts while frame k drains; 1: default."""

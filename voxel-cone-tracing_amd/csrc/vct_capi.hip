@@ -795,6 +795,25 @@ int vct_create(const vct_config* cfg, vct_ctx** out) {
     memset(c->light_vp, 0, sizeof(c->light_vp));
     c->light_vp[0] = c->light_vp[5] = c->light_vp[10] = c->light_vp[15] = 1.0f;
     c->gb_current = c->gb_tiled;
+    {
+        // once per process and device: the texture path's UNORM8 conversion must be the exact decode the trace kernels
+        // count on (it is on gfx950).  No other path is compiled in: a device where it is not fails here, loudly.
+        static std::mutex lock;
+        static std::map<int, unsigned long long> verdict;
+        std::lock_guard<std::mutex> g(lock);
+        auto it = verdict.find(dev);
+        if (it == verdict.end()) {
+            uint64_t bad = 0;
+            const int rc = vct_selftest_texel_buffer(c, &bad);
+            if (rc != VCT_OK) { const std::string m = c->err; vct_destroy(c); return fail(nullptr, rc, m); }
+            it = verdict.emplace(dev, bad).first;
+        }
+        if (it->second) {
+            vct_destroy(c);
+            return fail(nullptr, VCT_ERR_DEVICE, "this device's typed-buffer loads do not convert UNORM8 to exactly c / 255 (" +
+                        std::to_string(it->second) + " of 4096 channel values differ): rebuild with -DVCT_HW_UNORM=0");
+        }
+    }
     *out = c;
     return VCT_OK;
 }
@@ -2100,6 +2119,38 @@ int vct_selftest_const_divide(vct_ctx* c, float d, uint64_t* mismatches) {
     if (v[0]) {      // not a failure of the call: leave one offending x readable for diagnosis
         char msg[96];
         snprintf(msg, sizeof(msg), "const divide by %.9g: %llu mismatches, e.g. x bits 0x%08llx", d, v[0], v[1]);
+        c->err = msg;
+    }
+    return VCT_OK;
+}
+
+// The trace kernels fetch texels through typed-buffer loads and rely on the texture path converting a UNORM8 channel to
+// exactly (float)c / 255.0f.  Every byte value in every channel position (1,024 texels) through that path against the
+// library's exact decode; *mismatches = channels that differ (0 on gfx950: tools/unorm_probe.hip).
+int vct_selftest_texel_buffer(vct_ctx* c, uint64_t* mismatches) {
+    if (!c || !mismatches) return VCT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint32_t> h(1024);
+    for (uint32_t i = 0; i < 1024u; ++i) {
+        const uint32_t b = i & 255u, k = i >> 8;       // byte b in channel k, the other channels vary with it
+        const uint32_t o0 = (b * 7u + 3u) & 255u, o1 = 255u - b, o2 = (b * 13u + 5u) & 255u;
+        const uint32_t ch[4] = {o0, o1, o2, b};
+        h[i] = ch[(0 + 3 - k) & 3] | (ch[(1 + 3 - k) & 3] << 8) | (ch[(2 + 3 - k) & 3] << 16) | (ch[(3 + 3 - k) & 3] << 24);
+    }
+    uint32_t* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, h.size() * sizeof(uint32_t)));
+    hipError_t e = hipMemcpyAsync(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->stats, 0, 2 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = vct_launch_texel_buffer_selftest(d, (uint32_t)h.size(), c->stats, c->stream);
+    unsigned long long v[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(v, c->stats, sizeof(v), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIP_TRY(c, e);
+    *mismatches = v[0];
+    if (v[0]) {
+        char msg[128];
+        snprintf(msg, sizeof(msg), "texel buffer: %llu channel values differ from (float)c / 255.0f, e.g. texel 0x%08llx", v[0], v[1]);
         c->err = msg;
     }
     return VCT_OK;

@@ -427,6 +427,8 @@ hipError_t vct_launch_tex_mip(const uint32_t* parent, int pw, int ph, uint32_t* 
 hipError_t vct_launch_untile_gbuffer(const float* tiled, float* planes_linear, int w, int h, hipStream_t s);
 hipError_t vct_launch_trace(const VctTraceParams& p, int variant, hipStream_t s);
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s);
+// typed-buffer texel loads (RGBA8 UNORM -> four floats in the texture path) against the exact decode, n texels
+hipError_t vct_launch_texel_buffer_selftest(const uint32_t* texels, uint32_t n, unsigned long long* out, hipStream_t s);
 hipError_t vct_launch_area_divide_selftest(uint64_t seed, uint64_t count, unsigned long long* out, hipStream_t s);
 hipError_t vct_launch_linear_to_morton(const uint32_t* lin, uint32_t* mor, int N, hipStream_t s);
 hipError_t vct_launch_morton_to_linear(const uint32_t* mor, uint32_t* lin, int N, hipStream_t s);

@@ -1758,7 +1758,27 @@ k_divide_selftest(float d, float r, float aux, unsigned long long* mismatches) {
     if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
 }
 
+// The texel buffer's conversion against the exact decode, texel by texel: out[0] = channels that differ, out[1] = the
+// first offending texel word (vct_selftest_texel_buffer; vct_create runs it once per process)
+__global__ void __launch_bounds__(256)
+k_texel_buffer_selftest(const uint32_t* texels, uint32_t n, unsigned long long* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 d = texel_f32(level_texel_buffer(texels), i);
+    const uint32_t t = texels[i];
+    const float want[4] = {vct_unorm8_to_float(t & 0xffu), vct_unorm8_to_float((t >> 8) & 0xffu),
+                           vct_unorm8_to_float((t >> 16) & 0xffu), vct_unorm8_to_float(t >> 24)};
+    const float got[4] = {d.x, d.y, d.z, d.w};
+    for (int ch = 0; ch < 4; ++ch)
+        if (__float_as_uint(got[ch]) != __float_as_uint(want[ch])) { atomicAdd(&out[0], 1ull); out[1] = t; }
+}
+
 }  // namespace
+
+hipError_t vct_launch_texel_buffer_selftest(const uint32_t* texels, uint32_t n, unsigned long long* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_texel_buffer_selftest, dim3((n + 255u) / 256u), dim3(256), 0, s, texels, n, out);
+    return hipGetLastError();
+}
 
 hipError_t vct_launch_divide_selftest(float d, unsigned long long* mismatches, hipStream_t s) {
     const float r = 1.0f / d;
