@@ -721,8 +721,9 @@ def main():
                 "rel_l2_loose_vs_exact_frame": float(np.sqrt(((a - b) ** 2).sum() / max((a ** 2).sum(), 1e-30))),
                 "halves_that_differ": int((exact != loose).sum()),
                 "cone_steps_exact": int(exact_steps), "cone_steps_loose": int(loose_steps),
-                "note": "loose = config.trace_variant 3: unorm8 * RN(1/255) (wrong in the last bit for 126 bytes), x * RN(1/d) "
-                        "for the constant divisions; opt-in, never `value`",
+                "note": "loose = config.trace_variant 3: x * RN(1/d) for the constant divisions (rounds 4-5 it also decoded UNORM8 "
+                        "as c * RN(1/255), wrong in the last bit for 126 bytes; since round 6 texels arrive decoded -- exactly -- "
+                        "from the texture path in both variants); opt-in, never `value`",
             }
         default_workload = (args.scene == "atrium" and (V, w, h) == (256, 1920, 1080) and not args.obj
                             and args.variant == 0 and not args.anisotropic and args.bounces == 1)

@@ -14,24 +14,29 @@
 // tile; A/B variants), k_bounce_list/_march/_bricks (second bounce, same march), k_divide_selftest.
 //
 // Mapping: lane = pixel of the tile, a wave marches its cones one after the other.  The kernel
-// is VALU-issue bound (profiles/r01a: 995 M VALU wave-instructions per 1080p frame, half of the
-// wave cycles spent waiting to issue, 12 % waiting on memory), and on gfx950 only fp32
+// was VALU-issue bound from round 1 (profiles/r01a: 995 M VALU wave-instructions per 1080p frame, half of the
+// wave cycles spent waiting to issue, 12 % waiting on memory) to round 5 (543 M), and on gfx950 only fp32
 // fma/mul/add and plain logic ops issue in 2 cycles per wave -- conversions, floor, bit-field,
-// 3-operand integer ops take 4 (tools/valu_bench.hip).  The dominant cost per march step is
+// 3-operand integer ops take 4 (tools/valu_bench.hip).  The dominant cost per march step was
 // turning 2 x 8 RGBA8 texels into 64 floats (cvt + exact /255) and the Morton address of each, so
-// the sampler is organised to do that work once per wave instead of once per lane:
+// the sampler is organised to do that work once per wave instead of once per lane -- and since round 6 the
+// conversion itself is left to the texture path: a level is read as an RGBA8 UNORM TEXEL BUFFER (typed-buffer
+// loads, level_texel_buffer / texel_f32 below), whose UNORM8 -> fp32 conversion is bit for bit (float)c / 255.0f
+// on this GPU (tools/unorm_probe.hip, vct_selftest_texel_buffer).  447 M VALU wave-instructions per frame now,
+// vector pipes 83 % busy, 38 % of the wave-cycles waiting on memory (profiles/r06f_final.txt).
 //
 //   cooperative sample (the common case): the 64 trilinear footprints of a tile at one march
 //   step almost always fall inside one 4x4x4 texel block of the level (neighbouring pixels trace
 //   near-parallel cones; ~85 % of wave-level samples of the 1080p bench frame).  The block is
 //   anchored at the centre pixel's footprint; lane l fetches block texel (l&3, (l>>2)&3, l>>4)
 //   with ONE load (Morton index = scalar-unit spread of the anchor + a per-lane dilated-integer
-//   add), decodes its 4 channels once, parks the float4 in a wave-private 1 KiB LDS slab, and
+//   add; the four channels arrive as floats), parks the float4 in a wave-private 1 KiB LDS slab, and
 //   every lane gathers its own 8 texels with ds_read_b128 at constant offsets {0,1,4,5,16,..}.
 //   If the whole block is zero (ballot) the sample is exactly 0 and everything else is skipped.
 //
-//   per-lane sample (incoherent waves: silhouettes, random G-buffers): 8 loads + 32 decodes per
-//   lane as in a plain gather, with the +1 neighbours derived by dilated increments.
+//   per-lane sample (incoherent waves: silhouettes, random G-buffers): 8 texel loads per lane as in a
+//   plain gather (phases of 2 + 2 + 4), the dilated coordinates from the anchor path's table, the +1
+//   neighbours derived by dilated increments.
 //
 // Both produce the same bits.  Divisions by wave-uniform constants use one FMA correction round
 // instead of the 10-instruction IEEE sequence, for divisors the device has verified exhaustively
@@ -122,7 +127,7 @@ __device__ __forceinline__ vct_v4i32 level_texel_buffer(const uint32_t* level_ba
     const uint64_t a = (uint64_t)level_base;
     vct_v4i32 r;
     r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) | (4u << 16)));     // base[47:32] | stride 4
+    r.y = __builtin_amdgcn_readfirstlane((int)(((uint32_t)(a >> 32) & 0xffffu) | (4u << 16)));     // base[47:32] | stride 4
     r.z = 0x40000000;                   // records: no level has more than 2^30 texels
     r.w = 0x50fac;                      // DST_SEL x,y,z,w = R,G,B,A | NUM_FORMAT_UNORM << 12 | DATA_FORMAT_8_8_8_8 << 15
     return r;
