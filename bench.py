@@ -880,6 +880,9 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
     lane-step where the per-texel figure of SURVEY.md 8d counts 64 B), so `frac` is the VALU issue rate
     against 1024 SIMDs x 2.4 GHz / 2 cycles -- a LOWER bound of pipe utilisation, since a third of the
     kernel's instructions are 4-cycle ops.  The HBM-side numbers are kept next to it."""
+    # (round 6: with the texels decoded by the texture path the kernel issues 18 % fewer instructions and is no longer
+    # bound by issue alone -- pipes 83 % busy, 38 % of the wave-cycles parked on memory; the VALU figure stays the
+    # reported roofline because it is still the resource closest to its limit)
     r = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
          "frac": None, "traffic": None,
          "hbm_algorithmic": {"bytes_per_launch": int(alg_bytes), "GBps": round(alg_gbs, 1),
@@ -924,6 +927,9 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
         scyc, salu = prof.get("salu_issue_cycles_per_instr"), wi.get("salu")
         if scyc and salu and gpu_cyc:
             r["salu_pipe_busy_model"] = round(salu * scyc / 1024.0 / gpu_cyc, 3)
+    for k in ("wave_cycles_waiting_on_memory", "wave_cycles_waiting_to_issue"):      # SQ_WAIT_ANY / SQ_WAIT_INST_ANY over SQ_WAVE_CYCLES
+        if prof.get(k) is not None and not prof.get("scale_by_steps"):
+            r[k] = round(prof[k], 3)
     hbm = prof.get("hbm_bytes_per_launch")
     if hbm:
         r["traffic"] = round(hbm / (kernel_ms * 1e-3) / 1e9, 1)

@@ -58,7 +58,7 @@ def main():
                         trace_name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
                     if "k_trace_tile" in r["Kernel_Name"] and r["Counter_Name"] in (
                             "FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
-                            "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"):
+                            "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"):
                         traffic.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     if "FETCH_SIZE" in traffic and "WRITE_SIZE" in traffic and len(sys.argv) > 3:
         import json
@@ -85,6 +85,13 @@ def main():
                                                         if k.startswith("SQ_INSTS_")},
                        "gpu_cycles_per_launch": (sum(traffic["GRBM_GUI_ACTIVE"]) / len(traffic["GRBM_GUI_ACTIVE"]) / 8.0
                                                  if "GRBM_GUI_ACTIVE" in traffic else None),
+                       # of the kernel's wave-cycles: parked on s_waitcnt (memory) / stalled at issue (SQ_WAIT_ANY, SQ_WAIT_INST_ANY)
+                       "wave_cycles_waiting_on_memory": (sum(traffic["SQ_WAIT_ANY"]) / max(sum(traffic["SQ_WAVE_CYCLES"]), 1.0)
+                                                         if "SQ_WAIT_ANY" in traffic and "SQ_WAVE_CYCLES" in traffic and
+                                                         len(traffic["SQ_WAIT_ANY"]) == len(traffic["SQ_WAVE_CYCLES"]) else None),
+                       "wave_cycles_waiting_to_issue": (sum(traffic["SQ_WAIT_INST_ANY"]) / max(sum(traffic["SQ_WAVE_CYCLES"]), 1.0)
+                                                        if "SQ_WAIT_INST_ANY" in traffic and "SQ_WAVE_CYCLES" in traffic and
+                                                        len(traffic["SQ_WAIT_INST_ANY"]) == len(traffic["SQ_WAVE_CYCLES"]) else None),
                        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, calibrated with tools/fetch_calib.hip"}, fh, indent=1)
         lines.append(f"== trace kernel HBM bytes per launch (corrected): {(2.0 * fetch + write) * 1024.0:.4g} ==")
     # HBM traffic of EVERY kernel per dispatch (same correction), for bench.py's stage_roofline
