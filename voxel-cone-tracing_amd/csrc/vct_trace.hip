@@ -232,6 +232,9 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
                                // which returns a texel as four floats -- bit for bit (float)c / 255.0f for every byte
                                // (tools/unorm_probe.hip) -- so the exact decode (cvt + mul + fma per channel) is not issued at all
 #endif
+#ifndef VCT_CELLS_HW
+#define VCT_CELLS_HW 0
+#endif
 #ifndef VCT_LANE_PAIRS
 #define VCT_LANE_PAIRS 0
 #endif
@@ -547,6 +550,29 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             mz0 = vct_spread3((uint32_t)ck0) << 2; mz1 = vct_spread3((uint32_t)ck1) << 2;
         }
         constexpr bool hw_texels = VCT_HW_UNORM && !VCT_LUT && !VCT_PAIR_LOAD && !(VCT_CELLS && CELLS);
+        if (VCT_CELLS_HW && VCT_HW_UNORM && VCT_CELLS && CELLS && WRAP && lv.off != 0u) {
+            // EXPERIMENT: the footprint record read as eight texels of a texel buffer laid over the records (decoded by the
+            // texture path; eight 4-byte requests into one 32-byte sector instead of two 16-byte ones + 32 decodes)
+            const vct_v4i32 cbuf = level_texel_buffer((const uint32_t*)(cells + ((size_t)lv.off << 5)));
+            const uint32_t ri = (mx0 | my0 | mz0) << 3;
+            const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
+            const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
+            {
+                const float4 f0 = texel_f32(cbuf, ri), f1 = texel_f32(cbuf, ri + 1u), f2 = texel_f32(cbuf, ri + 2u), f3 = texel_f32(cbuf, ri + 3u);
+                const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
+#define VCT_ACC(ch) r.ch = w0 * f0.ch; r.ch = fmaf(w1, f1.ch, r.ch); r.ch = fmaf(w2, f2.ch, r.ch); r.ch = fmaf(w3, f3.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float4 f4 = texel_f32(cbuf, ri + 4u), f5 = texel_f32(cbuf, ri + 5u), f6 = texel_f32(cbuf, ri + 6u), f7 = texel_f32(cbuf, ri + 7u);
+                const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
+#define VCT_ACC(ch) r.ch = fmaf(w4, f4.ch, r.ch); r.ch = fmaf(w5, f5.ch, r.ch); r.ch = fmaf(w6, f6.ch, r.ch); r.ch = fmaf(w7, f7.ch, r.ch);
+                VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
+#undef VCT_ACC
+            }
+        } else
         if (hw_texels) {
             // eight typed-buffer loads: every texel arrives as four floats; one z plane at a time
             const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
