@@ -232,6 +232,9 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
                                // which returns a texel as four floats -- bit for bit (float)c / 255.0f for every byte
                                // (tools/unorm_probe.hip) -- so the exact decode (cvt + mul + fma per channel) is not issued at all
 #endif
+#ifndef VCT_LANE_HYBRID
+#define VCT_LANE_HYBRID 0
+#endif
 #ifndef VCT_CELLS_HW
 #define VCT_CELLS_HW 0
 #endif
@@ -634,6 +637,18 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
 #undef VCT_ACC
             }
             __builtin_amdgcn_sched_barrier(0);
+#if VCT_LANE_HYBRID
+            {   // EXPERIMENT: the upper plane through plain loads + the exact decode (4 B per lane and load through the data
+                // return path instead of 16): balances the vector pipes against the texture path on per-lane-heavy scenes
+                const uint32_t t4 = base[mx0 | my0 | mz1], t5 = base[mx1 | my0 | mz1];
+                const uint32_t t6 = base[mx0 | my1 | mz1], t7 = base[mx1 | my1 | mz1];
+                const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
+#define VCT_ACC(ch, sh) r.ch = fmaf(w4, vct_unorm8_to_float((t4 >> sh) & 0xffu), r.ch); r.ch = fmaf(w5, vct_unorm8_to_float((t5 >> sh) & 0xffu), r.ch); \
+                        r.ch = fmaf(w6, vct_unorm8_to_float((t6 >> sh) & 0xffu), r.ch); r.ch = fmaf(w7, vct_unorm8_to_float((t7 >> sh) & 0xffu), r.ch);
+                VCT_ACC(x, 0) VCT_ACC(y, 8) VCT_ACC(z, 16) VCT_ACC(w, 24)
+#undef VCT_ACC
+            }
+#else
             {
                 const float4 f4 = texel_f32(tb, mx0 | my0 | mz1), f5 = texel_f32(tb, mx1 | my0 | mz1);
                 const float4 f6 = texel_f32(tb, mx0 | my1 | mz1), f7 = texel_f32(tb, mx1 | my1 | mz1);
@@ -642,6 +657,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
                 VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
 #undef VCT_ACC
             }
+#endif
 #elif VCT_LANE_RECOMPUTE_XY
             // (the x|y parts are formed again for the upper plane instead of being kept across the lower one)
             {
