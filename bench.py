@@ -911,6 +911,9 @@ def roofline_block(prof, kernel_ms, cone_steps, alg_bytes, alg_gbs):
         rate = valu / (kernel_ms * 1e-3) / 1e9
         r["achieved"] = round(rate, 1)
         r["frac"] = round(rate / VALU_PEAK_GINSTR, 4)
+        r["frac_reading"] = ("an ISSUE RATE, not a speed: round 6 took 18 % of the kernel's instructions away (the UNORM8 decode is done by "
+                             "the texture path: 543 -> 447 M wave-instructions per launch), the kernel got 10 % faster (0.612 -> 0.55 ms) "
+                             "and this fraction FELL from 0.72 to 0.66; see valu_pipe_busy_model, wave_cycles_waiting_on_memory and useful_frac")
         r["valu_wave_instructions_per_launch"] = int(valu)
         r["valu_wave_instructions_per_64_cone_steps"] = round(valu * 64 / max(cone_steps, 1), 1)
         # `frac` counts every instruction as a 2-cycle issue; a third of this kernel's mix are 4-cycle ops.
