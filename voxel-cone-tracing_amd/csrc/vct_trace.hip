@@ -232,6 +232,9 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
                                // which returns a texel as four floats -- bit for bit (float)c / 255.0f for every byte
                                // (tools/unorm_probe.hip) -- so the exact decode (cvt + mul + fma per channel) is not issued at all
 #endif
+#ifndef VCT_ANISO_HW
+#define VCT_ANISO_HW 0         // EXPERIMENT: the anisotropic sampler's directional blocks through typed loads too
+#endif
 #ifndef VCT_LANE_HYBRID
 #define VCT_LANE_HYBRID 0
 #endif
@@ -809,12 +812,24 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
                                  (((saz | ~MZ) + lb.sbz) & MZ);
             const unsigned long long mneg[3] = {mx, my, mz};
             const bool lneg[3] = {ac.nx, ac.ny, ac.nz};
+#if VCT_HW_UNORM && VCT_ANISO_HW
+            // texels decoded by the texture path (sample_level): the up to six directional blocks arrive as float4s
+            float4 fpos[3], fneg[3];
+            const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {          // all block loads first (up to 6 in flight)
+                fpos[k] = mneg[k] != m ? texel_f32(level_texel_buffer(chain_of(2 * k) + lv.off), idx) : zero4;          // some lane is >= 0
+                fneg[k] = mneg[k] != 0ull ? texel_f32(level_texel_buffer(chain_of(2 * k + 1) + lv.off), idx) : zero4;   // some lane is < 0
+            }
+            auto bits4 = [](const float4& f) { return __float_as_uint(f.x) | __float_as_uint(f.y) | __float_as_uint(f.z) | __float_as_uint(f.w); };
+#else
             uint32_t tpos[3], tneg[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {          // all block loads first (up to 6 in flight)
                 tpos[k] = mneg[k] != m ? (chain_of(2 * k) + lv.off)[idx] : 0u;          // some lane is >= 0
                 tneg[k] = mneg[k] != 0ull ? (chain_of(2 * k + 1) + lv.off)[idx] : 0u;   // some lane is < 0
             }
+#endif
             const int slot = act ? (dz * 4 + dy) * 4 + dx : 0;
             const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
             const float ab00 = a0 * b0, ab10 = a * b0, ab01 = a0 * b, ab11 = a * b;
@@ -825,6 +840,11 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 F4 r = {0.0f, 0.0f, 0.0f, 0.0f};
+#if VCT_HW_UNORM && VCT_ANISO_HW
+                if (ballot64((bits4(fpos[k]) | bits4(fneg[k])) != 0u) != 0ull) {
+                    if (mneg[k] != m) blk[lb.lane] = fpos[k];
+                    if (mneg[k] != 0ull) alt[lb.lane] = fneg[k];
+#else
                 if (ballot64((tpos[k] | tneg[k]) != 0u) != 0ull) {
                     auto dec = [](uint32_t t) {
                         float4 d;
@@ -834,6 +854,7 @@ __device__ __forceinline__ F4 sample_aniso(const VctTraceParams& p, const VctLev
                     };
                     if (mneg[k] != m) blk[lb.lane] = dec(tpos[k]);
                     if (mneg[k] != 0ull) alt[lb.lane] = dec(tneg[k]);
+#endif
                     wave_sync();
                     const float4* q = (lneg[k] ? alt : blk) + slot;
                     const float4 t0 = q[0], t1 = q[1], t2 = q[4], t3v = q[5];
