@@ -18,13 +18,13 @@ __device__ v4f vct_buffer_load_format(v4i rsrc, int voffset, int soffset, int au
 // structured form: stride 4, the texel INDEX in vindex -- a 4 GiB level (2^30 texels) is addressed in full
 __device__ v4f vct_struct_buffer_load_format(v4i rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.format.v4f32");
 
-__global__ void k_probe_struct(const uint32_t* texels, float* out, int n, uint32_t big_index, float* big_out) {
+__global__ void k_probe_struct(const uint32_t* texels, float* out, int n, uint32_t big_index, float* big_out, uint32_t records = 0x40000000u) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t base = (uint64_t)texels;
     v4i rsrc;
     rsrc.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)base);
     rsrc.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(base >> 32) | (4u << 16)));      // stride 4 bytes
-    rsrc.z = (int)0x40000000u;                                                                // records (texels)
+    rsrc.z = __builtin_amdgcn_readfirstlane((int)records);                                    // records (texels)
     rsrc.w = 0x50fac;
     const v4f r = vct_struct_buffer_load_format(rsrc, i < n ? i : 0, 0, 0, 0);
     if (i < n) { out[4 * i] = r.x; out[4 * i + 1] = r.y; out[4 * i + 2] = r.z; out[4 * i + 3] = r.w; }
@@ -120,6 +120,31 @@ int main() {
             printf("the same texel through the structured form (stride 4, index 2^30 - 1, 2^30 records): %s (%g %g %g %g)\n", ok2 ? "read correctly" : "NOT read", q[0], q[1], q[2], q[3]);
             if (!ok2) ++bad;
         } else printf("4 GiB allocation failed: range check not probed\n");
+        if (big) hipFree(big);
+        if (bo) hipFree(bo);
+    }
+    // beyond 2^30 records: the packed buffer of a scene's material textures is indexed by 32-bit texel offsets, so the
+    // structured form has to reach any of 2^32 - 1 texels (16 GiB) with num_records 0xffffffff
+    {
+        uint8_t* big = nullptr; float* bo = nullptr;
+        const size_t G16 = (size_t)1 << 34;
+        if (hipMalloc(&big, G16) == hipSuccess && hipMalloc(&bo, 16) == hipSuccess) {
+            const uint32_t idx[4] = {0x40000005u, 0x80000007u, 0xc0000009u, 0xfffffffeu};
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t tex = 0x80ff4001u + (uint32_t)k;      // bytes 0x01 + k, 0x40, 0xff, 0x80
+                hipMemcpy(big + (size_t)idx[k] * 4, &tex, 4, hipMemcpyHostToDevice);
+                hipMemset(bo, 0, 16);
+                hipLaunchKernelGGL(k_probe_struct, dim3(1), dim3(64), 0, 0, (const uint32_t*)big, o, 1, idx[k], bo, 0xffffffffu);
+                float q[4];
+                hipMemcpy(q, bo, 16, hipMemcpyDeviceToHost);
+                const float w[4] = {(float)(1 + k) / 255.0f, 64.0f / 255.0f, 1.0f, 128.0f / 255.0f};
+                const bool ok = memcmp(q, w, 16) == 0;
+                printf("structured form, 2^32 - 1 records, texel index 0x%08x of a 16 GiB buffer: %s (%g %g %g %g)\n", idx[k], ok ? "read correctly" : "NOT read", q[0], q[1], q[2], q[3]);
+                if (!ok) ++bad;
+            }
+        } else printf("16 GiB allocation failed: indices beyond 2^30 not probed\n");
+        if (big) hipFree(big);
+        if (bo) hipFree(bo);
     }
     hipMemset(o, 0xff, n * 16);
     hipLaunchKernelGGL(k_probe_struct, dim3(4), dim3(64), 0, 0, d, o, n, 0u, (float*)nullptr);
