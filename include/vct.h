@@ -273,7 +273,11 @@ int vct_synchronize(vct_ctx* ctx);
  * shared and ordered by events inside the library:
  * a stage that writes shared state (uploads, vct_render_shadow_map, vct_inject_light, vct_build_mips,
  * vct_bounce, vct_gi_pass) first waits for everything the other slot has in flight, and the other slot's
- * next work waits for it.  Frames are bit-identical to the one-slot frames.  vct_synchronize waits for both
+ * next work waits for it (one cross-stream wait per slot selection: later producers of the same selection
+ * skip theirs).  So passes that REWRITE the chain every frame -- vct_gi_pass with a moving light -- run one after
+ * the other whatever the slot, and pay the cross-queue hand-over: 0.818 ms per pass on one slot, 0.842 on two
+ * (configs[1]; configs[4] equal) -- two slots are for frames that share a chain (Render(): raster + trace).
+ * Frames are bit-identical to the one-slot frames.  vct_synchronize waits for both
  * slots.  n = 1 (default) releases the second slot.  Not with config.debug_outputs or trace_variant 4.  A rank of a
  * multi-GPU frame may use it too: vct_frame_step traces on the selected slot's stream, so slab k + 1 starts while slab k
  * drains (a slab launch pays the same ~20 us as a whole frame: a third of an 8-way slab); vct_comm_sync waits for both.

@@ -71,7 +71,21 @@ def slot_render():
     render(S)
 
 
+def gi(c):
+    c.gi_pass(inp["light_vp"], inp["view_proj"])
+
+
+def slot_gi():
+    S.select_frame_slot(kk[0] & 1); kk[0] += 1
+    gi(S)
+
+
 for rnd in range(2):
+    g1 = timed(lambda: (gi(A), gi(A)), 50) / 2
+    g2 = timed(lambda: (gi(A), gi(B)), 50) / 2
+    g3 = timed(lambda: (slot_gi(), slot_gi()), 50) / 2
+    print(f"round {rnd}: vct_gi_pass one context {g1:.4f} ms/pass, two CONTEXTS alternating {g2:.4f} ({100 * (g1 / g2 - 1):+.1f} %), "
+          f"one context with two frame slots {g3:.4f}", flush=True)
     t1 = timed(lambda: (A.trace_resident(), A.trace_resident())) / 2
     t2 = timed(lambda: (A.trace_resident(), B.trace_resident())) / 2
     r1 = timed(lambda: (render(A), render(A))) / 2

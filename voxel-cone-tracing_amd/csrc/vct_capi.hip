@@ -243,16 +243,20 @@ void slot_load(vct_ctx* c, const VctFrameSlot& s) {
 // other slot has in flight, and the next slot switch makes the other stream wait for it (produced_since_switch).
 int pipeline_join(vct_ctx* c) {
     if (c->frames_in_flight < 2) return VCT_OK;
+    c->produced_since_switch = true;
+    if (c->joined_since_switch) return VCT_OK;      // (vct_ctx.h: nothing new can be on the other stream)
     HIP_TRY(c, hipEventRecord(c->ev_xslot, c->slots[1 - c->cur_slot].stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_xslot, 0));
-    c->produced_since_switch = true;
+    c->joined_since_switch = true;
     return VCT_OK;
 }
 // Uploads free and reallocate buffers the other slot's kernels may still read: the host waits for that slot.
 int pipeline_drain(vct_ctx* c) {
     if (c->frames_in_flight < 2) return VCT_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->slots[1 - c->cur_slot].stream));
     c->produced_since_switch = true;
+    if (c->drained_since_switch) return VCT_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->slots[1 - c->cur_slot].stream));
+    c->drained_since_switch = c->joined_since_switch = true;      // (a finished stream needs no GPU-side wait either)
     return VCT_OK;
 }
 #define PIPE_TRY(call)                    \
@@ -1927,7 +1931,7 @@ int vct_set_frames_in_flight(vct_ctx* c, int32_t n) {
         c->raster_dirty[2] = true;
         c->raster_set[2] = c->bin_set[2] = 0;
         c->frames_in_flight = 1;
-        c->produced_since_switch = false;
+        c->produced_since_switch = c->joined_since_switch = c->drained_since_switch = false;
         return VCT_OK;
     }
     // a second slot: its own stream, timing events, G-buffer, frame and per-tile step counts (190 MB + 17 MB at 1080p)
@@ -1958,7 +1962,7 @@ int vct_set_frames_in_flight(vct_ctx* c, int32_t n) {
     slot_save(c, c->slots[0]);
     c->cur_slot = 0;
     c->frames_in_flight = 2;
-    c->produced_since_switch = false;
+    c->produced_since_switch = c->joined_since_switch = c->drained_since_switch = false;
     return VCT_OK;
 }
 
@@ -1976,14 +1980,20 @@ int vct_select_frame_slot(vct_ctx* c, int32_t slot) {
         return fail(c, VCT_ERR_INVALID, "vct_select_frame_slot: slot outside [0, frames in flight)");
     if (slot == c->cur_slot) return VCT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    bool waited = false;
     if (c->produced_since_switch) {      // shared state was written on this slot's stream: the other stream's next work follows it
         HIP_TRY(c, hipEventRecord(c->ev_xslot, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->slots[slot].stream, c->ev_xslot, 0));
         c->produced_since_switch = false;
+        waited = true;
     }
     slot_save(c, c->slots[c->cur_slot]);
     slot_load(c, c->slots[slot]);
     c->cur_slot = slot;
+    // the stream left behind may hold work the next producer must follow -- unless the wait above already put the selected
+    // stream behind all of it (the stream left behind receives nothing more until it is selected again)
+    c->joined_since_switch = waited;
+    c->drained_since_switch = false;
     return VCT_OK;
 }
 
