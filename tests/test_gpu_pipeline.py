@@ -166,6 +166,93 @@ def test_cone_apertures_change_between_frames_in_flight(vct):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_call_orders_give_what_a_synchronised_context_gives(vct, seed):
+    """Producers (shadow map, voxelize / inject / mips, the one-call pass), G-buffer passes, traces, slot switches and
+    read-backs in a random order on a two-slot context, against the same calls on a context that waits for the GPU after
+    every call (nothing ever in flight there, so no ordering can go wrong).  What the library skips -- one cross-stream
+    wait per slot selection, the switch's own wait counting as the join -- must not show.  (Checked against a build
+    without the joins: this test fails there, the tests above do not -- at their sizes the GPU is done before the host's
+    next call.)"""
+    rng = np.random.default_rng(seed)
+    # a whole 1080p frame: its trace runs for a few hundred microseconds, long enough for the calls behind it to be issued
+    # while it is still running
+    w, h = 1920, 1080
+    cams_n, lights_n = 5, 5
+    # the call list first, so that the asynchronous context runs it without a pause
+    ops = [("produce", 0)]
+    slot, traced, has_gb = 0, [False, False], [False, False]
+    for rnd in range(12):
+        s0 = int(rng.integers(2))
+        ops.append(("switch", s0)); slot = s0
+        has_gb[slot] = True
+        # a frame on slot s0, with or without new shared state in front of it ...
+        r = rng.random()
+        if r < 0.2 and traced[slot]:
+            ops.append(("produce", int(rng.integers(lights_n))))        # new shared state and nothing else
+        elif r < 0.4:
+            ops.append(("gi", int(rng.integers(lights_n)), int(rng.integers(cams_n))))
+            traced[slot] = True
+        else:
+            if r < 0.6:
+                ops.append(("produce", int(rng.integers(lights_n))))
+            ops.append(("gbuffer", int(rng.integers(cams_n)))); ops.append(("trace",))
+            traced[slot] = True
+        # ... and, while its trace is still running, the other slot: shared state rewritten at once (the case the joins are
+        # for -- nothing was produced on s0 since the switch, so the switch itself waits for nothing), or only read
+        ops.append(("switch", 1 - s0)); slot = 1 - s0
+        if has_gb[slot] and rng.random() < 0.5:
+            # the resident G-buffer traced again at once: if s0's frame came with new shared state, this trace must wait for
+            # it (the switch's wait), and nothing but that wait makes it
+            ops.append(("trace",)); traced[slot] = True
+            ops.append(("read",))
+        r = rng.random()
+        if r < 0.4:
+            ops.append(("produce", int(rng.integers(lights_n))))
+        elif r < 0.6:
+            ops.append(("gi", int(rng.integers(lights_n)), int(rng.integers(cams_n)))); traced[slot] = has_gb[slot] = True
+        if rng.random() < 0.6:
+            ops.append(("gbuffer", int(rng.integers(cams_n)))); ops.append(("trace",)); traced[slot] = True
+            has_gb[slot] = True
+        if rng.random() < 0.5 and traced[slot]:
+            ops.append(("read",))
+        ops.append(("switch", s0)); slot = s0
+        ops.append(("read",))
+
+    def run(sync):
+        c, sc = make(vct, w, h, V=128)
+        cams = cameras(sc, w, h, cams_n)
+        Ls = lights(lights_n)
+        c.set_frames_in_flight(2)
+        frames = []
+        for op in ops:
+            if op[0] == "produce":
+                c.set_light_direction(Ls[op[1]])
+                c.render_shadow_map(sc.light_view_proj(Ls[op[1]]))
+                c.voxelize(); c.inject_light(); c.build_mips()
+            elif op[0] == "gi":
+                c.set_light_direction(Ls[op[1]]); c.set_camera_position(cams[op[2]][0])
+                c.gi_pass(sc.light_view_proj(Ls[op[1]]), cams[op[2]][1])
+            elif op[0] == "gbuffer":
+                c.set_camera_position(cams[op[1]][0]); c.render_gbuffer(cams[op[1]][1])
+            elif op[0] == "trace":
+                c.trace_resident()
+            elif op[0] == "switch":
+                c.select_frame_slot(op[1])
+            elif op[0] == "read":
+                frames.append((c.download_frame(), c.last_step_count()))
+            if sync:
+                c.synchronize()
+        c.close()
+        return frames
+
+    got, want = run(False), run(True)
+    assert len(got) == len(want) >= 12
+    for k, ((fa, sa), (fb, sb)) in enumerate(zip(got, want)):
+        assert np.array_equal(fa, fb), f"seed {seed}: read-back {k} differs"
+        assert sa == sb
+
+
 def test_what_two_frames_in_flight_refuses(vct):
     ctx, sc = make(vct, 64, 48, 32)
     with pytest.raises(vct.VctError):
