@@ -171,9 +171,11 @@ def test_random_call_orders_give_what_a_synchronised_context_gives(vct, seed):
     """Producers (shadow map, voxelize / inject / mips, the one-call pass), G-buffer passes, traces, slot switches and
     read-backs in a random order on a two-slot context, against the same calls on a context that waits for the GPU after
     every call (nothing ever in flight there, so no ordering can go wrong).  What the library skips -- one cross-stream
-    wait per slot selection, the switch's own wait counting as the join -- must not show.  (Checked against a build
-    without the joins: this test fails there, the tests above do not -- at their sizes the GPU is done before the host's
-    next call.)"""
+    wait per slot selection, the switch's own wait counting as the join -- must not show.  (Checked against mutated
+    builds: without the producers' joins, or without the wait of the slot switch, this test fails and the tests above do
+    not -- at their sizes the GPU is done before the host's next call.  A build without the host-side drains passes
+    everything: hipFree and the runtime's copy from pageable memory wait for the device by themselves -- 570 us of host
+    time for "trace, switch, new apertures, trace" either way -- so the drains are a guarantee, not an observable.)"""
     rng = np.random.default_rng(seed)
     # a whole 1080p frame: its trace runs for a few hundred microseconds, long enough for the calls behind it to be issued
     # while it is still running
@@ -201,13 +203,18 @@ def test_random_call_orders_give_what_a_synchronised_context_gives(vct, seed):
         # ... and, while its trace is still running, the other slot: shared state rewritten at once (the case the joins are
         # for -- nothing was produced on s0 since the switch, so the switch itself waits for nothing), or only read
         ops.append(("switch", 1 - s0)); slot = 1 - s0
+        if rng.random() < 0.3:
+            ops.append(("apertures", int(rng.integers(3))))       # a new step table while the other slot's trace reads the old one
         if has_gb[slot] and rng.random() < 0.5:
             # the resident G-buffer traced again at once: if s0's frame came with new shared state, this trace must wait for
             # it (the switch's wait), and nothing but that wait makes it
             ops.append(("trace",)); traced[slot] = True
             ops.append(("read",))
         r = rng.random()
-        if r < 0.4:
+        if r < 0.12:
+            # a new mesh: buffers the other slot's kernels may still read are freed and re-allocated (the host waits: drain)
+            ops.append(("remesh", int(rng.integers(2)))); ops.append(("produce", int(rng.integers(lights_n))))
+        elif r < 0.4:
             ops.append(("produce", int(rng.integers(lights_n))))
         elif r < 0.6:
             ops.append(("gi", int(rng.integers(lights_n)), int(rng.integers(cams_n)))); traced[slot] = has_gb[slot] = True
@@ -221,6 +228,8 @@ def test_random_call_orders_give_what_a_synchronised_context_gives(vct, seed):
 
     def run(sync):
         c, sc = make(vct, w, h, V=128)
+        meshes = [sc.Scene(sc.ATRIUM, 0.15, 1234), sc.Scene(sc.ATRIUM, 0.2, 99)]
+        aps = [(0.577, 0.07), (0.577, 0.2), (0.45, 0.105)]
         cams = cameras(sc, w, h, cams_n)
         Ls = lights(lights_n)
         c.set_frames_in_flight(2)
@@ -239,6 +248,12 @@ def test_random_call_orders_give_what_a_synchronised_context_gives(vct, seed):
                 c.trace_resident()
             elif op[0] == "switch":
                 c.select_frame_slot(op[1])
+            elif op[0] == "remesh":
+                m = meshes[op[1]]
+                c.upload_triangles(m.pos, m.material, m.albedo)
+                c.upload_mesh_attributes(*m.frames(), m.specular)
+            elif op[0] == "apertures":
+                c.set_cone_apertures(*aps[op[1]])
             elif op[0] == "read":
                 frames.append((c.download_frame(), c.last_step_count()))
             if sync:
