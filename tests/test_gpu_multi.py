@@ -74,6 +74,40 @@ def test_native_frame_step_one_rank_communicator(vct):
     ctx.close()
 
 
+def test_frame_steps_of_changing_frames_gather_each_frame(vct):
+    """Three different 1080p frames in a cycle through the communicator's TWO gather buffers: the gather of a step must
+    wait for that step's trace (0.4 ms here), or it picks up what the buffer held two steps earlier -- another camera's
+    frame.  (The test above steps the same frame three times: a gather that ran too early would copy identical bytes.
+    On ONE rank the root's slab is traced in place and the read-back waits for the context's stream as well, so even a
+    build whose communication stream does not wait for the trace passes here -- that wait can only be observed with a
+    second GPU; this test pins the buffer cycle and the changing content.)"""
+    from voxel_cone_tracing_amd import scene as sc
+    w, h = 1920, 1080
+    ctx, _ = small_pipeline(vct, w, h, V=128)
+    cams = [sc.default_camera(position=(-56.0 + 4.0 * k, -9.0 + k, 2.0 - k), yaw=6.0 * k, pitch=8.0 - 2.0 * k) for k in range(3)]
+    vps = [sc.camera_view_proj(c, w, h) for c in cams]
+    want = []
+    for c, vp in zip(cams, vps):
+        ctx.set_camera_position(tuple(c.position)); ctx.render_gbuffer(vp)
+        want.append(ctx.trace_current())
+    assert not np.array_equal(want[0], want[1]) and not np.array_equal(want[1], want[2])
+    ctx.comm_init(vct.comm_unique_id(), 0, 1)
+    for i in range(9):
+        k = i % 3
+        ctx.set_camera_position(tuple(cams[k].position)); ctx.render_gbuffer(vps[k])
+        ctx.frame_step()
+        assert np.array_equal(ctx.comm_download_frame(), want[k]), f"step {i}"
+    # ... and two steps back to back before the read-back (the second one's buffer is the other one)
+    for i in range(6):
+        k = i % 3
+        ctx.set_camera_position(tuple(cams[k].position)); ctx.render_gbuffer(vps[k])
+        ctx.frame_step()
+        if i & 1:
+            assert np.array_equal(ctx.comm_download_frame(), want[k]), f"pair {i}"
+    ctx.comm_destroy()
+    ctx.close()
+
+
 def test_slab_raster_equals_rows_of_full_raster(vct):
     ctx, vp = small_pipeline(vct, w=203, h=117)          # ragged size
     ctx.render_gbuffer(vp)

@@ -268,6 +268,53 @@ def test_random_call_orders_give_what_a_synchronised_context_gives(vct, seed):
         assert sa == sb
 
 
+@pytest.mark.parametrize("shape", ["frame", "shadow"])
+def test_one_call_passes_back_to_back_into_their_own_targets(vct, shape):
+    """vct_gi_pass forks its main draw onto a second stream: the draw must wait for the previous pass (fork), its shading
+    kernel for the shadow map of THIS pass, the trace for the G-buffer (join).  Passes with a moving light and camera are
+    issued back to back, each frame into its own device buffer (vct_set_frame_target), and compared with the same passes
+    run one at a time.  "frame": 1080p, where the previous trace is still running when the next pass is issued; "shadow":
+    a small frame under a 4096^2 shadow map of the whole atrium, where the main draw's visibility raster is done long
+    before the shadow pass.  (Mutated builds: without the join "frame" fails, without the shadow wait "shadow" fails --
+    neither was noticed by the small passes of the other tests, which run to completion before the host's next call.
+    Without the fork wait everything passes: the shading kernel, the draw's only writer of the G-buffer, is already
+    behind this pass's shadow map and thereby behind the previous trace; the wait stays as a guarantee.)"""
+    import torch
+    from voxel_cone_tracing_amd import scene as sc
+    if shape == "frame":
+        w, h, V, S, detail = 1920, 1080, 128, 512, 0.15
+    else:
+        w, h, V, S, detail = 200, 120, 64, 4096, 1.0
+    scene = sc.Scene(sc.ATRIUM, detail, 1234)
+    ctx = vct.Context(vct.default_config(voxel_dim=V, width=w, height=h, shadow_map_size=S))
+    ctx.upload_triangles(scene.pos, scene.material, scene.albedo)
+    ctx.upload_mesh_attributes(*scene.frames(), scene.specular)
+    n = 6
+    cams = cameras(sc, w, h, n)
+    Ls = lights(n)
+
+    def one(k):
+        ctx.set_light_direction(Ls[k]); ctx.set_camera_position(cams[k][0])
+        ctx.gi_pass(sc.light_view_proj(Ls[k]), cams[k][1])
+
+    want = []
+    for k in range(n):
+        one(k)
+        want.append(ctx.download_frame())
+    targets = [torch.zeros((h, w, 4), dtype=torch.float16, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(n):
+            ctx.set_frame_target(targets[k].data_ptr())
+            one(k)
+        ctx.synchronize()
+        for k in range(n):
+            got = targets[k].cpu().numpy().view(np.uint16)
+            assert np.array_equal(got.reshape(want[k].shape), want[k].view(np.uint16).reshape(want[k].shape)), f"{shape}: pass {k} (round {rep})"
+    ctx.set_frame_target(None)
+    ctx.close()
+
+
 def test_what_two_frames_in_flight_refuses(vct):
     ctx, sc = make(vct, 64, 48, 32)
     with pytest.raises(vct.VctError):
