@@ -199,7 +199,8 @@ struct Voxel_Cone_Tracing {
     // 2: consecutive Render() calls alternate between two frame slots of the context (vct_set_frames_in_flight: own
     // stream, G-buffer and frame each), so frame k + 1's raster and trace start while frame k's trace drains -- what the
     // GL driver does with the reference's frames (R/main.cpp:77-94 never waits for one).  Frame() returns the frame of
-    // the last Render().  Same pixels; configs[1]: 0.77 -> 0.75 ms per Render().  Set before init.
+    // the last Render().  Same pixels; configs[1]: 0.715 -> 0.694 ms per Render(), configs[4] 4.25 -> 4.02.  Frames that are
+    // whole GI passes (DynamicLight) stay on one slot: they rewrite the chain and cannot overlap.  Set before init.
     int FramesInFlight = 1;
     int Bounces = 1;    // 2 = re-inject the lit voxels once (the "2 bounces" of the reference's README.md:16,
                         // which its code does not implement: VCT.h:138-139 injects once); set before init
@@ -294,17 +295,22 @@ struct Voxel_Cone_Tracing {
         hc.z_near = 0.1f; hc.z_far = 1000.0f;                                              // VCT.h:162
         float vp[16];
         vcth_camera_view_proj(&hc, screen_width, screen_height, vp);                       // VCT.h:161-163
-        int32_t slots = 1;
-        if (vct_get_frames_in_flight(ctx, &slots, nullptr, nullptr) == VCT_OK && slots == 2)        // frame k in slot k & 1
-            if (!check(vct_select_frame_slot(ctx, (int32_t)(frame_no++ & 1u)), "vct_select_frame_slot")) return;
+        // frame k in slot k & 1 -- unless every Render() is a whole GI pass (DynamicLight): passes that rewrite the chain run
+        // one after the other whatever the slot and would only pay the hand-over between hardware queues (include/vct.h:
+        // 0.842 ms per pass on alternating slots against 0.818 on one), so they stay on the slot that is selected
         int32_t row0 = 0, row1 = 0;
-        if (vct_comm_slab(ctx, &row0, &row1) == VCT_OK) {       // multi-GPU: this rank's slab, one gather
+        const bool rank_ctx = vct_comm_slab(ctx, &row0, &row1) == VCT_OK;
+        const bool whole_pass = !rank_ctx && DynamicLight && Bounces < 2;
+        int32_t slots = 1;
+        if (!whole_pass && vct_get_frames_in_flight(ctx, &slots, nullptr, nullptr) == VCT_OK && slots == 2)
+            if (!check(vct_select_frame_slot(ctx, (int32_t)(frame_no++ & 1u)), "vct_select_frame_slot")) return;
+        if (rank_ctx) {                                          // multi-GPU: this rank's slab, one gather
             if (!check(vct_render_gbuffer_rows(ctx, vp, row0, row1), "vct_render_gbuffer_rows")) return;
             if (!check(vct_frame_step(ctx), "vct_frame_step")) return;
             frame_on_host = false;
             return;
         }
-        if (DynamicLight && Bounces < 2) {
+        if (whole_pass) {
             vcth_light_view_proj(L, DepthViewProjectionMatrix.m);                          // VCT.h:84-86, per frame
             const int32_t mode = ReferenceVoxelization ? VCT_VOX_REFERENCE : VCT_VOX_CONSERVATIVE_AVG;
             if (!check(vct_gi_pass(ctx, DepthViewProjectionMatrix.m, vp, mode), "vct_gi_pass")) return;

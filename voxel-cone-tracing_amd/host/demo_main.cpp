@@ -80,23 +80,25 @@ int main(int argc, char** argv) {
     const char* ppm = nullptr;
     bool dynamic_light = false;
     const char* idfile = nullptr;
-    for (int i = 1; i + 1 < argc; i += 2) {
-        if (!strcmp(argv[i], "--gpus")) gpus = atoi(argv[i + 1]);
-        else if (!strcmp(argv[i], "--rank")) rank = atoi(argv[i + 1]);
-        else if (!strcmp(argv[i], "--idfile")) idfile = argv[i + 1];
+    for (int i = 1; i + 1 < argc; ++i) {
+        if (!strcmp(argv[i], "--gpus")) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--rank")) rank = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--idfile")) idfile = argv[++i];
     }
     if (gpus > 0 && rank < 0) return launch_ranks(gpus, argc, argv);
-    for (int i = 1; i + 1 < argc; i += 2) {
-        if (!strcmp(argv[i], "--scene")) scene = argv[i + 1];
-        else if (!strcmp(argv[i], "--voxels")) voxels = atoi(argv[i + 1]);
-        else if (!strcmp(argv[i], "--size")) sscanf(argv[i + 1], "%dx%d", &w, &h);
-        else if (!strcmp(argv[i], "--shadow")) shadow = atoi(argv[i + 1]);
-        else if (!strcmp(argv[i], "--frames")) frames = atoi(argv[i + 1]);
-        else if (!strcmp(argv[i], "--bounces")) bounces = atoi(argv[i + 1]);
-        else if (!strcmp(argv[i], "--ppm")) ppm = argv[i + 1];
-        else if (!strcmp(argv[i], "--frames-in-flight")) in_flight = atoi(argv[i + 1]);
+    // (options with a value consume it; --dynamic-light has none and may stand anywhere)
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--dynamic-light")) { dynamic_light = true; continue; }
+        if (i + 1 >= argc) break;
+        if (!strcmp(argv[i], "--scene")) scene = argv[++i];
+        else if (!strcmp(argv[i], "--voxels")) voxels = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--size")) sscanf(argv[++i], "%dx%d", &w, &h);
+        else if (!strcmp(argv[i], "--shadow")) shadow = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--frames")) frames = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--bounces")) bounces = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--ppm")) ppm = argv[++i];
+        else if (!strcmp(argv[i], "--frames-in-flight")) in_flight = atoi(argv[++i]);
     }
-    for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], "--dynamic-light")) dynamic_light = true;
     GLFWwindow* window = nullptr;          // no window system on a compute node
 
     camera.MovementSpeed = 5.0f;           // R/main.cpp:64-65
