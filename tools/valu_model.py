@@ -4,7 +4,7 @@
     tools/valu_model.py  [--write]
 
 Compiles csrc/vct_trace.hip to gfx950 assembly, takes the specular march loop of
-k_trace_tile_split<true,1,false,false> (the diffuse loop has the same body), splits it at its labels into
+k_trace_tile_split<true,1,false,false,false,true> (the whole-frame instantiation; the diffuse loop has the same body), splits it at its labels into
   head      position, three constant divisions, level-1 coordinates, anchor, coverage test
   coop      cooperative block: Morton offset, load, decode, LDS slab, 8-texel gather, interpolation
   fallback  per-lane gather
@@ -69,7 +69,7 @@ def main():
                         "-fno-slp-vectorize", "-fPIC", "-Wno-unused-function", "-S", "--cuda-device-only", "-o", out, src],
                        check=True, capture_output=True)
         text = open(out).read()
-    m = re.search(r"^_ZN12_GLOBAL__N_118k_trace_tile_splitILb1ELi1ELb0ELb0ELb0EEEv14VctTraceParams:.*?\.end_amdhsa_kernel", text, re.S | re.M)
+    m = re.search(r"^_ZN12_GLOBAL__N_118k_trace_tile_splitILb1ELi1ELb0ELb0ELb0ELb1EEEv14VctTraceParams:.*?\.end_amdhsa_kernel", text, re.S | re.M)
     body = m.group(0).split("\n")
     # the specular march = the largest depth-1 inner loop (the diffuse march, inside the cone loop, is depth 2 and has the
     # same body; small depth-1 loops, if any, are prologue code)

@@ -253,6 +253,9 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #ifndef VCT_QUARTER_GATHER
 #define VCT_QUARTER_GATHER 0
 #endif
+#ifndef VCT_LOAD_PRIO
+#define VCT_LOAD_PRIO 1        // (A/B, 4 interleaved rounds: kernel -1.7 %, one-stream step -1.3 %, vct_gi_pass -0.9 % on the atrium; street 4K -0.5 %)
+#endif
 #ifndef VCT_CELLS_ARITH
 #define VCT_CELLS_ARITH 1      // the footprint-record instantiation keeps the arithmetic (it is memory bound: see sample_level)
 #endif
@@ -280,13 +283,20 @@ struct MarchStats {
 // [GL] tri(level): trilinear, texel centres, REPEAT (or clamp).  `level` is wave-uniform; must be
 // called in wave-uniform control flow with at least one lane `act`.  Lanes without `act` help
 // fetch the block and return garbage-free zeros / unused values.
-template <bool WRAP, bool COOP, bool LOOSE = false, bool CELLS = false>
+template <bool WRAP, bool COOP, bool LOOSE = false, bool CELLS = false, bool PRIO = false>
 __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, const VctLevelRef lv,
                                            float ux, float uy, float uz, bool act, unsigned long long am,
                                            float4* __restrict__ blk, const LaneBlock& lb, MarchStats& ms,
                                            const char* __restrict__ cells = nullptr) {
     // `am` is ballot64(act), passed in so that compound predicates are ANDed as lane masks on the
     // scalar unit (a ballot of `x && y` costs a v_cndmask + v_cmp_ne pair to materialise the bool).
+    // Issue priority raised from here until the sample's loads are out (VCT_LOAD_PRIO, round 6): a wave that is forming
+    // addresses gets its instructions ahead of the waves that are folding texels, so its loads leave earlier and more of
+    // their latency lies under the other waves' arithmetic.  PRIO is a template parameter: the launches of whole frames
+    // take the instantiation with it, slab launches the one without -- there the priority goes to the specular waves, the
+    // tail of a short launch (spec_prio; 8-way slabs 0.0881 ms with that against 0.0900 with this).  The same choice behind
+    // a wave-uniform flag cost the default kernel 60 B of scratch per lane.
+    if (VCT_LOAD_PRIO && PRIO) __builtin_amdgcn_s_setprio(1);
     const int m = lv.m;
     const float fN = lv.fN;
     // ux * fN is exact (power of two), so the fused form is the oracle's (ux*fN) - 0.5f bit for bit
@@ -378,6 +388,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         }
 #if VCT_HW_UNORM && !VCT_LUT
         const float4 d = texel_f32(tb, idx);
+        if (VCT_LOAD_PRIO && PRIO) __builtin_amdgcn_s_setprio(0);
         // (channels are >= +0: the block is empty iff no channel has a bit set)
         const bool any_texel = ballot64((__float_as_uint(d.x) | __float_as_uint(d.y) | __float_as_uint(d.z) | __float_as_uint(d.w)) != 0u) != 0ull;
 #else
@@ -655,6 +666,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             {
                 const float4 f4 = texel_f32(tb, mx0 | my0 | mz1), f5 = texel_f32(tb, mx1 | my0 | mz1);
                 const float4 f6 = texel_f32(tb, mx0 | my1 | mz1), f7 = texel_f32(tb, mx1 | my1 | mz1);
+                if (VCT_LOAD_PRIO && PRIO) __builtin_amdgcn_s_setprio(0);
                 const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
 #define VCT_ACC(ch) r.ch = fmaf(w4, f4.ch, r.ch); r.ch = fmaf(w5, f5.ch, r.ch); r.ch = fmaf(w6, f6.ch, r.ch); r.ch = fmaf(w7, f7.ch, r.ch);
                 VCT_ACC(x) VCT_ACC(y) VCT_ACC(z) VCT_ACC(w)
@@ -740,6 +752,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
 #endif
         }
 #undef VCT_TEXEL
+        if (VCT_LOAD_PRIO && PRIO) __builtin_amdgcn_s_setprio(0);
         const float a0 = 1.0f - a, b0 = 1.0f - b, c0 = 1.0f - c;
         const float wg[8] = {(a0 * b0) * c0, (a * b0) * c0, (a0 * b) * c0, (a * b) * c0,
                              (a0 * b0) * c,  (a * b0) * c,  (a0 * b) * c,  (a * b) * c};
@@ -923,10 +936,10 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
         const float uy = fmaf(div_const<FASTDIV>(py, p.half_G_aux, p.half_G_rcp), 0.5f, 0.5f); \
         const float uz = fmaf(div_const<FASTDIV>(pz, p.half_G_aux, p.half_G_rcp), 0.5f, 0.5f); \
         F4 vc = (ANISO && st.level >= 1) ? sample_aniso<WRAP, COOP>(p, st.l1, ux, uy, uz, act, live, blk, lb, ac, ms) \
-                                         : sample_level<WRAP, COOP, FASTDIV == 2, CELLS>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms, p.cells_biased); \
+                                         : sample_level<WRAP, COOP, FASTDIV == 2, CELLS, PRIO>(p.chain, st.l1, ux, uy, uz, act, live, blk, lb, ms, p.cells_biased); \
         if (st.two_levels) { \
             const F4 t2 = ANISO ? sample_aniso<WRAP, COOP>(p, st.l2, ux, uy, uz, act, live, blk + 64, lb, ac, ms) \
-                                : sample_level<WRAP, COOP, FASTDIV == 2, CELLS>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms, p.cells_biased); \
+                                : sample_level<WRAP, COOP, FASTDIV == 2, CELLS, PRIO>(p.chain, st.l2, ux, uy, uz, act, live, blk + 64, lb, ms, p.cells_biased); \
             const float g = st.omf;      /* 1 - frac, from the table */ \
             vc.x = fmaf(st.frac, t2.x, g * vc.x); \
             vc.y = fmaf(st.frac, t2.y, g * vc.y); \
@@ -943,7 +956,7 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
             ++steps; \
         }
 
-template <bool WRAP, int FASTDIV, bool COOP, bool ANISO = false, bool CELLS = false>
+template <bool WRAP, int FASTDIV, bool COOP, bool ANISO = false, bool CELLS = false, bool PRIO = false>
 __device__ __forceinline__ F4 cone_march(const VctTraceParams& p, bool alive, F3 start, F3 dir,
                                          const VctStep* tab_global, int n,
                                          float4* __restrict__ blk, const LaneBlock& lb,
@@ -1014,7 +1027,7 @@ template <bool WRAP, int FASTDIV, bool COOP>
 __device__ __forceinline__ void cone_march3(const VctTraceParams& p, bool alive, F3 start, const F3 dirs[3],
                                             const VctStep* tab_global, int n, float4* __restrict__ blk,
                                             const LaneBlock& lb, ConeAcc out[3], MarchStats& ms) {
-    constexpr bool ANISO = false, CELLS = false;
+    constexpr bool ANISO = false, CELLS = false, PRIO = false;
     const StepTable tab = (StepTable)tab_global;
     AnisoCone ac = {0.0f, 0.0f, 0.0f, false, false, false};
     ConeAcc c0 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0}, c1 = c0, c2 = c0;
@@ -1280,7 +1293,7 @@ static_assert(VCT_SPLIT == 3 || VCT_SPLIT == 4 || VCT_SPLIT == 7, "VCT_SPLIT mus
 // spilling under the 80 of the default kernel)
 // CELLS: the per-lane sampler reads footprint records (p.cells_biased != null; vct_set_footprint_records) -- an
 // instantiation of its own, because the same code behind a run-time test cost the default kernel 2 % (0.608 -> 0.620 ms)
-template <bool WRAP, int FASTDIV, bool ANISO, bool COMPACT = false, bool CELLS = false>
+template <bool WRAP, int FASTDIV, bool ANISO, bool COMPACT = false, bool CELLS = false, bool PRIO = false>
 __global__ void __launch_bounds__(64 * VCT_SPLIT, ANISO ? VCT_ANISO_MIN_WAVES : VCT_TRACE_MIN_WAVES)
 k_trace_tile_split(const VctTraceParams p) {
     __shared__ float4 lds_blk[VCT_SPLIT][ANISO ? 4 : 2][64];   // per wave: level-1 slab, level-2 slab (+ their "-axis" slabs)
@@ -1393,7 +1406,7 @@ k_trace_tile_split(const VctTraceParams p) {
                         k0.z * ddx + k1.z * ddy + k2.z * ddz);
             dir = normalize3(dir);
             int st;
-            const F4 c = cone_march<WRAP, FASTDIV, true, ANISO, CELLS>(p, alive, start, dir, p.steps_diffuse,
+            const F4 c = cone_march<WRAP, FASTDIV, true, ANISO, CELLS, PRIO>(p, alive, start, dir, p.steps_diffuse,
                                                                 p.n_diffuse, blk, lb, st, ms);
             total += st;
             lds_cone[i][lane] = make_float4(c.x, c.y, c.z, c.w);
@@ -1408,7 +1421,8 @@ k_trace_tile_split(const VctTraceParams p) {
         // tail: raised issue priority lets them run ahead of the diffuse waves, which have the slack.  Pays when the
         // launch is a slab of a multi-GPU frame (8-way slabs of the 1080p frame: 0.1085 -> 0.1052 ms mean, 0.115 ->
         // 0.111 ms max), costs 0.5 % on the whole frame: the host sets it for launches of at most half the frame.
-        if (p.spec_prio) __builtin_amdgcn_s_setprio(1);
+        // (the PRIO instantiation -- whole frames -- sets and resets the priority around every sample's loads instead)
+        if (!PRIO && p.spec_prio) __builtin_amdgcn_s_setprio(1);
         // specular cone along reflect(-E, N) with the bump normal                 trace.fs:217-218
         const F3 P = f3(VCT_GB(0), VCT_GB(1), VCT_GB(2)), Nw = f3(VCT_GB(3), VCT_GB(4), VCT_GB(5));
         const F3 N = f3(VCT_GB(12), VCT_GB(13), VCT_GB(14));
@@ -1416,7 +1430,7 @@ k_trace_tile_split(const VctTraceParams p) {
         const F3 E = normalize3(f3(p.cam[0] - P.x, p.cam[1] - P.y, p.cam[2] - P.z));   // :181
         const F3 Rd = normalize3(reflect3(f3(E.x * -1.0f, E.y * -1.0f, E.z * -1.0f), N));  // :217
         int st6;
-        const F4 sc = cone_march<WRAP, FASTDIV, true, ANISO, CELLS>(p, alive, start, Rd, p.steps_specular,
+        const F4 sc = cone_march<WRAP, FASTDIV, true, ANISO, CELLS, PRIO>(p, alive, start, Rd, p.steps_specular,
                                                              p.n_specular, blk, lb, st6, ms);
         total += st6;
         lds_cone[6][lane] = make_float4(sc.x, sc.y, sc.z, sc.w);
@@ -1802,6 +1816,8 @@ hipError_t launch_v(const VctTraceParams& p, int variant, int ntiles, hipStream_
     if (p.aniso) hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     else if (VCT_CELLS && WRAP && p.cells_biased)
         hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false, false, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
+    else if (VCT_LOAD_PRIO && !p.spec_prio)     // a whole frame (or most of one): issue priority around the samples' loads (sample_level)
+        hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false, false, false, true>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     else hipLaunchKernelGGL((k_trace_tile_split<WRAP, FASTDIV, false>), dim3(blocks), dim3(64 * VCT_SPLIT), 0, s, p);
     return hipGetLastError();
 }
