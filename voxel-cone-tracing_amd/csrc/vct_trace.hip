@@ -256,6 +256,9 @@ __device__ __forceinline__ float unorm8_of(UnormLut lut, uint32_t t, bool use_lu
 #ifndef VCT_LOAD_PRIO
 #define VCT_LOAD_PRIO 1        // (A/B, 4 interleaved rounds: kernel -1.7 %, one-stream step -1.3 %, vct_gi_pass -0.9 % on the atrium; street 4K -0.5 %)
 #endif
+#ifndef VCT_LOAD_PRIO_MODE
+#define VCT_LOAD_PRIO_MODE 1   // (A/B) 1: reset behind the load instructions; 2: cooperative path resets behind its LDS reads; 3: raised from the start of the march step
+#endif
 #ifndef VCT_CELLS_ARITH
 #define VCT_CELLS_ARITH 1      // the footprint-record instantiation keeps the arithmetic (it is memory bound: see sample_level)
 #endif
@@ -388,7 +391,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         }
 #if VCT_HW_UNORM && !VCT_LUT
         const float4 d = texel_f32(tb, idx);
-        if (VCT_LOAD_PRIO && PRIO) __builtin_amdgcn_s_setprio(0);
+        if (VCT_LOAD_PRIO && PRIO && VCT_LOAD_PRIO_MODE != 2) __builtin_amdgcn_s_setprio(0);
         // (channels are >= +0: the block is empty iff no channel has a bit set)
         const bool any_texel = ballot64((__float_as_uint(d.x) | __float_as_uint(d.y) | __float_as_uint(d.z) | __float_as_uint(d.w)) != 0u) != 0ull;
 #else
@@ -396,6 +399,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
         const bool any_texel = ballot64(t != 0u) != 0ull;
 #endif
         if (VCT_STATS) { if (any_texel) ++ms.coop_hit; else ++ms.coop_zero; }
+        if (VCT_LOAD_PRIO && PRIO && VCT_LOAD_PRIO_MODE == 2 && !any_texel) __builtin_amdgcn_s_setprio(0);
         if (any_texel) {     // all 64 texels zero: every footprint sums to exactly +0
 #if !(VCT_HW_UNORM && !VCT_LUT)
             float4 d;
@@ -465,6 +469,7 @@ __device__ __forceinline__ F4 sample_level(const uint32_t* __restrict__ chain, c
             const float4 t0 = q[0], t1 = q[1], t2 = q[4], t3 = q[5];
             const float4 t4 = q[16], t5 = q[17], t6 = q[20], t7 = q[21];
             wave_sync();
+            if (VCT_LOAD_PRIO && PRIO && VCT_LOAD_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(0);
             const float w0 = ab00 * c0, w1 = ab10 * c0, w2 = ab01 * c0, w3 = ab11 * c0;
             const float w4 = ab00 * c, w5 = ab10 * c, w6 = ab01 * c, w7 = ab11 * c;
 #define VCT_ACC(ch)                                                                           \
@@ -929,6 +934,7 @@ __device__ __forceinline__ VctStep load_step(StepTable t, int k) {
 //   sample:   textureLod = blend of the two levels (frac == 0: one level, decided in the table)
 //   composite: trace.fs:100 (colour), :101 (occlusion), :102 (alpha), front to back
 #define VCT_MARCH_STEP(st, act, live)                                                                        \
+        if (VCT_LOAD_PRIO && PRIO && VCT_LOAD_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(1); \
         const float px = start.x + dir.x * st.dist; \
         const float py = start.y + dir.y * st.dist; \
         const float pz = start.z + dir.z * st.dist; \
