@@ -88,10 +88,11 @@ def parse():
     ap.add_argument("--slabs", default="balanced", choices=["balanced", "equal", "interleaved"],
                     help="N > 1: balanced = slab boundaries of equal cone-step cost from the first frame's per-row step "
                          "histogram (vct_slab_partition_weighted), equal = ceil(tile_rows / N) rows per rank")
-    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("VCT_BENCH_FRAMES_IN_FLIGHT", "2")), choices=[1, 2],
-                    help="N = 1: 2 = consecutive steps alternate between two frame slots (vct_set_frames_in_flight: own stream, "
-                         "G-buffer and frame each), so that step k + 1 starts while step k drains -- what a renderer's frame "
-                         "loop does; 1 = every step on one stream, each launch waiting for the one before")
+    ap.add_argument("--frames-in-flight", type=int, default=int(os.environ.get("VCT_BENCH_FRAMES_IN_FLIGHT", "1")), choices=[1, 2],
+                    help="1 (default) = every step on one stream, each launch behind the one before; 2 = consecutive steps "
+                         "alternate between two frame slots (vct_set_frames_in_flight: own stream, G-buffer and frame each), "
+                         "so that step k + 1 starts while step k drains.  With 1 at N = 1 the two-slot form of the same K "
+                         "steps is timed afterwards and reported beside (frames_in_flight.ms_per_step_two_slots)")
     ap.add_argument("--timeout", type=float, default=float(os.environ.get("VCT_BENCH_TIMEOUT_S", "900")),
                     help="self-launched N > 1 run: seconds before the parent kills every rank and exits non-zero")
     return ap.parse_args()
@@ -305,6 +306,7 @@ def main():
             if args.bounces != 2 and world == 1:
                 # the same six stages as ONE call (vct_gi_pass: G-buffer raster on a second stream beside the
                 # voxel stages) -- wall time of the whole pass, events around the calls, mean of 20 after 5 warm-ups
+                ctx.set_trace_timing(False)       # a frame loop: no timing events around the trace (include/vct.h)
                 for _ in range(5):
                     ctx.gi_pass(inp["light_vp"], inp["view_proj"])
                 ef = [ev(), ev()]
@@ -313,6 +315,7 @@ def main():
                     ctx.gi_pass(inp["light_vp"], inp["view_proj"])
                 ef[1].record()
                 ctx.synchronize()
+                ctx.set_trace_timing(True)
                 gi_fused = ef[0].elapsed_time(ef[1]) / 20.0
             stage_counts = ctx.stage_counts()
             inp["planes"] = ctx.download_gbuffer()     # host copy only for the CPU baseline / checks
@@ -452,7 +455,7 @@ def main():
         except vct.VctError as e:                 # (a second G-buffer did not fit, ...): one frame at a time, and the line says so
             print(f"[bench] two frames in flight unavailable ({e}); one frame at a time", file=sys.stderr)
             fif = 1
-    if fif == 2:
+    def setup_slot1():
         ctx.select_frame_slot(1)
         if native and args.slabs == "interleaved":
             if inp["scene"] is not None:
@@ -471,6 +474,9 @@ def main():
             ctx.trace_gbuffer_rows(r0, r1)
         assert ctx.last_step_count() == steps_slab
         ctx.select_frame_slot(0)
+
+    if fif == 2:
+        setup_slot1()
     comm_stream = torch.cuda.Stream(device=local_rank) if (use_dist and not native) else None
     traced = [torch.cuda.Event() for _ in range(len(fgs))]
     gathered = [torch.cuda.Event() for _ in range(len(fgs))]
@@ -516,6 +522,10 @@ def main():
     # counts) during which the GPU idles and drops its clocks; the first ~25 launches after that run up to 18 % slow
     # (rocprof kernel trace: 808 -> 685 us over 20 ms).  A renderer runs frame after frame, so the steady state is what
     # is measured: PREROLL launches of the same step bring the clocks back before the W warm-up steps.
+    # The timed steps are issued the way a frame loop issues them: without the two timing events that vct_last_trace_ms
+    # reads around every launch (vct_set_trace_timing: they cost a launch ~7 us of dispatch gaps); the kernel time is
+    # measured afterwards, in its own untimed loop, with the events back on.
+    ctx.set_trace_timing(False)
     for _ in range(PREROLL_STEPS):
         one_step()
     for _ in range(args.warmup):
@@ -543,10 +553,31 @@ def main():
                 ctx.trace_resident()
         fence()
         dt_one = time.perf_counter() - t1     # the same K steps on ONE stream: what frames_in_flight buys, same run
+    ctx.set_trace_timing(True)
     for _ in range(min(args.steps, 20)):
         ctx.trace_resident()
         kernel_ms.append(ctx.last_trace_ms())
     fence()
+    ctx.set_trace_timing(False)
+    dt_two = None
+    if fif == 1 and not use_dist and args.variant != 4 and args.frames_in_flight == 1:
+        # ... and the other way round: the same K steps alternating between two frame slots, timed beside the headline
+        try:
+            ctx.set_frames_in_flight(2)
+            setup_slot1()
+            for k in range(PREROLL_STEPS + args.warmup):
+                ctx.select_frame_slot(k & 1); ctx.trace_resident()
+            fence()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                ctx.select_frame_slot(k & 1); ctx.trace_resident()
+            fence()
+            dt_two = time.perf_counter() - t1
+            ctx.select_frame_slot(0)
+            ctx.set_frames_in_flight(1)
+        except vct.VctError as e:
+            print(f"[bench] two frames in flight unavailable ({e}); not measured", file=sys.stderr)
+    ctx.set_trace_timing(True)
 
     # N > 1 lines explain themselves: what RCCL says the communicator is, every rank's slab kernel time, step count and
     # exchange-step time (untimed reads, after the timed region)
@@ -651,9 +682,16 @@ def main():
                        "slab_tile_rows": [b - a for a, b in slab_rows]},
             "frames_in_flight": {"n": fif, "slot_streams_overlap": ctx.frame_slot_streams_overlap() if fif == 2 else None,
                                  "ms_per_step_one_stream": None if dt_one is None else round(dt_one / args.steps * 1e3, 4),
-                                 "note": "n = 2: consecutive steps alternate between two frame slots (own stream, own resident "
-                                         "G-buffer of the same view, own frame): a step starts while the one before it drains; "
-                                         "`trace_kernel_ms` and the roofline block are launches that have the GPU to themselves"},
+                                 "ms_per_step_two_slots": None if dt_two is None else round(dt_two / args.steps * 1e3, 4),
+                                 "note": "n = the form `ms_per_step` / `value` were timed in (1: every step on one stream; 2: consecutive "
+                                         "steps alternate between two frame slots -- own stream, own resident G-buffer of the same view, "
+                                         "own frame -- so a step starts while the one before it drains); the other form of the same K "
+                                         "steps is timed right after it and reported here.  Since the timing events around a launch "
+                                         "can be switched off (trace_timing_events) one stream leaves no gap for a second slot to hide "
+                                         "on trace-only steps; the frame loop (raster + trace) keeps a small gain: DESIGN.md 3.6"},
+            "trace_timing_events": "off in the timed steps and in gi_pass_one_call_ms (vct_set_trace_timing(0): the way a frame loop "
+                                   "issues launches -- the two events vct_last_trace_ms reads cost a launch ~7 us of dispatch gaps); "
+                                   "on for trace_kernel_ms, measured in its own loop",
             "cone_steps_per_frame": total_steps,
             "gathered_frame_equals_single_gpu_frame": gather_ok,
             "host_issue_us_per_step": round(t_issue / args.steps * 1e6, 2),

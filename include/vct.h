@@ -385,6 +385,12 @@ int vct_last_trace_stats(vct_ctx* ctx, uint64_t out[16]);
 int vct_get_stage_counts(vct_ctx* ctx, uint64_t out[8]);
 /* Device time of the last trace kernel launch in milliseconds (HIP events on the ctx stream). */
 int vct_last_trace_ms(vct_ctx* ctx, float* ms);
+/* on = 0: march launches (trace, slab step, bounce) are no longer bracketed by the two timing events that
+ * vct_last_trace_ms reads (it then reports VCT_ERR_INVALID for such a launch).  Default on.  The events cost a launch
+ * ~7 us of dispatch gaps on this GPU -- configs[1], steps on one stream: 0.549 -> 0.542 ms; a 1/8 slab's 0.12 ms step
+ * pays the same 7 us -- so a frame loop switches them off (the facade does; bench.py does for its timed region and
+ * measures the kernel time in a separate loop with them on).  No reference counterpart (round 6). */
+int vct_set_trace_timing(vct_ctx* ctx, int32_t on);
 /* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the
  * device pointers of the resident tiled G-buffer / RGBA16F frame. */
 /* Self-test of the kernel's constant division (x / d as fma(x, r_hi, x * r_lo), r_hi + r_lo = 1/d to 48 bits):

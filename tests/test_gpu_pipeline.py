@@ -318,6 +318,36 @@ def test_one_call_passes_back_to_back_into_their_own_targets(vct, shape):
     ctx.close()
 
 
+def test_trace_timing_switch(vct):
+    """vct_set_trace_timing(0): march launches without the two timing events -- same frame, same step count;
+    vct_last_trace_ms then refuses (it has nothing to read) until a launch is timed again."""
+    w, h = 328, 200
+    ctx, sc = make(vct, w, h)
+    ctx.render_shadow_map(sc.light_view_proj((0.0, 1.0, 0.25)))
+    ctx.voxelize(); ctx.inject_light(); ctx.build_mips()
+    pos, vp = cameras(sc, w, h, 1)[0]
+    ctx.set_camera_position(pos); ctx.render_gbuffer(vp)
+    want = ctx.trace_current()
+    steps = ctx.last_step_count()
+    assert ctx.last_trace_ms() > 0.0
+    ctx.set_trace_timing(False)
+    ctx.trace_resident()
+    assert np.array_equal(ctx.download_frame(), want) and ctx.last_step_count() == steps
+    with pytest.raises(vct.VctError):
+        ctx.last_trace_ms()
+    ctx.set_frames_in_flight(2)                      # the switch is the context's, the "was timed" flag the slot's
+    ctx.select_frame_slot(1); ctx.render_gbuffer(vp); ctx.trace_resident()
+    with pytest.raises(vct.VctError):
+        ctx.last_trace_ms()
+    ctx.set_trace_timing(True)
+    ctx.trace_resident()
+    assert ctx.last_trace_ms() > 0.0 and np.array_equal(ctx.download_frame(), want)
+    ctx.select_frame_slot(0)
+    with pytest.raises(vct.VctError):
+        ctx.last_trace_ms()                          # slot 0's last launch was not timed
+    ctx.close()
+
+
 def test_what_two_frames_in_flight_refuses(vct):
     ctx, sc = make(vct, 64, 48, 32)
     with pytest.raises(vct.VctError):

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "vct_comm_set_timeout_ms", "vct_last_row_steps", "vct_slab_partition_weighted", "vct_comm_set_slab_rows",
     "vct_get_stage_counts", "vct_comm_info", "vct_comm_last_gather_ms", "vct_set_footprint_records",
     "vct_set_frames_in_flight", "vct_get_frames_in_flight", "vct_select_frame_slot", "vct_selftest_texel_buffer",
+    "vct_set_trace_timing",
 ]
 
 
@@ -138,6 +139,7 @@ _lib.vct_upload_mesh_uvs.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_set_frames_in_flight.argtypes = [C.c_void_p, C.c_int32]
 _lib.vct_get_frames_in_flight.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.vct_select_frame_slot.argtypes = [C.c_void_p, C.c_int32]
+_lib.vct_set_trace_timing.argtypes = [C.c_void_p, C.c_int32]
 _lib.vct_selftest_texel_buffer.argtypes = [C.c_void_p, C.c_void_p]
 _lib.vct_upload_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
 
@@ -536,6 +538,10 @@ class Context:
         self._ck(_lib.vct_get_stage_counts(self._h, v), "vct_get_stage_counts")
         return dict(zip(("triangles", "vox_candidates", "reserved", "accumulator_bricks", "touched_bricks",
                          "comm_reserved_cus", "raster_form", "vox_items"), (int(x) for x in v)))
+
+    def set_trace_timing(self, on=True):
+        """Bracket march launches with the timing events last_trace_ms() reads (default on; ~7 us per launch: include/vct.h)."""
+        self._ck(_lib.vct_set_trace_timing(self._h, int(bool(on))), "vct_set_trace_timing")
 
     def last_trace_ms(self):
         v = C.c_float()

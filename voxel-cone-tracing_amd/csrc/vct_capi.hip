@@ -228,7 +228,7 @@ void slot_save(const vct_ctx* c, VctFrameSlot& s) {
     s.gb_tiled = c->gb_tiled; s.gb_current = c->gb_current; s.frame = c->frame; s.frame_target = c->frame_target;
     s.tile_steps = c->tile_steps;
     s.last_row0 = c->last_row0; s.last_row1 = c->last_row1; s.last_row_stride = c->last_row_stride;
-    s.have_trace = c->have_trace; s.last_trace_compacted = c->last_trace_compacted;
+    s.have_trace = c->have_trace; s.last_trace_compacted = c->last_trace_compacted; s.last_trace_timed = c->last_trace_timed;
     s.last_was_screen_trace = c->last_was_screen_trace; s.have_gbuffer = c->have_gbuffer;
 }
 void slot_load(vct_ctx* c, const VctFrameSlot& s) {
@@ -236,7 +236,7 @@ void slot_load(vct_ctx* c, const VctFrameSlot& s) {
     c->gb_tiled = s.gb_tiled; c->gb_current = s.gb_current; c->frame = s.frame; c->frame_target = s.frame_target;
     c->tile_steps = s.tile_steps;
     c->last_row0 = s.last_row0; c->last_row1 = s.last_row1; c->last_row_stride = s.last_row_stride;
-    c->have_trace = s.have_trace; c->last_trace_compacted = s.last_trace_compacted;
+    c->have_trace = s.have_trace; c->last_trace_compacted = s.last_trace_compacted; c->last_trace_timed = s.last_trace_timed;
     c->last_was_screen_trace = s.last_was_screen_trace; c->have_gbuffer = s.have_gbuffer;
 }
 // A stage that WRITES state both slots read (shadow map, chain, accumulators): on the GPU it waits for everything the
@@ -393,9 +393,10 @@ int launch_trace(vct_ctx* c, int row0, int row1, uint16_t* out_base = nullptr, i
         p.vt_count = c->vt_pix + nt * 64;
         HIP_TRY(c, hipMemsetAsync(p.vt_count, 0, sizeof(uint32_t), c->stream));
     }
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (c->time_traces) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));      // (vct_set_trace_timing)
     HIP_TRY(c, vct_launch_trace(p, variant, c->stream));       // an empty row range (a rank without rows) launches nothing
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if (c->time_traces) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->last_trace_timed = c->time_traces;
     c->last_row0 = row0;
     c->last_row1 = row1;
     c->last_row_stride = row_stride > 1 ? row_stride : 1;
@@ -1593,9 +1594,10 @@ int vct_bounce(vct_ctx* c) {
     p.bounce_list_cap = c->bounce_list_cap;
     p.brick_over = c->brick_over;
     HIP_TRY(c, hipMemsetAsync(c->step_counter, 0, VCT_STEP_COUNTERS * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (c->time_traces) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, vct_launch_bounce(p, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if (c->time_traces) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->last_trace_timed = c->time_traces;
     HIP_TRY(c, vct_launch_build_mips(c->chain_b, c->cfg.voxel_dim, b_sparse ? c->brick_prev : nullptr,
                                      b_sparse ? c->mip_seen_b : nullptr, c->stream));
     // the directional chains always describe the chain the trace reads (the bounce itself gathers
@@ -2107,9 +2109,17 @@ int vct_last_trace_stats(vct_ctx* c, uint64_t out[16]) {
 #endif
 }
 
+int vct_set_trace_timing(vct_ctx* c, int32_t on) {
+    if (!c) return VCT_ERR_INVALID;
+    c->time_traces = on != 0;
+    return VCT_OK;
+}
+
 int vct_last_trace_ms(vct_ctx* c, float* ms) {
     if (!c || !ms) return VCT_ERR_INVALID;
     if (!c->have_trace) return fail(c, VCT_ERR_INVALID, "no trace has run");
+    if (!c->last_trace_timed)
+        return fail(c, VCT_ERR_INVALID, "vct_last_trace_ms: the last trace was issued with timing off (vct_set_trace_timing)");
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     return VCT_OK;

@@ -36,6 +36,7 @@ struct VctFrameSlot {
     uint32_t* tile_steps = nullptr;
     int last_row0 = 0, last_row1 = 0, last_row_stride = 1;
     bool have_trace = false, last_trace_compacted = false, last_was_screen_trace = false, have_gbuffer = false;
+    bool last_trace_timed = false;      // the slot's last march launch was bracketed by its timing events
 };
 
 struct vct_ctx {
@@ -80,6 +81,10 @@ struct vct_ctx {
     int last_row0 = 0, last_row1 = 0;
     int last_row_stride = 1;          // the last screen trace took every last_row_stride-th tile row of [last_row0, last_row1)
     bool have_trace = false;
+    // vct_set_trace_timing: bracket every march launch with the two timing events vct_last_trace_ms reads.  On by default
+    // (every entry point keeps working); a frame loop switches it off -- the two events cost a launch ~7 us of dispatch
+    // gaps on this GPU (one-stream step 0.549 -> 0.542 ms, a 1/8 slab's 0.12 ms step the same 7 us).
+    bool time_traces = true, last_trace_timed = false;
     bool last_trace_compacted = false;    // ... of trace_variant 4: counts per virtual tile, no per-row histogram
     bool last_was_screen_trace = false;   // the step counters hold a screen trace (indexed by tile row), not a bounce
     bool have_gbuffer = false;        // a G-buffer is resident (uploaded by vct_trace or rendered)

@@ -238,6 +238,9 @@ struct Voxel_Cone_Tracing {
             if (!check(vct_comm_init(ctx, CommId, Rank, World), "vct_comm_init")) return;
         if (FramesInFlight == 2)
             if (!check(vct_set_frames_in_flight(ctx, 2), "vct_set_frames_in_flight")) return;
+        // a frame loop: no timing events around the trace launches (they cost a launch ~7 us; vct_last_trace_ms wants
+        // vct_set_trace_timing(ctx, 1) before the frame it is to time)
+        if (!check(vct_set_trace_timing(ctx, 0), "vct_set_trace_timing")) return;
         if (!model.Load(model_path)) { last_status = VCT_ERR_INVALID; return; }
 
         // VCT.h:84-86 and :128-134 (the projections are kept as public data; the HIP voxelizer maps
