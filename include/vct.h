@@ -281,8 +281,12 @@ int vct_synchronize(vct_ctx* ctx);
  * slots.  n = 1 (default) releases the second slot.  Not with config.debug_outputs or trace_variant 4.  A rank of a
  * multi-GPU frame may use it too: vct_frame_step traces on the selected slot's stream, so slab k + 1 starts while slab k
  * drains (a slab launch pays the same ~20 us as a whole frame: a third of an 8-way slab); vct_comm_sync waits for both.
- * Measured (tools/pipe_probe.py, bench.py `frames_in_flight`): configs[1] trace 0.626 -> 0.598 ms per
- * frame, Render() 0.773 -> 0.738; configs[4] (4K, 1024^3, a 1.8 ms raster pass) loses -- hence opt-in. */
+ * Measured: with the round-5 kernel and the timing events of vct_last_trace_ms around every launch, configs[1] trace
+ * 0.617 -> 0.591 ms per step, Render() 0.752 -> 0.725.  Most of that turned out to be the events themselves (~7 us of
+ * dispatch gaps per launch, which a second stream hides): with vct_set_trace_timing(ctx, 0) one stream runs a
+ * trace-only step in the kernel's own time (0.540 ms against 0.548 on two slots; a 1/8 slab step 0.112 either way) and
+ * two slots keep 1-2 % only where frames are long (configs[4] trace 2.64 -> 2.58, configs[2] 2.42 -> 2.39, Render()
+ * 0.702 -> 0.697) -- opt-in, default 1. */
 int vct_set_frames_in_flight(vct_ctx* ctx, int32_t n);
 /* streams_overlap: 1 when the second slot's stream was seen to run beside the first at set-up (HIP shares a few hardware
  * queues between a process' streams; the library probes candidates until one overlaps), 0: no such stream was found --
