@@ -93,6 +93,9 @@ def parse():
                          "alternate between two frame slots (vct_set_frames_in_flight: own stream, G-buffer and frame each), "
                          "so that step k + 1 starts while step k drains.  With 1 at N = 1 the two-slot form of the same K "
                          "steps is timed afterwards and reported beside (frames_in_flight.ms_per_step_two_slots)")
+    ap.add_argument("--no-two-slots", action="store_true",
+                    help="do not time the two-slot form of the K steps beside the one-stream steps (profiled runs: every "
+                         "trace launch of the kernel trace then has the GPU to itself)")
     ap.add_argument("--timeout", type=float, default=float(os.environ.get("VCT_BENCH_TIMEOUT_S", "900")),
                     help="self-launched N > 1 run: seconds before the parent kills every rank and exits non-zero")
     return ap.parse_args()
@@ -560,7 +563,7 @@ def main():
     fence()
     ctx.set_trace_timing(False)
     dt_two = None
-    if fif == 1 and not use_dist and args.variant != 4 and args.frames_in_flight == 1:
+    if fif == 1 and not use_dist and args.variant != 4 and args.frames_in_flight == 1 and not args.no_two_slots:
         # ... and the other way round: the same K steps alternating between two frame slots, timed beside the headline
         try:
             ctx.set_frames_in_flight(2)

@@ -11,7 +11,7 @@ run() {   # name, pmc-passes ("yes"/"no"), bench args...
   local name=$1 pmc=$2; shift 2
   local OUT=$ROOT/gpurun_out/prof_${TAG}_$name
   mkdir -p "$OUT"
-  local BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-sweep --frames-in-flight 1 $*"
+  local BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-sweep --frames-in-flight 1 --no-two-slots $*"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 10 --warmup 2 > "$OUT/trace.log" 2>&1
   if [ "$pmc" = yes ]; then
     i=0

@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-sweep --frames-in-flight 1 $*"
+BENCH="python3 $ROOT/bench.py --cpu-seconds 0 --no-sweep --frames-in-flight 1 --no-two-slots $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 20 --warmup 3 > "$OUT/trace.log" 2>&1
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
