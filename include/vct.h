@@ -393,7 +393,9 @@ int vct_last_trace_ms(vct_ctx* ctx, float* ms);
  * vct_last_trace_ms reads (it then reports VCT_ERR_INVALID for such a launch).  Default on.  The events cost a launch
  * ~7 us of dispatch gaps on this GPU -- configs[1], steps on one stream: 0.549 -> 0.542 ms; a 1/8 slab's 0.12 ms step
  * pays the same 7 us -- so a frame loop switches them off (the facade does; bench.py does for its timed region and
- * measures the kernel time in a separate loop with them on).  No reference counterpart (round 6). */
+ * measures the kernel time in a separate loop with them on).  The exchange step of a multi-GPU frame keeps its own
+ * pair (vct_comm_last_gather_ms) on the communication stream: leaving those out as well measured no different.
+ * No reference counterpart (round 6). */
 int vct_set_trace_timing(vct_ctx* ctx, int32_t on);
 /* Raw handles for interop (torch tensors wrap these): HIP stream of the context and the
  * device pointers of the resident tiled G-buffer / RGBA16F frame. */
