@@ -286,7 +286,7 @@ int vct_synchronize(vct_ctx* ctx);
  * dispatch gaps per launch, which a second stream hides): with vct_set_trace_timing(ctx, 0) one stream runs a
  * trace-only step in the kernel's own time (0.540 ms against 0.548 on two slots; a 1/8 slab step 0.112 either way) and
  * two slots keep 1-2 % only where frames are long (configs[4] trace 2.64 -> 2.58, configs[2] 2.42 -> 2.39, Render()
- * 0.702 -> 0.697) -- opt-in, default 1. */
+ * 0.70 -> 0.69) -- opt-in, default 1. */
 int vct_set_frames_in_flight(vct_ctx* ctx, int32_t n);
 /* streams_overlap: 1 when the second slot's stream was seen to run beside the first at set-up (HIP shares a few hardware
  * queues between a process' streams; the library probes candidates until one overlaps), 0: no such stream was found --

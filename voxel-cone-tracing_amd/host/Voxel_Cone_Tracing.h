@@ -200,7 +200,7 @@ struct Voxel_Cone_Tracing {
     // stream, G-buffer and frame each), so frame k + 1's raster and trace start while frame k's trace drains -- what the
     // GL driver does with the reference's frames (R/main.cpp:77-94 never waits for one).  Frame() returns the frame of
     // the last Render().  Same pixels.  What it buys is small since the facade issues its frames without timing events
-    // (vct_set_trace_timing: those were most of the gap a second slot hides): configs[1] 0.702 -> 0.697 ms per Render(),
+    // (vct_set_trace_timing: those were most of the gap a second slot hides): configs[1] 0.70 -> 0.69 ms per Render(),
     // erratic at configs[4].  Frames that are whole GI passes (DynamicLight) stay on one slot.  Set before init.
     int FramesInFlight = 1;
     int Bounces = 1;    // 2 = re-inject the lit voxels once (the "2 bounces" of the reference's README.md:16,
